@@ -1,0 +1,85 @@
+"""ctypes binding of libfrenetgpu.so (include/frenet_gpu.h).
+
+There is no CPU implementation behind this module: loading fails loudly when the
+HIP library has not been built, and every call fails when no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
+
+FP_ABI_VERSION = 1
+FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
+FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
+FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED, FLAG_INFEASIBLE = 1, 2, 4, 8, 7
+FLAG_N_SHIFT, FLAG_M_SHIFT = 8, 20
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint32)
+
+# every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy",
+                    "fp_plan_dense", "fp_eval_trajs")
+
+
+class FpParams(C.Structure):
+    _fields_ = [("nd", C.c_int32), ("nv", C.c_int32), ("nt", C.c_int32), ("check_stride", C.c_int32),
+                ("tick_t", C.c_double), ("cost_horizon", C.c_double),
+                ("w_speed", C.c_double), ("w_accel", C.c_double), ("w_jerk", C.c_double), ("w_offset", C.c_double),
+                ("veh_l", C.c_double), ("veh_w", C.c_double), ("max_speed", C.c_double), ("max_accel", C.c_double)]
+
+
+class FpBatch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("F", C.c_int32), ("NX", C.c_int32), ("S", C.c_int32), ("T_obs", C.c_int32), ("n_obs", C.c_int32),
+                ("d_samples", C.c_void_p), ("t_samples", C.c_void_p), ("v_samples", C.c_void_p), ("target_speed", C.c_void_p),
+                ("ego", C.c_void_p), ("frame_of", C.c_void_p), ("scene_of", C.c_void_p), ("t_now", C.c_void_p),
+                ("nx", C.c_void_p), ("knots", C.c_void_p), ("coef", C.c_void_p),
+                ("obs_pose", C.c_void_p), ("obs_dims", C.c_void_p), ("final_time_step", C.c_void_p)]
+
+
+class FpResult(C.Structure):
+    _fields_ = [("best_idx", C.c_void_p), ("best_cost", C.c_void_p), ("cost_tbl", C.c_void_p), ("flag_tbl", C.c_void_p),
+                ("stats", C.c_void_p)]
+
+
+class FrenetGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libfrenetgpu error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libfrenetgpu.so (built by `make -C fiss_plus_planner_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C fiss_plus_planner_amd/csrc).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.fp_abi_version.restype = C.c_int
+    L.fp_last_error.restype = C.c_char_p
+    L.fp_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.fp_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.fp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.fp_ctx_destroy.argtypes = [C.c_void_p]
+    L.fp_plan_dense.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpResult), C.c_int, C.c_void_p]
+    L.fp_eval_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int32, C.c_int, C.c_void_p]
+    if L.fp_abi_version() != FP_ABI_VERSION:
+        raise ImportError(f"libfrenetgpu ABI {L.fp_abi_version()} != binding {FP_ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise FrenetGpuError(rc, load().fp_last_error().decode(errors="replace"))

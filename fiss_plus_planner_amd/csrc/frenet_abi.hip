@@ -1,0 +1,323 @@
+// frenet_abi.hip - the C ABI of libfrenetgpu.so (include/frenet_gpu.h).
+//
+// Host-side responsibilities only: argument validation, the per-ctx device staging
+// arena used by FP_MEM_HOST calls, error strings.  No planning arithmetic happens on
+// the host: if there is no usable GPU every entry point fails with FP_ENODEV/FP_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "frenet_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return fail(FP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));     \
+    } while (0)
+
+// A grow-only device arena; host-memory calls carve their staging copies out of it.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return FP_OK;
+        if (base) {
+            hipError_t e = hipFree(base);
+            base = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return fail(FP_EHIP, "hipFree failed: %s", hipGetErrorString(e));
+        }
+        size_t want = bytes + bytes / 4 + (1u << 20);
+        hipError_t e = hipMalloc((void**)&base, want);
+        if (e != hipSuccess) return fail(FP_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        cap = want;
+        return FP_OK;
+    }
+    void reset() { used = 0; }
+    void* take(size_t bytes)
+    {
+        size_t off = (used + 255) & ~size_t(255);
+        used = off + bytes;
+        return base + off;
+    }
+    static size_t padded(size_t bytes) { return ((bytes + 255) & ~size_t(255)) + 256; }
+};
+
+}  // namespace
+
+struct fp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;  // used by FP_MEM_HOST calls
+    Arena arena;
+};
+
+namespace {
+
+int check_params(const fp_params* p)
+{
+    if (!p) return fail(FP_EINVAL, "params is NULL");
+    if (p->nd < 1 || p->nv < 1 || p->nt < 1) return fail(FP_EINVAL, "lattice sizes must be >= 1 (got %d,%d,%d)", p->nd, p->nv, p->nt);
+    if ((long)p->nd * p->nv * p->nt > FP_MAX_CAND) return fail(FP_ELIMIT, "nd*nv*nt = %ld exceeds FP_MAX_CAND", (long)p->nd * p->nv * p->nt);
+    if (p->check_stride < 1) return fail(FP_EINVAL, "check_stride must be >= 1");
+    if (!(p->tick_t > 0)) return fail(FP_EINVAL, "tick_t must be > 0");
+    return FP_OK;
+}
+
+int check_batch(const fp_batch* b)
+{
+    if (!b) return fail(FP_EINVAL, "batch is NULL");
+    if (b->B < 0 || b->F < 1 || b->NX < 2) return fail(FP_EINVAL, "bad batch sizes B=%d F=%d NX=%d", b->B, b->F, b->NX);
+    if (b->NX > FP_MAX_KNOTS) return fail(FP_ELIMIT, "NX=%d exceeds FP_MAX_KNOTS", b->NX);
+    if (!b->d_samples || !b->t_samples || !b->v_samples || !b->target_speed || !b->ego || !b->frame_of || !b->scene_of ||
+        !b->t_now || !b->nx || !b->knots || !b->coef)
+        return fail(FP_EINVAL, "batch has a NULL array");
+    if (b->S > 0 && b->n_obs > 0 && (!b->obs_pose || !b->obs_dims || !b->final_time_step))
+        return fail(FP_EINVAL, "batch has obstacles but a NULL obstacle array");
+    return FP_OK;
+}
+
+// Host-side validation of the index arrays (only possible for FP_MEM_HOST calls).
+int check_batch_host(const fp_params* p, const fp_batch* b)
+{
+    for (int i = 0; i < b->B; ++i) {
+        if (b->frame_of[i] < 0 || b->frame_of[i] >= b->F) return fail(FP_EINVAL, "frame_of[%d]=%d out of range", i, b->frame_of[i]);
+        if (b->scene_of[i] >= b->S) return fail(FP_EINVAL, "scene_of[%d]=%d out of range", i, b->scene_of[i]);
+        if (b->t_now[i] < 0) return fail(FP_EINVAL, "t_now[%d]=%d is negative", i, b->t_now[i]);
+    }
+    for (int f = 0; f < b->F; ++f)
+        if (b->nx[f] < 2 || b->nx[f] > b->NX) return fail(FP_EINVAL, "nx[%d]=%d out of range", f, b->nx[f]);
+    for (int k = 0; k < p->nt; ++k) {
+        const double n = b->t_samples[k] / p->tick_t;
+        if (!(n > 0) || n > FP_MAX_POINTS) return fail(FP_ELIMIT, "t_samples[%d]=%g needs more than FP_MAX_POINTS points", k, b->t_samples[k]);
+    }
+    return FP_OK;
+}
+
+struct Staged {
+    fp_batch dev;
+    size_t bytes = 0;
+};
+
+size_t batch_bytes(const fp_params* p, const fp_batch* b)
+{
+    size_t n = 0;
+    n += Arena::padded(sizeof(double) * p->nd) + Arena::padded(sizeof(double) * p->nt);
+    n += Arena::padded(sizeof(double) * (size_t)b->B * p->nv) + Arena::padded(sizeof(double) * b->B);
+    n += Arena::padded(sizeof(double) * (size_t)b->B * 6) + 3 * Arena::padded(sizeof(int32_t) * b->B);
+    n += Arena::padded(sizeof(int32_t) * b->F) + Arena::padded(sizeof(double) * (size_t)b->F * b->NX) +
+         Arena::padded(sizeof(double) * (size_t)b->F * 8 * b->NX);
+    n += Arena::padded(sizeof(double) * (size_t)b->S * b->T_obs * b->n_obs * 4) + Arena::padded(sizeof(double) * (size_t)b->S * b->n_obs * 2) +
+         Arena::padded(sizeof(int32_t) * (b->S > 0 ? b->S : 1));
+    return n;
+}
+
+template <typename T>
+int push(fp_ctx* ctx, const T* host, size_t count, const T** dev_out)
+{
+    T* d = (T*)ctx->arena.take(sizeof(T) * (count ? count : 1));
+    if (count) HIP_TRY(hipMemcpyAsync(d, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    *dev_out = d;
+    return FP_OK;
+}
+
+int stage_batch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, fp_batch* dev)
+{
+    *dev = *b;
+    int rc;
+#define PUSH(field, count) if ((rc = push(ctx, b->field, (size_t)(count), &dev->field)) != FP_OK) return rc
+    PUSH(d_samples, p->nd);
+    PUSH(t_samples, p->nt);
+    PUSH(v_samples, (size_t)b->B * p->nv);
+    PUSH(target_speed, b->B);
+    PUSH(ego, (size_t)b->B * 6);
+    PUSH(frame_of, b->B);
+    PUSH(scene_of, b->B);
+    PUSH(t_now, b->B);
+    PUSH(nx, b->F);
+    PUSH(knots, (size_t)b->F * b->NX);
+    PUSH(coef, (size_t)b->F * 8 * b->NX);
+    const bool has_obs = b->S > 0 && b->n_obs > 0;
+    PUSH(obs_pose, has_obs ? (size_t)b->S * b->T_obs * b->n_obs * 4 : 0);
+    PUSH(obs_dims, has_obs ? (size_t)b->S * b->n_obs * 2 : 0);
+    PUSH(final_time_step, has_obs ? b->S : 0);
+#undef PUSH
+    if (!has_obs) dev->n_obs = 0;
+    return FP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fp_abi_version(void) { return FP_ABI_VERSION; }
+
+const char* fp_last_error(void) { return g_last_error.c_str(); }
+
+int fp_device_count(int* count)
+{
+    if (!count) return fail(FP_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(FP_ENODEV, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return FP_OK;
+}
+
+int fp_device_info(int device, char* buf, int buflen, int* compute_units, int64_t* hbm_bytes)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (buf && buflen > 0) snprintf(buf, (size_t)buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return FP_OK;
+}
+
+int fp_ctx_create(int device, fp_ctx** out)
+{
+    if (!out) return fail(FP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FP_ENODEV, "no HIP device visible: the engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail(FP_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    fp_ctx* ctx = new (std::nothrow) fp_ctx();
+    if (!ctx) return fail(FP_ENOMEM, "out of host memory");
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(FP_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return FP_OK;
+}
+
+int fp_ctx_destroy(fp_ctx* ctx)
+{
+    if (!ctx) return FP_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    delete ctx;
+    return FP_OK;
+}
+
+int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    int rc;
+    if ((rc = check_params(params)) != FP_OK) return rc;
+    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");
+    if (batch->B == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t C = (size_t)params->nd * params->nv * params->nt;
+    const size_t B = (size_t)batch->B;
+    fp::KernelArgs ka;
+    ka.p = *params;
+    if (mem == FP_MEM_DEVICE) {
+        ka.b = *batch;
+        if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
+        ka.r = *result;
+        hipError_t e = fp::launch_lattice_percand(ka, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
+        return FP_OK;
+    }
+    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
+    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(double) * B) +
+                  Arena::padded(sizeof(int32_t) * B * 4);
+    if (result->cost_tbl) need += Arena::padded(sizeof(double) * B * C);
+    if (result->flag_tbl) need += Arena::padded(sizeof(uint32_t) * B * C);
+    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
+    ctx->arena.reset();
+    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
+    ka.r.best_idx = (int32_t*)ctx->arena.take(sizeof(int32_t) * B);
+    ka.r.best_cost = (double*)ctx->arena.take(sizeof(double) * B);
+    ka.r.stats = result->stats ? (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 4) : nullptr;
+    ka.r.cost_tbl = result->cost_tbl ? (double*)ctx->arena.take(sizeof(double) * B * C) : nullptr;
+    ka.r.flag_tbl = result->flag_tbl ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B * C) : nullptr;
+    hipError_t e = fp::launch_lattice_percand(ka, ctx->stream);
+    if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(result->best_idx, ka.r.best_idx, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(result->best_cost, ka.r.best_cost, sizeof(double) * B, hipMemcpyDeviceToHost, ctx->stream));
+    if (result->stats) HIP_TRY(hipMemcpyAsync(result->stats, ka.r.stats, sizeof(int32_t) * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (result->cost_tbl) HIP_TRY(hipMemcpyAsync(result->cost_tbl, ka.r.cost_tbl, sizeof(double) * B * C, hipMemcpyDeviceToHost, ctx->stream));
+    if (result->flag_tbl) HIP_TRY(hipMemcpyAsync(result->flag_tbl, ka.r.flag_tbl, sizeof(uint32_t) * B * C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FP_OK;
+}
+
+int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states, double* cost,
+                  uint32_t* flags, double* traj, int32_t stride, int mem, void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    int rc;
+    if ((rc = check_params(params)) != FP_OK) return rc;
+    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    if (K < 1 || !end_states) return fail(FP_EINVAL, "K must be >= 1 and end_states non-NULL");
+    if (traj && stride < FP_MAX_POINTS) return fail(FP_EINVAL, "traj stride must be >= FP_MAX_POINTS (%d)", FP_MAX_POINTS);
+    if (batch->B == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t BK = (size_t)batch->B * K;
+    fp::KernelArgs ka;
+    ka.p = *params;
+    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (mem == FP_MEM_DEVICE) {
+        ka.b = *batch;
+        if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
+        hipError_t e = fp::launch_eval_trajs(ka, K, end_states, cost, flags, traj, stride, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "eval kernel launch failed: %s", hipGetErrorString(e));
+        return FP_OK;
+    }
+    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
+    for (size_t i = 0; i < BK; ++i) {
+        const double n = end_states[3 * i + 2] / params->tick_t;
+        if (!(n > 0) || n > FP_MAX_POINTS) return fail(FP_ELIMIT, "end_states[%zu].T=%g needs 1..FP_MAX_POINTS points", i, end_states[3 * i + 2]);
+    }
+    const size_t traj_doubles = traj ? BK * FP_ARR_COUNT * (size_t)stride : 0;
+    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(double) * BK * 3) + Arena::padded(sizeof(double) * BK) +
+                  Arena::padded(sizeof(uint32_t) * BK) + Arena::padded(sizeof(double) * traj_doubles);
+    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
+    ctx->arena.reset();
+    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
+    const double* d_end = nullptr;
+    if ((rc = push(ctx, end_states, BK * 3, &d_end)) != FP_OK) return rc;
+    double* d_cost = (double*)ctx->arena.take(sizeof(double) * BK);
+    uint32_t* d_flags = (uint32_t*)ctx->arena.take(sizeof(uint32_t) * BK);
+    double* d_traj = traj ? (double*)ctx->arena.take(sizeof(double) * traj_doubles) : nullptr;
+    hipError_t e = fp::launch_eval_trajs(ka, K, d_end, d_cost, d_flags, d_traj, stride, ctx->stream);
+    if (e != hipSuccess) return fail(FP_EHIP, "eval kernel launch failed: %s", hipGetErrorString(e));
+    if (cost) HIP_TRY(hipMemcpyAsync(cost, d_cost, sizeof(double) * BK, hipMemcpyDeviceToHost, ctx->stream));
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, sizeof(uint32_t) * BK, hipMemcpyDeviceToHost, ctx->stream));
+    if (traj) HIP_TRY(hipMemcpyAsync(traj, d_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FP_OK;
+}
+
+}  // extern "C"

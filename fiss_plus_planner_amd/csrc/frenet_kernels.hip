@@ -1,0 +1,370 @@
+// frenet_kernels.hip - gfx950 kernels of the Frenet sampling-and-scoring engine.
+//
+// Kernel inventory (DESIGN.md has the roofline accounting of each):
+//   lattice_percand_kernel   one workgroup per ego, one lane per lattice candidate: generation,
+//                            cost, Frenet->Cartesian, constraint + collision flags, block argmin.
+//   eval_trajs_kernel        one lane per explicit-end-state trajectory; optional full
+//                            FrenetTrajectory dump (winner epilogue / FISS+ refinement / all_trajs).
+//
+// LDS per workgroup: the ego's reference-line spline (knots + 8 coefficient rows) and the
+// rows of its obstacle table that the collision horizon can touch, converted once to
+// (x, y, cos, sin) so that the per-pose test does no trigonometry.
+#include "frenet_device.h"
+#include "frenet_kernels.h"
+
+namespace fp {
+
+// ---------------------------------------------------------------------------
+// per-workgroup shared state
+// ---------------------------------------------------------------------------
+struct EgoCtx {
+    // start state
+    double s0, s_d0, s_dd0, d0, d_d0, d_dd0;
+    double target_speed;
+    // spline in LDS
+    SplineLds sp;
+    // obstacles
+    const double* obs_lds;   // [rows][n_obs][4] = x, y, cos, sin (x = NaN: no state) or nullptr
+    const double* obs_dim;   // [n_obs][4] = hl, hw, bounding radius, unused
+    const double* obs_glb;   // global pose table of the scene (fallback when LDS is too small)
+    int n_obs, T_obs, rows, t_now, horizon_cap;  // horizon_cap = final_time_step - t_now
+};
+
+struct TrajOut {
+    double cost;
+    uint32_t flags;  // FP_FLAG_* | N<<8 | M<<20
+};
+
+__device__ __forceinline__ int lds_layout_doubles(int nx, int n_obs, int rows)
+{
+    return nx * 9 + n_obs * 4 + rows * n_obs * 4;
+}
+
+// Stage spline + obstacle rows of ego `b` into LDS.  All threads of the block take part.
+__device__ void stage_ego(const KernelArgs& ka, int b, double* lds, EgoCtx& e, int lds_doubles)
+{
+    const fp_batch& bt = ka.b;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const double* eg = bt.ego + (size_t)b * 6;
+    e.s0 = eg[0]; e.s_d0 = eg[1]; e.s_dd0 = eg[2]; e.d0 = eg[3]; e.d_d0 = eg[4]; e.d_dd0 = eg[5];
+    e.target_speed = bt.target_speed[b];
+    const int f = bt.frame_of[b];
+    const int nx = bt.nx[f];
+    const int NX = bt.NX;
+    double* knots = lds;
+    double* coef = lds + nx;
+    const double* gk = bt.knots + (size_t)f * NX;
+    const double* gc = bt.coef + (size_t)f * 8 * NX;
+    for (int i = tid; i < nx; i += nth) knots[i] = gk[i];
+    for (int i = tid; i < 8 * nx; i += nth) {
+        const int r = i / nx, c = i - r * nx;
+        coef[r * nx + c] = gc[(size_t)r * NX + c];
+    }
+    e.sp.knots = knots;
+    e.sp.coef = coef;
+    e.sp.nx = nx;
+    e.sp.ld = nx;
+
+    const int sc = bt.scene_of[b];
+    e.t_now = bt.t_now[b];
+    e.n_obs = (sc >= 0) ? bt.n_obs : 0;
+    e.T_obs = bt.T_obs;
+    e.obs_lds = nullptr;
+    e.obs_dim = nullptr;
+    e.obs_glb = nullptr;
+    e.rows = 0;
+    e.horizon_cap = 0;
+    if (e.n_obs > 0) {
+        const int n = e.n_obs;
+        e.horizon_cap = bt.final_time_step[sc] - e.t_now;
+        const int stride = ka.p.check_stride;
+        int hmax = e.horizon_cap < FP_MAX_POINTS ? e.horizon_cap : FP_MAX_POINTS;
+        if (hmax < 0) hmax = 0;
+        int rows = (hmax + stride - 1) / stride;  // poses 0, stride, 2*stride, ... < hmax
+        // rows past the end of the table hold no state at all: do not stage them
+        const int in_table = bt.T_obs - e.t_now;
+        const int rows_tab = in_table > 0 ? (in_table + stride - 1) / stride : 0;
+        if (rows_tab < rows) rows = rows_tab;
+        double* dim = coef + 8 * nx;
+        const double* gd = bt.obs_dims + (size_t)sc * n * 2;
+        for (int j = tid; j < n; j += nth) {
+            const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
+            dim[4 * j] = hl;
+            dim[4 * j + 1] = hw;
+            dim[4 * j + 2] = sqrt(fma(hl, hl, hw * hw));
+            dim[4 * j + 3] = 0.0;
+        }
+        e.obs_dim = dim;
+        e.obs_glb = bt.obs_pose + (size_t)sc * bt.T_obs * n * 4;
+        if (lds_layout_doubles(nx, n, rows) <= lds_doubles) {
+            double* tab = dim + 4 * n;
+            for (int i = tid; i < rows * n; i += nth) {
+                const int r = i / n, j = i - r * n;
+                const int ts = r * stride + e.t_now;
+                double x = __builtin_nan(""), y = 0.0, c = 1.0, s = 0.0;
+                if (ts >= 0 && ts < bt.T_obs) {
+                    const double* ps = e.obs_glb + ((size_t)ts * n + j) * 4;
+                    if (ps[3] != 0.0) {
+                        x = ps[0];
+                        y = ps[1];
+                        sincos(ps[2], &s, &c);
+                    }
+                }
+                tab[4 * i] = x; tab[4 * i + 1] = y; tab[4 * i + 2] = c; tab[4 * i + 3] = s;
+            }
+            e.obs_lds = tab;
+            e.rows = rows;
+        }
+    }
+    __syncthreads();
+}
+
+// ego box at pose index i (absolute obstacle row i + t_now) against every obstacle
+__device__ __forceinline__ bool pose_collides(const KernelArgs& ka, const EgoCtx& e, int i, double x, double y, double c, double s)
+{
+    if (!(x == x) || !(y == y) || !(c == c)) return true;  // polygon construction fails in the reference -> "collision" (:178-182)
+    Obb ego{x, y, c, s, 0.5 * ka.p.veh_l, 0.5 * ka.p.veh_w};
+    const double r_e = sqrt(fma(ego.hl, ego.hl, ego.hw * ego.hw));
+    const int n = e.n_obs;
+    const int stride = ka.p.check_stride;
+    if (e.obs_lds) {
+        if (i / stride >= e.rows) return false;  // beyond the table: state_at_time() is None for every obstacle
+        const double* row = e.obs_lds + (size_t)(i / stride) * n * 4;
+        for (int j = 0; j < n; ++j) {
+            const double ox = row[4 * j], oy = row[4 * j + 1];
+            const double R = (r_e + e.obs_dim[4 * j + 2]) * (1.0 + 1e-12);
+            const double dx = ox - x, dy = oy - y;
+            if (!(fma(dx, dx, dy * dy) <= R * R)) continue;  // also skips NaN (no state)
+            Obb ob{ox, oy, row[4 * j + 2], row[4 * j + 3], e.obs_dim[4 * j], e.obs_dim[4 * j + 1]};
+            if (obb_overlap(ego, ob)) return true;
+        }
+    } else {
+        const int ts = i + e.t_now;
+        if (ts < 0 || ts >= e.T_obs) return false;
+        const double* row = e.obs_glb + (size_t)ts * n * 4;
+        for (int j = 0; j < n; ++j) {
+            if (row[4 * j + 3] == 0.0) continue;
+            const double ox = row[4 * j], oy = row[4 * j + 1];
+            const double R = (r_e + e.obs_dim[4 * j + 2]) * (1.0 + 1e-12);
+            const double dx = ox - x, dy = oy - y;
+            if (!(fma(dx, dx, dy * dy) <= R * R)) continue;
+            double oc, os;
+            sincos(row[4 * j + 2], &os, &oc);
+            Obb ob{ox, oy, oc, os, e.obs_dim[4 * j], e.obs_dim[4 * j + 1]};
+            if (obb_overlap(ego, ob)) return true;
+        }
+    }
+    return false;
+}
+
+// One trajectory: generation + cost + conversion + flags (+ optional dump).
+// `dump` = nullptr or the [16][stride] block of this trajectory.
+template <bool DUMP>
+__device__ TrajOut traj_eval(const KernelArgs& ka, const EgoCtx& e, double d_end, double v_end, double T_end, bool do_collision,
+                             double* dump, int stride_d)
+{
+    const fp_params& p = ka.p;
+    const int N = arange_len(T_end, p.tick_t);
+    TrajOut out;
+    if (N <= 0 || N > FP_MAX_POINTS) {
+        out.cost = __builtin_nan("");
+        out.flags = FP_FLAG_INFEASIBLE;
+        return out;
+    }
+    const Quintic lat = quintic_bvp(e.d0, e.d_d0, e.d_dd0, d_end, 0.0, 0.0, T_end);
+    const Quartic lon = quartic_bvp(e.s0, e.s_d0, e.s_dd0, v_end, 0.0, T_end);
+    double sum_v = 0, sum_as = 0, sum_ad = 0, sum_js = 0, sum_jd = 0, sum_d = 0;
+    uint32_t flags = 0;
+    int M = -1, seg = -1;
+    double xp = 0, yp = 0, hc = 1.0, hs = 0.0;
+    const bool check = do_collision && e.n_obs > 0;
+    const int cstride = p.check_stride;
+    bool hit = false;
+    for (int i = 0; i < N; ++i) {
+        const double t = (double)i * p.tick_t;
+        double d, d_d, d_dd, d_ddd, s, s_d, s_dd, s_ddd;
+        quintic_eval(lat, t, d, d_d, d_dd, d_ddd);
+        quartic_eval(lon, t, s, s_d, s_dd, s_ddd);
+        const double ev = s_d - e.target_speed;
+        sum_v = fma(ev, ev, sum_v);
+        sum_as = fma(s_dd, s_dd, sum_as);
+        sum_ad = fma(d_dd, d_dd, sum_ad);
+        sum_js = fma(s_ddd, s_ddd, sum_js);
+        sum_jd = fma(d_ddd, d_ddd, sum_jd);
+        sum_d = fma(d, d, sum_d);
+        if (s_d > p.max_speed) flags |= FP_FLAG_SPEED;
+        if (fabs(s_dd) > p.max_accel) flags |= FP_FLAG_ACCEL;
+        if (DUMP) {
+            dump[FP_ARR_T * stride_d + i] = t;
+            dump[FP_ARR_S * stride_d + i] = s; dump[FP_ARR_S_D * stride_d + i] = s_d;
+            dump[FP_ARR_S_DD * stride_d + i] = s_dd; dump[FP_ARR_S_DDD * stride_d + i] = s_ddd;
+            dump[FP_ARR_D * stride_d + i] = d; dump[FP_ARR_D_D * stride_d + i] = d_d;
+            dump[FP_ARR_D_DD * stride_d + i] = d_dd; dump[FP_ARR_D_DDD * stride_d + i] = d_ddd;
+        }
+        if (M < 0) {
+            seg = spline_segment(e.sp, s, seg);
+            if (seg < 0) {
+                M = i;  // calc_position -> None: truncate (frenet_optimal_planner.py:112-113)
+            } else {
+                double px, py, tx, ty, x, y;
+                spline_frame(e.sp, seg, s - e.sp.knots[seg], px, py, tx, ty);
+                frenet_to_cartesian(px, py, tx, ty, d, x, y);
+                if (DUMP) { dump[FP_ARR_X * stride_d + i] = x; dump[FP_ARR_Y * stride_d + i] = y; }
+                if (i >= 1) {
+                    const double ddx = x - xp, ddy = y - yp;
+                    step_heading(ddx, ddy, hc, hs);
+                    if (DUMP) {
+                        dump[FP_ARR_YAW * stride_d + i - 1] = atan2(ddy, ddx);
+                        dump[FP_ARR_DS * stride_d + i - 1] = hypot(ddx, ddy);
+                    }
+                    const int k = i - 1;  // pose k now has its heading
+                    if (check && !hit && (k % cstride) == 0 && k < e.horizon_cap) hit = pose_collides(ka, e, k, xp, yp, hc, hs);
+                }
+                xp = x;
+                yp = y;
+            }
+        }
+    }
+    if (M < 0) M = N;
+    if (check && !hit) {
+        const int k = M - 1;  // last pose repeats the previous heading (:129)
+        if (M >= 2) {
+            if ((k % cstride) == 0 && k < e.horizon_cap) hit = pose_collides(ka, e, k, xp, yp, hc, hs);
+        } else if (M == 1 && e.horizon_cap >= 1) {
+            hit = true;  // traj.yaw is empty -> IndexError -> bare except -> collision (:178-182)
+        }
+    }
+    if (hit) flags |= FP_FLAG_COLLISION;
+    if (M < N) flags |= FP_FLAG_TRUNCATED;
+    // cost_function.py:41-50, same grouping
+    const double cost_time = p.cost_horizon - (double)(N - 1) * p.tick_t;
+    const double cost_speed = p.w_speed * sum_v;
+    const double cost_accel = p.w_accel * sum_as + p.w_accel * sum_ad;
+    const double cost_jerk = p.w_jerk * sum_js + p.w_jerk * sum_jd;
+    const double cost_offset = p.w_offset * sum_d;
+    out.cost = (cost_time + 0.0 + cost_speed + cost_accel + cost_jerk + cost_offset) / (double)N;
+    out.flags = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+    if (DUMP && M >= 2) {
+        // yaw[M-1] = yaw[M-2]; c = diff(yaw)/ds; c_d = diff(c)/dt; c_dd = diff(c_d)/dt  (:127-134)
+        double* yaw = dump + FP_ARR_YAW * stride_d;
+        double* ds = dump + FP_ARR_DS * stride_d;
+        double* c = dump + FP_ARR_C * stride_d;
+        double* c_d = dump + FP_ARR_C_D * stride_d;
+        double* c_dd = dump + FP_ARR_C_DD * stride_d;
+        yaw[M - 1] = yaw[M - 2];
+        for (int i = 0; i < M - 1; ++i) c[i] = (yaw[i + 1] - yaw[i]) / ds[i];
+        for (int i = 0; i < M - 2; ++i) c_d[i] = (c[i + 1] - c[i]) / p.tick_t;
+        for (int i = 0; i < M - 3; ++i) c_dd[i] = (c_d[i + 1] - c_d[i]) / p.tick_t;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// dense lattice, one lane per candidate
+// ---------------------------------------------------------------------------
+__global__ void lattice_percand_kernel(KernelArgs ka, int lds_doubles)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ Best wave_best_slot[16];
+    const int b = blockIdx.x;
+    EgoCtx e;
+    stage_ego(ka, b, lds, e, lds_doubles);
+    const fp_params& p = ka.p;
+    const int C = p.nd * p.nv * p.nt;
+    const double* vs = ka.b.v_samples + (size_t)b * p.nv;
+    Best mine{0.0, -1};
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int iv = c % p.nv, it = (c / p.nv) % p.nt, id = c / (p.nv * p.nt);
+        const TrajOut o = traj_eval<false>(ka, e, ka.b.d_samples[id], vs[iv], ka.b.t_samples[it], true, nullptr, 0);
+        if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = o.cost;
+        if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = o.flags;
+        // `min_cost >= cost` is False for NaN: a NaN cost can never win (:266)
+        if (!(o.flags & FP_FLAG_INFEASIBLE) && o.cost == o.cost) mine = best_merge(mine, Best{o.cost, c});
+    }
+    mine = wave_best(mine);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    if (lane == 0) wave_best_slot[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + kWave - 1) / kWave;
+        Best r = wave_best_slot[0];
+        for (int w = 1; w < nw; ++w) r = best_merge(r, wave_best_slot[w]);
+        ka.r.best_idx[b] = r.idx;
+        ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
+        if (ka.r.stats) {  // frenet_optimal_planner.py:254-256
+            int32_t* st = ka.r.stats + (size_t)b * 4;
+            st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// explicit end states, one lane per trajectory
+// ---------------------------------------------------------------------------
+__global__ void eval_trajs_kernel(KernelArgs ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
+                                  int stride, int lds_doubles)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x;
+    EgoCtx e;
+    stage_ego(ka, b, lds, e, lds_doubles);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const double* es = end_states + ((size_t)b * K + k) * 3;
+        TrajOut o;
+        if (traj) {
+            double* dump = traj + ((size_t)b * K + k) * FP_ARR_COUNT * stride;
+            for (int i = 0; i < FP_ARR_COUNT * stride; ++i) dump[i] = __builtin_nan("");
+            o = traj_eval<true>(ka, e, es[0], es[1], es[2], true, dump, stride);
+        } else {
+            o = traj_eval<false>(ka, e, es[0], es[1], es[2], true, nullptr, 0);
+        }
+        if (cost) cost[(size_t)b * K + k] = o.cost;
+        if (flags) flags[(size_t)b * K + k] = o.flags;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static int ego_lds_bytes(const fp_params& p, const fp_batch& b, int max_bytes, int* lds_doubles)
+{
+    int hmax = FP_MAX_POINTS;
+    const int rows = (hmax + p.check_stride - 1) / p.check_stride;
+    const long base = (long)b.NX * 9 + (long)b.n_obs * 4;
+    long full = base + (long)rows * b.n_obs * 4;
+    // never more rows than the table has
+    const long rows_tab = ((long)b.T_obs + p.check_stride - 1) / p.check_stride;
+    if (rows_tab < rows) full = base + rows_tab * b.n_obs * 4;
+    long use = full * 8 <= max_bytes ? full : base;  // obstacle rows stay in HBM/L2 when they do not fit
+    *lds_doubles = (int)use;
+    return (int)(use * 8);
+}
+
+hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream)
+{
+    const int C = ka.p.nd * ka.p.nv * ka.p.nt;
+    int threads = ((C + kWave - 1) / kWave) * kWave;
+    if (threads > 1024) threads = 1024;
+    int lds_doubles = 0;
+    const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
+    hipError_t err = hipFuncSetAttribute((const void*)lattice_percand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(lattice_percand_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, lds_doubles);
+    return hipGetLastError();
+}
+
+hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
+                             int stride, hipStream_t stream)
+{
+    int threads = ((K + kWave - 1) / kWave) * kWave;
+    if (threads > 256) threads = 256;
+    int lds_doubles = 0;
+    const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
+    hipError_t err = hipFuncSetAttribute((const void*)eval_trajs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(eval_trajs_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, K, end_states, cost, flags, traj, stride,
+                       lds_doubles);
+    return hipGetLastError();
+}
+
+}  // namespace fp

@@ -1,0 +1,141 @@
+"""FrenetEngine - thin Python handle on one fp_ctx (one GPU).
+
+Two ways in, matching the two memory spaces of the C ABI:
+
+* numpy (`plan_dense`, `eval_trajs`): host arrays; the library stages them through its own
+  device arena, runs the kernels and copies the results back (FP_MEM_HOST).  This is what
+  the drop-in planner classes use.
+* device pointers (`plan_dense_device`, `eval_trajs_device`): the caller keeps the problem
+  batch resident in HBM (e.g. torch tensors; only `.data_ptr()` crosses the boundary) and the
+  calls just enqueue kernels on the given HIP stream (FP_MEM_DEVICE).  This is what bench.py
+  and the multi-GPU shard runner use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _abi
+from .batch import ProblemBatch
+
+TRAJ_STRIDE = _abi.FP_MAX_POINTS
+
+# CostFunction("WX1") weights, reference common/cost/cost_function.py:6-12 (w_T and w_D are unused there)
+COST_WX1 = dict(cost_horizon=10.0, w_speed=1.0, w_accel=0.1, w_jerk=0.1, w_offset=10.0)
+
+
+def make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
+    p = _abi.FpParams()
+    p.nd, p.nv, p.nt = nd or batch.nd, nv or batch.nv, nt or batch.nt
+    p.check_stride = int(batch.check_stride)
+    p.tick_t = float(batch.tick_t)
+    p.cost_horizon, p.w_speed, p.w_accel, p.w_jerk, p.w_offset = (COST_WX1[k] for k in ("cost_horizon", "w_speed", "w_accel", "w_jerk", "w_offset"))
+    p.veh_l, p.veh_w, p.max_speed, p.max_accel = float(batch.veh_l), float(batch.veh_w), float(batch.max_speed), float(batch.max_accel)
+    return p
+
+
+_BATCH_PTRS = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+               "obs_pose", "obs_dims", "final_time_step")
+
+
+def _host_batch(batch: ProblemBatch) -> _abi.FpBatch:
+    fb = _abi.FpBatch()
+    fb.B, fb.F, fb.NX, fb.S, fb.T_obs, fb.n_obs = batch.B, batch.F, batch.NX, batch.S, batch.T_obs, batch.n_obs
+    for name in _BATCH_PTRS:
+        a = getattr(batch, name)
+        setattr(fb, name, a.ctypes.data if a.size else None)
+    return fb
+
+
+def device_batch(sizes, ptrs: dict) -> _abi.FpBatch:
+    """FpBatch from raw device addresses (ints).  sizes: object with B, F, NX, S, T_obs, n_obs."""
+    fb = _abi.FpBatch()
+    fb.B, fb.F, fb.NX, fb.S, fb.T_obs, fb.n_obs = sizes.B, sizes.F, sizes.NX, sizes.S, sizes.T_obs, sizes.n_obs
+    for name in _BATCH_PTRS:
+        setattr(fb, name, ptrs.get(name) or None)
+    return fb
+
+
+def unpack_flags(flags: np.ndarray):
+    """flag word -> (bits, N, M)."""
+    return flags & 0xFF, (flags >> _abi.FLAG_N_SHIFT) & 0xFFF, (flags >> _abi.FLAG_M_SHIFT) & 0xFFF
+
+
+class FrenetEngine:
+    def __init__(self, device: int = 0):
+        self._lib = _abi.load()
+        self._ctx = C.c_void_p()
+        _abi.check(self._lib.fp_ctx_create(int(device), C.byref(self._ctx)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.fp_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ host arrays
+    def plan_dense(self, batch: ProblemBatch, tables: bool = True):
+        """FrenetOptimalPlanner.plan() for every ego of the batch (reference frenet_optimal_planner.py:247-270).
+
+        Returns best_idx [B] (flat (i_d*nt+i_T)*nv+i_v, -1 = none), best_cost [B], stats [B,4] and, with
+        tables=True, cost [B,C] and flags [B,C].
+        """
+        B, Cn = batch.B, batch.C
+        out = SimpleNamespace(best_idx=np.empty(B, dtype=np.int32), best_cost=np.empty(B), stats=np.empty((B, 4), dtype=np.int32),
+                              cost=np.empty((B, Cn)) if tables else None, flags=np.empty((B, Cn), dtype=np.uint32) if tables else None)
+        res = _abi.FpResult()
+        res.best_idx, res.best_cost, res.stats = out.best_idx.ctypes.data, out.best_cost.ctypes.data, out.stats.ctypes.data
+        res.cost_tbl = out.cost.ctypes.data if tables else None
+        res.flag_tbl = out.flags.ctypes.data if tables else None
+        p = make_params(batch)
+        fb = _host_batch(batch)
+        _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
+        return out
+
+    def eval_trajs(self, batch: ProblemBatch, end_states: np.ndarray, dump: bool = False):
+        """Explicit end states [B,K,3] = (d_end, v_end, T_end) -> cost [B,K], flags [B,K] (+ traj [B,K,16,stride])."""
+        es = np.ascontiguousarray(end_states, dtype=np.float64)
+        B, K = es.shape[0], es.shape[1]
+        assert B == batch.B and es.shape[2] == 3
+        cost = np.empty((B, K)); flags = np.empty((B, K), dtype=np.uint32)
+        traj = np.empty((B, K, 16, TRAJ_STRIDE)) if dump else None
+        p = make_params(batch)
+        fb = _host_batch(batch)
+        _abi.check(self._lib.fp_eval_trajs(self._ctx, C.byref(p), C.byref(fb), K, es.ctypes.data, cost.ctypes.data, flags.ctypes.data,
+                                           traj.ctypes.data if dump else None, TRAJ_STRIDE, _abi.FP_MEM_HOST, None))
+        return SimpleNamespace(cost=cost, flags=flags, traj=traj)
+
+    # ------------------------------------------------------------------ resident device memory
+    def plan_dense_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_cost: int, stats: int = 0,
+                          cost_tbl: int = 0, flag_tbl: int = 0, stream: int = 0):
+        """Enqueue the dense pass on `stream`; every argument is a device address (int)."""
+        res = _abi.FpResult()
+        res.best_idx, res.best_cost = best_idx, best_cost
+        res.stats, res.cost_tbl, res.flag_tbl = stats or None, cost_tbl or None, flag_tbl or None
+        _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(params), C.byref(fb), C.byref(res), _abi.FP_MEM_DEVICE, stream or None))
+
+    def eval_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, K: int, end_states: int, cost: int, flags: int,
+                          traj: int = 0, stream: int = 0):
+        _abi.check(self._lib.fp_eval_trajs(self._ctx, C.byref(params), C.byref(fb), K, end_states, cost or None, flags or None,
+                                           traj or None, TRAJ_STRIDE, _abi.FP_MEM_DEVICE, stream or None))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib = _abi.load()
+    rc = lib.fp_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

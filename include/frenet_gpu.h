@@ -1,0 +1,140 @@
+/*
+ * frenet_gpu.h - C ABI of libfrenetgpu.so, the MI355X (gfx950) Frenet trajectory
+ * sampling-and-scoring engine.
+ *
+ * This is the drop-in boundary for the candidate-generation hot path of
+ * SS47816/fiss_plus_planner.  The reference is pure Python and has no FFI of its
+ * own; each entry point below names the reference code it replaces (paths relative
+ * to the reference checkout).  Bindings: ctypes (fiss_plus_planner_amd/_abi.py);
+ * the stub a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FP_E* code on failure;
+ *     fp_last_error() returns a thread-local description.  Nothing throws.
+ *   - all arrays are contiguous, little-endian, float64 / int32 / uint32.
+ *   - `mem` says where EVERY pointer of the call lives: FP_MEM_HOST (the library
+ *     stages through device buffers it owns inside the ctx, runs, copies back and
+ *     synchronises before returning) or FP_MEM_DEVICE (pointers are device
+ *     addresses on the ctx's GPU; the call only enqueues work on `stream` and
+ *     returns; no synchronisation, no allocation).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - a ctx is bound to one device; calls on one ctx must not overlap in time.
+ */
+#ifndef FRENET_GPU_H
+#define FRENET_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP_ABI_VERSION 1
+
+/* error codes */
+#define FP_OK 0
+#define FP_EINVAL (-1)  /* bad argument */
+#define FP_EHIP (-2)    /* HIP runtime error (see fp_last_error) */
+#define FP_ENOMEM (-3)
+#define FP_ELIMIT (-4)  /* problem exceeds a compiled-in limit (FP_MAX_*) */
+#define FP_ENODEV (-5)  /* no usable gfx950 device */
+
+/* memory space of the pointers of a call */
+#define FP_MEM_HOST 0
+#define FP_MEM_DEVICE 1
+
+/* compiled-in limits */
+#define FP_MAX_POINTS 128   /* N = ceil(T / tick_t) per trajectory */
+#define FP_MAX_KNOTS 512    /* reference-line knots per frame */
+#define FP_MAX_CAND 4096    /* nd*nv*nt */
+
+/* candidate flag word: low bits = why a candidate is infeasible, then N and M */
+#define FP_FLAG_SPEED 1u      /* any(s_d > max_speed)       frenet_optimal_planner.py:152 */
+#define FP_FLAG_ACCEL 2u      /* any(|s_dd| > max_accel)    frenet_optimal_planner.py:155 */
+#define FP_FLAG_COLLISION 4u  /* has_collision()            frenet_optimal_planner.py:168-195 */
+#define FP_FLAG_TRUNCATED 8u  /* M < N: left the spline     frenet_optimal_planner.py:112-113 */
+#define FP_FLAG_INFEASIBLE 7u
+#define FP_FLAG_N_SHIFT 8     /* bits 8..19  N = len(t) */
+#define FP_FLAG_M_SHIFT 20    /* bits 20..31 M = len(x) */
+
+/* rows of a [16][stride] trajectory dump = FrenetTrajectory series, frenet.py:129-146 */
+enum {
+    FP_ARR_T = 0, FP_ARR_S, FP_ARR_S_D, FP_ARR_S_DD, FP_ARR_S_DDD, FP_ARR_D, FP_ARR_D_D, FP_ARR_D_DD, FP_ARR_D_DDD,
+    FP_ARR_X, FP_ARR_Y, FP_ARR_YAW, FP_ARR_DS, FP_ARR_C, FP_ARR_C_D, FP_ARR_C_DD, FP_ARR_COUNT
+};
+
+typedef struct fp_ctx fp_ctx;
+
+/* Settings + vehicle + cost weights.
+ * Replaces: FrenetOptimalPlannerSettings (frenet_optimal_planner.py:38-56), Vehicle
+ * (common/vehicle/vehicle.py:15-46), CostFunction("WX1") weights (common/cost/cost_function.py:6-12). */
+typedef struct {
+    int32_t nd, nv, nt;     /* num_width, num_speed, num_t */
+    int32_t check_stride;   /* check_res of has_collision (2)              :202 */
+    double tick_t;          /* 0.1 */
+    double cost_horizon;    /* the 10.0 of `cost_time = 10.0 - t[-1]`      cost_function.py:42 */
+    double w_speed, w_accel, w_jerk, w_offset; /* w_V=1, w_A=0.1, w_J=0.1, w_LC=10 */
+    double veh_l, veh_w;    /* ego footprint */
+    double max_speed, max_accel;
+} fp_params;
+
+/* A batch of B independent ego planning problems (layout: DESIGN.md "problem batch"). */
+typedef struct {
+    int32_t B, F, NX, S, T_obs, n_obs;
+    const double* d_samples;     /* [nd]        np.linspace(-sw/2, sw/2, nd)      :75 */
+    const double* t_samples;     /* [nt]        np.linspace(min_t, max_t, nt)     :78 */
+    const double* v_samples;     /* [B][nv]     np.linspace(lowest, highest, nv)  :89 */
+    const double* target_speed;  /* [B]         settings.highest_speed            :250 */
+    const double* ego;           /* [B][6]      s, s_d, s_dd, d, d_d, d_dd        frenet.py:15-27 */
+    const int32_t* frame_of;     /* [B]         index into the frame table */
+    const int32_t* scene_of;     /* [B]         index into the scene table, -1 = no obstacles */
+    const int32_t* t_now;        /* [B]         time_step_now */
+    const int32_t* nx;           /* [F]         knots per frame */
+    const double* knots;         /* [F][NX]     cumulative chord length, +inf padded   cubic_spline.py:162-168 */
+    const double* coef;          /* [F][8][NX]  ax bx cx dx ay by cy dy                cubic_spline.py:30-43 */
+    const double* obs_pose;      /* [S][T_obs][n_obs][4]  x, y, yaw, valid(0/1) */
+    const double* obs_dims;      /* [S][n_obs][2]         length, width */
+    const int32_t* final_time_step; /* [S]      obstacles[0].prediction.final_time_step :173 */
+} fp_batch;
+
+/* Outputs of the dense lattice pass; any pointer except best_idx/best_cost may be NULL. */
+typedef struct {
+    int32_t* best_idx;   /* [B]     flat FOP index (i_d*nt+i_T)*nv+i_v of the argmin, -1 = no survivor  :263-268 */
+    double* best_cost;   /* [B]     its cost_final (NaN when -1) */
+    double* cost_tbl;    /* [B][C]  cost_final of every candidate                                       :99 */
+    uint32_t* flag_tbl;  /* [B][C]  FP_FLAG_* | N << 8 | M << 20 */
+    int32_t* stats;      /* [B][4]  num_iter, generated, validated, collision_checks                    :254-256 */
+} fp_result;
+
+int fp_abi_version(void);
+const char* fp_last_error(void);
+
+/* Number of visible HIP devices / name+arch of one (buf may be NULL). */
+int fp_device_count(int* count);
+int fp_device_info(int device, char* buf, int buflen, int* compute_units, int64_t* hbm_bytes);
+
+int fp_ctx_create(int device, fp_ctx** out);
+int fp_ctx_destroy(fp_ctx* ctx);
+
+/* Dense lattice pass = FrenetOptimalPlanner.plan() for B egos at once:
+ *   calc_frenet_paths (:69-104) + CostFunction.cost_total (cost_function.py:41-50)
+ *   + calc_global_paths (:106-138) + check_constraints (:140-160)
+ *   + check_collisions/has_collision (:168-208) + argmin with the `>=` tie rule (:263-268).
+ * The tables also feed the FOP+/FISS/FISS+ drop-ins (cost-ordered validation and
+ * the index walks read them instead of generating candidates one by one). */
+int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem,
+                  void* stream);
+
+/* Explicit end states: K trajectories per ego with end state (d_end, v_end, T_end)
+ *   = generate_trajectory_by_end_state (fiss_plus_planner.py:172-205) / generate_trajectory
+ *   (fiss_planner.py:101-138) + calc_global_paths + check_constraints + has_collision.
+ * end_states [B][K][3]; cost [B][K]; flags [B][K]; traj NULL or [B][K][16][stride] (NaN padded),
+ * the full FrenetTrajectory series of every requested trajectory (winner epilogue,
+ * FISS+ refinement, all_trajs visualisation payload). */
+int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states,
+                  double* cost, uint32_t* flags, double* traj, int32_t stride, int mem, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRENET_GPU_H */

@@ -1,0 +1,509 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Build-container only (needs /root/reference; see refshim.py).  Usage:
+
+    python tests/golden/gen_golden.py [g1 g2 g3 g4 g5 g6 g7 g8 ...]   (default: all)
+
+Every fixture is self-contained data: the inputs (problem-batch arrays, so the
+GPU box can rebuild the identical problem without the reference) and the
+reference's outputs.  Collision outcomes come from the reference's own
+has_collision() running on refshim's convex-polygon stand-in for shapely, i.e.
+they are pinned to OUR separating-axis test, not to GEOS ("collision parity
+unpinned").
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+import xml.etree.ElementTree as ET
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import refshim  # noqa: E402
+
+R = refshim.load_reference()
+
+from fiss_plus_planner_amd import synth  # noqa: E402
+from fiss_plus_planner_amd.batch import ProblemBatch  # noqa: E402
+
+ARRAYS = ["t", "s", "s_d", "s_dd", "s_ddd", "d", "d_d", "d_dd", "d_ddd", "x", "y", "yaw", "ds", "c", "c_d", "c_dd"]
+BATCH_FIELDS = ["d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots",
+                "coef", "obs_pose", "obs_dims", "final_time_step", "samp_min", "samp_max", "samp_res"]
+BATCH_SCALARS = ["veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride"]
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def batch_to_dict(b: ProblemBatch, prefix="in_"):
+    out = {prefix + k: getattr(b, k) for k in BATCH_FIELDS if getattr(b, k) is not None}
+    out[prefix + "scalars"] = np.array([getattr(b, k) for k in BATCH_SCALARS], dtype=np.float64)
+    return out
+
+
+def vehicle_for(b: ProblemBatch):
+    p = refshim.vw_vanagon_params()
+    p.l, p.w = b.veh_l, b.veh_w
+    p.longitudinal.v_max, p.longitudinal.a_max = b.max_speed, b.max_accel
+    return R.Vehicle(p)
+
+
+def make_planner(kind: str, b: ProblemBatch, e: int, refine_iters=3):
+    veh = vehicle_for(b)
+    if kind == "FOP":
+        pl = R.FrenetOptimalPlanner(R.FrenetOptimalPlannerSettings(b.nd, b.nv, b.nt), veh, None)
+    elif kind == "FOP+":
+        pl = R.FopPlusPlanner(R.FrenetOptimalPlannerSettings(b.nd, b.nv, b.nt), veh, None)
+    elif kind == "FISS":
+        pl = R.FissPlanner(R.FissPlannerSettings(b.nd, b.nv, b.nt), veh, None)
+    elif kind == "FISS+":
+        st = R.FissPlusPlannerSettings(b.nd, b.nv, b.nt, refine_iters)
+        st.time_limit = 1e9  # the limit is enforced even with has_time_limit=False (fiss_plus_planner.py:296-298)
+        pl = R.FissPlusPlanner(st, veh, None)
+    else:
+        raise ValueError(kind)
+    f = int(b.frame_of[e])
+    nx = int(b.nx[f])
+    pts = np.column_stack([b.coef[f, 0, :nx], b.coef[f, 4, :nx]])
+    pl.generate_frenet_frame(pts)
+    return pl
+
+
+def ego_state(b: ProblemBatch, e: int):
+    s, s_d, s_dd, d, d_d, d_dd = b.ego[e]
+    return R.FrenetState(t=0.0, s=s, s_d=s_d, s_dd=s_dd, d=d, d_d=d_d, d_dd=d_dd)
+
+
+def obstacles_for(b: ProblemBatch, e: int):
+    sc = int(b.scene_of[e])
+    if sc < 0 or b.n_obs == 0:
+        return []
+    return refshim.obstacles_from_table(b.obs_pose[sc], b.obs_dims[sc], int(b.final_time_step[sc]))
+
+
+def dump_traj(fp, stride=128):
+    out = np.full((16, stride), np.nan)
+    for k, name in enumerate(ARRAYS):
+        a = np.asarray(getattr(fp, name), dtype=np.float64)
+        out[k, : len(a)] = a
+    return out
+
+
+# ---------------------------------------------------------------------------
+# special inputs
+# ---------------------------------------------------------------------------
+def with_overrides(b: ProblemBatch, **kw) -> ProblemBatch:
+    d = {k: getattr(b, k) for k in BATCH_FIELDS + BATCH_SCALARS}
+    d.update(kw)
+    return ProblemBatch(**d, meta=dict(b.meta))
+
+
+def short_frame_batch(b: ProblemBatch, n_keep=25) -> ProblemBatch:
+    """Cut every centerline to its first n_keep knots (120 m) so trajectories run off the end."""
+    from fiss_plus_planner_amd.spline import build_frames
+
+    pts = np.stack([b.coef[:, 0, :], b.coef[:, 4, :]], axis=-1)
+    n = np.full(b.F, n_keep)
+    knots, coef = build_frames(pts, n)
+    return with_overrides(b, knots=knots, coef=coef, nx=n)
+
+
+def fop_cases():
+    """(name, batch) list used by g3/g4."""
+    cases = []
+    c2 = synth.make_batch(4, 5, 5, 5, 10, 100, False, 9102)
+    cases.append(("c2_static10", c2))
+    c3 = synth.make_batch(3, 9, 9, 7, 50, 50, True, 9103)
+    cases.append(("c3_moving50", c3))
+    c0 = synth.make_batch(3, 5, 5, 5, 0, 0, False, 9100)
+    cases.append(("c0_noobs", c0))
+    # truncation: short centerline; ego 2 starts beyond the end (M = 0)
+    ct = short_frame_batch(synth.make_batch(4, 5, 5, 5, 10, 100, False, 9104), 25)
+    ego = ct.ego.copy()
+    ego[2, 0] = 130.0
+    ego[3, 0] = 119.5  # M = 1 for slow candidates
+    ego[3, 1] = 0.5
+    cases.append(("trunc", with_overrides(ct, ego=ego)))
+    # constraint violations: tight vehicle limits
+    cv = synth.make_batch(3, 5, 5, 5, 10, 100, False, 9105)
+    cases.append(("limits", with_overrides(cv, max_speed=11.0, max_accel=1.2)))
+    # exact mirror ties (d = d_d = d_dd = 0) - FOP "last minimum wins"
+    cm = synth.make_batch(2, 5, 5, 5, 0, 0, False, 9106)
+    ego = cm.ego.copy()
+    ego[:, 3:] = 0.0
+    cases.append(("mirror", with_overrides(cm, ego=ego)))
+    # later planning cycle: t_now > 0 shortens the collision horizon
+    cn = synth.make_batch(2, 5, 5, 5, 10, 60, True, 9107)
+    cases.append(("tnow", with_overrides(cn, t_now=np.array([7, 40]))))
+    return cases
+
+
+# ---------------------------------------------------------------------------
+def g1():
+    rng = np.random.default_rng(11)
+    K = 64
+    q5 = np.column_stack([rng.uniform(-2, 2, K), rng.uniform(-1, 1, K), rng.uniform(-1, 1, K), rng.uniform(-1, 1, K),
+                          np.zeros(K), np.zeros(K), rng.uniform(2, 12, K)])
+    q5[K // 2:, 4:6] = rng.uniform(-0.5, 0.5, (K - K // 2, 2))
+    q4 = np.column_stack([rng.uniform(0, 80, K), rng.uniform(0, 15, K), rng.uniform(-2, 2, K), rng.uniform(0, 14, K),
+                          np.zeros(K), rng.uniform(2, 12, K)])
+    c5 = np.empty((K, 6)); c4 = np.empty((K, 5))
+    ts = rng.uniform(0, 10, (K, 4))
+    e5 = np.empty((K, 4, 4)); e4 = np.empty((K, 4, 4))
+    for k in range(K):
+        p = R.QuinticPolynomial(*q5[k])
+        c5[k] = [p.a0, p.a1, p.a2, p.a3, p.a4, p.a5]
+        q = R.QuarticPolynomial(*q4[k])
+        c4[k] = [q.a0, q.a1, q.a2, q.a3, q.a4]
+        for m, t in enumerate(ts[k]):
+            t = np.float64(t)
+            e5[k, m] = [p.calc_point(t), p.calc_first_derivative(t), p.calc_second_derivative(t), p.calc_third_derivative(t)]
+            e4[k, m] = [q.calc_point(t), q.calc_first_derivative(t), q.calc_second_derivative(t), q.calc_third_derivative(t)]
+    save("g1_poly.npz", quintic_in=q5, quintic_coef=c5, quartic_in=q4, quartic_coef=c4, eval_t=ts, quintic_eval=e5, quartic_eval=e4)
+
+
+def flensburg():
+    """Centerline [203,1397,785] + obstacle table parsed from the reference's data file."""
+    root = ET.parse(os.path.join(refshim.REFERENCE_ROOT, "data/demo/DEU_Flensburg-1_1_T-1.xml")).getroot()
+
+    def bound(ll, tag):
+        return np.array([[float(p.find("x").text), float(p.find("y").text)] for p in ll.find(tag).findall("point")])
+
+    lanelets = {int(ll.get("id")): ll for ll in root.findall("lanelet")}
+    route = [203, 1397, 785]
+    succ = [int(s.get("ref")) for s in lanelets[route[-1]].findall("successor")]
+    if succ:  # global_planner.py:68-75 appends successor[0] of the last lanelet
+        route = route + [succ[0]]
+    centers = [(bound(lanelets[i], "leftBound") + bound(lanelets[i], "rightBound")) / 2 for i in route]
+    cc = np.concatenate(centers)
+    _, uniq = np.unique(cc, return_index=True, axis=0)
+    cc = cc[np.sort(uniq)]  # global_planner.py:79-82
+    goal_c = centers[2] if len(route) >= 3 else centers[-1]
+    goal_center = ((bound(lanelets[785], "leftBound") + bound(lanelets[785], "rightBound")) / 2)
+    goal_center = goal_center[int((goal_center.shape[0] - 1) / 2)]  # planning.py:57-58
+    obs = []
+    T = 0
+    for ob in root.findall("dynamicObstacle"):
+        rect = ob.find("shape/rectangle")
+        l, w = float(rect.find("length").text), float(rect.find("width").text)
+        states = {}
+
+        def rd(st):
+            t = int(st.find("time/exact").text)
+            states[t] = (float(st.find("position/point/x").text), float(st.find("position/point/y").text),
+                         float(st.find("orientation/exact").text))
+
+        rd(ob.find("initialState"))
+        for st in ob.find("trajectory").findall("state"):
+            rd(st)
+        obs.append((l, w, states))
+        T = max(T, max(states) + 1)
+    pose = np.zeros((T, len(obs), 4))
+    dims = np.zeros((len(obs), 2))
+    for j, (l, w, states) in enumerate(obs):
+        dims[j] = [l, w]
+        for t, (x, y, yaw) in states.items():
+            pose[t, j] = [x, y, yaw, 1.0]
+    fts0 = max(obs[0][2])  # obstacles[0].prediction.final_time_step
+    init = root.find("planningProblem/initialState")
+    init_state = np.array([float(init.find("position/point/x").text), float(init.find("position/point/y").text),
+                           float(init.find("orientation/exact").text), float(init.find("velocity/exact").text)])
+    return SimpleNamespace(route=np.array(route), centerline=cc, pose=pose, dims=dims, final_time_step=fts0,
+                           init_state=init_state, goal_center=goal_center)
+
+
+def g2():
+    fl = flensburg()
+    x = np.linspace(0, 400, 81)
+    sets = {"flens": fl.centerline, "sinus": np.column_stack([x, 5.5 * np.sin(x / 47.0)])}
+    out = {}
+    rng = np.random.default_rng(22)
+    for name, pts in sets.items():
+        sp = R.CubicSpline2D(pts[:, 0], pts[:, 1])
+        n = len(pts)
+        knots = np.array(sp.s, dtype=np.float64)
+        coef = np.zeros((8, n))
+        for r, one in ((0, sp.sx), (4, sp.sy)):
+            coef[r] = one.a; coef[r + 1, : n - 1] = one.b; coef[r + 2] = one.c; coef[r + 3, : n - 1] = one.d
+        s_eval = np.concatenate([rng.uniform(-5, knots[-1] + 5, 180), knots[:10], knots[1:11] - 1e-9, [knots[-1] - 1e-12, -1e-9]])
+        ev = np.full((len(s_eval), 4), np.nan)
+        for k, s in enumerate(s_eval):
+            s = np.float64(s)
+            if s == knots[-1]:
+                continue
+            px, py = sp.calc_position(s)
+            if px is None:
+                continue
+            ev[k] = [px, py, sp.calc_yaw(s), sp.calc_curvature(s)]
+        veh = R.Vehicle(refshim.vw_vanagon_params())
+        pl = R.FrenetOptimalPlanner(R.FrenetOptimalPlannerSettings(), veh, None)
+        _, ref = pl.generate_frenet_frame(pts)
+        out.update({f"{name}_pts": pts, f"{name}_knots": knots, f"{name}_coef": coef, f"{name}_s_eval": s_eval,
+                    f"{name}_eval": ev, f"{name}_refline": ref})
+    save("g2_spline.npz", **out)
+
+
+def g3():
+    out = {}
+    names = []
+    for name, b in fop_cases():
+        t0 = time.time()
+        names.append(name)
+        C = b.C
+        cost = np.empty((b.B, C)); N = np.empty((b.B, C), dtype=np.int32); M = np.empty((b.B, C), dtype=np.int32)
+        speed = np.zeros((b.B, C), dtype=bool); accel = np.zeros((b.B, C), dtype=bool); coll = np.zeros((b.B, C), dtype=bool)
+        dumps = np.full((b.B, 3, 16, 128), np.nan)
+        dump_idx = np.zeros((b.B, 3), dtype=np.int32)
+        for e in range(b.B):
+            pl = make_planner("FOP", b, e)
+            pl.settings.highest_speed = float(b.target_speed[e])
+            obstacles = obstacles_for(b, e)
+            fpl = pl.calc_global_paths(pl.calc_frenet_paths(ego_state(b, e)))
+            for i, fp in enumerate(fpl):
+                cost[e, i] = fp.cost_final; N[e, i] = len(fp.t); M[e, i] = len(fp.x)
+                speed[e, i] = any(v > pl.vehicle.max_speed for v in fp.s_d)
+                accel[e, i] = any(abs(a) > pl.vehicle.max_accel for a in fp.s_dd)
+                coll[e, i] = pl.has_collision(fp, obstacles, int(b.t_now[e]), 2)[0]
+            trunc = [i for i in range(C) if M[e, i] < N[e, i]]
+            pick = [0, C // 2 + 1, trunc[len(trunc) // 2] if trunc else C - 1]
+            for k, i in enumerate(pick):
+                dump_idx[e, k] = i
+                dumps[e, k] = dump_traj(fpl[i])
+        out.update(batch_to_dict(b, f"{name}_in_"))
+        out.update({f"{name}_cost": cost, f"{name}_N": N, f"{name}_M": M, f"{name}_speed": speed, f"{name}_accel": accel,
+                    f"{name}_coll": coll, f"{name}_dumps": dumps, f"{name}_dump_idx": dump_idx})
+        print(f"  g3 {name}: {time.time() - t0:.1f}s  coll={coll.mean():.2f} trunc={(M < N).mean():.2f} "
+              f"speed={speed.mean():.2f} accel={accel.mean():.2f}")
+    out["names"] = np.array(names)
+    save("g3_fop_tables.npz", **out)
+
+
+def run_plan(kind, b, e, prev_best_idx=None, trace=None):
+    pl = make_planner(kind, b, e)
+    if prev_best_idx is not None:
+        pl.prev_best_idx = np.array(prev_best_idx)
+    if trace is not None and kind == "FISS+":
+        orig = pl.generate_trajectory_by_end_state
+
+        def hooked(end_state):
+            J = orig(end_state)
+            trace.append([end_state.d, end_state.s_d, end_state.t, J])
+            return J
+
+        pl.generate_trajectory_by_end_state = hooked
+    try:
+        best = pl.plan(ego_state(b, e), float(b.target_speed[e]), obstacles_for(b, e), int(b.t_now[e]))
+        err = ""
+    except ValueError as ex:  # FISS/FISS+ exact-tie crash ("truth value of an array ...")
+        best, err = None, str(ex)[:60]
+    return pl, best, err
+
+
+def g4():
+    out = {}
+    names = []
+    for name, b in fop_cases():
+        for kind in ("FOP", "FOP+", "FISS", "FISS+"):
+            bb = b
+            if kind in ("FISS", "FISS+"):
+                if name == "mirror":
+                    continue  # the reference raises ValueError on exact ties
+                # FISS samples d over max_road_width - w + 0.3 (fiss_planner.py:40)
+                sw = 3.5 - b.veh_w + 0.3
+                d, rd = np.linspace(-sw / 2, sw / 2, b.nd, retstep=True)
+                smin = b.samp_min.copy(); smax = b.samp_max.copy(); sres = b.samp_res.copy()
+                smin[:, 0] = -sw / 2; smax[:, 0] = sw / 2; sres[:, 0] = rd
+                bb = with_overrides(b, d_samples=d, samp_min=smin, samp_max=smax, samp_res=sres)
+            t0 = time.time()
+            key = f"{name}_{kind}"
+            names.append(key)
+            B = bb.B
+            idx = np.full((B, 3), -1, dtype=np.int32); flat = np.full(B, -1, dtype=np.int32)
+            cost = np.full(B, np.nan); stats = np.zeros((B, 4), dtype=np.int32); end = np.full((B, 3), np.nan)
+            found = np.zeros(B, dtype=bool); win = np.full((B, 16, 128), np.nan); NM = np.zeros((B, 2), dtype=np.int32)
+            traces = np.full((B, 21, 4), np.nan); prev_out = np.full((B, 3), -1, dtype=np.int32)
+            for e in range(B):
+                tr = []
+                pl, best, err = run_plan(kind, bb, e, trace=tr)
+                assert not err, (key, e, err)
+                stats[e] = [pl.stats.num_iter, pl.stats.num_trajs_generated, pl.stats.num_trajs_validated, pl.stats.num_collison_checks]
+                if tr:
+                    traces[e, : len(tr)] = np.array(tr)
+                if getattr(pl, "prev_best_idx", None) is not None:
+                    prev_out[e] = pl.prev_best_idx
+                if best is None:
+                    continue
+                found[e] = True
+                cost[e] = best.cost_final
+                NM[e] = [len(best.t), len(best.x)]
+                win[e] = dump_traj(best)
+                if kind in ("FOP", "FOP+"):
+                    pl2 = make_planner("FOP", bb, e)
+                    pl2.settings.highest_speed = float(bb.target_speed[e])
+                    fpl = pl2.calc_frenet_paths(ego_state(bb, e))
+                    hits = [i for i, fp in enumerate(fpl) if np.array_equal(fp.d, best.d) and np.array_equal(fp.s, best.s)]
+                    if len(hits) == 1:
+                        flat[e] = hits[0]
+                    else:  # mirror ties have distinct d arrays, so this cannot happen
+                        raise AssertionError((key, e, hits))
+                else:
+                    idx[e] = best.idx
+                    es = best.end_state
+                    end[e] = [es.d, es.s_d, es.t]
+            out.update(batch_to_dict(bb, f"{key}_in_"))
+            out.update({f"{key}_flat": flat, f"{key}_idx": idx, f"{key}_cost": cost, f"{key}_stats": stats, f"{key}_end": end,
+                        f"{key}_found": found, f"{key}_win": win, f"{key}_NM": NM, f"{key}_trace": traces,
+                        f"{key}_prev_out": prev_out})
+            print(f"  g4 {key}: {time.time() - t0:.1f}s found={found.tolist()} stats={stats.tolist()}")
+    out["names"] = np.array(names)
+    save("g4_plan.npz", **out)
+
+
+def closed_loop(kind, fl, nd=5, nv=5, nt=5, max_cycles=100):
+    """planners/benchmark/planning.py:101-162 with duck-typed obstacles."""
+    veh = R.Vehicle(refshim.vw_vanagon_params())
+    if kind == "FOP":
+        pl = R.FrenetOptimalPlanner(R.FrenetOptimalPlannerSettings(nd, nv, nt), veh, None)
+    elif kind == "FOP+":
+        pl = R.FopPlusPlanner(R.FrenetOptimalPlannerSettings(nd, nv, nt), veh, None)
+    elif kind == "FISS":
+        pl = R.FissPlanner(R.FissPlannerSettings(nd, nv, nt), veh, None)
+    else:
+        st = R.FissPlusPlannerSettings(nd, nv, nt)
+        st.time_limit = 1e9
+        pl = R.FissPlusPlanner(st, veh, None)
+    _, ref = pl.generate_frenet_frame(fl.centerline)
+    start = R.State(t=0.0, x=fl.init_state[0], y=fl.init_state[1], yaw=fl.init_state[2], v=fl.init_state[3], a=0.0)
+    cur = R.FrenetState()
+    cur.from_state(start, ref)
+    obstacles = refshim.obstacles_from_table(fl.pose, fl.dims, fl.final_time_step)
+    rows = []
+    states = []
+    for i in range(min(fl.final_time_step, max_cycles)):
+        start_vec = [cur.s, cur.s_d, cur.s_dd, cur.d, cur.d_d, cur.d_dd]
+        best = pl.plan(cur, 13.5, obstacles, i)
+        st = pl.stats
+        if best is None:
+            rows.append(start_vec + [np.nan, 0, 0, -1, -1, -1, st.num_iter, st.num_trajs_generated, st.num_trajs_validated,
+                                     st.num_collison_checks, np.nan, np.nan, np.nan])
+            break
+        cs = best.state_at_time_step(1)
+        cur = best.frenet_state_at_time_step(1)
+        es = best.end_state
+        rows.append(start_vec + [best.cost_final, len(best.t), len(best.x), *[int(v) for v in best.idx], st.num_iter,
+                                 st.num_trajs_generated, st.num_trajs_validated, st.num_collison_checks,
+                                 *( [es.d, es.s_d, es.t] if es is not None else [np.nan] * 3)])
+        states.append([cs.x, cs.y, cs.yaw])
+        if np.hypot(cs.x - fl.goal_center[0], cs.y - fl.goal_center[1]) <= veh.l / 2:
+            break
+        if np.hypot(cs.x - ref[-1, 0], cs.y - ref[-1, 1]) <= 3.0:
+            break
+    return np.array(rows, dtype=np.float64), np.array(states), ref
+
+
+def g5(kinds=("FOP+", "FISS", "FISS+", "FOP")):
+    fl = flensburg()
+    path = os.path.join(HERE, "g5_closed_loop.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    out.update(centerline=fl.centerline, obs_pose=fl.pose, obs_dims=fl.dims, final_time_step=np.array(fl.final_time_step),
+               init_state=fl.init_state, goal_center=fl.goal_center, route=fl.route,
+               columns=np.array(["s", "s_d", "s_dd", "d", "d_d", "d_dd", "cost", "N", "M", "i_d", "i_v", "i_t", "num_iter",
+                                 "generated", "validated", "collision_checks", "end_d", "end_v", "end_T"]))
+    for kind in kinds:
+        t0 = time.time()
+        rows, states, ref = closed_loop(kind, fl)
+        out[f"{kind}_rows"] = rows
+        out[f"{kind}_states"] = states
+        out["refline"] = ref
+        print(f"  g5 {kind}: {len(rows)} cycles in {time.time() - t0:.1f}s  cost0={rows[0, 6]:.6f}")
+        save("g5_closed_loop.npz", **out)
+
+
+def g7():
+    fl = flensburg()
+    veh = R.Vehicle(refshim.vw_vanagon_params())
+    pl = R.FrenetOptimalPlanner(R.FrenetOptimalPlannerSettings(), veh, None)
+    sp, ref = pl.generate_frenet_frame(fl.centerline)
+    rng = np.random.default_rng(77)
+    K = 24
+    s = rng.uniform(1, sp.s[-1] - 1, K)
+    poses = np.empty((K, 4)); outv = np.empty((K, 6))
+    for k in range(K):
+        px, py = sp.calc_position(s[k]); yaw = sp.calc_yaw(s[k])
+        off = rng.uniform(-3, 3)
+        poses[k] = [px - off * np.sin(yaw), py + off * np.cos(yaw), yaw + rng.uniform(-0.6, 0.6), rng.uniform(0, 15)]
+    poses[0] = fl.init_state
+    poses[1, :2] = ref[0, :2] + [-2.0, 0.3]      # behind the first waypoint
+    poses[2, :2] = ref[-1, :2] + [1.0, -0.5]     # past the last waypoint
+    for k in range(K):
+        fs = R.FrenetState()
+        fs.from_state(R.State(t=0.0, x=poses[k, 0], y=poses[k, 1], yaw=poses[k, 2], v=poses[k, 3]), ref)
+        outv[k] = [fs.s, fs.s_d, fs.s_dd, fs.d, fs.d_d, fs.d_dd]
+    save("g7_from_state.npz", refline=ref, poses=poses, frenet=outv)
+
+
+def g8():
+    b = synth.make_batch(2, 5, 6, 4, 0, 0, False, 9108, kind="FISS")
+    ests = []
+    prevs = [None, (0, 0, 0), (4, 5, 3), (2, 1, 3)]
+    for e in range(b.B):
+        for prev in prevs:
+            pl = make_planner("FISS", b, e)
+            pl.settings.highest_speed = float(b.target_speed[e])
+            pl.prev_best_idx = None if prev is None else np.array(prev)
+            t3 = pl.sample_end_frenet_states()
+            ests.append([[[tr.cost_est for tr in row] for row in plane] for plane in t3])
+    out = batch_to_dict(b)
+    save("g8_cost_est.npz", est=np.array(ests).reshape(b.B, len(prevs), b.nd, b.nv, b.nt),
+         prev=np.array([(-1, -1, -1) if p is None else p for p in prevs], dtype=np.int32), **out)
+
+
+def g6():
+    """FISS/FISS+ with history heuristic (prev_best_idx) and refinement traces on dynamic scenes."""
+    b0 = synth.make_batch(6, 9, 9, 7, 50, 50, True, 9109, kind="FISS+")
+    prevs = [None, (4, 8, 6), (0, 0, 0), (8, 4, 3), None, (2, 7, 5)]
+    out = batch_to_dict(b0)
+    for kind in ("FISS", "FISS+"):
+        B = b0.B
+        idx = np.full((B, 3), -1, dtype=np.int32); cost = np.full(B, np.nan); stats = np.zeros((B, 4), dtype=np.int32)
+        end = np.full((B, 3), np.nan); traces = np.full((B, 21, 4), np.nan); found = np.zeros(B, dtype=bool)
+        prev_out = np.full((B, 3), -1, dtype=np.int32)
+        for e in range(B):
+            tr = []
+            pl, best, err = run_plan(kind, b0, e, prev_best_idx=prevs[e], trace=tr)
+            assert not err, err
+            stats[e] = [pl.stats.num_iter, pl.stats.num_trajs_generated, pl.stats.num_trajs_validated, pl.stats.num_collison_checks]
+            if tr:
+                traces[e, : len(tr)] = np.array(tr)
+            if pl.prev_best_idx is not None:
+                prev_out[e] = pl.prev_best_idx
+            if best is not None:
+                found[e] = True; idx[e] = best.idx; cost[e] = best.cost_final
+                end[e] = [best.end_state.d, best.end_state.s_d, best.end_state.t]
+        out.update({f"{kind}_idx": idx, f"{kind}_cost": cost, f"{kind}_stats": stats, f"{kind}_end": end, f"{kind}_trace": traces,
+                    f"{kind}_found": found, f"{kind}_prev_out": prev_out})
+        print(f"  g6 {kind}: stats={stats.tolist()} idx={idx.tolist()}")
+    out["prev_in"] = np.array([(-1, -1, -1) if p is None else p for p in prevs], dtype=np.int32)
+    save("g6_fiss_search.npz", **out)
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5"]
+    for g in todo:
+        t0 = time.time()
+        print(f"== {g}")
+        if g.startswith("g5:"):
+            g5(tuple(g[3:].split(",")))
+        else:
+            globals()[g]()
+        print(f"== {g} done in {time.time() - t0:.1f}s")

@@ -1,0 +1,223 @@
+"""Import shim for generating golden vectors from the Python reference.
+
+RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).  It is never imported
+by the product, by `-m gpu` tests, by smoke() or by bench.py: the GPU box has no
+/root/reference.  The vectors it helps to produce are committed as .npz files
+next to this script.
+
+What it does
+------------
+The reference planners (planners/*.py) import two third-party packages that are
+not installed here and cannot be installed (no network):
+
+* ``commonroad`` - only for type hints (``Scenario``, ``Obstacle``), see
+  planners/frenet_optimal_planner.py:5, planners/fop_plus_planner.py:3-4.
+  -> empty stub classes.
+* ``shapely`` (pinned 2.0.0 in environment.yml:184) - ``Polygon``,
+  ``affinity.translate``, ``affinity.rotate`` and ``Polygon.intersects`` at
+  planners/frenet_optimal_planner.py:162-195 and planners/common/vehicle/vehicle.py:31.
+  -> a small stand-in for exactly those four calls on convex polygons
+  (closed-set separating-axis test).  This is OUR code, not shapely's: collision
+  parity against real GEOS is therefore UNPINNED (stated in DESIGN.md); the
+  stand-in is itself pinned by hand-computed known-answer tests in
+  tests/test_oracle_kats.py.
+
+Everything else (polynomials, cubic spline, cost, FrenetState/FrenetTrajectory,
+the four planner classes) is the unmodified reference, imported by path.
+"""
+from __future__ import annotations
+
+import math
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+
+REFERENCE_ROOT = "/root/reference"
+
+
+# --------------------------------------------------------------------------
+# mini "shapely": convex polygons only
+# --------------------------------------------------------------------------
+class Polygon:
+    """Convex polygon given by its exterior ring (closing point optional)."""
+
+    def __init__(self, coords):
+        pts = np.asarray(coords, dtype=float).reshape(-1, 2)
+        if len(pts) >= 2 and np.array_equal(pts[0], pts[-1]):
+            pts = pts[:-1]
+        if len(pts) < 3:
+            raise ValueError("A polygon needs at least 3 distinct vertices")
+        if not np.all(np.isfinite(pts)):
+            raise ValueError("non-finite polygon coordinate")
+        self.pts = pts
+
+    @property
+    def bounds(self):
+        mn = self.pts.min(axis=0)
+        mx = self.pts.max(axis=0)
+        return (mn[0], mn[1], mx[0], mx[1])
+
+    @property
+    def is_empty(self):
+        return False
+
+    def _axes(self):
+        e = np.roll(self.pts, -1, axis=0) - self.pts
+        return np.stack([-e[:, 1], e[:, 0]], axis=1)
+
+    def intersects(self, other: "Polygon") -> bool:
+        """Closed-set separating axis test (touching counts as intersecting)."""
+        for ax in np.concatenate([self._axes(), other._axes()]):
+            pa = self.pts @ ax
+            pb = other.pts @ ax
+            if pa.max() < pb.min() or pb.max() < pa.min():
+                return False
+        return True
+
+
+class _Affinity:
+    @staticmethod
+    def translate(geom: Polygon, xoff=0.0, yoff=0.0, zoff=0.0) -> Polygon:
+        return Polygon(geom.pts + np.array([xoff, yoff], dtype=float))
+
+    @staticmethod
+    def rotate(geom: Polygon, angle, origin="center", use_radians=False) -> Polygon:
+        if not use_radians:
+            angle = angle * math.pi / 180.0
+        cosp = math.cos(angle)
+        sinp = math.sin(angle)
+        if abs(cosp) < 2.5e-16:
+            cosp = 0.0
+        if abs(sinp) < 2.5e-16:
+            sinp = 0.0
+        if origin != "center":
+            raise NotImplementedError(origin)
+        minx, miny, maxx, maxy = geom.bounds
+        x0 = (minx + maxx) / 2.0
+        y0 = (miny + maxy) / 2.0
+        xoff = x0 - x0 * cosp + y0 * sinp
+        yoff = y0 - x0 * sinp - y0 * cosp
+        x = geom.pts[:, 0]
+        y = geom.pts[:, 1]
+        return Polygon(np.stack([cosp * x - sinp * y + xoff, sinp * x + cosp * y + yoff], axis=1))
+
+
+affinity = _Affinity()
+
+
+# --------------------------------------------------------------------------
+# duck-typed commonroad obstacle (what has_collision() touches,
+# planners/frenet_optimal_planner.py:173,187-189)
+# --------------------------------------------------------------------------
+class StubObstacle:
+    """Rectangle obstacle with per-time-step poses.
+
+    poses: [T,3] array of (x, y, yaw) for absolute time steps 0..T-1; a row of
+    NaN means "no state at that step" (state_at_time -> None).
+    final_time_step mirrors TrajectoryPrediction.final_time_step (= T-1 when the
+    prediction covers steps 1..T-1 after the initial state at step 0).
+    """
+
+    def __init__(self, length: float, width: float, poses: np.ndarray, final_time_step: int | None = None):
+        poses = np.asarray(poses, dtype=float).reshape(-1, 3)
+        self.poses = poses
+        hl, hw = length / 2.0, width / 2.0
+        # commonroad Rectangle(length, width) centred at the origin, orientation 0
+        self.obstacle_shape = SimpleNamespace(
+            shapely_object=Polygon([(-hl, -hw), (-hl, hw), (hl, hw), (hl, -hw)]), length=length, width=width
+        )
+        fts = poses.shape[0] - 1 if final_time_step is None else final_time_step
+        self.prediction = SimpleNamespace(final_time_step=fts)
+
+    def state_at_time(self, t: int):
+        if t < 0 or t >= self.poses.shape[0] or not np.isfinite(self.poses[t, 0]):
+            return None
+        x, y, yaw = self.poses[t]
+        return SimpleNamespace(position=np.array([x, y]), orientation=float(yaw), time_step=t)
+
+
+def obstacles_from_table(pose: np.ndarray, dims: np.ndarray, final_time_step: int) -> list:
+    """pose [T,n,4]=(x,y,yaw,valid), dims [n,2]=(l,w) -> list of StubObstacle."""
+    T, n, _ = pose.shape
+    out = []
+    for j in range(n):
+        p = pose[:, j, :3].copy()
+        p[pose[:, j, 3] == 0.0] = np.nan
+        out.append(StubObstacle(dims[j, 0], dims[j, 1], p, final_time_step))
+    return out
+
+
+# --------------------------------------------------------------------------
+# vehicle parameters (VW_VANAGON = commonroad vehicle type 3; values of
+# commonroad-vehicle-models parameters_vehicle3 recalled from memory - the
+# package is not installed, so they are inputs of every API here, not truths)
+# --------------------------------------------------------------------------
+def vw_vanagon_params() -> SimpleNamespace:
+    return SimpleNamespace(
+        l=4.569,
+        w=1.844,
+        a=1.1489,
+        b=1.2859,
+        T_f=1.5740,
+        T_r=1.5740,
+        longitudinal=SimpleNamespace(v_max=41.7, a_max=11.5),
+        steering=SimpleNamespace(max=1.023, min=-1.023, v_max=0.4, v_min=-0.4, kappa_dot_max=0.4, kappa_dot_dot_max=20.0),
+    )
+
+
+_installed = False
+
+
+def install():
+    """Register the stub modules and put the reference on sys.path."""
+    global _installed
+    if _installed:
+        return
+    cr = types.ModuleType("commonroad")
+    cr_s = types.ModuleType("commonroad.scenario")
+    cr_ss = types.ModuleType("commonroad.scenario.scenario")
+    cr_so = types.ModuleType("commonroad.scenario.obstacle")
+    cr_ss.Scenario = type("Scenario", (), {})
+    cr_so.Obstacle = type("Obstacle", (), {})
+    cr.scenario = cr_s
+    cr_s.scenario = cr_ss
+    cr_s.obstacle = cr_so
+    sh = types.ModuleType("shapely")
+    sh_g = types.ModuleType("shapely.geometry")
+    sh.Polygon = Polygon
+    sh.affinity = affinity
+    sh.geometry = sh_g
+    sh_g.Polygon = Polygon
+    for name, mod in [
+        ("commonroad", cr),
+        ("commonroad.scenario", cr_s),
+        ("commonroad.scenario.scenario", cr_ss),
+        ("commonroad.scenario.obstacle", cr_so),
+        ("shapely", sh),
+        ("shapely.geometry", sh_g),
+    ]:
+        sys.modules.setdefault(name, mod)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    _installed = True
+
+
+def load_reference():
+    """Return a namespace with the reference classes used by the generators."""
+    install()
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # `cost_type is "WX1"` SyntaxWarning in cost_function.py:6
+        from planners.common.cost.cost_function import CostFunction
+        from planners.common.geometry.cubic_spline import CubicSpline1D, CubicSpline2D
+        from planners.common.geometry.polynomial import QuarticPolynomial, QuinticPolynomial
+        from planners.common.scenario.frenet import FrenetState, FrenetTrajectory, State
+        from planners.common.vehicle.vehicle import Vehicle
+        from planners.fiss_planner import FissPlanner, FissPlannerSettings
+        from planners.fiss_plus_planner import FissPlusPlanner, FissPlusPlannerSettings
+        from planners.fop_plus_planner import FopPlusPlanner
+        from planners.frenet_optimal_planner import FrenetOptimalPlanner, FrenetOptimalPlannerSettings, Stats
+    return SimpleNamespace(**{k: v for k, v in locals().items() if not k.startswith("_") and k != "warnings"})
