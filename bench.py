@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the Frenet candidate hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU a batch of
+2048 synthetic ego problems, 9x9x7 (d, v, T) lattice = 567 candidates per ego, 50 dynamic rectangle
+obstacles with a 5 s / 50-step pose table, one 81-knot reference spline per ego.  One "step" = one
+full pass of the hot path over the batch: lattice generation + cost + Frenet->Cartesian +
+speed/acceleration masks + OBB collision + per-ego argmin (+ winner epilogue), inputs resident in HBM,
+results (best index / cost per ego) copied to pinned host memory.  N > 1: every rank owns its own
+2048-ego shard (weak scaling, no collectives on the data path; torch.distributed only for the
+barrier and the max-over-ranks of the elapsed time).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TF = 78.6   # MI355X FP64 vector peak (datasheet; the kernel's real bound)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--egos", type=int, default=2048, help="egos per GPU")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--tables", action="store_true", help="also write the dense cost/flag tables (materialised mode)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_ego(batch, tables: bool) -> float:
+    """Bytes one ego problem must move through HBM once (DESIGN.md 'algorithmic bytes')."""
+    nx = int(batch.nx.max())
+    reads = 6 * 8 + 8 + 3 * 4 + batch.nv * 8 + 9 * 8 * nx            # ego, target speed, ids, v samples, spline
+    if batch.n_obs:
+        reads += 32 * batch.T_obs * batch.n_obs + 16 * batch.n_obs + 4  # pose table, dims, final_time_step
+    writes = 4 + 8 + 16                                                   # best idx, best cost, stats
+    if tables:
+        writes += 12 * batch.C
+    return float(reads + writes)
+
+
+def flops_per_ego(batch) -> float:
+    """Algorithmic FP64 flop count (SURVEY.md 8d accounting, upper bound: no early exit / broad phase)."""
+    N = batch.points_per_candidate()
+    pts = batch.nd * batch.nv * int(N.sum())
+    horizon = min(int(batch.final_time_step.max()) if batch.n_obs else 0, int(N.max()))
+    poses = batch.C * ((horizon + batch.check_stride - 1) // batch.check_stride)
+    return 96.0 * pts + 60.0 * poses * batch.n_obs + 40.0 * batch.C
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from fiss_plus_planner_amd import synth
+    from fiss_plus_planner_amd.engine import FrenetEngine, device_batch, make_params
+
+    # ---- this rank's shard, generated directly (every ego has its own RNG stream)
+    batch = synth.make_config(args.config, B=args.egos, ego_offset=rank * args.egos)
+    dev = torch.device("cuda", local_rank)
+    names = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+             "obs_pose", "obs_dims", "final_time_step")
+    dten = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in names}
+    fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in dten.items()})
+    params = make_params(batch)
+    B, C = batch.B, batch.C
+    best_idx = torch.empty(B, dtype=torch.int32, device=dev)
+    best_cost = torch.empty(B, dtype=torch.float64, device=dev)
+    stats = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    cost_tbl = torch.empty((B, C), dtype=torch.float64, device=dev) if args.tables else None
+    flag_tbl = torch.empty((B, C), dtype=torch.int32, device=dev) if args.tables else None
+    h_idx = torch.empty(B, dtype=torch.int32).pin_memory()
+    h_cost = torch.empty(B, dtype=torch.float64).pin_memory()
+    eng = FrenetEngine(local_rank)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        eng.plan_dense_device(params, fb, best_idx.data_ptr(), best_cost.data_ptr(), stats.data_ptr(),
+                              cost_tbl.data_ptr() if args.tables else 0, flag_tbl.data_ptr() if args.tables else 0,
+                              stream=stream.cuda_stream)
+
+    def fetch():
+        h_idx.copy_(best_idx, non_blocking=True)
+        h_cost.copy_(best_cost, non_blocking=True)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+        fetch()
+    barrier()
+
+    # ---- timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+        fetch()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # ---- parity gate + CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same egos.
+    # Runs AFTER the timed region (libgomp workers spin after a parallel region and would steal the launch thread's core);
+    # a parity failure aborts before anything is printed.
+    cpu_baseline = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from oracle import oracle as O
+
+        O.build()
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        probe = O.problems_from_batch(batch, range(min(16, B)))
+        t0 = time.perf_counter()
+        O.fop_plan_batch(probe, threads=cores)
+        per_ego = (time.perf_counter() - t0) / len(probe)
+        n_s = int(max(16, min(B, args.cpu_seconds / max(per_ego, 1e-6))))
+        probs = O.problems_from_batch(batch, range(n_s))
+        t0 = time.perf_counter()
+        o_idx, o_cost = O.fop_plan_batch(probs, threads=cores)
+        dt = time.perf_counter() - t0
+        g_idx, g_cost = h_idx.numpy()[:n_s], h_cost.numpy()[:n_s]
+        if not np.array_equal(g_idx, o_idx):
+            raise SystemExit(f"PARITY FAILURE: selected index differs on egos {np.nonzero(g_idx != o_idx)[0][:8].tolist()}")
+        ok = o_idx >= 0
+        if ok.any() and np.abs(g_cost[ok] - o_cost[ok]).max() > 1e-6:
+            raise SystemExit("PARITY FAILURE: best cost differs by more than 1e-6")
+        cpu_baseline = {"value": n_s * C / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+                        "sample": f"first {n_s} egos of the same batch ({n_s * C} candidates), oracle/libfrenet_oracle.so with "
+                                  f"OpenMP over egos, {dt:.1f} s; GPU index/cost parity checked on this sample before timing"}
+
+
+    if rank == 0:
+        total_cand = world * B * C * args.steps
+        value = total_cand / elapsed
+        bytes_launch = algorithmic_bytes_per_ego(batch, args.tables) * B
+        flops_launch = flops_per_ego(batch) * B
+        ach_gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
+        ach_tf = flops_launch / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"config{args.config}_B{B}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "candidate trajectories/sec (gen+cost+collision)", "value": value, "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {B} egos/GPU x {batch.nd}x{batch.nv}x{batch.nt} lattice "
+                                   f"({C} cand/ego), {batch.n_obs} {'dynamic' if batch.meta.get('moving') else 'static'} obstacles, "
+                                   f"T_obs={batch.T_obs}, stride-2 OBB checks, FOP argmin",
+                       "egos_per_gpu": B, "candidates_per_ego": C, "tables_written": bool(args.tables),
+                       "parallelism": f"ego-shard x{world} (no collectives)", "input_digest": batch.digest()[:16]},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "lattice_percand_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "fused kernel is FP64-VALU bound, not HBM bound; see valu_fp64"},
+            "valu_fp64": {"achieved": ach_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TF,
+                          "algorithmic_flops_per_launch": flops_launch},
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

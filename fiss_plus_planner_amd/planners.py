@@ -1,0 +1,337 @@
+"""Drop-in planner classes: same names, constructor and plan() signature as the reference
+(planners/frenet_optimal_planner.py, fop_plus_planner.py, fiss_planner.py, fiss_plus_planner.py).
+
+What runs where
+---------------
+Every trajectory evaluation (polynomials, cost, Frenet->Cartesian, speed/acceleration masks, OBB
+collision tests, FOP argmin) runs in the gfx950 kernels behind the C ABI.  The host keeps only what the
+reference also keeps per planner object - settings, the reference-line spline, the cross-cycle state
+(`prev_best_idx`, `best_traj`) - plus the data-dependent *order of visits* of FOP+/FISS/FISS+, which is a
+walk over the GPU-computed dense tables (search.py).  There is no CPU evaluation path: constructing a
+planner without a GPU / built library raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import search
+from .batch import FISS_KINDS, ProblemBatch
+from .engine import TRAJ_STRIDE, FrenetEngine, unpack_flags
+from .frenet import FrenetState, FrenetTrajectory
+from .obstacles import ObstacleTable, flatten_obstacles
+from .spline import CubicSpline2D
+from .vehicle import Vehicle
+
+
+class Stats:
+    """reference frenet_optimal_planner.py:15-36"""
+
+    def __init__(self, num_iter=0, num_trajs_generated=0, num_trajs_validated=0, num_collison_checks=0):
+        self.num_iter = num_iter
+        self.num_trajs_generated = num_trajs_generated
+        self.num_trajs_validated = num_trajs_validated
+        self.num_collison_checks = num_collison_checks
+
+    def __add__(self, other):
+        self.num_iter += other.num_iter
+        self.num_trajs_generated += other.num_trajs_generated
+        self.num_trajs_validated += other.num_trajs_validated
+        self.num_collison_checks += other.num_collison_checks
+        return self
+
+    def average(self, value: int):
+        self.num_iter /= value
+        self.num_trajs_generated /= value
+        self.num_trajs_validated /= value
+        self.num_collison_checks /= value
+        return self
+
+    def as_tuple(self):
+        return (self.num_iter, self.num_trajs_generated, self.num_trajs_validated, self.num_collison_checks)
+
+
+class FrenetOptimalPlannerSettings:
+    """reference frenet_optimal_planner.py:38-56"""
+
+    def __init__(self, num_width: int = 5, num_speed: int = 5, num_t: int = 5):
+        self.tick_t = 0.1
+        self.max_road_width = 3.5
+        self.num_width = num_width
+        self.highest_speed = 13.4112
+        self.lowest_speed = 0.0
+        self.num_speed = num_speed
+        self.min_t = 8.0
+        self.max_t = 10.0
+        self.num_t = num_t
+        self.check_obstacle = True   # present in the reference, never read there either
+        self.check_boundary = True
+
+
+class FissPlannerSettings(FrenetOptimalPlannerSettings):
+    """reference fiss_planner.py:13-18"""
+
+    def __init__(self, num_width: int = 5, num_speed: int = 5, num_t: int = 5):
+        super().__init__(num_width, num_speed, num_t)
+        self.w_heuristic = 10.0
+        self.vis_all_candidates = False
+
+
+class FissPlusPlannerSettings(FissPlannerSettings):
+    """reference fiss_plus_planner.py:15-22.  The reference enforces `time_limit` inside refine_solution even with
+    has_time_limit=False (wall-clock dependent); here refinement always runs its max_refine_iters rounds."""
+
+    def __init__(self, num_width: int = 5, num_speed: int = 5, num_t: int = 5, refine_iters: int = 3):
+        super().__init__(num_width, num_speed, num_t)
+        self.refine_trajectory = True
+        self.max_refine_iters = refine_iters
+        self.has_time_limit = False
+        self.time_limit = 0.5
+        self.decaying_factor = 0.5
+
+
+_shared_engines: dict[int, FrenetEngine] = {}
+
+
+def _engine_for(device: int) -> FrenetEngine:
+    if device not in _shared_engines:
+        _shared_engines[device] = FrenetEngine(device)
+    return _shared_engines[device]
+
+
+class FrenetOptimalPlanner:
+    """FOP: exhaustive lattice, argmin over the feasible candidates (reference frenet_optimal_planner.py:58-278)."""
+
+    KIND = "FOP"
+
+    def __init__(self, planner_settings: FrenetOptimalPlannerSettings, ego_vehicle: Vehicle, scenario=None, *,
+                 device: int = 0, engine: FrenetEngine | None = None, materialize_all: bool = False):
+        self.settings = planner_settings
+        self.vehicle = ego_vehicle
+        self.cubic_spline = None
+        self.best_traj = None
+        self.all_trajs = []
+        self.stats = Stats()
+        self.materialize_all = materialize_all  # fill all_trajs with every candidate (visualisation payload)
+        self._engine = engine if engine is not None else _engine_for(device)
+        self._obs_cache = (None, None)
+        self.last_tables = None  # (cost [C], flags [C]) of the last dense pass, flat FOP order
+
+    # ------------------------------------------------------------------ frame
+    def generate_frenet_frame(self, centerline_pts: np.ndarray):
+        """reference :272-278 -> (CubicSpline2D, [n', 4] = x, y, yaw, kappa every 0.1 m)."""
+        pts = np.asarray(centerline_pts, dtype=np.float64)
+        self.cubic_spline = CubicSpline2D(pts[:, 0], pts[:, 1])
+        s = np.arange(0, self.cubic_spline.s[-1], 0.1)
+        x, y, yaw, kappa = self.cubic_spline.sample(s)
+        return self.cubic_spline, np.column_stack((x, y, yaw, kappa))
+
+    # ------------------------------------------------------------------ problem marshalling
+    def _obstacle_table(self, obstacles) -> ObstacleTable | None:
+        if isinstance(obstacles, ObstacleTable):
+            return obstacles
+        if obstacles is None or len(obstacles) == 0:
+            return None  # has_collision: empty list -> no collision (:170-171)
+        key = (id(obstacles), len(obstacles))
+        if self._obs_cache[0] != key:
+            self._obs_cache = (key, flatten_obstacles(obstacles))
+        return self._obs_cache[1]
+
+    def _sampling_width(self) -> float:
+        return self.settings.max_road_width - self.vehicle.w + (0.3 if self.KIND in FISS_KINDS else 0.0)
+
+    def _make_batch(self, frenet_state: FrenetState, obstacles, time_step_now: int) -> ProblemBatch:
+        if self.cubic_spline is None:
+            raise RuntimeError("generate_frenet_frame() must be called before plan()")
+        st = self.settings
+        sw = self._sampling_width()
+        d, rd = np.linspace(-sw / 2, sw / 2, st.num_width, retstep=True)
+        t, rt = np.linspace(st.min_t, st.max_t, st.num_t, retstep=True)
+        v, rv = np.linspace(st.lowest_speed, st.highest_speed, st.num_speed, retstep=True)
+        tab = self._obstacle_table(obstacles)
+        sp = self.cubic_spline
+        if tab is None:
+            pose, dims, fts, scene = np.zeros((0, 1, 0, 4)), np.zeros((0, 0, 2)), np.zeros(0, dtype=np.int32), -1
+        else:
+            pose, dims, fts, scene = tab.pose[None], tab.dims[None], np.array([tab.final_time_step], dtype=np.int32), 0
+        return ProblemBatch(
+            d_samples=d, t_samples=t, v_samples=v[None], target_speed=np.array([st.highest_speed]),
+            ego=frenet_state.as_start_vector()[None], frame_of=[0], scene_of=[scene], t_now=[time_step_now],
+            nx=[len(sp.knots)], knots=sp.knots[None], coef=sp.coef[None], obs_pose=pose, obs_dims=dims, final_time_step=fts,
+            veh_l=self.vehicle.l, veh_w=self.vehicle.w, max_speed=self.vehicle.max_speed, max_accel=self.vehicle.max_accel,
+            tick_t=st.tick_t, check_stride=2,
+            samp_min=np.array([[-sw / 2, st.lowest_speed, st.min_t]]), samp_max=np.array([[sw / 2, st.highest_speed, st.max_t]]),
+            samp_res=np.array([[rd, rv, rt]]))
+
+    def _materialize(self, batch: ProblemBatch, end_states: np.ndarray, idxs=None):
+        """end_states [K,3] -> list of FrenetTrajectory (full series from the GPU dump)."""
+        es = np.asarray(end_states, dtype=np.float64).reshape(1, -1, 3)
+        out = self._engine.eval_trajs(batch, es, dump=True)
+        _, N, M = unpack_flags(out.flags[0])
+        trajs = []
+        for k in range(es.shape[1]):
+            end = FrenetState(t=es[0, k, 2], s=0.0, s_d=es[0, k, 1], d=es[0, k, 0])
+            trajs.append(FrenetTrajectory.from_dump(out.traj[0, k], int(N[k]), int(M[k]), out.cost[0, k], end,
+                                                    None if idxs is None else idxs[k]))
+        return trajs, out
+
+    def _end_state_of_flat(self, batch: ProblemBatch, flat: int):
+        nv, nt = batch.nv, batch.nt
+        iv, it, i_d = flat % nv, (flat // nv) % nt, flat // (nv * nt)
+        return np.array([batch.d_samples[i_d], batch.v_samples[0, iv], batch.t_samples[it]]), (i_d, iv, it)
+
+    def _dense(self, batch: ProblemBatch):
+        out = self._engine.plan_dense(batch, tables=True)
+        self.last_tables = (out.cost[0], out.flags[0])
+        if self.materialize_all:
+            es = np.array([self._end_state_of_flat(batch, c)[0] for c in range(batch.C)])
+            trajs, _ = self._materialize(batch, es)
+            self.all_trajs.append(trajs)
+        else:
+            self.all_trajs.append([])
+        return out
+
+    # ------------------------------------------------------------------ plan
+    def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
+        """reference :247-270.  Returns the minimum-cost feasible FrenetTrajectory; when no candidate survives the
+        reference returns its previous `best_traj` (stale object or None) - reproduced."""
+        self.stats = Stats()
+        self.settings.highest_speed = max_target_speed
+        batch = self._make_batch(frenet_state, obstacles, time_step_now)
+        out = self._dense(batch)
+        C = batch.C
+        self.stats = Stats(0, C, C, C)
+        best = int(out.best_idx[0])
+        if best >= 0:
+            es, (i_d, iv, it) = self._end_state_of_flat(batch, best)
+            trajs, _ = self._materialize(batch, es[None])
+            self.best_traj = trajs[0]
+            self.best_traj.lattice_index = best
+        return self.best_traj
+
+
+class FopPlusPlanner(FrenetOptimalPlanner):
+    """FOP+: validate in cost order, stop at the first survivor (reference fop_plus_planner.py:11-41)."""
+
+    KIND = "FOP+"
+
+    def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
+        self.stats = Stats()
+        self.settings.highest_speed = max_target_speed
+        batch = self._make_batch(frenet_state, obstacles, time_step_now)
+        out = self._dense(batch)
+        best, st = search.fopplus_search(out.cost[0], out.flags[0])
+        self.stats = Stats(*st)
+        if best is None:
+            return None
+        es, _ = self._end_state_of_flat(batch, best)
+        trajs, _ = self._materialize(batch, es[None])
+        self.best_traj = trajs[0]
+        self.best_traj.lattice_index = best
+        return self.best_traj
+
+
+class FissPlanner(FrenetOptimalPlanner):
+    """FISS: heuristic initial guess + gradient walk on the index grid (reference fiss_planner.py:20-270)."""
+
+    KIND = "FISS"
+    _search = staticmethod(search.fiss_search)
+
+    def __init__(self, planner_settings: FissPlannerSettings, ego_vehicle: Vehicle, scenario=None, **kw):
+        super().__init__(planner_settings, ego_vehicle, scenario, **kw)
+        self.sampling_res = np.empty(3)
+        self.sampling_min = np.empty(3)
+        self.sampling_max = np.empty(3)
+        self.sizes = None
+        self.start_state = None
+        self.prev_best_idx = None
+
+    def _coarse(self, frenet_state, max_target_speed, obstacles, time_step_now):
+        self.stats = Stats()
+        self.settings.highest_speed = max_target_speed
+        self.start_state = frenet_state
+        self.best_traj = None
+        batch = self._make_batch(frenet_state, obstacles, time_step_now)
+        self.sampling_min, self.sampling_max, self.sampling_res = batch.samp_min[0].copy(), batch.samp_max[0].copy(), batch.samp_res[0].copy()
+        self.sizes = np.array([batch.nd, batch.nv, batch.nt])
+        out = self._dense(batch)
+        J, F = search.tables_to_dvt(out.cost[0], out.flags[0], batch.nd, batch.nv, batch.nt)
+        E = search.cost_est_table(batch.d_samples, batch.v_samples[0], batch.t_samples, self.sampling_min, self.sampling_max,
+                                  self.prev_best_idx, self.settings.w_heuristic)
+        idx, st = self._search(J, F, E)
+        self.stats = Stats(*st)
+        return batch, idx
+
+    def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
+        batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
+        if idx is None:
+            return None
+        es = np.array([batch.d_samples[idx[0]], batch.v_samples[0, idx[1]], batch.t_samples[idx[2]]])
+        trajs, _ = self._materialize(batch, es[None], [np.array(idx)])
+        self.best_traj = trajs[0]
+        self.prev_best_idx = self.best_traj.idx  # persists across cycles (:252)
+        return self.best_traj
+
+
+class FissPlusPlanner(FissPlanner):
+    """FISS+: best-first frontier search + continuous refinement (reference fiss_plus_planner.py:24-326)."""
+
+    KIND = "FISS+"
+    _search = staticmethod(search.fissplus_search)
+
+    def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
+        batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
+        if idx is None:
+            return None
+        x = np.array([batch.d_samples[idx[0]], batch.v_samples[0, idx[1]], batch.t_samples[idx[2]]])
+        coarse_cost = float(self.last_tables[0][(idx[0] * batch.nt + idx[2]) * batch.nv + idx[1]])
+        self.prev_best_idx = np.array(idx)  # stays the coarse index even if a refined trajectory wins (:140)
+        winner = (x, np.array(idx))
+        st = self.settings
+        if st.refine_trajectory and st.max_refine_iters > 0:
+            refined = self._refine(batch, x, coarse_cost)
+            if refined is not None:
+                winner = (refined, np.array([-1, -1, -1]))
+        trajs, _ = self._materialize(batch, winner[0][None], [winner[1]])
+        self.best_traj = trajs[0]
+        return self.best_traj
+
+    def _refine(self, batch: ProblemBatch, x: np.ndarray, coarse_cost: float):
+        """refine_solution + gradient_decent (reference :207-326): per round six probe trajectories at
+        clip(x -/+ res_dim e_dim), finite-difference gradient, resolution decay, one trajectory at the new x.
+        All 7 trajectories of a round are evaluated on the GPU (two launches: 6 probes, then the step)."""
+        st = self.settings
+        res = self.sampling_res  # decays in place like the reference (aliases self.sampling_res, :282)
+        cand = []  # (cost, order, end_state, flags)
+        lo, hi = self.sampling_min, self.sampling_max
+        for _ in range(st.max_refine_iters):
+            probes = np.empty((6, 3)); x_l = []; x_r = []
+            for dim in range(3):
+                a = x.copy(); a[dim] -= res[dim]; a = np.clip(a, lo, hi)
+                b = x.copy(); b[dim] += res[dim]; b = np.clip(b, lo, hi)
+                probes[2 * dim], probes[2 * dim + 1] = a, b
+                x_l.append(a); x_r.append(b)
+            if np.isnan(probes).any():
+                break
+            out = self._engine.eval_trajs(batch, probes[None])
+            self.stats.num_trajs_generated += 6
+            for k in range(6):
+                cand.append((float(out.cost[0, k]), len(cand), probes[k].copy(), int(out.flags[0, k])))
+            x_new, res_new = search.refine_step(out.cost[0, 0::2], out.cost[0, 1::2], x_l, x_r, x, res, st.decaying_factor, lo, hi)
+            res[:] = res_new
+            if x_new is None:
+                break  # zero gradient: the reference raises inside np.arange(nan); we stop refining
+            out1 = self._engine.eval_trajs(batch, x_new[None, None])
+            self.stats.num_trajs_generated += 1
+            cand.append((float(out1.cost[0, 0]), len(cand), x_new.copy(), int(out1.flags[0, 0])))
+            x = x_new
+        # refined_trajs PriorityQueue: pop in cost order while cost <= coarse cost (:301-323)
+        for cost, _, es, fl in sorted(cand, key=lambda c: (c[0], c[1])):
+            if cost > coarse_cost:
+                break
+            self.stats.num_trajs_validated += 1
+            if fl & 3:
+                continue
+            self.stats.num_collison_checks += 1
+            if not (fl & 4):
+                return es
+        return None

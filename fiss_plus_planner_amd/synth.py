@@ -2,7 +2,7 @@
 
 Deterministic: numpy Generator(PCG64([seed, ego])).  One sinusoidal centerline and one
 obstacle scene per ego.  Obstacles are rectangles that sit on (static) or drive along
-(dynamic) the ego's own road: ~10 % of them in the ego lane ahead of the ego (lead
+(dynamic) the ego's own road: ~15 % of them in the ego lane ahead of the ego (lead
 vehicles, |d| <= 1 m), the rest in the neighbouring lanes on both sides (2.9 m <= |d| <= 7.5 m)
 from 15 m behind to 120 m ahead.  (SURVEY.md 8d proposed d ~ U(-4, 4) for every obstacle;
 with 50 obstacles that blocks the lane so densely that ~99 % of the fan collides within the
@@ -78,16 +78,16 @@ def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving
         if n_obs > 0:
             dims[b, :, 0] = rng.uniform(3.5, 7.5, n_obs)
             dims[b, :, 1] = rng.uniform(1.6, 2.3, n_obs)
-            n_lane = max(1, int(round(0.1 * n_obs)))
+            n_lane = max(1, int(round(0.15 * n_obs)))
             side = rng.uniform(2.9, 7.5, n_obs) * np.where(rng.uniform(size=n_obs) < 0.5, -1.0, 1.0)
             lane = rng.uniform(-1.0, 1.0, n_obs)
-            ahead_lane = rng.uniform(20, 120, n_obs)
+            ahead_lane = rng.uniform(12, 90, n_obs)
             ahead_side = rng.uniform(-15, 120, n_obs)
             in_lane = np.arange(n_obs) < n_lane
             do[b] = np.where(in_lane, lane, side)
             so[b] = np.maximum(ego[b, 0] + np.where(in_lane, ahead_lane, ahead_side), 1.0)
             if moving:
-                vo[b] = rng.uniform(2, 12, n_obs)
+                vo[b] = rng.uniform(0, 10, n_obs)
     knots, coef = build_frames(pts)
     if n_obs > 0:
         tt = np.arange(T_obs) * st.tick_t

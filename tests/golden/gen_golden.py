@@ -131,8 +131,9 @@ def fop_cases():
     ct = short_frame_batch(synth.make_batch(4, 5, 5, 5, 10, 100, False, 9104), 25)
     ego = ct.ego.copy()
     ego[2, 0] = 130.0
-    ego[3, 0] = 119.5  # M = 1 for slow candidates
+    ego[3, 0] = ct.knots[3, 24] - 0.02  # M = 1: s(0) is on the spline, s(0.1) is already past its end
     ego[3, 1] = 0.5
+    ego[3, 2] = 0.0
     cases.append(("trunc", with_overrides(ct, ego=ego)))
     # constraint violations: tight vehicle limits
     cv = synth.make_batch(3, 5, 5, 5, 10, 100, False, 9105)

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads here (no GPU) and exports every symbol include/frenet_gpu.h declares;
+without a device every entry point fails loudly instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from fiss_plus_planner_amd import _abi
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_abi.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fiss_plus_planner_amd", "csrc"), "-s"])
+    return _abi.load()
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "frenet_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_abi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for sym in _declared_symbols():
+        assert hasattr(lib, sym), sym
+    assert lib.fp_abi_version() == _abi.FP_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    # 4 int32 + 10 double ; 6 int32 + 14 pointers ; 5 pointers
+    assert C.sizeof(_abi.FpParams) == 4 * 4 + 10 * 8
+    assert C.sizeof(_abi.FpBatch) == 6 * 4 + 14 * 8
+    assert C.sizeof(_abi.FpResult) == 5 * 8
+
+
+def test_no_device_means_loud_failure(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    ctx = C.c_void_p()
+    rc = lib.fp_ctx_create(0, C.byref(ctx))
+    assert rc == -5 and not ctx
+    assert b"no CPU fallback" in lib.fp_last_error()
+    from fiss_plus_planner_amd.engine import FrenetEngine
+
+    with pytest.raises(_abi.FrenetGpuError):
+        FrenetEngine(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "fiss_plus_planner_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), f"{f} mentions the oracle"

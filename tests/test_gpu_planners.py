@@ -1,0 +1,162 @@
+"""GPU: the four drop-in planner classes against the golden plan() results of the reference
+(tests/golden/g4_plan.npz, g6_fiss_search.npz) and the Flensburg closed loop (g5_closed_loop.npz).
+
+Bars: selected index / Stats exact, cost_final within 1e-6 (observed ~1e-13), winner series within 1e-6.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, batch_from_golden, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+def _planner(kind, b, engine, refine_iters=3):
+    from fiss_plus_planner_amd import planners as P
+    from fiss_plus_planner_amd.vehicle import Vehicle, vw_vanagon_params
+
+    vp = vw_vanagon_params()
+    vp.l, vp.w = b.veh_l, b.veh_w
+    vp.longitudinal.v_max, vp.longitudinal.a_max = b.max_speed, b.max_accel
+    veh = Vehicle(vp)
+    cls, st = {"FOP": (P.FrenetOptimalPlanner, P.FrenetOptimalPlannerSettings), "FOP+": (P.FopPlusPlanner, P.FrenetOptimalPlannerSettings),
+               "FISS": (P.FissPlanner, P.FissPlannerSettings), "FISS+": (P.FissPlusPlanner, P.FissPlusPlannerSettings)}[kind]
+    return cls(st(b.nd, b.nv, b.nt), veh, None, engine=engine)
+
+
+def _inputs(b, e):
+    from fiss_plus_planner_amd.frenet import FrenetState
+    from fiss_plus_planner_amd.obstacles import ObstacleTable
+
+    f = int(b.frame_of[e]); nx = int(b.nx[f])
+    pts = np.column_stack([b.coef[f, 0, :nx], b.coef[f, 4, :nx]])
+    s, s_d, s_dd, d, d_d, d_dd = b.ego[e]
+    fs = FrenetState(t=0.0, s=s, s_d=s_d, s_dd=s_dd, d=d, d_d=d_d, d_dd=d_dd)
+    sc = int(b.scene_of[e])
+    obs = [] if sc < 0 or b.n_obs == 0 else ObstacleTable(b.obs_pose[sc], b.obs_dims[sc], int(b.final_time_step[sc]))
+    return pts, fs, obs
+
+
+def _check_winner(best, want_dump, NM):
+    from fiss_plus_planner_amd.frenet import ARRAY_NAMES
+
+    assert len(best.t) == NM[0] and len(best.x) == NM[1]
+    for k, name in enumerate(ARRAY_NAMES):
+        got = np.asarray(getattr(best, name))
+        want = want_dump[k][~np.isnan(want_dump[k])]
+        assert len(got) == len(want), name
+        if name in ("c", "c_d", "c_dd"):
+            # curvature = diff(yaw)/ds amplifies rounding at crawl speed: relative comparison
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=name)
+        else:
+            np.testing.assert_allclose(got, want, rtol=0, atol=TOL, err_msg=name)
+
+
+def _g4_keys():
+    p = os.path.join(GOLDEN, "g4_plan.npz")
+    return [str(n) for n in np.load(p)["names"]] if os.path.exists(p) else []
+
+
+@pytest.mark.parametrize("key", _g4_keys())
+def test_plan_matches_reference(engine, key):
+    g = load_golden("g4_plan.npz")
+    b = batch_from_golden(g, f"{key}_in_")
+    kind = key.rsplit("_", 1)[1]
+    for e in range(b.B):
+        pl = _planner(kind, b, engine)
+        pts, fs, obs = _inputs(b, e)
+        pl.generate_frenet_frame(pts)
+        best = pl.plan(fs, float(b.target_speed[e]), obs, int(b.t_now[e]))
+        found = bool(g[f"{key}_found"][e])
+        assert (best is not None) == found, (key, e)
+        assert pl.stats.as_tuple() == tuple(g[f"{key}_stats"][e]), (key, e)
+        if not found:
+            continue
+        assert abs(best.cost_final - g[f"{key}_cost"][e]) < TOL
+        if kind in ("FOP", "FOP+"):
+            assert best.lattice_index == g[f"{key}_flat"][e]
+        else:
+            np.testing.assert_array_equal(best.idx, g[f"{key}_idx"][e])
+            np.testing.assert_allclose([best.end_state.d, best.end_state.s_d, best.end_state.t], g[f"{key}_end"][e], atol=1e-9)
+            np.testing.assert_array_equal(pl.prev_best_idx, g[f"{key}_prev_out"][e])
+        _check_winner(best, g[f"{key}_win"][e], g[f"{key}_NM"][e])
+
+
+@pytest.mark.parametrize("kind", ["FISS", "FISS+"])
+def test_history_heuristic_and_refinement(engine, kind):
+    g = load_golden("g6_fiss_search.npz")
+    b = batch_from_golden(g, "in_")
+    for e in range(b.B):
+        pl = _planner(kind, b, engine)
+        pts, fs, obs = _inputs(b, e)
+        pl.generate_frenet_frame(pts)
+        prev = g["prev_in"][e]
+        pl.prev_best_idx = None if prev[0] < 0 else prev.copy()
+        best = pl.plan(fs, float(b.target_speed[e]), obs, int(b.t_now[e]))
+        assert pl.stats.as_tuple() == tuple(g[f"{kind}_stats"][e]), e
+        assert (best is not None) == bool(g[f"{kind}_found"][e])
+        if best is not None:
+            assert abs(best.cost_final - g[f"{kind}_cost"][e]) < TOL
+            np.testing.assert_allclose([best.end_state.d, best.end_state.s_d, best.end_state.t], g[f"{kind}_end"][e], atol=1e-9)
+            np.testing.assert_array_equal(pl.prev_best_idx, g[f"{kind}_prev_out"][e])
+
+
+def _closed_loop(kind, g, engine):
+    """planners/benchmark/planning.py:101-162 on the Flensburg fixture inputs."""
+    from fiss_plus_planner_amd import planners as P
+    from fiss_plus_planner_amd.frenet import FrenetState, State
+    from fiss_plus_planner_amd.obstacles import ObstacleTable
+    from fiss_plus_planner_amd.vehicle import Vehicle
+
+    veh = Vehicle()
+    cls, st = {"FOP": (P.FrenetOptimalPlanner, P.FrenetOptimalPlannerSettings), "FOP+": (P.FopPlusPlanner, P.FrenetOptimalPlannerSettings),
+               "FISS": (P.FissPlanner, P.FissPlannerSettings), "FISS+": (P.FissPlusPlanner, P.FissPlusPlannerSettings)}[kind]
+    pl = cls(st(5, 5, 5), veh, None, engine=engine)
+    _, ref = pl.generate_frenet_frame(g["centerline"])
+    np.testing.assert_allclose(ref, g["refline"], rtol=0, atol=1e-9)
+    init = g["init_state"]
+    cur = FrenetState()
+    cur.from_state(State(t=0.0, x=init[0], y=init[1], yaw=init[2], v=init[3], a=0.0), ref)
+    fts = int(g["final_time_step"])
+    obstacles = ObstacleTable(g["obs_pose"][:fts], g["obs_dims"], fts)
+    rows, states = [], []
+    for i in range(fts):
+        start = [cur.s, cur.s_d, cur.s_dd, cur.d, cur.d_d, cur.d_dd]
+        best = pl.plan(cur, 13.5, obstacles, i)
+        if best is None:
+            break
+        cs = best.state_at_time_step(1)
+        cur = best.frenet_state_at_time_step(1)
+        rows.append(SimpleNamespace(start=start, cost=best.cost_final, N=len(best.t), M=len(best.x), idx=best.idx, stats=pl.stats.as_tuple(),
+                                    end=[best.end_state.d, best.end_state.s_d, best.end_state.t]))
+        states.append([cs.x, cs.y, cs.yaw])
+        if np.hypot(cs.x - g["goal_center"][0], cs.y - g["goal_center"][1]) <= veh.l / 2:
+            break
+        if np.hypot(cs.x - ref[-1, 0], cs.y - ref[-1, 1]) <= 3.0:
+            break
+    return rows, np.array(states)
+
+
+@pytest.mark.parametrize("kind", ["FOP", "FOP+", "FISS", "FISS+"])
+def test_flensburg_closed_loop(engine, kind):
+    g = load_golden("g5_closed_loop.npz")
+    if f"{kind}_rows" not in g.files:
+        pytest.skip(f"no closed-loop golden for {kind}")
+    want = g[f"{kind}_rows"]
+    rows, states = _closed_loop(kind, g, engine)
+    assert len(rows) == len(want)
+    for i, (r, w) in enumerate(zip(rows, want)):
+        np.testing.assert_allclose(r.start, w[0:6], rtol=0, atol=1e-7, err_msg=f"cycle {i} start state")
+        assert abs(r.cost - w[6]) < TOL, i
+        assert (r.N, r.M) == (int(w[7]), int(w[8])), i
+        if kind in ("FISS", "FISS+"):
+            np.testing.assert_array_equal(r.idx, w[9:12].astype(int), err_msg=f"cycle {i}")
+        assert r.stats == tuple(int(v) for v in w[12:16]), i
+        if kind in ("FISS", "FISS+"):  # FOP/FOP+ trajectories carry no end_state in the reference
+            np.testing.assert_allclose(r.end, w[16:19], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(states, g[f"{kind}_states"], rtol=0, atol=1e-6)
