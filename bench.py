@@ -194,11 +194,14 @@ def main():
                        "egos_per_gpu": B, "candidates_per_ego": C, "tables_written": bool(args.tables),
                        "parallelism": f"ego-shard x{world} (no collectives)", "input_digest": batch.digest()[:16]},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "lattice_percand_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "lattice_fused_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "fused kernel is FP64-VALU bound, not HBM bound; see valu_fp64"},
-            "valu_fp64": {"achieved": ach_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TF,
-                          "algorithmic_flops_per_launch": flops_launch},
+            "valu_fp64": {"reference_algorithm_rate": ach_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                          "reference_algorithm_flops_per_launch": flops_launch,
+                          "note": "flops the reference's per-candidate algorithm would need (SURVEY 8d accounting) / kernel time; "
+                                  "the kernel executes far fewer (profile sharing, broad phase) - executed-instruction "
+                                  "counts from rocprofv3 PMC are in DESIGN.md"},
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

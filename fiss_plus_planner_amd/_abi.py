@@ -22,7 +22,7 @@ _ip = C.POINTER(C.c_int32)
 _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
-EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy",
+EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option",
                     "fp_plan_dense", "fp_eval_trajs")
 
 
@@ -71,6 +71,7 @@ def load() -> C.CDLL:
     L.fp_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.fp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.fp_ctx_destroy.argtypes = [C.c_void_p]
+    L.fp_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.fp_plan_dense.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpResult), C.c_int, C.c_void_p]
     L.fp_eval_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int32, C.c_int, C.c_void_p]

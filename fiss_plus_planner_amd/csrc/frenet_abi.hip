@@ -69,6 +69,7 @@ struct fp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // used by FP_MEM_HOST calls
     Arena arena;
+    int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
 };
 
 namespace {
@@ -226,6 +227,17 @@ int fp_ctx_destroy(fp_ctx* ctx)
     return FP_OK;
 }
 
+int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
+{
+    if (!ctx || !name) return fail(FP_EINVAL, "ctx/name is NULL");
+    if (strcmp(name, "lattice_kernel") == 0) {
+        if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_kernel must be 0 (auto), 1 (per-candidate) or 2 (fused)");
+        ctx->lattice_kernel = value;
+        return FP_OK;
+    }
+    return fail(FP_EINVAL, "unknown option '%s'", name);
+}
+
 int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
 {
     if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
@@ -243,7 +255,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
-        hipError_t e = fp::launch_lattice_percand(ka, (hipStream_t)stream);
+        hipError_t e = fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel);
         if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
         return FP_OK;
     }
@@ -261,7 +273,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     ka.r.stats = result->stats ? (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 4) : nullptr;
     ka.r.cost_tbl = result->cost_tbl ? (double*)ctx->arena.take(sizeof(double) * B * C) : nullptr;
     ka.r.flag_tbl = result->flag_tbl ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B * C) : nullptr;
-    hipError_t e = fp::launch_lattice_percand(ka, ctx->stream);
+    hipError_t e = fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel);
     if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpyAsync(result->best_idx, ka.r.best_idx, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(result->best_cost, ka.r.best_cost, sizeof(double) * B, hipMemcpyDeviceToHost, ctx->stream));

@@ -15,7 +15,12 @@ struct KernelArgs {
     fp_result r;
 };
 
+// Production dense-lattice kernel (profile sharing + compacted collision).  Returns hipErrorInvalidValue when the
+// problem does not fit it (LDS budget / index widths); launch_lattice then uses the lane-per-candidate kernel.
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
+// Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
+hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which);
 hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
                              int stride, hipStream_t stream);
 

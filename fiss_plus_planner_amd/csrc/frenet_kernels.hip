@@ -347,10 +347,25 @@ hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream)
     if (threads > 1024) threads = 1024;
     int lds_doubles = 0;
     const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
-    hipError_t err = hipFuncSetAttribute((const void*)lattice_percand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (err != hipSuccess) return err;
+    static int configured = -1;
+    if (bytes > configured) {
+        hipError_t err = hipFuncSetAttribute((const void*)lattice_percand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (err != hipSuccess) return err;
+        configured = bytes;
+    }
     hipLaunchKernelGGL(lattice_percand_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, lds_doubles);
     return hipGetLastError();
+}
+
+hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which)
+{
+    if (which == 1) return launch_lattice_percand(ka, stream);
+    hipError_t e = launch_lattice_fused(ka, stream);
+    if (e == hipErrorInvalidValue && which != 2) {
+        (void)hipGetLastError();
+        return launch_lattice_percand(ka, stream);
+    }
+    return e;
 }
 
 hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
@@ -360,8 +375,12 @@ hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_stat
     if (threads > 256) threads = 256;
     int lds_doubles = 0;
     const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
-    hipError_t err = hipFuncSetAttribute((const void*)eval_trajs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (err != hipSuccess) return err;
+    static int configured = -1;
+    if (bytes > configured) {
+        hipError_t err = hipFuncSetAttribute((const void*)eval_trajs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (err != hipSuccess) return err;
+        configured = bytes;
+    }
     hipLaunchKernelGGL(eval_trajs_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, K, end_states, cost, flags, traj, stride,
                        lds_doubles);
     return hipGetLastError();

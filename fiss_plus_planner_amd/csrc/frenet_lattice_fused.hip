@@ -1,0 +1,435 @@
+// frenet_lattice_fused.hip - the production dense-lattice kernel (gfx950).
+//
+// One workgroup per ego problem.  The lattice is separable, and the kernel is built around that:
+//
+//   * the longitudinal polynomial s(t) depends on (T, v) only  -> nt*nv "lon profiles"
+//   * the lateral polynomial d(t) depends on (d_end, T) only    -> nd*nt "lat profiles"
+//   * the reference-line frame (position + unit tangent at s(t)) belongs to the lon profile, so the
+//     spline is evaluated nt*nv*N times per ego, not nd*nv*nt*N times (9x fewer at 9x9x7)
+//   * cost_final = (time + lon sums + lat sums) / N recombines per candidate with the reference's grouping
+//
+// Per time-horizon slice i_T (all candidates that share T):
+//   phase A  one wavefront per profile, one lane per time point: quartic/quintic evaluation, ballot for the
+//            speed/accel masks and for the truncation index M (first point off the spline), DPP tree sums
+//            for the cost terms, spline frames of the points the collision horizon can touch -> LDS
+//   phase B  broad phase: every (checked pose of a lon profile) x (obstacle at that time step) pair is tested
+//            with a circle fattened by the largest lateral offset of the slice; lanes run over the contiguous
+//            [time][obstacle] table (conflict-free LDS reads), survivors are compacted with ballot/popcount
+//            into a per-wave LDS queue
+//            narrow phase: the queue is drained 64 lanes at a time, lane = (hit, lateral sample): exact ego
+//            centre + heading, exact circle test, 4-axis separating-axis test (closed: touching collides)
+// Finally one lane per candidate assembles cost + flag word and a wave/LDS argmin with FOP's
+// "last minimum wins" rule picks the winner.
+//
+// Semantics restated from the reference (paths relative to its checkout):
+//   lattice + cost      planners/frenet_optimal_planner.py:69-104, planners/common/cost/cost_function.py:41-50
+//   Frenet->Cartesian   planners/frenet_optimal_planner.py:106-138 (truncation at the spline end :112-113)
+//   constraints         planners/frenet_optimal_planner.py:140-160
+//   collision           planners/frenet_optimal_planner.py:168-208 (stride 2, horizon from obstacles[0], M==1 -> collision)
+//   argmin              planners/frenet_optimal_planner.py:263-268
+#include "frenet_device.h"
+#include "frenet_kernels.h"
+
+namespace fp {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+constexpr int kQueueCap = 192;  // per-wave hit queue: < 64 pending + one full push of 64, rounded up
+
+struct __attribute__((aligned(16))) Frame {  // reference-line frame of one lon-profile point
+    double px, py, tx, ty;
+};
+struct __attribute__((aligned(16))) ObsPose {
+    double x, y, c, s;
+};
+struct __attribute__((aligned(16))) ObsDim {
+    double hl, hw, r, pad;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ void lds_wave_sync()
+{
+    // LDS operations of one wavefront are issued and served in order; this only stops the compiler
+    // from moving queue reads above queue writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS carve-up (all offsets in bytes, 16-byte aligned)
+struct Layout {
+    int knots, coef, dim, pose, frames, lat, dmax, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
+};
+
+__host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
+
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt)
+{
+    Layout L;
+    int o = 0;
+    L.knots = o;    o = align16(o + 8 * nx_max);
+    L.coef = o;     o = align16(o + 64 * nx_max);
+    L.dim = o;      o = align16(o + 32 * n_obs);
+    L.pose = o;     o = align16(o + 32 * rows * n_obs);
+    L.frames = o;   o = align16(o + 32 * nv * hp);
+    L.lat = o;      o = align16(o + 8 * nd * hp);
+    L.dmax = o;     o = align16(o + 8 * hp);
+    L.lon_sum = o;  o = align16(o + 24 * nt * nv);   // sum_v, sum_as, sum_js
+    L.lat_sum = o;  o = align16(o + 24 * nd * nt);   // sum_ad, sum_jd, sum_d
+    L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
+    L.coll = o;     o = align16(o + nd * nv * nt);
+    L.queue = o;    o = align16(o + 4 * kQueueCap * kWaves);
+    L.best = o;     o = align16(o + 16 * kWaves);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    const int nd = p.nd, nv = p.nv, nt = p.nt;
+    const int C = nd * nv * nt;
+    const int stride = p.check_stride;
+    const double tick = p.tick_t;
+
+    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt);
+    double* s_knots = (double*)(smem + L.knots);
+    double* s_coef = (double*)(smem + L.coef);
+    ObsDim* s_dim = (ObsDim*)(smem + L.dim);
+    ObsPose* s_pose = (ObsPose*)(smem + L.pose);
+    Frame* s_frames = (Frame*)(smem + L.frames);
+    double* s_lat = (double*)(smem + L.lat);
+    double* s_dmax = (double*)(smem + L.dmax);
+    double* s_lon_sum = (double*)(smem + L.lon_sum);
+    double* s_lat_sum = (double*)(smem + L.lat_sum);
+    int2* s_lon_meta = (int2*)(smem + L.lon_meta);
+    unsigned char* s_coll = smem + L.coll;
+    uint32_t* s_queue = (uint32_t*)(smem + L.queue) + wave * kQueueCap;
+    Best* s_best = (Best*)(smem + L.best);
+
+    // ---------------------------------------------------------------- stage: ego, spline, obstacle rows
+    const double* eg = bt.ego + (size_t)b * 6;
+    const double s0 = eg[0], s_d0 = eg[1], s_dd0 = eg[2], d0 = eg[3], d_d0 = eg[4], d_dd0 = eg[5];
+    const double target_speed = bt.target_speed[b];
+    const int f = bt.frame_of[b];
+    const int nx = bt.nx[f];
+    {
+        const double* gk = bt.knots + (size_t)f * bt.NX;
+        const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
+        for (int i = tid; i < nx; i += kThreads) s_knots[i] = gk[i];
+        for (int i = tid; i < 8 * nx; i += kThreads) {
+            const int r = i / nx, c = i - r * nx;
+            s_coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
+        }
+    }
+    SplineLds sp{s_knots, s_coef, nx, nx};
+
+    const int sc = bt.scene_of[b];
+    const int n_obs = sc >= 0 ? bt.n_obs : 0;
+    const int t_now = bt.t_now[b];
+    int horizon_cap = 0;  // final_time_step - time_step_now (:173-174)
+    int rows = 0;         // obstacle rows that exist for this ego: poses k = r*stride, k + t_now < T_obs
+    if (n_obs > 0) {
+        horizon_cap = bt.final_time_step[sc] - t_now;
+        int h = horizon_cap < FP_MAX_POINTS ? horizon_cap : FP_MAX_POINTS;
+        if (h < 0) h = 0;
+        rows = (h + stride - 1) / stride;
+        const int in_table = bt.T_obs - t_now;
+        const int rows_tab = in_table > 0 ? (in_table + stride - 1) / stride : 0;
+        if (rows_tab < rows) rows = rows_tab;
+        if (rows > rows_max) rows = rows_max;  // cannot happen: rows_max is the launch-time bound of the same formula
+        const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
+        for (int j = tid; j < n_obs; j += kThreads) {
+            const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
+            s_dim[j] = ObsDim{hl, hw, sqrt(fma(hl, hl, hw * hw)), 0.0};
+        }
+        const double* gp = bt.obs_pose + (size_t)sc * bt.T_obs * n_obs * 4;
+        for (int i = tid; i < rows * n_obs; i += kThreads) {
+            const int r = i / n_obs, j = i - r * n_obs;
+            const double* ps = gp + ((size_t)(r * stride + t_now) * n_obs + j) * 4;
+            ObsPose o{__builtin_nan(""), 0.0, 1.0, 0.0};  // x = NaN: no state at this step (state_at_time -> None)
+            if (ps[3] != 0.0) {
+                o.x = ps[0];
+                o.y = ps[1];
+                sincos(ps[2], &o.s, &o.c);
+            }
+            s_pose[i] = o;
+        }
+    }
+    for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
+    // points whose frame the collision stage can touch: 0 .. hp-1 (pose k needs point k+1 for its heading)
+    const int pose_limit = rows * stride < horizon_cap ? rows * stride : horizon_cap;  // poses k < pose_limit (and k < M)
+    int hp = pose_limit > 0 ? pose_limit + 1 : 0;
+    if (hp > hp_max) hp = hp_max;
+    const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
+    const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
+    __syncthreads();
+
+    const double* v_samples = bt.v_samples + (size_t)b * nv;
+    int qlen = 0;  // wave-uniform length of this wave's hit queue
+
+    for (int it = 0; it < nt; ++it) {
+        const double T = bt.t_samples[it];
+        const int N = arange_len(T, tick);
+        // ------------------------------------------------------------ phase A: profiles of this slice
+        for (int task = wave; task < nv + nd; task += kWaves) {
+            if (task < nv) {
+                const int iv = task;
+                const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
+                double sum_v = 0, sum_as = 0, sum_js = 0;
+                unsigned long long off_lo = 0, off_hi = 0;
+                bool bad_speed = false, bad_accel = false;
+                int seg = -1;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int i = lane + half * kWave;
+                    bool off = false;
+                    if (i < N) {
+                        const double t = (double)i * tick;
+                        double s, s_d, s_dd, s_ddd;
+                        quartic_eval(q, t, s, s_d, s_dd, s_ddd);
+                        const double ev = s_d - target_speed;
+                        sum_v = fma(ev, ev, sum_v);
+                        sum_as = fma(s_dd, s_dd, sum_as);
+                        sum_js = fma(s_ddd, s_ddd, sum_js);
+                        bad_speed |= s_d > p.max_speed;
+                        bad_accel |= fabs(s_dd) > p.max_accel;
+                        seg = spline_segment(sp, s, -1);
+                        off = seg < 0;
+                        if (!off && i < hp) {
+                            Frame fr;
+                            spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
+                            s_frames[iv * hp_max + i] = fr;
+                        }
+                    }
+                    const unsigned long long m = __ballot(off);
+                    if (half == 0) off_lo = m; else off_hi = m;
+                }
+                sum_v = wave_sum(sum_v);
+                sum_as = wave_sum(sum_as);
+                sum_js = wave_sum(sum_js);
+                const bool any_speed = __ballot(bad_speed) != 0ull;
+                const bool any_accel = __ballot(bad_accel) != 0ull;
+                if (lane == 0) {
+                    const int M = off_lo ? __ffsll((long long)off_lo) - 1 : (off_hi ? kWave + __ffsll((long long)off_hi) - 1 : N);
+                    double* o = s_lon_sum + 3 * (it * nv + iv);
+                    o[0] = sum_v; o[1] = sum_as; o[2] = sum_js;
+                    s_lon_meta[it * nv + iv] = make_int2(M, (any_speed ? FP_FLAG_SPEED : 0) | (any_accel ? FP_FLAG_ACCEL : 0));
+                }
+            } else {
+                const int id = task - nv;
+                const Quintic q = quintic_bvp(d0, d_d0, d_dd0, bt.d_samples[id], 0.0, 0.0, T);
+                double sum_ad = 0, sum_jd = 0, sum_d = 0;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int i = lane + half * kWave;
+                    if (i < N) {
+                        const double t = (double)i * tick;
+                        double d, d_d, d_dd, d_ddd;
+                        quintic_eval(q, t, d, d_d, d_dd, d_ddd);
+                        sum_ad = fma(d_dd, d_dd, sum_ad);
+                        sum_jd = fma(d_ddd, d_ddd, sum_jd);
+                        sum_d = fma(d, d, sum_d);
+                        if (i < hp) s_lat[id * hp_max + i] = d;
+                    }
+                }
+                sum_ad = wave_sum(sum_ad);
+                sum_jd = wave_sum(sum_jd);
+                sum_d = wave_sum(sum_d);
+                if (lane == 0) {
+                    double* o = s_lat_sum + 3 * (id * nt + it);
+                    o[0] = sum_ad; o[1] = sum_jd; o[2] = sum_d;
+                }
+            }
+        }
+        __syncthreads();
+        if (n_obs > 0 && hp > 0) {
+            // largest lateral offset of the slice at every stored point: fattens the broad-phase circle
+            for (int i = tid; i < hp && i < N; i += kThreads) {
+                double m = 0.0;
+                for (int id = 0; id < nd; ++id) m = fmax(m, fabs(s_lat[id * hp_max + i]));
+                s_dmax[i] = m;
+            }
+            __syncthreads();
+
+            // -------------------------------------------------------- phase B: collision of this slice
+            // exact narrow phase on up to 64 (hit, lateral sample) pairs taken from the queue tail
+            auto narrow = [&](int n_hits) {
+                const int items = n_hits * nd;
+                for (int base = 0; base < items; base += kWave) {
+                    const int e = base + lane;
+                    if (e < items) {
+                        const int h = e / nd, id = e - h * nd;
+                        const uint32_t code = s_queue[qlen - n_hits + h];
+                        const int iv = code >> 24, r = (code >> 12) & 0xFFF, j = code & 0xFFF;
+                        const int cand = (id * nt + it) * nv + iv;
+                        if (!s_coll[cand]) {
+                            const int k = r * stride;
+                            const int M = s_lon_meta[it * nv + iv].x;
+                            // heading of pose k: forward difference, or the previous one for the last point (:127-129)
+                            const int ka_ = (k + 1 < M) ? k : k - 1;
+                            const Frame f0 = s_frames[iv * hp_max + ka_], f1 = s_frames[iv * hp_max + ka_ + 1];
+                            const double da = s_lat[id * hp_max + ka_], db = s_lat[id * hp_max + ka_ + 1];
+                            double xa, ya, xb, yb;
+                            frenet_to_cartesian(f0.px, f0.py, f0.tx, f0.ty, da, xa, ya);
+                            frenet_to_cartesian(f1.px, f1.py, f1.tx, f1.ty, db, xb, yb);
+                            Obb ego;
+                            step_heading(xb - xa, yb - ya, ego.c, ego.s);
+                            ego.x = (ka_ == k) ? xa : xb;
+                            ego.y = (ka_ == k) ? ya : yb;
+                            ego.hl = veh_hl;
+                            ego.hw = veh_hw;
+                            const ObsPose op = s_pose[r * n_obs + j];
+                            const ObsDim od = s_dim[j];
+                            bool hit;
+                            if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
+                                hit = true;  // polygon construction fails in the reference -> collision (:178-182)
+                            } else {
+                                const double R = (r_ego + od.r) * (1.0 + 1e-12);
+                                const double dx = op.x - ego.x, dy = op.y - ego.y;
+                                hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                            }
+                            if (hit) s_coll[cand] = 1;
+                        }
+                    }
+                }
+            };
+
+            const int hits_per_round = kWave / nd > 0 ? kWave / nd : 1;
+            const int n_items = rows * n_obs;
+            for (int e0 = wave * kWave; e0 < n_items; e0 += kThreads) {
+                const int e = e0 + lane;
+                const bool live = e < n_items;
+                int r = 0, j = 0;
+                double ox = __builtin_nan(""), oy = 0.0, orad = 0.0;
+                if (live) {
+                    r = e / n_obs;
+                    j = e - r * n_obs;
+                    const ObsPose op = s_pose[e];
+                    ox = op.x;
+                    oy = op.y;
+                    orad = s_dim[j].r;
+                }
+                const int k = r * stride;
+                const double fat = live && k < N && k < hp ? (r_ego + orad + s_dmax[k]) * (1.0 + 1e-12) : 0.0;
+                for (int iv = 0; iv < nv; ++iv) {
+                    const int M = s_lon_meta[it * nv + iv].x;
+                    bool pass = false;
+                    if (live && k < M && k < pose_limit && M >= 2) {
+                        const Frame fr = s_frames[iv * hp_max + k];
+                        const double dx = ox - fr.px, dy = oy - fr.py;
+                        const double d2 = fma(dx, dx, dy * dy);
+                        pass = (d2 <= fat * fat) || !(fr.px == fr.px);  // NaN obstacle (no state) never passes; NaN pose always does
+                        pass = pass && (ox == ox);
+                    }
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {
+                        if (pass) {
+                            const int off = __popcll(m & ((1ull << lane) - 1ull));
+                            s_queue[qlen + off] = ((uint32_t)iv << 24) | ((uint32_t)r << 12) | (uint32_t)j;
+                        }
+                        qlen += __popcll(m);
+                        lds_wave_sync();
+                        while (qlen >= hits_per_round) {
+                            narrow(hits_per_round);
+                            qlen -= hits_per_round;
+                        }
+                    }
+                }
+            }
+            if (qlen > 0) {
+                lds_wave_sync();
+                narrow(qlen);
+                qlen = 0;
+            }
+        }
+        __syncthreads();  // frames / lat / dmax are rewritten by the next slice
+    }
+
+    // ---------------------------------------------------------------- per-candidate assembly + argmin
+    Best mine{0.0, -1};
+    for (int c = tid; c < C; c += kThreads) {
+        const int iv = c % nv, it = (c / nv) % nt, id = c / (nv * nt);
+        const double T = bt.t_samples[it];
+        const int N = arange_len(T, tick);
+        const double* ls = s_lon_sum + 3 * (it * nv + iv);
+        const double* ds = s_lat_sum + 3 * (id * nt + it);
+        const int2 meta = s_lon_meta[it * nv + iv];
+        const int M = meta.x;
+        uint32_t flags = (uint32_t)meta.y;
+        bool hit = s_coll[c] != 0;
+        if (n_obs > 0 && M == 1 && horizon_cap >= 1) hit = true;  // traj.yaw is empty -> IndexError -> collision (:178-182)
+        if (hit) flags |= FP_FLAG_COLLISION;
+        if (M < N) flags |= FP_FLAG_TRUNCATED;
+        // cost_function.py:41-50, same grouping as the reference
+        const double cost_time = p.cost_horizon - (double)(N - 1) * tick;
+        const double cost_speed = p.w_speed * ls[0];
+        const double cost_accel = p.w_accel * ls[1] + p.w_accel * ds[0];
+        const double cost_jerk = p.w_jerk * ls[2] + p.w_jerk * ds[1];
+        const double cost_offset = p.w_offset * ds[2];
+        const double cost = (cost_time + 0.0 + cost_speed + cost_accel + cost_jerk + cost_offset) / (double)N;
+        if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = cost;
+        if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+        if (!(flags & FP_FLAG_INFEASIBLE) && cost == cost) mine = best_merge(mine, Best{cost, c});
+    }
+    mine = wave_best(mine);
+    if (lane == 0) s_best[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        Best r = s_best[0];
+        for (int w = 1; w < kWaves; ++w) r = best_merge(r, s_best[w]);
+        ka.r.best_idx[b] = r.idx;
+        ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
+        if (ka.r.stats) {
+            int32_t* st = ka.r.stats + (size_t)b * 4;
+            st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
+        }
+    }
+}
+
+// Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the
+// lane-per-candidate kernel, which keeps oversized obstacle tables in HBM/L2).
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream)
+{
+    const fp_params& p = ka.p;
+    const fp_batch& b = ka.b;
+    if (p.nd > kWave || p.nv > 255 || b.n_obs > 4095) return hipErrorInvalidValue;
+    const int stride = p.check_stride;
+    int rows = 0, hp = 0;
+    if (b.n_obs > 0) {
+        rows = (FP_MAX_POINTS + stride - 1) / stride;
+        const int rows_tab = (b.T_obs + stride - 1) / stride;
+        if (rows_tab < rows) rows = rows_tab;
+        hp = rows * stride + 1;
+        if (hp > FP_MAX_POINTS) hp = FP_MAX_POINTS;
+        if (rows > 4095) return hipErrorInvalidValue;
+    }
+    const Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt);
+    if (L.total > 150 * 1024) return hipErrorInvalidValue;
+    static int configured_bytes = -1;
+    if (L.total > configured_bytes) {
+        hipError_t e = hipFuncSetAttribute((const void*)lattice_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+        if (e != hipSuccess) return e;
+        configured_bytes = L.total;
+    }
+    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B), dim3(kThreads), L.total, stream, ka, rows, hp);
+    return hipGetLastError();
+}
+
+}  // namespace fp

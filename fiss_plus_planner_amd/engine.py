@@ -75,6 +75,10 @@ class FrenetEngine:
             self._lib.fp_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
+    def set_option(self, name: str, value: int):
+        """Diagnostic knobs of the ctx, e.g. set_option("lattice_kernel", 1) pins the lane-per-candidate kernel."""
+        _abi.check(self._lib.fp_ctx_set_option(self._ctx, name.encode(), int(value)))
+
     def __del__(self):
         try:
             self.close()

@@ -303,6 +303,9 @@ class FissPlusPlanner(FissPlanner):
         res = self.sampling_res  # decays in place like the reference (aliases self.sampling_res, :282)
         cand = []  # (cost, order, end_state, flags)
         lo, hi = self.sampling_min, self.sampling_max
+        # The coarse cost is re-evaluated by the same kernel as the refined trajectories: a probe clipped back onto x is
+        # the same trajectory and must tie with it exactly (`cost > coarse cost` ends the validation loop, :303-304).
+        coarse_cost = float(self._engine.eval_trajs(batch, x[None, None]).cost[0, 0])
         for _ in range(st.max_refine_iters):
             probes = np.empty((6, 3)); x_l = []; x_r = []
             for dim in range(3):

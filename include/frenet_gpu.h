@@ -116,6 +116,11 @@ int fp_device_info(int device, char* buf, int buflen, int* compute_units, int64_
 int fp_ctx_create(int device, fp_ctx** out);
 int fp_ctx_destroy(fp_ctx* ctx);
 
+/* Diagnostic knobs.  "lattice_kernel": 0 = auto (default), 1 = lane-per-candidate kernel, 2 = fused
+ * profile-sharing kernel only (fails with FP_EHIP if the problem does not fit it).  Results are identical
+ * (flags / indices exactly, costs to ~1e-13); used by the A/B parity tests and by profiling. */
+int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
+
 /* Dense lattice pass = FrenetOptimalPlanner.plan() for B egos at once:
  *   calc_frenet_paths (:69-104) + CostFunction.cost_total (cost_function.py:41-50)
  *   + calc_global_paths (:106-138) + check_constraints (:140-160)
