@@ -90,6 +90,17 @@ __device__ __forceinline__ int arange_len(double T, double tick)
     return n > 0.0 ? (int)n : 0;
 }
 
+// 1/sqrt(x) to ~1 ulp: hardware seed (v_rsq_f64, ~2^-23 relative) + two Newton steps.
+// Used for the unit tangent / heading vectors; replaces a full sqrt + divide.
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+
 // ---------------------------------------------------------------------------
 // Reference-line spline, staged in LDS as knots[NX] + coef[8][NX].
 // Segment rule = bisect.bisect(knots, s) - 1 (cubic_spline.py:112-116) with the
@@ -134,7 +145,7 @@ __device__ __forceinline__ void spline_frame(const SplineLds& sp, int i, double 
     const double gx = fma(fma(3.0 * dx3, dx, 2.0 * cx), dx, bx);
     const double gy = fma(fma(3.0 * dy3, dx, 2.0 * cy), dx, by);
     // cos/sin(atan2(gy, gx)): normalise the tangent instead of atan2 + sincos
-    const double inv = 1.0 / sqrt(fma(gx, gx, gy * gy));
+    const double inv = rsqrt_nr(fma(gx, gx, gy * gy));
     tx = gx * inv;
     ty = gy * inv;
 }
@@ -175,7 +186,7 @@ __device__ __forceinline__ void step_heading(double dx, double dy, double& c, do
 {
     const double h2 = fma(dx, dx, dy * dy);
     if (h2 > 0.0) {
-        const double inv = 1.0 / sqrt(h2);
+        const double inv = rsqrt_nr(h2);
         c = dx * inv;
         s = dy * inv;
     } else {

@@ -34,7 +34,7 @@ namespace fp {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
 constexpr int kQueueCap = 192;  // per-wave hit queue: < 64 pending + one full push of 64, rounded up
 
@@ -66,7 +66,7 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, dim, pose, frames, lat, dmax, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -77,6 +77,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     int o = 0;
     L.knots = o;    o = align16(o + 8 * nx_max);
     L.coef = o;     o = align16(o + 64 * nx_max);
+    L.lut = o;      o = align16(o + 2 * (2 * nx_max + 1));  // uint16 segment hint per arclength bucket
     L.dim = o;      o = align16(o + 32 * n_obs);
     L.pose = o;     o = align16(o + 32 * rows * n_obs);
     L.frames = o;   o = align16(o + 32 * nv * hp);
@@ -93,6 +94,21 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
 }
 
 }  // namespace
+
+__device__ __forceinline__ double gk_first(const fp_batch& bt, int f) { return bt.knots[(size_t)f * bt.NX]; }
+__device__ __forceinline__ double gk_last(const fp_batch& bt, int f, int nx) { return bt.knots[(size_t)f * bt.NX + nx - 1]; }
+
+// segment of s (known to be inside [knot0, knot_last)) from the bucket table + walk
+__device__ __forceinline__ int lut_segment(const double* knots, const unsigned short* lut, int nx, double s, double knot0,
+                                           double inv_bucket_w, int n_buckets)
+{
+    int bkt = (int)((s - knot0) * inv_bucket_w);
+    bkt = bkt < 0 ? 0 : (bkt > n_buckets ? n_buckets : bkt);
+    int seg = lut[bkt];
+    while (seg > 0 && s < knots[seg]) --seg;            // rounding at a bucket edge
+    while (seg < nx - 2 && s >= knots[seg + 1]) ++seg;  // knots inside the bucket
+    return seg;
+}
 
 __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max)
 {
@@ -111,6 +127,7 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
     const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
+    unsigned short* s_lut = (unsigned short*)(smem + L.lut);
     ObsDim* s_dim = (ObsDim*)(smem + L.dim);
     ObsPose* s_pose = (ObsPose*)(smem + L.pose);
     Frame* s_frames = (Frame*)(smem + L.frames);
@@ -139,6 +156,24 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
         }
     }
     SplineLds sp{s_knots, s_coef, nx, nx};
+    // Arclength buckets -> segment hint: lut[b] = bisect_right(knots, k0 + b*width) - 1, 2*nx buckets.  A point then
+    // needs one table read plus a short walk instead of a log2(nx) search (knots may be non-uniform: the walk fixes it).
+    const int n_buckets = 2 * nx;
+    const double knot0 = gk_first(bt, f), knot_last = gk_last(bt, f, nx);
+    const double bucket_w = (knot_last - knot0) / (double)n_buckets;
+    const double inv_bucket_w = bucket_w > 0.0 ? 1.0 / bucket_w : 0.0;
+    __syncthreads();
+    for (int bkt = tid; bkt <= n_buckets; bkt += kThreads) {
+        const double sb = knot0 + (double)bkt * bucket_w;
+        int lo = 0, hi = nx;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sb < s_knots[mid]) hi = mid; else lo = mid + 1;
+        }
+        int seg = lo - 1;
+        seg = seg < 0 ? 0 : (seg > nx - 2 ? nx - 2 : seg);
+        s_lut[bkt] = (unsigned short)seg;
+    }
 
     const int sc = bt.scene_of[b];
     const int n_obs = sc >= 0 ? bt.n_obs : 0;
@@ -195,7 +230,6 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
                 double sum_v = 0, sum_as = 0, sum_js = 0;
                 unsigned long long off_lo = 0, off_hi = 0;
                 bool bad_speed = false, bad_accel = false;
-                int seg = -1;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int i = lane + half * kWave;
@@ -210,9 +244,9 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
                         sum_js = fma(s_ddd, s_ddd, sum_js);
                         bad_speed |= s_d > p.max_speed;
                         bad_accel |= fabs(s_dd) > p.max_accel;
-                        seg = spline_segment(sp, s, -1);
-                        off = seg < 0;
+                        off = !(s >= knot0) || !(s < knot_last);  // calc_position -> None (cubic_spline.py:56-59)
                         if (!off && i < hp) {
+                            const int seg = lut_segment(s_knots, s_lut, nx, s, knot0, inv_bucket_w, n_buckets);
                             Frame fr;
                             spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
                             s_frames[iv * hp_max + i] = fr;
@@ -270,18 +304,19 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
 
             // -------------------------------------------------------- phase B: collision of this slice
             // exact narrow phase on up to 64 (hit, lateral sample) pairs taken from the queue tail
+            const uint32_t inv_nd = (65536u + (uint32_t)nd - 1u) / (uint32_t)nd;  // e / nd == (e * inv_nd) >> 16 for e < 128
             auto narrow = [&](int n_hits) {
                 const int items = n_hits * nd;
                 for (int base = 0; base < items; base += kWave) {
                     const int e = base + lane;
                     if (e < items) {
-                        const int h = e / nd, id = e - h * nd;
+                        const int h = (int)(((uint32_t)e * inv_nd) >> 16), id = e - h * nd;
                         const uint32_t code = s_queue[qlen - n_hits + h];
                         const int iv = code >> 24, r = (code >> 12) & 0xFFF, j = code & 0xFFF;
                         const int cand = (id * nt + it) * nv + iv;
-                        if (!s_coll[cand]) {
-                            const int k = r * stride;
-                            const int M = s_lon_meta[it * nv + iv].x;
+                        const int k = r * stride;
+                        const int M = s_lon_meta[it * nv + iv].x;
+                        if (k < M && M >= 2 && !s_coll[cand]) {
                             // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                             const int ka_ = (k + 1 < M) ? k : k - 1;
                             const Frame f0 = s_frames[iv * hp_max + ka_], f1 = s_frames[iv * hp_max + ka_ + 1];
@@ -327,17 +362,18 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
                     orad = s_dim[j].r;
                 }
                 const int k = r * stride;
-                const double fat = live && k < N && k < hp ? (r_ego + orad + s_dmax[k]) * (1.0 + 1e-12) : 0.0;
+                // Poses beyond a profile's M hold stale frames: they may pass here and are rejected by the narrow phase
+                // (k < M is tested there), which keeps the per-profile M out of this loop.
+                const bool usable = live && k < N && k < pose_limit && (ox == ox);
+                double fat2 = -1.0;
+                if (usable) {
+                    const double fat = (r_ego + orad + s_dmax[k]) * (1.0 + 1e-12);
+                    fat2 = fat * fat;
+                }
                 for (int iv = 0; iv < nv; ++iv) {
-                    const int M = s_lon_meta[it * nv + iv].x;
-                    bool pass = false;
-                    if (live && k < M && k < pose_limit && M >= 2) {
-                        const Frame fr = s_frames[iv * hp_max + k];
-                        const double dx = ox - fr.px, dy = oy - fr.py;
-                        const double d2 = fma(dx, dx, dy * dy);
-                        pass = (d2 <= fat * fat) || !(fr.px == fr.px);  // NaN obstacle (no state) never passes; NaN pose always does
-                        pass = pass && (ox == ox);
-                    }
+                    const double2 pq = *(const double2*)&s_frames[iv * hp_max + k];
+                    const double dx = ox - pq.x, dy = oy - pq.y;
+                    const bool pass = usable && !(fma(dx, dx, dy * dy) > fat2);  // a NaN pose passes (-> "collision" downstream)
                     const unsigned long long m = __ballot(pass);
                     if (m) {
                         if (pass) {
