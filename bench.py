@@ -49,7 +49,10 @@ def algorithmic_bytes_per_ego(batch, tables: bool) -> float:
     nx = int(batch.nx.max())
     reads = 6 * 8 + 8 + 3 * 4 + batch.nv * 8 + 9 * 8 * nx            # ego, target speed, ids, v samples, spline
     if batch.n_obs:
-        reads += 32 * batch.T_obs * batch.n_obs + 16 * batch.n_obs + 4  # pose table, dims, final_time_step
+        # only the pose rows has_collision() can query: steps t_now, t_now+stride, ... below min(final_time_step, T_obs)
+        horizon = min(int(batch.final_time_step.max()) - int(batch.t_now.min()), batch.T_obs - int(batch.t_now.min()), 128)
+        rows = max(0, (horizon + batch.check_stride - 1) // batch.check_stride)
+        reads += 32 * rows * batch.n_obs + 16 * batch.n_obs + 4         # pose rows, dims, final_time_step
     writes = 4 + 8 + 16                                                   # best idx, best cost, stats
     if tables:
         writes += 12 * batch.C
