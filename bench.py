@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--tables", action="store_true", help="also write the dense cost/flag tables (materialised mode)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-ego plan-cycle latency leg (configs[0])")
     return ap.parse_args()
 
 
@@ -53,7 +54,8 @@ def algorithmic_bytes_per_ego(batch, tables: bool) -> float:
         horizon = min(int(batch.final_time_step.max()) - int(batch.t_now.min()), batch.T_obs - int(batch.t_now.min()), 128)
         rows = max(0, (horizon + batch.check_stride - 1) // batch.check_stride)
         reads += 32 * rows * batch.n_obs + 16 * batch.n_obs + 4         # pose rows, dims, final_time_step
-    writes = 4 + 8 + 16                                                   # best idx, best cost, stats
+    writes = 4 + 8 + 16                                                   # best idx, best cost, stats  (lattice kernel only;
+    #                                                                       the epilogue kernel writes 16 KiB/ego on top)
     if tables:
         writes += 12 * batch.C
     return float(reads + writes)
@@ -103,6 +105,8 @@ def main():
     stats = torch.empty((B, 4), dtype=torch.int32, device=dev)
     cost_tbl = torch.empty((B, C), dtype=torch.float64, device=dev) if args.tables else None
     flag_tbl = torch.empty((B, C), dtype=torch.int32, device=dev) if args.tables else None
+    best_flags = torch.empty(B, dtype=torch.int32, device=dev)
+    best_traj = torch.empty((B, 16, 128), dtype=torch.float64, device=dev)   # winner epilogue output, stays in HBM
     h_idx = torch.empty(B, dtype=torch.int32).pin_memory()
     h_cost = torch.empty(B, dtype=torch.float64).pin_memory()
     eng = FrenetEngine(local_rank)
@@ -112,6 +116,9 @@ def main():
         eng.plan_dense_device(params, fb, best_idx.data_ptr(), best_cost.data_ptr(), stats.data_ptr(),
                               cost_tbl.data_ptr() if args.tables else 0, flag_tbl.data_ptr() if args.tables else 0,
                               stream=stream.cuda_stream)
+
+    def epilogue():
+        eng.winner_trajs_device(params, fb, best_idx.data_ptr(), best_flags.data_ptr(), best_traj.data_ptr(), stream=stream.cuda_stream)
 
     def fetch():
         h_idx.copy_(best_idx, non_blocking=True)
@@ -124,6 +131,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+        epilogue()
         fetch()
     barrier()
 
@@ -133,8 +141,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record(stream)
-        step()
+        step()                    # lattice kernel (the dominant kernel: events bracket exactly this launch)
         ev[k][1].record(stream)
+        epilogue()                # winner series of every ego -> HBM
         fetch()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -173,6 +182,30 @@ def main():
                                   f"OpenMP over egos, {dt:.1f} s; GPU index/cost parity checked on this sample before timing"}
 
 
+    # ---- plan-cycle latency (rank 0, N=1): BASELINE configs[0] - single ego, FOP 5x5x5, DEU_Flensburg-1_1_T-1 closed loop,
+    # timed around plan() exactly where the reference times it (planners/benchmark/planning.py:124-128).  Inputs are the
+    # committed fixture arrays (centerline + the XML's 27 rectangle obstacles), see tests/golden/gen_golden.py:flensburg().
+    plan_cycle = None
+    fixture = os.path.join(ROOT, "tests", "golden", "g5_closed_loop.npz")
+    if rank == 0 and world == 1 and not args.no_latency and os.path.exists(fixture):
+        from fiss_plus_planner_amd import planners as P
+        from fiss_plus_planner_amd.closed_loop import run_closed_loop
+        from fiss_plus_planner_amd.obstacles import ObstacleTable
+        from fiss_plus_planner_amd.vehicle import Vehicle
+
+        g = np.load(fixture)
+        fts = int(g["final_time_step"])
+        table = ObstacleTable(g["obs_pose"][:fts], g["obs_dims"], fts)
+        plan_cycle = {"config": "BASELINE.json configs[0]: single ego, DEU_Flensburg-1_1_T-1, 5x5x5 lattice, 27 dynamic obstacles, closed loop",
+                      "unit": "ms", "timed": "wall time of plan() per cycle, B=1 through the host-buffer C ABI (H2D + kernels + D2H)"}
+        for kind, cls, st in (("FOP", P.FrenetOptimalPlanner, P.FrenetOptimalPlannerSettings), ("FISS+", P.FissPlusPlanner, P.FissPlusPlannerSettings)):
+            pl = cls(st(5, 5, 5), Vehicle(), None, engine=eng)
+            run_closed_loop(pl, g["centerline"], g["init_state"], table, g["goal_center"], max_cycles=3)  # warm-up
+            pl = cls(st(5, 5, 5), Vehicle(), None, engine=eng)
+            res = run_closed_loop(pl, g["centerline"], g["init_state"], table, g["goal_center"])
+            ms = res.plan_seconds * 1e3
+            plan_cycle[kind] = {"p50": float(np.median(ms)), "p90": float(np.percentile(ms, 90)), "cycles": len(ms)}
+
     if rank == 0:
         total_cand = world * B * C * args.steps
         value = total_cand / elapsed
@@ -188,7 +221,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "candidate trajectories/sec (gen+cost+collision)", "value": value, "unit": "candidates/s",
+            "metric": "candidate trajectories/sec (gen+cost+collision) per GPU; plan-cycle p50 latency", "value": value, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {B} egos/GPU x {batch.nd}x{batch.nv}x{batch.nt} lattice "
@@ -206,6 +239,7 @@ def main():
                                   "the kernel executes far fewer (profile sharing, broad phase) - executed-instruction "
                                   "counts from rocprofv3 PMC are in DESIGN.md"},
             "cpu_baseline": cpu_baseline,
+            "plan_cycle_latency": plan_cycle,
         }
         print(json.dumps(line))
     if dist is not None:

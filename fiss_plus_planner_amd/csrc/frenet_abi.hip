@@ -245,6 +245,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     if ((rc = check_params(params)) != FP_OK) return rc;
     if ((rc = check_batch(batch)) != FP_OK) return rc;
     if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");
+    if (result->best_traj && !result->best_flags) return fail(FP_EINVAL, "result.best_traj requires result.best_flags");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t C = (size_t)params->nd * params->nv * params->nt;
@@ -257,6 +258,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.r = *result;
         hipError_t e = fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel);
         if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
+        if (result->best_traj) {
+            e = fp::launch_winner_traj(ka, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
+        }
         return FP_OK;
     }
     if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
@@ -265,6 +270,8 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
                   Arena::padded(sizeof(int32_t) * B * 4);
     if (result->cost_tbl) need += Arena::padded(sizeof(double) * B * C);
     if (result->flag_tbl) need += Arena::padded(sizeof(uint32_t) * B * C);
+    const size_t traj_doubles = result->best_traj ? B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS : 0;
+    need += Arena::padded(sizeof(uint32_t) * B) + Arena::padded(sizeof(double) * traj_doubles);
     if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
     ctx->arena.reset();
     if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
@@ -273,13 +280,68 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     ka.r.stats = result->stats ? (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 4) : nullptr;
     ka.r.cost_tbl = result->cost_tbl ? (double*)ctx->arena.take(sizeof(double) * B * C) : nullptr;
     ka.r.flag_tbl = result->flag_tbl ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B * C) : nullptr;
+    ka.r.best_flags = result->best_flags ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B) : nullptr;
+    ka.r.best_traj = result->best_traj ? (double*)ctx->arena.take(sizeof(double) * traj_doubles) : nullptr;
     hipError_t e = fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel);
     if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
+    if (result->best_traj) {
+        e = fp::launch_winner_traj(ka, ctx->stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(result->best_traj, ka.r.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(result->best_flags, ka.r.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipMemcpyAsync(result->best_idx, ka.r.best_idx, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(result->best_cost, ka.r.best_cost, sizeof(double) * B, hipMemcpyDeviceToHost, ctx->stream));
     if (result->stats) HIP_TRY(hipMemcpyAsync(result->stats, ka.r.stats, sizeof(int32_t) * B * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (result->cost_tbl) HIP_TRY(hipMemcpyAsync(result->cost_tbl, ka.r.cost_tbl, sizeof(double) * B * C, hipMemcpyDeviceToHost, ctx->stream));
     if (result->flag_tbl) HIP_TRY(hipMemcpyAsync(result->flag_tbl, ka.r.flag_tbl, sizeof(uint32_t) * B * C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FP_OK;
+}
+
+int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
+                    double* best_traj, int mem, void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    int rc;
+    if ((rc = check_params(params)) != FP_OK) return rc;
+    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    if (!best_idx || !best_flags || !best_traj) return fail(FP_EINVAL, "best_idx/best_flags/best_traj must not be NULL");
+    if (batch->B == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch->B;
+    const size_t traj_doubles = B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS;
+    fp::KernelArgs ka;
+    ka.p = *params;
+    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (mem == FP_MEM_DEVICE) {
+        ka.b = *batch;
+        ka.r.best_idx = const_cast<int32_t*>(best_idx);
+        ka.r.best_flags = best_flags;
+        ka.r.best_traj = best_traj;
+        hipError_t e = fp::launch_winner_traj(ka, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
+        return FP_OK;
+    }
+    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
+    const int C = params->nd * params->nv * params->nt;
+    for (size_t i = 0; i < B; ++i)
+        if (best_idx[i] >= C) return fail(FP_EINVAL, "best_idx[%zu]=%d out of range", i, best_idx[i]);
+    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(uint32_t) * B) +
+                  Arena::padded(sizeof(double) * traj_doubles);
+    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
+    ctx->arena.reset();
+    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
+    const int32_t* d_idx = nullptr;
+    if ((rc = push(ctx, best_idx, B, &d_idx)) != FP_OK) return rc;
+    ka.r.best_idx = const_cast<int32_t*>(d_idx);
+    ka.r.best_flags = (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B);
+    ka.r.best_traj = (double*)ctx->arena.take(sizeof(double) * traj_doubles);
+    hipError_t e = fp::launch_winner_traj(ka, ctx->stream);
+    if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(best_traj, ka.r.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(best_flags, ka.r.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FP_OK;
 }
@@ -298,7 +360,7 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
     const size_t BK = (size_t)batch->B * K;
     fp::KernelArgs ka;
     ka.p = *params;
-    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr};
+    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;

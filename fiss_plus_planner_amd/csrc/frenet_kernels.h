@@ -21,6 +21,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which);
+// Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
+hipError_t launch_winner_traj(const KernelArgs& ka, hipStream_t stream);
 hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
                              int stride, hipStream_t stream);
 

@@ -92,11 +92,12 @@ class FrenetEngine:
         self.close()
 
     # ------------------------------------------------------------------ host arrays
-    def plan_dense(self, batch: ProblemBatch, tables: bool = True):
+    def plan_dense(self, batch: ProblemBatch, tables: bool = True, winner: bool = False):
         """FrenetOptimalPlanner.plan() for every ego of the batch (reference frenet_optimal_planner.py:247-270).
 
         Returns best_idx [B] (flat (i_d*nt+i_T)*nv+i_v, -1 = none), best_cost [B], stats [B,4] and, with
-        tables=True, cost [B,C] and flags [B,C].
+        tables=True, cost [B,C] and flags [B,C]; with winner=True also best_flags [B] and best_traj [B,16,128]
+        (the argmin's full series, computed by the epilogue kernel of the same call).
         """
         B, Cn = batch.B, batch.C
         out = SimpleNamespace(best_idx=np.empty(B, dtype=np.int32), best_cost=np.empty(B), stats=np.empty((B, 4), dtype=np.int32),
@@ -105,6 +106,10 @@ class FrenetEngine:
         res.best_idx, res.best_cost, res.stats = out.best_idx.ctypes.data, out.best_cost.ctypes.data, out.stats.ctypes.data
         res.cost_tbl = out.cost.ctypes.data if tables else None
         res.flag_tbl = out.flags.ctypes.data if tables else None
+        out.best_flags = np.empty(B, dtype=np.uint32) if winner else None
+        out.best_traj = np.empty((B, 16, TRAJ_STRIDE)) if winner else None
+        res.best_flags = out.best_flags.ctypes.data if winner else None
+        res.best_traj = out.best_traj.ctypes.data if winner else None
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
@@ -125,12 +130,18 @@ class FrenetEngine:
 
     # ------------------------------------------------------------------ resident device memory
     def plan_dense_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_cost: int, stats: int = 0,
-                          cost_tbl: int = 0, flag_tbl: int = 0, stream: int = 0):
+                          cost_tbl: int = 0, flag_tbl: int = 0, stream: int = 0, best_flags: int = 0, best_traj: int = 0):
         """Enqueue the dense pass on `stream`; every argument is a device address (int)."""
         res = _abi.FpResult()
         res.best_idx, res.best_cost = best_idx, best_cost
         res.stats, res.cost_tbl, res.flag_tbl = stats or None, cost_tbl or None, flag_tbl or None
+        res.best_flags, res.best_traj = best_flags or None, best_traj or None
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(params), C.byref(fb), C.byref(res), _abi.FP_MEM_DEVICE, stream or None))
+
+    def winner_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_flags: int, best_traj: int, stream: int = 0):
+        """Enqueue the winner epilogue alone (device addresses)."""
+        _abi.check(self._lib.fp_winner_trajs(self._ctx, C.byref(params), C.byref(fb), best_idx, best_flags, best_traj,
+                                             _abi.FP_MEM_DEVICE, stream or None))
 
     def eval_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, K: int, end_states: int, cost: int, flags: int,
                           traj: int = 0, stream: int = 0):

@@ -179,8 +179,8 @@ class FrenetOptimalPlanner:
         iv, it, i_d = flat % nv, (flat // nv) % nt, flat // (nv * nt)
         return np.array([batch.d_samples[i_d], batch.v_samples[0, iv], batch.t_samples[it]]), (i_d, iv, it)
 
-    def _dense(self, batch: ProblemBatch):
-        out = self._engine.plan_dense(batch, tables=True)
+    def _dense(self, batch: ProblemBatch, winner: bool = False):
+        out = self._engine.plan_dense(batch, tables=True, winner=winner)
         self.last_tables = (out.cost[0], out.flags[0])
         if self.materialize_all:
             es = np.array([self._end_state_of_flat(batch, c)[0] for c in range(batch.C)])
@@ -197,14 +197,13 @@ class FrenetOptimalPlanner:
         self.stats = Stats()
         self.settings.highest_speed = max_target_speed
         batch = self._make_batch(frenet_state, obstacles, time_step_now)
-        out = self._dense(batch)
+        out = self._dense(batch, winner=True)  # one call: lattice kernel + winner epilogue kernel
         C = batch.C
         self.stats = Stats(0, C, C, C)
         best = int(out.best_idx[0])
         if best >= 0:
-            es, (i_d, iv, it) = self._end_state_of_flat(batch, best)
-            trajs, _ = self._materialize(batch, es[None])
-            self.best_traj = trajs[0]
+            _, N, M = unpack_flags(out.best_flags[:1])
+            self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], int(N[0]), int(M[0]), float(out.best_cost[0]))
             self.best_traj.lattice_index = best
         return self.best_traj
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 1
+#define FP_ABI_VERSION 2
 
 /* error codes */
 #define FP_OK 0
@@ -97,13 +97,17 @@ typedef struct {
     const int32_t* final_time_step; /* [S]      obstacles[0].prediction.final_time_step :173 */
 } fp_batch;
 
-/* Outputs of the dense lattice pass; any pointer except best_idx/best_cost may be NULL. */
+/* Outputs of the dense lattice pass; any pointer except best_idx/best_cost may be NULL.
+ * best_traj requires best_flags. */
 typedef struct {
     int32_t* best_idx;   /* [B]     flat FOP index (i_d*nt+i_T)*nv+i_v of the argmin, -1 = no survivor  :263-268 */
     double* best_cost;   /* [B]     its cost_final (NaN when -1) */
     double* cost_tbl;    /* [B][C]  cost_final of every candidate                                       :99 */
     uint32_t* flag_tbl;  /* [B][C]  FP_FLAG_* | N << 8 | M << 20 */
     int32_t* stats;      /* [B][4]  num_iter, generated, validated, collision_checks                    :254-256 */
+    uint32_t* best_flags; /* [B]    flag word (N, M) of the argmin, 0 when best_idx = -1 */
+    double* best_traj;   /* [B][16][FP_MAX_POINTS]  winner epilogue: the argmin's full FrenetTrajectory series (NaN padded;
+                            all NaN when best_idx = -1) = what plan() returns                           :264-270 */
 } fp_result;
 
 int fp_abi_version(void);
@@ -129,6 +133,12 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
  * the index walks read them instead of generating candidates one by one). */
 int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem,
                   void* stream);
+
+/* Winner epilogue on its own: full series of lattice candidate best_idx[b] for every ego -> best_flags [B],
+ * best_traj [B][16][FP_MAX_POINTS].  fp_plan_dense runs it itself when result.best_traj is set; exported separately so a
+ * caller can time / schedule the two kernels independently.  Replaces the object hand-back of plan() (:264-270). */
+int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
+                    double* best_traj, int mem, void* stream);
 
 /* Explicit end states: K trajectories per ego with end state (d_end, v_end, T_end)
  *   = generate_trajectory_by_end_state (fiss_plus_planner.py:172-205) / generate_trajectory

@@ -109,37 +109,16 @@ def test_history_heuristic_and_refinement(engine, kind):
 def _closed_loop(kind, g, engine):
     """planners/benchmark/planning.py:101-162 on the Flensburg fixture inputs."""
     from fiss_plus_planner_amd import planners as P
-    from fiss_plus_planner_amd.frenet import FrenetState, State
+    from fiss_plus_planner_amd.closed_loop import run_closed_loop
     from fiss_plus_planner_amd.obstacles import ObstacleTable
     from fiss_plus_planner_amd.vehicle import Vehicle
 
-    veh = Vehicle()
     cls, st = {"FOP": (P.FrenetOptimalPlanner, P.FrenetOptimalPlannerSettings), "FOP+": (P.FopPlusPlanner, P.FrenetOptimalPlannerSettings),
                "FISS": (P.FissPlanner, P.FissPlannerSettings), "FISS+": (P.FissPlusPlanner, P.FissPlusPlannerSettings)}[kind]
-    pl = cls(st(5, 5, 5), veh, None, engine=engine)
-    _, ref = pl.generate_frenet_frame(g["centerline"])
-    np.testing.assert_allclose(ref, g["refline"], rtol=0, atol=1e-9)
-    init = g["init_state"]
-    cur = FrenetState()
-    cur.from_state(State(t=0.0, x=init[0], y=init[1], yaw=init[2], v=init[3], a=0.0), ref)
+    pl = cls(st(5, 5, 5), Vehicle(), None, engine=engine)
     fts = int(g["final_time_step"])
-    obstacles = ObstacleTable(g["obs_pose"][:fts], g["obs_dims"], fts)
-    rows, states = [], []
-    for i in range(fts):
-        start = [cur.s, cur.s_d, cur.s_dd, cur.d, cur.d_d, cur.d_dd]
-        best = pl.plan(cur, 13.5, obstacles, i)
-        if best is None:
-            break
-        cs = best.state_at_time_step(1)
-        cur = best.frenet_state_at_time_step(1)
-        rows.append(SimpleNamespace(start=start, cost=best.cost_final, N=len(best.t), M=len(best.x), idx=best.idx, stats=pl.stats.as_tuple(),
-                                    end=[best.end_state.d, best.end_state.s_d, best.end_state.t]))
-        states.append([cs.x, cs.y, cs.yaw])
-        if np.hypot(cs.x - g["goal_center"][0], cs.y - g["goal_center"][1]) <= veh.l / 2:
-            break
-        if np.hypot(cs.x - ref[-1, 0], cs.y - ref[-1, 1]) <= 3.0:
-            break
-    return rows, np.array(states)
+    res = run_closed_loop(pl, g["centerline"], g["init_state"], ObstacleTable(g["obs_pose"][:fts], g["obs_dims"], fts), g["goal_center"])
+    return res.cycles, np.array(res.states)
 
 
 @pytest.mark.parametrize("kind", ["FOP", "FOP+", "FISS", "FISS+"])
