@@ -11,7 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 2
+FP_ABI_VERSION = 3
+FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
 FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED, FLAG_INFEASIBLE = 1, 2, 4, 8, 7
@@ -23,7 +24,7 @@ _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option",
-                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs")
+                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss")
 
 
 class FpParams(C.Structure):
@@ -44,6 +45,15 @@ class FpBatch(C.Structure):
 class FpResult(C.Structure):
     _fields_ = [("best_idx", C.c_void_p), ("best_cost", C.c_void_p), ("cost_tbl", C.c_void_p), ("flag_tbl", C.c_void_p),
                 ("stats", C.c_void_p), ("best_flags", C.c_void_p), ("best_traj", C.c_void_p)]
+
+
+class FpFissOpts(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("max_refine_iters", C.c_int32), ("w_heuristic", C.c_double), ("decaying_factor", C.c_double)]
+
+
+class FpFissIo(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("samp_min", "samp_max", "samp_res", "prev_best_idx", "best_ijk", "best_cost", "end_state",
+                                          "refined", "stats", "trace", "best_flags", "best_traj")]
 
 
 class FrenetGpuError(RuntimeError):
@@ -76,6 +86,7 @@ def load() -> C.CDLL:
     L.fp_winner_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fp_eval_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int32, C.c_int, C.c_void_p]
+    L.fp_plan_fiss.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpFissOpts), C.POINTER(FpFissIo), C.c_int, C.c_void_p]
     if L.fp_abi_version() != FP_ABI_VERSION:
         raise ImportError(f"libfrenetgpu ABI {L.fp_abi_version()} != binding {FP_ABI_VERSION}: rebuild")
     _lib = L

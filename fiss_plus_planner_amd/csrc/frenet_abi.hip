@@ -68,7 +68,8 @@ struct Arena {
 struct fp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // used by FP_MEM_HOST calls
-    Arena arena;
+    Arena arena;                   // staging copies of FP_MEM_HOST calls
+    Arena scratch;                 // intermediate tables of multi-kernel entry points (fp_plan_fiss)
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
 };
 
@@ -223,6 +224,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     delete ctx;
     return FP_OK;
 }
@@ -259,7 +261,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         hipError_t e = fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel);
         if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
         if (result->best_traj) {
-            e = fp::launch_winner_traj(ka, (hipStream_t)stream);
+            e = fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream);
             if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
         }
         return FP_OK;
@@ -285,7 +287,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     hipError_t e = fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel);
     if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
     if (result->best_traj) {
-        e = fp::launch_winner_traj(ka, ctx->stream);
+        e = fp::launch_winner_traj(ka, nullptr, ctx->stream);
         if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
         HIP_TRY(hipMemcpyAsync(result->best_traj, ka.r.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipMemcpyAsync(result->best_flags, ka.r.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
@@ -319,7 +321,7 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
         ka.r.best_idx = const_cast<int32_t*>(best_idx);
         ka.r.best_flags = best_flags;
         ka.r.best_traj = best_traj;
-        hipError_t e = fp::launch_winner_traj(ka, (hipStream_t)stream);
+        hipError_t e = fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream);
         if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
         return FP_OK;
     }
@@ -338,11 +340,111 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
     ka.r.best_idx = const_cast<int32_t*>(d_idx);
     ka.r.best_flags = (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B);
     ka.r.best_traj = (double*)ctx->arena.take(sizeof(double) * traj_doubles);
-    hipError_t e = fp::launch_winner_traj(ka, ctx->stream);
+    hipError_t e = fp::launch_winner_traj(ka, nullptr, ctx->stream);
     if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpyAsync(best_traj, ka.r.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(best_flags, ka.r.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FP_OK;
+}
+
+int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, int mem,
+                 void* stream_v)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    int rc;
+    if ((rc = check_params(params)) != FP_OK) return rc;
+    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    if (!opts || !io) return fail(FP_EINVAL, "opts/io is NULL");
+    if (opts->kind != FP_FISS && opts->kind != FP_FISS_PLUS) return fail(FP_EINVAL, "opts.kind must be FP_FISS or FP_FISS_PLUS");
+    if (opts->max_refine_iters < 0 || opts->max_refine_iters * 7 > 64) return fail(FP_ELIMIT, "max_refine_iters must be in 0..9");
+    if (!io->samp_min || !io->samp_max || !io->samp_res || !io->prev_best_idx || !io->best_ijk || !io->best_cost || !io->end_state ||
+        !io->refined || !io->stats)
+        return fail(FP_EINVAL, "fp_fiss_io has a NULL mandatory array");
+    if (io->best_traj && !io->best_flags) return fail(FP_EINVAL, "io.best_traj requires io.best_flags");
+    if (batch->B == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch->B, C = (size_t)params->nd * params->nv * params->nt;
+    const int R = opts->kind == FP_FISS_PLUS ? opts->max_refine_iters : 0;
+    hipStream_t stream = mem == FP_MEM_DEVICE ? (hipStream_t)stream_v : ctx->stream;
+    if (mem != FP_MEM_DEVICE && mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+
+    // dense tables + per-ego dense results live in the scratch arena in both modes
+    const size_t scratch_need = Arena::padded(sizeof(double) * B * C) + Arena::padded(sizeof(uint32_t) * B * C) +
+                                Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(double) * B);
+    if (scratch_need > ctx->scratch.cap) HIP_TRY(hipStreamSynchronize(stream));  // the arena may be reallocated: drain its users
+    if ((rc = ctx->scratch.reserve(scratch_need)) != FP_OK) return rc;
+    ctx->scratch.reset();
+    fp::FissArgs fa;
+    fa.ka.p = *params;
+    fa.opts = *opts;
+    fa.opts.max_refine_iters = R;
+    fa.ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fa.ka.r.cost_tbl = (double*)ctx->scratch.take(sizeof(double) * B * C);
+    fa.ka.r.flag_tbl = (uint32_t*)ctx->scratch.take(sizeof(uint32_t) * B * C);
+    fa.ka.r.best_idx = (int32_t*)ctx->scratch.take(sizeof(int32_t) * B);
+    fa.ka.r.best_cost = (double*)ctx->scratch.take(sizeof(double) * B);
+    fa.cost_tbl = fa.ka.r.cost_tbl;
+    fa.flag_tbl = fa.ka.r.flag_tbl;
+    const size_t traj_doubles = io->best_traj ? B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS : 0;
+    const size_t trace_doubles = (io->trace && R > 0) ? B * (size_t)R * 7 * 4 : 0;
+    if (mem == FP_MEM_DEVICE) {
+        fa.ka.b = *batch;
+        if (!(batch->S > 0 && batch->n_obs > 0)) fa.ka.b.n_obs = 0;
+        fa.io = *io;
+    } else {
+        if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
+        size_t need = batch_bytes(params, batch) + 3 * Arena::padded(sizeof(double) * B * 3) + 2 * Arena::padded(sizeof(int32_t) * B * 3) +
+                      Arena::padded(sizeof(double) * B) + Arena::padded(sizeof(double) * B * 3) + Arena::padded(sizeof(int32_t) * B) +
+                      Arena::padded(sizeof(int32_t) * B * 4) + Arena::padded(sizeof(double) * trace_doubles) +
+                      Arena::padded(sizeof(uint32_t) * B) + Arena::padded(sizeof(double) * traj_doubles);
+        if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
+        ctx->arena.reset();
+        if ((rc = stage_batch(ctx, params, batch, &fa.ka.b)) != FP_OK) return rc;
+        fa.io = *io;
+        if ((rc = push(ctx, io->samp_min, B * 3, &fa.io.samp_min)) != FP_OK) return rc;
+        if ((rc = push(ctx, io->samp_max, B * 3, &fa.io.samp_max)) != FP_OK) return rc;
+        if ((rc = push(ctx, io->samp_res, B * 3, &fa.io.samp_res)) != FP_OK) return rc;
+        const int32_t* d_prev = nullptr;
+        if ((rc = push(ctx, (const int32_t*)io->prev_best_idx, B * 3, &d_prev)) != FP_OK) return rc;
+        fa.io.prev_best_idx = const_cast<int32_t*>(d_prev);
+        fa.io.best_ijk = (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 3);
+        fa.io.best_cost = (double*)ctx->arena.take(sizeof(double) * B);
+        fa.io.end_state = (double*)ctx->arena.take(sizeof(double) * B * 3);
+        fa.io.refined = (int32_t*)ctx->arena.take(sizeof(int32_t) * B);
+        fa.io.stats = (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 4);
+        fa.io.trace = trace_doubles ? (double*)ctx->arena.take(sizeof(double) * trace_doubles) : nullptr;
+        fa.io.best_flags = io->best_flags ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B) : nullptr;
+        fa.io.best_traj = io->best_traj ? (double*)ctx->arena.take(sizeof(double) * traj_doubles) : nullptr;
+    }
+    if (!(io->trace && R > 0)) fa.io.trace = nullptr;
+    hipError_t e = fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel);
+    if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
+    e = fp::launch_fiss_search(fa, stream);
+    if (e != hipSuccess) return fail(FP_EHIP, "search kernel launch failed: %s", hipGetErrorString(e));
+    if (R > 0) {
+        e = fp::launch_fiss_refine(fa, stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "refinement kernel launch failed: %s", hipGetErrorString(e));
+    }
+    if (fa.io.best_traj) {
+        fp::KernelArgs kw = fa.ka;
+        kw.r.best_flags = fa.io.best_flags;
+        kw.r.best_traj = fa.io.best_traj;
+        e = fp::launch_winner_traj(kw, fa.io.end_state, stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
+    }
+    if (mem == FP_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(io->prev_best_idx, fa.io.prev_best_idx, sizeof(int32_t) * B * 3, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(io->best_ijk, fa.io.best_ijk, sizeof(int32_t) * B * 3, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(io->best_cost, fa.io.best_cost, sizeof(double) * B, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(io->end_state, fa.io.end_state, sizeof(double) * B * 3, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(io->refined, fa.io.refined, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(io->stats, fa.io.stats, sizeof(int32_t) * B * 4, hipMemcpyDeviceToHost, stream));
+        if (trace_doubles) HIP_TRY(hipMemcpyAsync(io->trace, fa.io.trace, sizeof(double) * trace_doubles, hipMemcpyDeviceToHost, stream));
+        if (io->best_flags) HIP_TRY(hipMemcpyAsync(io->best_flags, fa.io.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, stream));
+        if (io->best_traj) HIP_TRY(hipMemcpyAsync(io->best_traj, fa.io.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     return FP_OK;
 }
 
@@ -372,6 +474,7 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
     if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
     for (size_t i = 0; i < BK; ++i) {
         const double n = end_states[3 * i + 2] / params->tick_t;
+        if (n != n) continue;  // NaN end state = "no trajectory": the kernels emit NaN cost / all-NaN series
         if (!(n > 0) || n > FP_MAX_POINTS) return fail(FP_ELIMIT, "end_states[%zu].T=%g needs 1..FP_MAX_POINTS points", i, end_states[3 * i + 2]);
     }
     const size_t traj_doubles = traj ? BK * FP_ARR_COUNT * (size_t)stride : 0;

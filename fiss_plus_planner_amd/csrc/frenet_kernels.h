@@ -17,12 +17,27 @@ struct KernelArgs {
 
 // Production dense-lattice kernel (profile sharing + compacted collision).  Returns hipErrorInvalidValue when the
 // problem does not fit it (LDS budget / index widths); launch_lattice then uses the lane-per-candidate kernel.
+// Arguments of the FISS / FISS+ batch kernels: the lattice arguments plus the dense tables and the fp_fiss_io arrays.
+struct FissArgs {
+    KernelArgs ka;
+    fp_fiss_opts opts;
+    fp_fiss_io io;
+    const double* cost_tbl;    // [B][C] flat FOP order
+    const uint32_t* flag_tbl;  // [B][C]
+};
+
+// One wavefront per ego: coarse FISS / FISS+ search over the dense tables.
+hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream);
+// One wavefront per ego: FISS+ refinement rounds + cost-ordered validation of the refined trajectories.
+hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream);
+
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which);
 // Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
-hipError_t launch_winner_traj(const KernelArgs& ka, hipStream_t stream);
+// end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
+hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);
 hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
                              int stride, hipStream_t stream);
 

@@ -128,6 +128,36 @@ class FrenetEngine:
                                            traj.ctypes.data if dump else None, TRAJ_STRIDE, _abi.FP_MEM_HOST, None))
         return SimpleNamespace(cost=cost, flags=flags, traj=traj)
 
+    def plan_fiss(self, batch: ProblemBatch, kind: str = "FISS+", prev_best_idx: np.ndarray | None = None, w_heuristic: float = 10.0,
+                  max_refine_iters: int = 3, decaying_factor: float = 0.5, winner: bool = False, trace: bool = False):
+        """FissPlanner.plan / FissPlusPlanner.plan for every ego of the batch, entirely on the device (fp_plan_fiss):
+        dense tables -> per-ego search walk -> (FISS+) refinement -> optional winner series.
+
+        batch.d_samples must be the FISS lattice (max_road_width - w + 0.3) and batch.samp_min/max/res must be set.
+        prev_best_idx [B,3] (-1 = None) is not modified; the updated copy is returned.
+        """
+        B = batch.B
+        plus = kind in ("FISS+", _abi.FP_FISS_PLUS)
+        R = max_refine_iters if plus else 0
+        prev = np.full((B, 3), -1, dtype=np.int32) if prev_best_idx is None else np.ascontiguousarray(prev_best_idx, dtype=np.int32).copy()
+        out = SimpleNamespace(prev_best_idx=prev, best_ijk=np.empty((B, 3), dtype=np.int32), best_cost=np.empty(B), end_state=np.empty((B, 3)),
+                              refined=np.empty(B, dtype=np.int32), stats=np.empty((B, 4), dtype=np.int32),
+                              trace=np.empty((B, max(R, 1) * 7, 4)) if trace and R > 0 else None,
+                              best_flags=np.empty(B, dtype=np.uint32) if winner else None,
+                              best_traj=np.empty((B, 16, TRAJ_STRIDE)) if winner else None)
+        opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
+        io = _abi.FpFissIo()
+        io.samp_min, io.samp_max, io.samp_res = batch.samp_min.ctypes.data, batch.samp_max.ctypes.data, batch.samp_res.ctypes.data
+        io.prev_best_idx, io.best_ijk, io.best_cost = prev.ctypes.data, out.best_ijk.ctypes.data, out.best_cost.ctypes.data
+        io.end_state, io.refined, io.stats = out.end_state.ctypes.data, out.refined.ctypes.data, out.stats.ctypes.data
+        io.trace = out.trace.ctypes.data if out.trace is not None else None
+        io.best_flags = out.best_flags.ctypes.data if winner else None
+        io.best_traj = out.best_traj.ctypes.data if winner else None
+        p = make_params(batch)
+        fb = _host_batch(batch)
+        _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(p), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_HOST, None))
+        return out
+
     # ------------------------------------------------------------------ resident device memory
     def plan_dense_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_cost: int, stats: int = 0,
                           cost_tbl: int = 0, flag_tbl: int = 0, stream: int = 0, best_flags: int = 0, best_traj: int = 0):
@@ -142,6 +172,10 @@ class FrenetEngine:
         """Enqueue the winner epilogue alone (device addresses)."""
         _abi.check(self._lib.fp_winner_trajs(self._ctx, C.byref(params), C.byref(fb), best_idx, best_flags, best_traj,
                                              _abi.FP_MEM_DEVICE, stream or None))
+
+    def plan_fiss_device(self, params: _abi.FpParams, fb: _abi.FpBatch, opts: _abi.FpFissOpts, io: _abi.FpFissIo, stream: int = 0):
+        """Enqueue the whole FISS / FISS+ pipeline (lattice, search, refinement, winner series); device addresses in `io`."""
+        _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(params), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_DEVICE, stream or None))
 
     def eval_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, K: int, end_states: int, cost: int, flags: int,
                           traj: int = 0, stream: int = 0):

@@ -235,8 +235,13 @@ class FissPlanner(FrenetOptimalPlanner):
     KIND = "FISS"
     _search = staticmethod(search.fiss_search)
 
-    def __init__(self, planner_settings: FissPlannerSettings, ego_vehicle: Vehicle, scenario=None, **kw):
+    def __init__(self, planner_settings: FissPlannerSettings, ego_vehicle: Vehicle, scenario=None, *, search_on: str = "device", **kw):
+        """search_on="device": the whole plan() is one fp_plan_fiss call (lattice, search walk, refinement and winner series
+        all on the GPU); "host": dense tables from the GPU, the index walk replayed in Python (search.py) - same results,
+        kept as an independent cross-check."""
         super().__init__(planner_settings, ego_vehicle, scenario, **kw)
+        assert search_on in ("device", "host")
+        self.search_on = search_on
         self.sampling_res = np.empty(3)
         self.sampling_min = np.empty(3)
         self.sampling_max = np.empty(3)
@@ -260,7 +265,38 @@ class FissPlanner(FrenetOptimalPlanner):
         self.stats = Stats(*st)
         return batch, idx
 
+    def _plan_on_device(self, frenet_state, max_target_speed, obstacles, time_step_now):
+        """plan() as ONE C-ABI call: fp_plan_fiss (reference fiss_planner.py:190-270 / fiss_plus_planner.py:61-170)."""
+        self.stats = Stats()
+        self.settings.highest_speed = max_target_speed
+        self.start_state = frenet_state
+        self.best_traj = None
+        batch = self._make_batch(frenet_state, obstacles, time_step_now)
+        self.sampling_min, self.sampling_max, self.sampling_res = batch.samp_min[0].copy(), batch.samp_max[0].copy(), batch.samp_res[0].copy()
+        self.sizes = np.array([batch.nd, batch.nv, batch.nt])
+        st = self.settings
+        plus = self.KIND == "FISS+"
+        R = st.max_refine_iters if (plus and st.refine_trajectory) else 0
+        prev = None if self.prev_best_idx is None else np.asarray(self.prev_best_idx, dtype=np.int32)[None]
+        out = self._engine.plan_fiss(batch, self.KIND, prev_best_idx=prev, w_heuristic=st.w_heuristic, max_refine_iters=R,
+                                     decaying_factor=getattr(st, "decaying_factor", 0.5), winner=True)
+        self.stats = Stats(*[int(v) for v in out.stats[0]])
+        self.all_trajs.append([])
+        if plus and R > 0 and not np.isnan(out.best_cost[0]):
+            self.sampling_res = self.sampling_res * st.decaying_factor ** R  # decays in place in the reference (:282)
+        if np.isnan(out.best_cost[0]):
+            return None
+        self.prev_best_idx = out.prev_best_idx[0].copy()
+        _, N, M = unpack_flags(out.best_flags[:1])
+        es = out.end_state[0]
+        end = FrenetState(t=es[2], s=0.0, s_d=es[1], d=es[0])
+        idx = np.array([-1, -1, -1]) if out.refined[0] else out.best_ijk[0].copy()
+        self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], int(N[0]), int(M[0]), float(out.best_cost[0]), end, idx)
+        return self.best_traj
+
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
+        if self.search_on == "device":
+            return self._plan_on_device(frenet_state, max_target_speed, obstacles, time_step_now)
         batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
         if idx is None:
             return None
@@ -278,6 +314,8 @@ class FissPlusPlanner(FissPlanner):
     _search = staticmethod(search.fissplus_search)
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
+        if self.search_on == "device":
+            return self._plan_on_device(frenet_state, max_target_speed, obstacles, time_step_now)
         batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
         if idx is None:
             return None

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 2
+#define FP_ABI_VERSION 3
 
 /* error codes */
 #define FP_OK 0
@@ -148,6 +148,45 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
  * FISS+ refinement, all_trajs visualisation payload). */
 int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states,
                   double* cost, uint32_t* flags, double* traj, int32_t stride, int mem, void* stream);
+
+/* ---- FISS / FISS+ for a whole batch, entirely on the device --------------------------------------------------
+ * fp_plan_fiss = FissPlanner.plan (fiss_planner.py:190-270) or FissPlusPlanner.plan (fiss_plus_planner.py:61-170)
+ * for B egos: dense lattice tables (fp_plan_dense kernels) -> one wavefront per ego replays the reference's
+ * visiting order over the tables (initial guess :140-150, gradient walk :152-188 / frontier search
+ * fiss_plus_planner.py:30-59,106-116, cost-ordered validation :229-258) -> FISS+ only: refinement
+ * (gradient_decent :207-277, refine_solution :279-326; 6 probes + 1 step per round, all rounds in one launch).
+ * Tie rule: exact cost ties resolve to the lower (i_d, i_v, i_t) raster index (the reference raises ValueError).
+ * The wall-clock `time_limit` of refine_solution is never applied. */
+#define FP_FISS 0
+#define FP_FISS_PLUS 1
+
+typedef struct {
+    int32_t kind;              /* FP_FISS or FP_FISS_PLUS */
+    int32_t max_refine_iters;  /* FissPlusPlannerSettings.max_refine_iters (3); 0 = no refinement */
+    double w_heuristic;        /* FissPlannerSettings.w_heuristic (10.0)          fiss_planner.py:16 */
+    double decaying_factor;    /* FissPlusPlannerSettings.decaying_factor (0.5)   fiss_plus_planner.py:22 */
+} fp_fiss_opts;
+
+typedef struct {
+    /* inputs, order (d, v, t): sampling_min / sampling_max / np.linspace retstep   fiss_planner.py:45-47,57-59,67-69 */
+    const double* samp_min;    /* [B][3] */
+    const double* samp_max;    /* [B][3] */
+    const double* samp_res;    /* [B][3] */
+    int32_t* prev_best_idx;    /* [B][3] in/out, -1 = None; updated to the coarse winner           :30,:252 / :140 */
+    /* outputs */
+    int32_t* best_ijk;         /* [B][3] coarse winner (i_d, i_v, i_t), -1 = none */
+    double* best_cost;         /* [B]    cost_final of the returned trajectory (NaN = none) */
+    double* end_state;         /* [B][3] (d, v, T) of the returned trajectory (refined or lattice) */
+    int32_t* refined;          /* [B]    1 when a refined trajectory replaced the coarse winner (its idx is [-1,-1,-1]) */
+    int32_t* stats;            /* [B][4] num_iter, generated, validated, collision_checks (incl. refinement) */
+    double* trace;             /* NULL or [B][max_refine_iters*7][4] = d, v, T, cost of every refinement trajectory */
+    uint32_t* best_flags;      /* NULL or [B] flag word (N, M) of the returned trajectory */
+    double* best_traj;         /* NULL or [B][16][FP_MAX_POINTS] its full series (requires best_flags) */
+} fp_fiss_io;
+
+/* In FP_MEM_DEVICE mode the ctx grows an internal scratch arena (dense tables, B*C*12 bytes) on first use. */
+int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io,
+                 int mem, void* stream);
 
 #ifdef __cplusplus
 }

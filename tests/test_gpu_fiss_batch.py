@@ -1,0 +1,104 @@
+"""GPU: the device-side FISS / FISS+ batch pipeline (fp_plan_fiss: lattice tables -> search-walk kernel ->
+refinement kernel -> winner series) against the reference goldens and the CPU oracle.
+
+Bars: selected index, Stats, prev_best_idx exact; costs / end states / refinement trace within 1e-6 (observed ~1e-12).
+"""
+import numpy as np
+import pytest
+
+from conftest import batch_from_golden, load_golden
+from fiss_plus_planner_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _g4_keys(kind):
+    import os
+    from conftest import GOLDEN
+    p = os.path.join(GOLDEN, "g4_plan.npz")
+    if not os.path.exists(p):
+        return []
+    return [str(n) for n in np.load(p)["names"] if str(n).endswith("_" + kind)]
+
+
+@pytest.mark.parametrize("key", _g4_keys("FISS") + _g4_keys("FISS+"))
+def test_batch_pipeline_matches_reference_g4(engine, key):
+    g = load_golden("g4_plan.npz")
+    b = batch_from_golden(g, f"{key}_in_")
+    kind = key.rsplit("_", 1)[1]
+    out = engine.plan_fiss(b, kind, trace=True, winner=True)
+    found = g[f"{key}_found"]
+    np.testing.assert_array_equal(out.stats, g[f"{key}_stats"])
+    np.testing.assert_array_equal(~np.isnan(out.best_cost), found)
+    np.testing.assert_array_equal(out.prev_best_idx, g[f"{key}_prev_out"])
+    for e in range(b.B):
+        if not found[e]:
+            assert (out.best_ijk[e] == -1).all() and np.isnan(out.best_traj[e]).all()
+            continue
+        assert abs(out.best_cost[e] - g[f"{key}_cost"][e]) < TOL
+        np.testing.assert_allclose(out.end_state[e], g[f"{key}_end"][e], rtol=0, atol=1e-9)
+        want_idx = g[f"{key}_idx"][e]
+        assert bool(out.refined[e]) == bool(want_idx[0] < 0)
+        if not out.refined[e]:
+            np.testing.assert_array_equal(out.best_ijk[e], want_idx)
+        if kind == "FISS+":
+            tr = g[f"{key}_trace"][e]
+            n = int((~np.isnan(tr[:, 0])).sum())
+            np.testing.assert_allclose(out.trace[e, :n], tr[:n], rtol=0, atol=1e-8)
+            assert np.isnan(out.trace[e, n:]).all()
+        # winner series vs the reference's trajectory object
+        NM = g[f"{key}_NM"][e]
+        fl = int(out.best_flags[e])
+        assert ((fl >> 8) & 0xFFF, fl >> 20) == (NM[0], NM[1])
+        want = g[f"{key}_win"][e]
+        got = out.best_traj[e]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        m = ~np.isnan(want)
+        np.testing.assert_allclose(got[:12][m[:12]], want[:12][m[:12]], rtol=0, atol=TOL)
+        np.testing.assert_allclose(got[m], want[m], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["FISS", "FISS+"])
+def test_batch_pipeline_history_heuristic_g6(engine, kind):
+    g = load_golden("g6_fiss_search.npz")
+    b = batch_from_golden(g, "in_")
+    out = engine.plan_fiss(b, kind, prev_best_idx=g["prev_in"])
+    np.testing.assert_array_equal(out.stats, g[f"{kind}_stats"])
+    found = g[f"{kind}_found"]
+    np.testing.assert_array_equal(~np.isnan(out.best_cost), found)
+    np.testing.assert_allclose(out.best_cost[found], g[f"{kind}_cost"][found], rtol=0, atol=TOL)
+    np.testing.assert_allclose(out.end_state[found], g[f"{kind}_end"][found], rtol=0, atol=1e-9)
+    # the reference leaves prev_best_idx untouched when nothing is found
+    want_prev = np.where(found[:, None], g[f"{kind}_prev_out"], g["prev_in"])
+    np.testing.assert_array_equal(out.prev_best_idx, want_prev)
+
+
+@pytest.mark.parametrize("cfg", [dict(B=24, nd=9, nv=9, nt=7, n_obs=50, T_obs=50, moving=True, seed=51),
+                                 dict(B=16, nd=5, nv=5, nt=5, n_obs=10, T_obs=100, moving=False, seed=52),
+                                 dict(B=6, nd=4, nv=3, nt=2, n_obs=0, T_obs=0, moving=False, seed=53)])
+@pytest.mark.parametrize("kind", ["FISS", "FISS+"])
+def test_batch_pipeline_vs_oracle(oracle, engine, cfg, kind):
+    b = synth.make_batch(cfg["B"], cfg["nd"], cfg["nv"], cfg["nt"], cfg["n_obs"], cfg["T_obs"], cfg["moving"], cfg["seed"], kind=kind)
+    rng = np.random.default_rng(cfg["seed"])
+    prev = np.where(rng.uniform(size=(b.B, 1)) < 0.5, -1, np.column_stack([rng.integers(0, b.nd, b.B), rng.integers(0, b.nv, b.B),
+                                                                          rng.integers(0, b.nt, b.B)])).astype(np.int32)
+    out = engine.plan_fiss(b, kind, prev_best_idx=prev, trace=True)
+    probs = oracle.problems_from_batch(b)
+    for e, p in enumerate(probs):
+        pv = None if prev[e, 0] < 0 else prev[e]
+        r = p.fiss_plan(pv) if kind == "FISS" else p.fissplus_plan(pv)
+        np.testing.assert_array_equal(out.stats[e], r.stats, err_msg=f"ego {e}")
+        found = not np.isnan(r.best_cost)
+        assert (not np.isnan(out.best_cost[e])) == found
+        np.testing.assert_array_equal(out.prev_best_idx[e], r.prev_best_idx)
+        if not found:
+            continue
+        assert abs(out.best_cost[e] - r.best_cost) < TOL
+        if kind == "FISS":
+            np.testing.assert_array_equal(out.best_ijk[e], r.best_ijk)
+        else:
+            assert bool(out.refined[e]) == r.refined
+            np.testing.assert_allclose(out.end_state[e], r.end_state, rtol=0, atol=1e-9)
+            n = int((~np.isnan(r.trace.reshape(-1, 4)[:, 0])).sum())
+            np.testing.assert_allclose(out.trace[e, :n], r.trace.reshape(-1, 4)[:n], rtol=0, atol=1e-8)

@@ -16,7 +16,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6
 
 
-def _planner(kind, b, engine, refine_iters=3):
+@pytest.fixture(params=["device", "host"])
+def search_on(request):
+    """FISS / FISS+ drop-ins run their index walk either on the GPU (fp_plan_fiss) or in Python over GPU tables."""
+    return request.param
+
+
+def _planner(kind, b, engine, refine_iters=3, search_on="device"):
     from fiss_plus_planner_amd import planners as P
     from fiss_plus_planner_amd.vehicle import Vehicle, vw_vanagon_params
 
@@ -26,7 +32,8 @@ def _planner(kind, b, engine, refine_iters=3):
     veh = Vehicle(vp)
     cls, st = {"FOP": (P.FrenetOptimalPlanner, P.FrenetOptimalPlannerSettings), "FOP+": (P.FopPlusPlanner, P.FrenetOptimalPlannerSettings),
                "FISS": (P.FissPlanner, P.FissPlannerSettings), "FISS+": (P.FissPlusPlanner, P.FissPlusPlannerSettings)}[kind]
-    return cls(st(b.nd, b.nv, b.nt), veh, None, engine=engine)
+    kw = {"search_on": search_on} if kind in ("FISS", "FISS+") else {}
+    return cls(st(b.nd, b.nv, b.nt), veh, None, engine=engine, **kw)
 
 
 def _inputs(b, e):
@@ -63,12 +70,14 @@ def _g4_keys():
 
 
 @pytest.mark.parametrize("key", _g4_keys())
-def test_plan_matches_reference(engine, key):
+def test_plan_matches_reference(engine, key, search_on):
     g = load_golden("g4_plan.npz")
     b = batch_from_golden(g, f"{key}_in_")
     kind = key.rsplit("_", 1)[1]
+    if kind in ("FOP", "FOP+") and search_on == "host":
+        pytest.skip("FOP/FOP+ have a single code path")
     for e in range(b.B):
-        pl = _planner(kind, b, engine)
+        pl = _planner(kind, b, engine, search_on=search_on)
         pts, fs, obs = _inputs(b, e)
         pl.generate_frenet_frame(pts)
         best = pl.plan(fs, float(b.target_speed[e]), obs, int(b.t_now[e]))
@@ -88,11 +97,11 @@ def test_plan_matches_reference(engine, key):
 
 
 @pytest.mark.parametrize("kind", ["FISS", "FISS+"])
-def test_history_heuristic_and_refinement(engine, kind):
+def test_history_heuristic_and_refinement(engine, kind, search_on):
     g = load_golden("g6_fiss_search.npz")
     b = batch_from_golden(g, "in_")
     for e in range(b.B):
-        pl = _planner(kind, b, engine)
+        pl = _planner(kind, b, engine, search_on=search_on)
         pts, fs, obs = _inputs(b, e)
         pl.generate_frenet_frame(pts)
         prev = g["prev_in"][e]
@@ -106,7 +115,7 @@ def test_history_heuristic_and_refinement(engine, kind):
             np.testing.assert_array_equal(pl.prev_best_idx, g[f"{kind}_prev_out"][e])
 
 
-def _closed_loop(kind, g, engine):
+def _closed_loop(kind, g, engine, search_on="device"):
     """planners/benchmark/planning.py:101-162 on the Flensburg fixture inputs."""
     from fiss_plus_planner_amd import planners as P
     from fiss_plus_planner_amd.closed_loop import run_closed_loop
@@ -115,19 +124,22 @@ def _closed_loop(kind, g, engine):
 
     cls, st = {"FOP": (P.FrenetOptimalPlanner, P.FrenetOptimalPlannerSettings), "FOP+": (P.FopPlusPlanner, P.FrenetOptimalPlannerSettings),
                "FISS": (P.FissPlanner, P.FissPlannerSettings), "FISS+": (P.FissPlusPlanner, P.FissPlusPlannerSettings)}[kind]
-    pl = cls(st(5, 5, 5), Vehicle(), None, engine=engine)
+    kw = {"search_on": search_on} if kind in ("FISS", "FISS+") else {}
+    pl = cls(st(5, 5, 5), Vehicle(), None, engine=engine, **kw)
     fts = int(g["final_time_step"])
     res = run_closed_loop(pl, g["centerline"], g["init_state"], ObstacleTable(g["obs_pose"][:fts], g["obs_dims"], fts), g["goal_center"])
     return res.cycles, np.array(res.states)
 
 
 @pytest.mark.parametrize("kind", ["FOP", "FOP+", "FISS", "FISS+"])
-def test_flensburg_closed_loop(engine, kind):
+def test_flensburg_closed_loop(engine, kind, search_on):
     g = load_golden("g5_closed_loop.npz")
     if f"{kind}_rows" not in g.files:
         pytest.skip(f"no closed-loop golden for {kind}")
+    if kind in ("FOP", "FOP+") and search_on == "host":
+        pytest.skip("FOP/FOP+ have a single code path")
     want = g[f"{kind}_rows"]
-    rows, states = _closed_loop(kind, g, engine)
+    rows, states = _closed_loop(kind, g, engine, search_on)
     assert len(rows) == len(want)
     for i, (r, w) in enumerate(zip(rows, want)):
         np.testing.assert_allclose(r.start, w[0:6], rtol=0, atol=1e-7, err_msg=f"cycle {i} start state")
