@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--egos", type=int, default=2048, help="egos per GPU")
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[N-1]; 4 = the FISS+ pipeline (dense tables + search walk + 3 refinement rounds)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--tables", action="store_true", help="also write the dense cost/flag tables (materialised mode)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-ego plan-cycle latency leg (configs[0])")
@@ -112,16 +113,40 @@ def main():
     eng = FrenetEngine(local_rank)
     stream = torch.cuda.current_stream(dev)
 
-    def step():
+    fiss = args.config == 4
+    if fiss:
+        from fiss_plus_planner_amd import _abi
+
+        f_t = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in ("samp_min", "samp_max", "samp_res")}
+        prev = torch.full((B, 3), -1, dtype=torch.int32, device=dev)
+        ijk = torch.empty((B, 3), dtype=torch.int32, device=dev)
+        end_state = torch.empty((B, 3), dtype=torch.float64, device=dev)
+        refined = torch.empty(B, dtype=torch.int32, device=dev)
+        opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS, 3, 10.0, 0.5)
+        io = _abi.FpFissIo()
+        io.samp_min, io.samp_max, io.samp_res = (f_t[k].data_ptr() for k in ("samp_min", "samp_max", "samp_res"))
+        io.prev_best_idx, io.best_ijk, io.best_cost, io.end_state = prev.data_ptr(), ijk.data_ptr(), best_cost.data_ptr(), end_state.data_ptr()
+        io.refined, io.stats, io.trace = refined.data_ptr(), stats.data_ptr(), None
+        io.best_flags, io.best_traj = best_flags.data_ptr(), best_traj.data_ptr()
+
+    def step_fiss():
+        prev.fill_(-1)  # every step plans the same cycle: no history carried over
+        eng.plan_fiss_device(params, fb, opts, io, stream=stream.cuda_stream)
+
+    def step_dense():
         eng.plan_dense_device(params, fb, best_idx.data_ptr(), best_cost.data_ptr(), stats.data_ptr(),
                               cost_tbl.data_ptr() if args.tables else 0, flag_tbl.data_ptr() if args.tables else 0,
                               stream=stream.cuda_stream)
 
+    step = step_fiss if fiss else step_dense
+
     def epilogue():
+        if fiss:
+            return  # fp_plan_fiss already produced the winner series
         eng.winner_trajs_device(params, fb, best_idx.data_ptr(), best_flags.data_ptr(), best_traj.data_ptr(), stream=stream.cuda_stream)
 
     def fetch():
-        h_idx.copy_(best_idx, non_blocking=True)
+        h_idx.copy_(refined if fiss else best_idx, non_blocking=True)
         h_cost.copy_(best_cost, non_blocking=True)
 
     def barrier():
@@ -157,7 +182,7 @@ def main():
     # Runs AFTER the timed region (libgomp workers spin after a parallel region and would steal the launch thread's core);
     # a parity failure aborts before anything is printed.
     cpu_baseline = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and not fiss:
         from oracle import oracle as O
 
         O.build()
@@ -207,7 +232,7 @@ def main():
             plan_cycle[kind] = {"p50": float(np.median(ms)), "p90": float(np.percentile(ms, 90)), "cycles": len(ms)}
 
     if rank == 0:
-        total_cand = world * B * C * args.steps
+        total_cand = world * B * (C + (21 if fiss else 0)) * args.steps  # config 4 counts the 21 refinement trajectories too
         value = total_cand / elapsed
         bytes_launch = algorithmic_bytes_per_ego(batch, args.tables) * B
         flops_launch = flops_per_ego(batch) * B
@@ -226,11 +251,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {B} egos/GPU x {batch.nd}x{batch.nv}x{batch.nt} lattice "
                                    f"({C} cand/ego), {batch.n_obs} {'dynamic' if batch.meta.get('moving') else 'static'} obstacles, "
-                                   f"T_obs={batch.T_obs}, stride-2 OBB checks, FOP argmin",
+                                   f"T_obs={batch.T_obs}, stride-2 OBB checks, " + ("FISS+ search + 3 refinement rounds" if fiss else "FOP argmin"),
                        "egos_per_gpu": B, "candidates_per_ego": C, "tables_written": bool(args.tables),
                        "parallelism": f"ego-shard x{world} (no collectives)", "input_digest": batch.digest()[:16]},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "lattice_fused_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "lattice_fused_kernel" if not fiss else "lattice_fused + fiss_search + fiss_refine + winner_traj (whole pipeline)",
+                         "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "fused kernel is FP64-VALU bound, not HBM bound; see valu_fp64"},
             "valu_fp64": {"reference_algorithm_rate": ach_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",

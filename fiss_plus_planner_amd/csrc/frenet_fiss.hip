@@ -8,7 +8,7 @@
 //     queue head    = argmin of J over "in queue" entries          (fiss_planner.py:207 / :229, heapq order)
 //     initial guess = argmin of E over not-yet-generated entries, LAST minimum  (fiss_planner.py:140-150)
 //     frontier pop  = argmin of J over frontier entries            (fiss_plus_planner.py:113)
-// each a strided scan + __shfl_xor butterfly.  State bytes (generated / in queue / frontier) sit in LDS.
+// each a strided scan over an LDS key array (+inf = absent) + a DPP wave minimum + ballot for the owner.
 //
 // Restated: fiss_planner.py:33-99 (cost_est), :101-138 (generate_trajectory -> table lookup), :140-188, :190-270;
 //           fiss_plus_planner.py:30-59, :80-148.
@@ -19,32 +19,34 @@ namespace fp {
 
 namespace {
 
-constexpr uint8_t kGen = 1, kInQ = 2, kFrontier = 4;
+constexpr uint8_t kGen = 1, kInQ = 2;
 
-struct Pick {
-    double v;
-    int q;
-};
-
-// lexicographic (value, index) minimum; prefer_high = break exact ties towards the HIGHER index
-template <bool PREFER_HIGH>
-__device__ __forceinline__ Pick pick_merge(Pick a, Pick b)
+// Wave-wide minimum of a double with DPP row operations (no LDS round trips): 4 butterfly steps inside each row of 16
+// lanes, then the four row results are combined through scalar registers.
+__device__ __forceinline__ double dpp_xor_f64(double v, int ctrl_sel)
 {
-    const bool take_b = b.q >= 0 && (a.q < 0 || b.v < a.v || (b.v == a.v && (PREFER_HIGH ? b.q > a.q : b.q < a.q)));
-    return take_b ? b : a;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_sel) {
+        case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+        case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+        case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+        default: lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return __hiloint2double(hi, lo);
 }
 
-template <bool PREFER_HIGH>
-__device__ __forceinline__ Pick wave_pick(Pick p)
+__device__ __forceinline__ double wave_min_f64(double v)
 {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        Pick o;
-        o.v = __shfl_xor(p.v, off, kWave);
-        o.q = __shfl_xor(p.q, off, kWave);
-        p = pick_merge<PREFER_HIGH>(p, o);
-    }
-    return p;
+    v = fmin(v, dpp_xor_f64(v, 0));
+    v = fmin(v, dpp_xor_f64(v, 1));
+    v = fmin(v, dpp_xor_f64(v, 2));
+    v = fmin(v, dpp_xor_f64(v, 3));  // every lane now holds the minimum of its row of 16
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double m = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    m = fmin(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
+    m = fmin(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
+    m = fmin(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
+    return m;
 }
 
 struct Walk {
@@ -52,6 +54,9 @@ struct Walk {
     const double* E;
     const uint8_t* F;
     uint8_t* st;
+    double* keyQ;   // J where "in queue", +inf elsewhere      -> queue head = argmin
+    double* keyF;   // J where "on the frontier", +inf elsewhere
+    double* keyG;   // E where not yet generated, +inf elsewhere -> initial guess = LAST argmin
     int nd, nv, nt, C, lane;
     int num_iter, num_generated, num_validated, num_checks;
 
@@ -64,32 +69,49 @@ struct Walk {
         const uint8_t s = st[q];
         if (s & kGen) return false;
         st[q] = s | kGen | kInQ;  // candidate_trajs.put((cost_final, idx))
+        keyQ[q] = cost;
+        keyG[q] = __builtin_inf();
         ++num_generated;
         return true;
     }
 
-    // argmin of J over entries whose state has `bit`; tie -> lower raster index (documented divergence)
-    __device__ __forceinline__ int head(uint8_t bit) const
+    // argmin over a key array (+inf = absent).  The scan issues all of a lane's loads before comparing (independent LDS
+    // reads), the wave minimum uses DPP, the owner is found with a ballot.  Exact ties: lowest raster index
+    // (PREFER_HIGH = false; documented divergence from the reference's ValueError) or highest (find_initial_guess).
+    template <bool PREFER_HIGH>
+    __device__ __forceinline__ int argmin_key(const double* key) const
     {
-        Pick p{0.0, -1};
-        for (int q = lane; q < C; q += kWave)
-            if (st[q] & bit) p = pick_merge<false>(p, Pick{J[q], q});
-        return wave_pick<false>(p).q;
+        double best = __builtin_inf();
+        int bq = -1;
+#pragma unroll 4
+        for (int q = lane; q < C; q += kWave) {
+            const double v = key[q];
+            if (PREFER_HIGH ? (v <= best && v < __builtin_inf()) : (v < best)) { best = v; bq = q; }
+        }
+        const double m = wave_min_f64(best);
+        if (!(m < __builtin_inf())) return -1;
+        const unsigned long long owners = __ballot(best == m && bq >= 0);
+        if (__popcll(owners) == 1) return __builtin_amdgcn_readlane(bq, __ffsll((long long)owners) - 1);
+        // exact tie across lanes: integer min / max of the candidates' raster indices
+        int cand = (best == m && bq >= 0) ? bq : (PREFER_HIGH ? -1 : 0x7fffffff);
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const int o = __shfl_xor(cand, off, kWave);
+            cand = PREFER_HIGH ? (o > cand ? o : cand) : (o < cand ? o : cand);
+        }
+        return cand;
     }
 
+    __device__ __forceinline__ int head_queue() const { return argmin_key<false>(keyQ); }
+    __device__ __forceinline__ int head_frontier() const { return argmin_key<false>(keyF); }
     // find_initial_guess (fiss_planner.py:140-150): `cost_est <= min_cost` keeps the LAST minimum
-    __device__ __forceinline__ int initial_guess() const
-    {
-        Pick p{0.0, -1};
-        for (int q = lane; q < C; q += kWave)
-            if (!(st[q] & kGen) && E[q] <= __builtin_inf()) p = pick_merge<true>(p, Pick{E[q], q});
-        return wave_pick<true>(p).q;
-    }
+    __device__ __forceinline__ int initial_guess() const { return argmin_key<true>(keyG); }
 
     // validation of the queue head (fiss_planner.py:229-258): returns 1 = answer, 0 = rejected
     __device__ __forceinline__ int validate(int q)
     {
         st[q] &= (uint8_t)~kInQ;
+        keyQ[q] = __builtin_inf();
         ++num_validated;
         const uint8_t f = F[q];
         if (f & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) return 0;
@@ -109,7 +131,10 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
     const int nd = p.nd, nv = p.nv, nt = p.nt, C = nd * nv * nt;
     double* J = (double*)smem;
     double* E = J + C;
-    uint8_t* F = (uint8_t*)(E + C);
+    double* keyQ = E + C;
+    double* keyF = keyQ + C;
+    double* keyG = keyF + C;
+    uint8_t* F = (uint8_t*)(keyG + C);
     uint8_t* st = F + C;
 
     // ---- tables: FOP flat order (i_d, i_T, i_v) -> FISS raster (i_d, i_v, i_t); cost_est (fiss_planner.py:33-99)
@@ -138,16 +163,47 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
             est += fa.opts.w_heuristic * (double)(a * a + bb * bb + c * c) / max_sqr_dist;
         }
         E[q] = est;
+        keyQ[q] = __builtin_inf();
+        keyF[q] = __builtin_inf();
+        keyG[q] = est <= __builtin_inf() ? est : __builtin_inf();  // a NaN estimate can never satisfy `<=`
     }
     __syncthreads();
 
-    Walk w{J, E, F, st, nd, nv, nt, C, lane, 0, 0, 0, 0};
+    // No feasible candidate anywhere in the lattice: the walk would generate and validate every sample, one per outer
+    // iteration, and give up (fiss_planner.py:203-206).  Its outcome is closed form: num_iter = C + 1, generated =
+    // validated = C, collision checks = samples that pass the constraints.  (Each iteration pops exactly one candidate.)
+    {
+        int feasible = 0, pass_constraints = 0;
+        for (int q = lane; q < C; q += kWave) {
+            feasible += (F[q] & FP_FLAG_INFEASIBLE) == 0;
+            pass_constraints += (F[q] & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) == 0;
+        }
+        if (__ballot(feasible != 0) == 0ull) {
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) pass_constraints += __shfl_xor(pass_constraints, off, kWave);
+            if (lane == 0) {
+                int32_t* out = fa.io.best_ijk + (size_t)b * 3;
+                out[0] = out[1] = out[2] = -1;
+                fa.io.best_cost[b] = __builtin_nan("");
+                double* es = fa.io.end_state + (size_t)b * 3;
+                es[0] = es[1] = es[2] = __builtin_nan("");
+                fa.io.refined[b] = 0;
+                int32_t* s4 = fa.io.stats + (size_t)b * 4;
+                s4[0] = C + 1; s4[1] = C; s4[2] = C; s4[3] = pass_constraints;
+            }
+            return;
+        }
+    }
+
+    Walk w{J, E, F, st, keyQ, keyF, keyG, nd, nv, nt, C, lane, 0, 0, 0, 0};
     const int sizes[3] = {nd, nv, nt};
     int best = -1;
     const bool plus = fa.opts.kind == FP_FISS_PLUS;
     for (;;) {
         ++w.num_iter;
-        int q = w.head(kInQ);
+        int q = w.head_queue();
+        const int generated_before = w.num_generated;
+        const int head_before = q;
         if (q < 0) {
             q = w.initial_guess();
             if (q < 0) break;  // every sample searched, nothing feasible (:203-206)
@@ -194,16 +250,17 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
                         int nb[3] = {idx[0], idx[1], idx[2]};
                         nb[dim] = n;
                         const int nq = w.raster(nb[0], nb[1], nb[2]);
-                        if (w.generate(nq, cost) && cost <= cost_center) st[nq] |= kFrontier;
+                        if (w.generate(nq, cost) && cost <= cost_center) keyF[nq] = cost;  // frontier_idxs.put((cost, idx))
                     }
                 }
-                const int nq = w.head(kFrontier);
+                const int nq = w.head_frontier();
                 if (nq < 0) break;
-                st[nq] &= (uint8_t)~kFrontier;
+                keyF[nq] = __builtin_inf();
                 idx[0] = nq / (nt * nv); idx[1] = (nq / nt) % nv; idx[2] = nq % nt;
             }
         }
-        q = w.head(kInQ);
+        // the queue head only changes when the exploration generated something
+        q = (head_before >= 0 && w.num_generated == generated_before) ? head_before : w.head_queue();
         if (q < 0) break;
         if (w.validate(q)) { best = q; break; }
     }
@@ -232,7 +289,7 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
 {
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
-    const int bytes = C * (8 + 8 + 1 + 1) + 16;
+    const int bytes = C * (5 * 8 + 1 + 1) + 16;
     hipLaunchKernelGGL(fiss_search_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa);
     return hipGetLastError();
 }

@@ -475,11 +475,11 @@ __global__ __launch_bounds__(kWave) void fiss_refine_kernel(FissArgs fa, int lds
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KernelArgs& ka = fa.ka;
     const int b = blockIdx.x, lane = threadIdx.x;
-    EgoCtx e;
-    stage_ego(ka, b, lds, e, lds_doubles);
     const int32_t* ijk = fa.io.best_ijk + (size_t)b * 3;
     const int R = fa.opts.max_refine_iters;
-    if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None
+    if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None (block-uniform exit)
+    EgoCtx e;
+    stage_ego(ka, b, lds, e, lds_doubles);
     const double nan = __builtin_nan("");
     double x[3], res[3], lo[3], hi[3];
 #pragma unroll
