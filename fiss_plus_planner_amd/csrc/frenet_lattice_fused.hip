@@ -36,7 +36,8 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kQueueCap = 192;  // per-wave hit queue: < 64 pending + one full push of 64, rounded up
+constexpr int kQueueCap = 128;   // per-wave hit queue: < 64 pending + one full push of 64
+constexpr int kItemCap = 128;    // per-wave item queue: < 64 pending + one full push of 64
 
 struct __attribute__((aligned(16))) Frame {  // reference-line frame of one lon-profile point
     double px, py, tx, ty;
@@ -66,7 +67,7 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -83,6 +84,10 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.frames = o;   o = align16(o + 32 * nv * hp);
     L.lat = o;      o = align16(o + 8 * nd * hp);
     L.dmax = o;     o = align16(o + 8 * hp);
+    L.ddmax = o;    o = align16(o + 8 * hp);
+    L.wfat = o;     o = align16(o + 8 * nv * hp);
+    L.grp = o;      o = align16(o + 32 * (rows > 0 ? rows : 1));       // per checked pose row: circle enclosing all lon profiles' points
+    L.iqueue = o;   o = align16(o + 2 * kItemCap * kWaves);                  // per-wave queue of (row, obstacle) items that pass the group test
     L.lon_sum = o;  o = align16(o + 24 * nt * nv);   // sum_v, sum_as, sum_js
     L.lat_sum = o;  o = align16(o + 24 * nd * nt);   // sum_ad, sum_jd, sum_d
     L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
@@ -133,6 +138,10 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
     Frame* s_frames = (Frame*)(smem + L.frames);
     double* s_lat = (double*)(smem + L.lat);
     double* s_dmax = (double*)(smem + L.dmax);
+    double* s_ddmax = (double*)(smem + L.ddmax);
+    double* s_wfat = (double*)(smem + L.wfat);
+    ObsDim* s_grp = (ObsDim*)(smem + L.grp);  // reused as {cx, cy, radius, -}
+    unsigned short* s_iqueue = (unsigned short*)(smem + L.iqueue) + wave * kItemCap;  // item index r * n_obs + j
     double* s_lon_sum = (double*)(smem + L.lon_sum);
     double* s_lat_sum = (double*)(smem + L.lat_sum);
     int2* s_lon_meta = (int2*)(smem + L.lon_meta);
@@ -296,9 +305,60 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
         if (n_obs > 0 && hp > 0) {
             // largest lateral offset of the slice at every stored point: fattens the broad-phase circle
             for (int i = tid; i < hp && i < N; i += kThreads) {
-                double m = 0.0;
-                for (int id = 0; id < nd; ++id) m = fmax(m, fabs(s_lat[id * hp_max + i]));
+                double m = 0.0, dd = 0.0;
+                for (int id = 0; id < nd; ++id) {
+                    const double di = s_lat[id * hp_max + i];
+                    m = fmax(m, fabs(di));
+                    if (i + 1 < hp && i + 1 < N) dd = fmax(dd, fabs(s_lat[id * hp_max + i + 1] - di));
+                }
                 s_dmax[i] = m;
+                s_ddmax[i] = dd;  // largest lateral step |d(i+1) - d(i)| over the lateral samples
+            }
+            __syncthreads();
+            // Lateral half-width of the whole fan at every checked pose, measured along the reference normal n_k:
+            //   every ego centre is P_k + d n_k with |d| <= dmax[k];  the ego box, whose heading deviates from the reference
+            //   tangent by alpha, reaches hw cos(alpha) + hl |sin(alpha)| <= min(r_ego, hw + hl sigma) along n_k, where
+            //   sigma >= |sin(alpha)| for every lateral sample follows from the heading vector
+            //   h = (P_{k+1} - P_k) + d_{k+1} n_{k+1} - d_k n_k:   |h . n_k| <= |dP.n_k| + max|d_{k+1} - d_k| + max|d_{k+1}| |1 - n_{k+1}.n_k|,
+            //   |h| >= |h . t_k| >= |dP.t_k| - max|d_{k+1}| |n_{k+1}.t_k|.
+            // n_k is then a separating-axis candidate for the broad phase (conservative: it can only over-accept).
+            // circle enclosing the reference points of ALL lon profiles at each checked pose row (stale frames beyond a profile's
+            // M only enlarge it): one test per (row, obstacle) item prunes the item for every profile at once
+            for (int r = tid; r < rows; r += kThreads) {
+                const int k = r * stride;
+                double cx = 0.0, cy = 0.0;
+                for (int iv = 0; iv < nv; ++iv) { cx += s_frames[iv * hp_max + k].px; cy += s_frames[iv * hp_max + k].py; }
+                cx /= (double)nv; cy /= (double)nv;
+                double r2 = 0.0;
+                for (int iv = 0; iv < nv; ++iv) {
+                    const double ax = s_frames[iv * hp_max + k].px - cx, ay = s_frames[iv * hp_max + k].py - cy;
+                    r2 = fmax(r2, fma(ax, ax, ay * ay));
+                }
+                const double rad = (k < N && k < hp) ? (sqrt(r2) + r_ego + s_dmax[k]) * (1.0 + 1e-9) + 1e-9 : 0.0;
+                s_grp[r] = ObsDim{cx, cy, rad, 0.0};
+            }
+            for (int e = tid; e < nv * rows; e += kThreads) {
+                const int iv = e / rows, r = e - iv * rows;
+                const int k = r * stride;
+                double wl = r_ego;
+                const int M = s_lon_meta[it * nv + iv].x;
+                if (k + 1 < M && k + 1 < hp && k + 1 < N) {
+                    const Frame f0 = s_frames[iv * hp_max + k], f1 = s_frames[iv * hp_max + k + 1];
+                    const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
+                    const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);   // dP . n_k,  n_k = (-ty, tx)
+                    const double a_t = fma(dpx, f0.tx, dpy * f0.ty);    // dP . t_k
+                    const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty); // n_{k+1} . n_k
+                    const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
+                    const double dm1 = s_dmax[k + 1];
+                    const double num = fabs(a_n) + s_ddmax[k] + dm1 * fabs(1.0 - nn);
+                    const double den = fabs(a_t) - dm1 * fabs(nt_);
+                    if (den > 0.0) {
+                        const double sigma = fmin(1.0, num / den * (1.0 + 1e-9) + 1e-12);
+                        wl = fmin(r_ego, fma(veh_hl, sigma, veh_hw));
+                    }
+                }
+                const double wf = (k < N && k < hp) ? (s_dmax[k] + wl) * (1.0 + 1e-12) + 1e-12 : 0.0;
+                s_wfat[iv * hp_max + k] = wf;
             }
             __syncthreads();
 
@@ -348,32 +408,38 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
 
             const int hits_per_round = kWave / nd > 0 ? kWave / nd : 1;
             const int n_items = rows * n_obs;
-            for (int e0 = wave * kWave; e0 < n_items; e0 += kThreads) {
-                const int e = e0 + lane;
-                const bool live = e < n_items;
+            int iqlen = 0;  // wave-uniform length of this wave's item queue
+
+            // broad phase proper on up to 64 queued (row, obstacle) items: loop over the lon profiles
+            auto broad = [&](int n_take) {
+                const bool live = lane < n_take;
                 int r = 0, j = 0;
-                double ox = __builtin_nan(""), oy = 0.0, orad = 0.0;
+                double ox = __builtin_nan(""), oy = 0.0, oc = 1.0, os = 0.0, orad = 0.0, ohl = 0.0, ohw = 0.0;
                 if (live) {
-                    r = e / n_obs;
-                    j = e - r * n_obs;
-                    const ObsPose op = s_pose[e];
-                    ox = op.x;
-                    oy = op.y;
-                    orad = s_dim[j].r;
+                    const int item = s_iqueue[iqlen - n_take + lane];
+                    r = item / n_obs;
+                    j = item - r * n_obs;
+                    const ObsPose op = s_pose[item];
+                    ox = op.x; oy = op.y; oc = op.c; os = op.s;
+                    const ObsDim od = s_dim[j];
+                    orad = od.r; ohl = od.hl; ohw = od.hw;
                 }
                 const int k = r * stride;
                 // Poses beyond a profile's M hold stale frames: they may pass here and are rejected by the narrow phase
                 // (k < M is tested there), which keeps the per-profile M out of this loop.
-                const bool usable = live && k < N && k < pose_limit && (ox == ox);
                 double fat2 = -1.0;
-                if (usable) {
+                if (live) {
                     const double fat = (r_ego + orad + s_dmax[k]) * (1.0 + 1e-12);
                     fat2 = fat * fat;
                 }
                 for (int iv = 0; iv < nv; ++iv) {
-                    const double2 pq = *(const double2*)&s_frames[iv * hp_max + k];
-                    const double dx = ox - pq.x, dy = oy - pq.y;
-                    const bool pass = usable && !(fma(dx, dx, dy * dy) > fat2);  // a NaN pose passes (-> "collision" downstream)
+                    const Frame fr = s_frames[iv * hp_max + k];
+                    const double dx = ox - fr.px, dy = oy - fr.py;
+                    // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre vs the
+                    // fan half-width + the obstacle's own reach along n_k.  A NaN pose passes both (-> "collision" downstream).
+                    const double w = fma(dy, fr.tx, -dx * fr.ty);
+                    const double reach = fma(ohl, fabs(fma(os, fr.tx, -oc * fr.ty)), ohw * fabs(fma(oc, fr.tx, os * fr.ty)));
+                    const bool pass = live && !(fma(dx, dx, dy * dy) > fat2) && !(fabs(w) > s_wfat[iv * hp_max + k] + reach);
                     const unsigned long long m = __ballot(pass);
                     if (m) {
                         if (pass) {
@@ -388,6 +454,36 @@ __global__ __launch_bounds__(kThreads) void lattice_fused_kernel(KernelArgs ka, 
                         }
                     }
                 }
+            };
+
+            for (int e0 = wave * kWave; e0 < n_items; e0 += kThreads) {
+                const int e = e0 + lane;
+                bool keep = false;
+                int r = 0, j = 0;
+                if (e < n_items) {
+                    r = e / n_obs;
+                    j = e - r * n_obs;
+                    const int k = r * stride;
+                    const double2 oxy = *(const double2*)&s_pose[e];
+                    const ObsDim g = s_grp[r];
+                    const double dx = oxy.x - g.hl, dy = oxy.y - g.hw, R = g.r + s_dim[j].r;
+                    keep = k < N && k < pose_limit && (oxy.x == oxy.x) && !(fma(dx, dx, dy * dy) > R * R);
+                }
+                const unsigned long long m = __ballot(keep);
+                if (m) {
+                    if (keep) s_iqueue[iqlen + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
+                    iqlen += __popcll(m);
+                    lds_wave_sync();
+                    if (iqlen >= kWave) {
+                        broad(kWave);
+                        iqlen -= kWave;
+                    }
+                }
+            }
+            if (iqlen > 0) {
+                lds_wave_sync();
+                broad(iqlen);
+                iqlen = 0;
             }
             if (qlen > 0) {
                 lds_wave_sync();
@@ -454,7 +550,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream)
         if (rows_tab < rows) rows = rows_tab;
         hp = rows * stride + 1;
         if (hp > FP_MAX_POINTS) hp = FP_MAX_POINTS;
-        if (rows > 4095) return hipErrorInvalidValue;
+        if (rows > 4095 || (long)rows * b.n_obs > 65535) return hipErrorInvalidValue;
     }
     const Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt);
     if (L.total > 150 * 1024) return hipErrorInvalidValue;
