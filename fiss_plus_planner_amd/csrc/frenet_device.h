@@ -198,6 +198,55 @@ __device__ __forceinline__ void step_heading(double dx, double dy, double& c, do
 // ---------------------------------------------------------------------------
 // wave / block reductions (64-lane wavefronts)
 // ---------------------------------------------------------------------------
+// DPP lane exchange inside a row of 16 lanes (no LDS round trip, unlike __shfl_xor -> ds_bpermute):
+//   0xB1 quad_perm[1,0,3,2] (xor 1), 0x4E quad_perm[2,3,0,1] (xor 2), 0x141 row_half_mirror, 0x140 row_mirror.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// after these four steps every lane holds the reduction of its row of 16 lanes
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double row16_min(double v)
+{
+    v = fmin(v, dpp_f64<0xB1>(v));
+    v = fmin(v, dpp_f64<0x4E>(v));
+    v = fmin(v, dpp_f64<0x141>(v));
+    v = fmin(v, dpp_f64<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ double row16_max(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ double lane_value(double v, int src_lane)  // src_lane must be wave-uniform
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+// sum over the 64 lanes, same value (and same summation tree) in every lane
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v = row16_sum(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+    v = row16_min(v);
+    return fmin(fmin(lane_value(v, 0), lane_value(v, 16)), fmin(lane_value(v, 32), lane_value(v, 48)));
+}
 struct Best {
     double cost;
     int idx;

@@ -21,34 +21,6 @@ namespace {
 
 constexpr uint8_t kGen = 1, kInQ = 2;
 
-// Wave-wide minimum of a double with DPP row operations (no LDS round trips): 4 butterfly steps inside each row of 16
-// lanes, then the four row results are combined through scalar registers.
-__device__ __forceinline__ double dpp_xor_f64(double v, int ctrl_sel)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    switch (ctrl_sel) {
-        case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
-        case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
-        case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
-        default: lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break; // row_mirror
-    }
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_min_f64(double v)
-{
-    v = fmin(v, dpp_xor_f64(v, 0));
-    v = fmin(v, dpp_xor_f64(v, 1));
-    v = fmin(v, dpp_xor_f64(v, 2));
-    v = fmin(v, dpp_xor_f64(v, 3));  // every lane now holds the minimum of its row of 16
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    double m = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-    m = fmin(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
-    m = fmin(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
-    m = fmin(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
-    return m;
-}
-
 struct Walk {
     const double* J;
     const double* E;
