@@ -60,7 +60,7 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -82,6 +82,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.grp = o;      o = align16(o + 32 * (rows > 0 ? rows : 1));       // per checked pose row: circle enclosing all lon profiles' points
     L.iqueue = o;   o = align16(o + 2 * kItemCap * kWaves);                  // per-wave queue of (row, obstacle) items that pass the group test
     L.pows = o;     o = align16(o + 8 * 11 * nt);    // power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per time-horizon slice
+    L.samples = o;  o = align16(o + 8 * (nt + nv + nd));  // t / v / d sample grids (read all over the kernel: keep them out of HBM latency)
     L.lon_sum = o;  o = align16(o + 24 * nt * nv);   // sum_v, sum_as, sum_js
     L.lat_sum = o;  o = align16(o + 24 * nd * nt);   // sum_ad, sum_jd, sum_d
     L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
@@ -137,6 +138,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     ObsDim* s_grp = (ObsDim*)(smem + L.grp);  // reused as {cx, cy, radius, -}
     unsigned short* s_iqueue = (unsigned short*)(smem + L.iqueue) + wave * kItemCap;  // item index r * n_obs + j
     double* s_pows = (double*)(smem + L.pows);
+    double* s_ts = (double*)(smem + L.samples);
+    double* s_vs = s_ts + nt;
+    double* s_ds = s_vs + nv;
     double* s_lon_sum = (double*)(smem + L.lon_sum);
     double* s_lat_sum = (double*)(smem + L.lat_sum);
     int2* s_lon_meta = (int2*)(smem + L.lon_meta);
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const double* gk = bt.knots + (size_t)f * bt.NX;
         const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
         for (int i = tid; i < nx; i += kThreads) s_knots[i] = gk[i];
+        for (int i = tid; i < nt + nv + nd; i += kThreads)
+            s_ts[i] = i < nt ? bt.t_samples[i] : (i < nt + nv ? bt.v_samples[(size_t)b * nv + (i - nt)] : bt.d_samples[i - nt - nv]);
         for (int i = tid; i < 8 * nx; i += kThreads) {
             const int r = i / nx, c = i - r * nx;
             s_coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
     __syncthreads();
 
-    const double* v_samples = bt.v_samples + (size_t)b * nv;
+    const double* v_samples = s_vs;
     int qlen = 0;  // wave-uniform length of this wave's hit queue
 
     // ---------------------------------------------------------------- phase A0 (once): masks / M / cost sums of every profile
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     //     1e-6 cost bar, and the expressions are even in the lateral boundary data, so mirrored candidates still tie bit-exactly.
     for (int task = wave; task < nt * (nv + 1); task += kWaves) {
         const int it = task / (nv + 1), iv = task - it * (nv + 1);
-        const double T = bt.t_samples[it];
+        const double T = s_ts[it];
         const int N = arange_len(T, tick);
         if (iv < nv) {
             const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     __syncthreads();
     for (int e = tid; e < nt * (nv + nd); e += kThreads) {
         const int it = e / (nv + nd), sub = e - it * (nv + nd);
-        const double T = bt.t_samples[it];
+        const double T = s_ts[it];
         const double* S = s_pows + it * 11;
         if (sub < nv) {
             const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[sub], 0.0, T);
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             o[0] = sv; o[1] = sa; o[2] = sj;
         } else {
             const int id = sub - nv;
-            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, bt.d_samples[id], 0.0, 0.0, T);
+            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, T);
             const double c[6] = {q.a0, q.a1, q.a2, q.a3, q.a4, q.a5};
             double sd = 0.0;  // sum d^2 = sum_k (c (*) c)_k S_k, degree 10
 #pragma unroll
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     __syncthreads();  // the final assembly reads the sums (with no obstacles there is no other barrier in between)
 
     for (int it = 0; n_obs > 0 && hp > 0 && it < nt; ++it) {
-        const double T = bt.t_samples[it];
+        const double T = s_ts[it];
         const int N = arange_len(T, tick);
         float* s_dmax = s_dmax2 + (it & 1) * hp_max;    // this slice's buffers (zeroed during the previous slice)
         float* s_ddmax = s_ddmax2 + (it & 1) * hp_max;
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
         for (int e = tid; e < nd * np; e += kThreads) {
             const int id = e / np, i = e - id * np;
-            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, bt.d_samples[id], 0.0, 0.0, T);
+            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, T);
             const double t = (double)i * tick;
             const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
             s_lat[id * hp_max + i] = d;
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     Best mine{0.0, -1};
     for (int c = tid; c < C; c += kThreads) {
         const int iv = c % nv, it = (c / nv) % nt, id = c / (nv * nt);
-        const double T = bt.t_samples[it];
+        const double T = s_ts[it];
         const int N = arange_len(T, tick);
         const double* ls = s_lon_sum + 3 * (it * nv + iv);
         const double* ds = s_lat_sum + 3 * (id * nt + it);
