@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 3
+FP_ABI_VERSION = 4
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
@@ -24,7 +24,7 @@ _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option",
-                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss")
+                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance")
 
 
 class FpParams(C.Structure):
@@ -39,7 +39,7 @@ class FpBatch(C.Structure):
                 ("d_samples", C.c_void_p), ("t_samples", C.c_void_p), ("v_samples", C.c_void_p), ("target_speed", C.c_void_p),
                 ("ego", C.c_void_p), ("frame_of", C.c_void_p), ("scene_of", C.c_void_p), ("t_now", C.c_void_p),
                 ("nx", C.c_void_p), ("knots", C.c_void_p), ("coef", C.c_void_p),
-                ("obs_pose", C.c_void_p), ("obs_dims", C.c_void_p), ("final_time_step", C.c_void_p)]
+                ("obs_pose", C.c_void_p), ("obs_dims", C.c_void_p), ("final_time_step", C.c_void_p), ("skip", C.c_void_p)]
 
 
 class FpResult(C.Structure):
@@ -54,6 +54,13 @@ class FpFissOpts(C.Structure):
 class FpFissIo(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("samp_min", "samp_max", "samp_res", "prev_best_idx", "best_ijk", "best_cost", "end_state",
                                           "refined", "stats", "trace", "best_flags", "best_traj")]
+
+
+class FpLoopIo(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ego", "t_now", "done", "cycles", "goal_xy", "cart_state")]
+
+
+RUNNING, DONE_GOAL, DONE_END_OF_LINE, DONE_NO_SOLUTION = 0, 1, 2, 3
 
 
 class FrenetGpuError(RuntimeError):
@@ -74,6 +81,13 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C fiss_plus_planner_amd/csrc).  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP runtime.  If torch is going to be used in this process (device tensors as
+    # plumbing), its runtime must be the one both sides share: load it first, otherwise a later `torch.cuda` init finds the
+    # system runtime already initialised and reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.fp_abi_version.restype = C.c_int
     L.fp_last_error.restype = C.c_char_p
@@ -87,6 +101,7 @@ def load() -> C.CDLL:
     L.fp_eval_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int32, C.c_int, C.c_void_p]
     L.fp_plan_fiss.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpFissOpts), C.POINTER(FpFissIo), C.c_int, C.c_void_p]
+    L.fp_advance.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.POINTER(FpLoopIo), C.c_int, C.c_void_p]
     if L.fp_abi_version() != FP_ABI_VERSION:
         raise ImportError(f"libfrenetgpu ABI {L.fp_abi_version()} != binding {FP_ABI_VERSION}: rebuild")
     _lib = L

@@ -129,7 +129,7 @@ size_t batch_bytes(const fp_params* p, const fp_batch* b)
     n += Arena::padded(sizeof(int32_t) * b->F) + Arena::padded(sizeof(double) * (size_t)b->F * b->NX) +
          Arena::padded(sizeof(double) * (size_t)b->F * 8 * b->NX);
     n += Arena::padded(sizeof(double) * (size_t)b->S * b->T_obs * b->n_obs * 4) + Arena::padded(sizeof(double) * (size_t)b->S * b->n_obs * 2) +
-         Arena::padded(sizeof(int32_t) * (b->S > 0 ? b->S : 1));
+         Arena::padded(sizeof(int32_t) * (b->S > 0 ? b->S : 1)) + Arena::padded(sizeof(int32_t) * b->B);
     return n;
 }
 
@@ -162,6 +162,7 @@ int stage_batch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, fp_batch* de
     PUSH(obs_pose, has_obs ? (size_t)b->S * b->T_obs * b->n_obs * 4 : 0);
     PUSH(obs_dims, has_obs ? (size_t)b->S * b->n_obs * 2 : 0);
     PUSH(final_time_step, has_obs ? b->S : 0);
+    if (b->skip) { PUSH(skip, b->B); }
 #undef PUSH
     if (!has_obs) dev->n_obs = 0;
     return FP_OK;
@@ -445,6 +446,58 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         if (io->best_traj) HIP_TRY(hipMemcpyAsync(io->best_traj, fa.io.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    return FP_OK;
+}
+
+int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, const double* end_state,
+               const fp_loop_io* io, int mem, void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    int rc;
+    if ((rc = check_params(params)) != FP_OK) return rc;
+    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    if ((best_idx == nullptr) == (end_state == nullptr)) return fail(FP_EINVAL, "exactly one of best_idx / end_state must be given");
+    if (!io || !io->ego || !io->t_now || !io->done || !io->cycles || !io->goal_xy) return fail(FP_EINVAL, "fp_loop_io has a NULL mandatory array");
+    if (batch->B == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch->B;
+    fp::KernelArgs ka;
+    ka.p = *params;
+    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (mem == FP_MEM_DEVICE) {
+        ka.b = *batch;
+        hipError_t e = fp::launch_advance(ka, best_idx, end_state, *io, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "advance kernel launch failed: %s", hipGetErrorString(e));
+        return FP_OK;
+    }
+    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
+    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(double) * B * 6) + 3 * Arena::padded(sizeof(int32_t) * B) +
+                  Arena::padded(sizeof(double) * B * 2) + 2 * Arena::padded(sizeof(double) * B * 3) + Arena::padded(sizeof(int32_t) * B);
+    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
+    ctx->arena.reset();
+    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
+    fp_loop_io dio = *io;
+    const double* c_ego = nullptr; const int32_t *c_tn = nullptr, *c_done = nullptr, *c_cyc = nullptr, *c_idx = nullptr; const double* c_es = nullptr;
+    if ((rc = push(ctx, (const double*)io->ego, B * 6, &c_ego)) != FP_OK) return rc;
+    if ((rc = push(ctx, (const int32_t*)io->t_now, B, &c_tn)) != FP_OK) return rc;
+    if ((rc = push(ctx, (const int32_t*)io->done, B, &c_done)) != FP_OK) return rc;
+    if ((rc = push(ctx, (const int32_t*)io->cycles, B, &c_cyc)) != FP_OK) return rc;
+    if ((rc = push(ctx, io->goal_xy, B * 2, &dio.goal_xy)) != FP_OK) return rc;
+    if (best_idx && (rc = push(ctx, best_idx, B, &c_idx)) != FP_OK) return rc;
+    if (end_state && (rc = push(ctx, end_state, B * 3, &c_es)) != FP_OK) return rc;
+    dio.ego = const_cast<double*>(c_ego); dio.t_now = const_cast<int32_t*>(c_tn);
+    dio.done = const_cast<int32_t*>(c_done); dio.cycles = const_cast<int32_t*>(c_cyc);
+    dio.cart_state = io->cart_state ? (double*)ctx->arena.take(sizeof(double) * B * 3) : nullptr;
+    if (dio.cart_state) HIP_TRY(hipMemsetAsync(dio.cart_state, 0xFF, sizeof(double) * B * 3, ctx->stream));  // NaN for egos that do not move
+    hipError_t e = fp::launch_advance(ka, c_idx, c_es, dio, ctx->stream);
+    if (e != hipSuccess) return fail(FP_EHIP, "advance kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(io->ego, dio.ego, sizeof(double) * B * 6, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(io->t_now, dio.t_now, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(io->done, dio.done, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(io->cycles, dio.cycles, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
+    if (io->cart_state) HIP_TRY(hipMemcpyAsync(io->cart_state, dio.cart_state, sizeof(double) * B * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FP_OK;
 }
 

@@ -101,6 +101,19 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
     const fp_batch& bt = fa.ka.b;
     const int b = blockIdx.x, lane = threadIdx.x;
     const int nd = p.nd, nv = p.nv, nt = p.nt, C = nd * nv * nt;
+    if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch
+        if (lane == 0) {
+            int32_t* out = fa.io.best_ijk + (size_t)b * 3;
+            out[0] = out[1] = out[2] = -1;
+            fa.io.best_cost[b] = __builtin_nan("");
+            double* es = fa.io.end_state + (size_t)b * 3;
+            es[0] = es[1] = es[2] = __builtin_nan("");
+            fa.io.refined[b] = 0;
+            int32_t* s4 = fa.io.stats + (size_t)b * 4;
+            s4[0] = s4[1] = s4[2] = s4[3] = 0;
+        }
+        return;
+    }
     double* J = (double*)smem;
     double* E = J + C;
     double* keyQ = E + C;

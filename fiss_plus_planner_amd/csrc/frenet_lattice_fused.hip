@@ -148,6 +148,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     uint32_t* s_queue = (uint32_t*)(smem + L.queue) + wave * kQueueCap;
     Best* s_best = (Best*)(smem + L.best);
 
+    if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch (block-uniform exit)
+        if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
+        return;
+    }
     // ---------------------------------------------------------------- stage: ego, spline, obstacle rows
     const double* eg = bt.ego + (size_t)b * 6;
     const double s0 = eg[0], s_d0 = eg[1], s_dd0 = eg[2], d0 = eg[3], d_d0 = eg[4], d_dd0 = eg[5];

@@ -1,0 +1,109 @@
+"""Problem batches resident in HBM and closed-loop stepping without host round trips.
+
+PyTorch is plumbing here (device allocations + the stream handle); every array crosses the C ABI as a raw
+device address.  `DeviceBatch` uploads a ProblemBatch once; `ClosedLoopRunner` enqueues
+[plan -> advance] x cycles on one stream (reference loop: planners/benchmark/planning.py:120-162) and only
+reads back at the end (or per cycle, when a trace is requested).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _abi
+from .batch import ProblemBatch
+from .engine import FrenetEngine, device_batch, make_params
+
+_NAMES = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+          "obs_pose", "obs_dims", "final_time_step")
+
+
+class DeviceBatch:
+    def __init__(self, batch: ProblemBatch, device: int = 0):
+        import torch
+
+        self.torch = torch
+        self.host = batch
+        self.dev = torch.device("cuda", device)
+        self.t = {k: torch.from_numpy(np.ascontiguousarray(getattr(batch, k))).to(self.dev) for k in _NAMES}
+        for k in ("samp_min", "samp_max", "samp_res"):
+            if getattr(batch, k) is not None:
+                self.t[k] = torch.from_numpy(getattr(batch, k)).to(self.dev)
+        self.params = make_params(batch)
+        self.fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in self.t.items() if k in _NAMES})
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.dev)
+
+    @property
+    def B(self):
+        return self.host.B
+
+    @property
+    def C(self):
+        return self.host.C
+
+
+class ClosedLoopRunner:
+    """[plan -> advance] for a whole batch on the device.  planner: "FOP" (fp_plan_dense) or "FISS"/"FISS+" (fp_plan_fiss)."""
+
+    def __init__(self, engine: FrenetEngine, dbatch: DeviceBatch, goal_xy: np.ndarray, planner: str = "FOP"):
+        torch = dbatch.torch
+        self.eng, self.db, self.planner = engine, dbatch, planner
+        B = dbatch.B
+        i32, f64 = torch.int32, torch.float64
+        self.best_idx = dbatch.empty(B, i32)
+        self.best_cost = dbatch.empty(B, f64)
+        self.stats = dbatch.empty((B, 4), i32)
+        self.done = torch.zeros(B, dtype=i32, device=dbatch.dev)
+        self.cycles = torch.zeros(B, dtype=i32, device=dbatch.dev)
+        self.goal = torch.from_numpy(np.ascontiguousarray(goal_xy, dtype=np.float64).reshape(B, 2)).to(dbatch.dev)
+        self.cart = torch.full((B, 3), float("nan"), dtype=f64, device=dbatch.dev)
+        dbatch.fb.skip = self.done.data_ptr()  # finished egos are not planned any more
+        self.io = _abi.FpLoopIo()
+        self.io.ego, self.io.t_now = dbatch.t["ego"].data_ptr(), dbatch.t["t_now"].data_ptr()
+        self.io.done, self.io.cycles = self.done.data_ptr(), self.cycles.data_ptr()
+        self.io.goal_xy, self.io.cart_state = self.goal.data_ptr(), self.cart.data_ptr()
+        if planner != "FOP":
+            self.prev = torch.full((B, 3), -1, dtype=i32, device=dbatch.dev)
+            self.ijk = dbatch.empty((B, 3), i32)
+            self.end_state = dbatch.empty((B, 3), f64)
+            self.refined = dbatch.empty(B, i32)
+            self.fopts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if planner == "FISS+" else _abi.FP_FISS, 3 if planner == "FISS+" else 0, 10.0, 0.5)
+            f = _abi.FpFissIo()
+            f.samp_min, f.samp_max, f.samp_res = (dbatch.t[k].data_ptr() for k in ("samp_min", "samp_max", "samp_res"))
+            f.prev_best_idx, f.best_ijk, f.best_cost, f.end_state = self.prev.data_ptr(), self.ijk.data_ptr(), self.best_cost.data_ptr(), self.end_state.data_ptr()
+            f.refined, f.stats, f.trace, f.best_flags, f.best_traj = self.refined.data_ptr(), self.stats.data_ptr(), None, None, None
+            self.fio = f
+
+    def step(self, stream: int = 0):
+        """One plan cycle for every running ego + the state hand-over, enqueued on `stream`."""
+        import ctypes as C
+
+        lib, ctx = self.eng._lib, self.eng._ctx
+        if self.planner == "FOP":
+            self.eng.plan_dense_device(self.db.params, self.db.fb, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
+            _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), self.best_idx.data_ptr(), None, C.byref(self.io),
+                                      _abi.FP_MEM_DEVICE, stream or None))
+        else:
+            self.eng.plan_fiss_device(self.db.params, self.db.fb, self.fopts, self.fio, stream=stream)
+            _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), None, self.end_state.data_ptr(), C.byref(self.io),
+                                      _abi.FP_MEM_DEVICE, stream or None))
+
+    def run(self, max_cycles: int, trace: bool = False):
+        torch = self.db.torch
+        stream = torch.cuda.current_stream(self.db.dev).cuda_stream
+        rows = []
+        for _ in range(max_cycles):
+            if trace:
+                start = self.db.t["ego"].cpu().numpy().copy()
+            self.step(stream)
+            if trace:
+                rows.append(SimpleNamespace(start=start, cost=self.best_cost.cpu().numpy().copy(), stats=self.stats.cpu().numpy().copy(),
+                                            done=self.done.cpu().numpy().copy(), cart=self.cart.cpu().numpy().copy()))
+                if (rows[-1].done != 0).all():
+                    break
+        torch.cuda.synchronize(self.db.dev)
+        return SimpleNamespace(done=self.done.cpu().numpy(), cycles=self.cycles.cpu().numpy(), ego=self.db.t["ego"].cpu().numpy(),
+                               t_now=self.db.t["t_now"].cpu().numpy(), cart=self.cart.cpu().numpy(), trace=rows)

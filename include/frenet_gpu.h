@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 3
+#define FP_ABI_VERSION 4
 
 /* error codes */
 #define FP_OK 0
@@ -95,6 +95,8 @@ typedef struct {
     const double* obs_pose;      /* [S][T_obs][n_obs][4]  x, y, yaw, valid(0/1) */
     const double* obs_dims;      /* [S][n_obs][2]         length, width */
     const int32_t* final_time_step; /* [S]      obstacles[0].prediction.final_time_step :173 */
+    const int32_t* skip;         /* NULL or [B]: egos with skip[b] != 0 are not planned (best_idx = -1, no table rows written);
+                                    the closed-loop driver passes its `done` array here */
 } fp_batch;
 
 /* Outputs of the dense lattice pass; any pointer except best_idx/best_cost may be NULL.
@@ -187,6 +189,32 @@ typedef struct {
 /* In FP_MEM_DEVICE mode the ctx grows an internal scratch arena (dense tables, B*C*12 bytes) on first use. */
 int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io,
                  int mem, void* stream);
+
+/* ---- closed-loop stepping on the device ---------------------------------------------------------------------
+ * fp_advance = the bookkeeping between two plan() calls of the reference's simulation loop
+ * (planners/benchmark/planning.py:131-162): next FrenetState = point 1 of the returned trajectory
+ * (frenet.py:185-196), time_step_now += 1, stop when there is no solution (:131-133), when the new position is within
+ * l/2 of the goal-lanelet centre (:154-157) or within 3 m of the end of the 0.1 m-resampled reference line (:158-161).
+ * (goal_region.is_reached(), :151, needs commonroad's goal geometry and is not evaluated.)
+ * The chosen trajectory is given either as a lattice index (best_idx, FOP order) or as explicit end states
+ * (end_state [B][3] = d, v, T; NaN = no solution) - exactly one of the two pointers is non-NULL.
+ * Plan + advance can be enqueued back to back on one stream for as many cycles as wanted: no host round trip. */
+#define FP_RUNNING 0
+#define FP_DONE_GOAL 1
+#define FP_DONE_END_OF_LINE 2
+#define FP_DONE_NO_SOLUTION 3
+
+typedef struct {
+    double* ego;            /* [B][6] in/out  (aliases fp_batch.ego) */
+    int32_t* t_now;         /* [B]    in/out  (aliases fp_batch.t_now) */
+    int32_t* done;          /* [B]    in/out  FP_RUNNING / FP_DONE_*  (pass it as fp_batch.skip to the plan calls) */
+    int32_t* cycles;        /* [B]    in/out  number of completed plan cycles */
+    const double* goal_xy;  /* [B][2] centre vertex of the goal lanelet                      planning.py:54-58 */
+    double* cart_state;     /* NULL or [B][3] out: x, y, yaw of the new state                planning.py:135 */
+} fp_loop_io;
+
+int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, const double* end_state,
+               const fp_loop_io* io, int mem, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header():
     # 4 int32 + 10 double ; 6 int32 + 14 pointers ; 5 pointers
     assert C.sizeof(_abi.FpParams) == 4 * 4 + 10 * 8
-    assert C.sizeof(_abi.FpBatch) == 6 * 4 + 14 * 8
+    assert C.sizeof(_abi.FpBatch) == 6 * 4 + 15 * 8
     assert C.sizeof(_abi.FpResult) == 7 * 8
 
 
