@@ -1,0 +1,134 @@
+"""CommonRoad 2020a scenario files -> the arrays the planners need (no commonroad-io dependency).
+
+Replaces, for the reference's demo inputs, `CommonRoadFileReader(...).open()` (planners/benchmark/planning.py:303) and
+`GlobalPlanner.plan_global_route` (planners/commonroad_interface/global_planner.py:22-106):
+
+* lanelet centre line = mean of the left and right bound vertices;
+* route = shortest successor-only lanelet sequence from the lanelet under the initial position to the goal lanelet
+  (the reference asks commonroad-route-planner for it; all five demo scenarios have a unique such route - SURVEY.md 8f);
+  like the reference (:68-75) the first successor of the last lanelet is appended when there is one;
+* centerline = concatenated centre vertices with duplicates removed, first occurrence kept (:79-82);
+* dynamic rectangle obstacles -> pose table [T, n, 4] = x, y, yaw, valid + dims [n, 2] (what has_collision() reads).
+
+Route choice parity with commonroad-route-planner is unpinned (package not installable offline).
+"""
+from __future__ import annotations
+
+import xml.etree.ElementTree as ET
+from collections import deque
+from dataclasses import dataclass
+
+import numpy as np
+
+from .obstacles import ObstacleTable
+
+
+@dataclass
+class Scenario:
+    benchmark_id: str
+    dt: float
+    route: list
+    centerline: np.ndarray        # [n, 2]
+    obstacles: ObstacleTable
+    init_state: np.ndarray        # x, y, yaw, v
+    goal_lanelet: int
+    goal_center: np.ndarray       # middle centre vertex of the goal lanelet (planning.py:54-58)
+    goal_speed: tuple | None      # (start, end) of the goal velocity interval, if any (planning.py:44-48)
+
+    @property
+    def max_speed(self) -> float:
+        return self.goal_speed[1] if self.goal_speed else 13.5  # planning.py:49-52
+
+
+def _points(node):
+    return np.array([[float(p.find("x").text), float(p.find("y").text)] for p in node.findall("point")])
+
+
+def _inside(poly: np.ndarray, x: float, y: float) -> bool:
+    inside = False
+    n = len(poly)
+    for i in range(n):
+        x1, y1 = poly[i]
+        x2, y2 = poly[(i + 1) % n]
+        if (y1 > y) != (y2 > y) and x < (x2 - x1) * (y - y1) / (y2 - y1) + x1:
+            inside = not inside
+    return inside
+
+
+def load_scenario(path: str) -> Scenario:
+    root = ET.parse(path).getroot()
+    lanelets = {}
+    for ll in root.findall("lanelet"):
+        left, right = _points(ll.find("leftBound")), _points(ll.find("rightBound"))
+        lanelets[int(ll.get("id"))] = dict(left=left, right=right, center=(left + right) / 2,
+                                           succ=[int(s.get("ref")) for s in ll.findall("successor")])
+    pp = root.find("planningProblem")
+    ini = pp.find("initialState")
+    init = np.array([float(ini.find("position/point/x").text), float(ini.find("position/point/y").text),
+                     float(ini.find("orientation/exact").text), float(ini.find("velocity/exact").text)])
+    goal = pp.find("goalState")
+    goal_lanelet = int(goal.find("position/lanelet").get("ref"))
+    gv = goal.find("velocity")
+    goal_speed = (float(gv.find("intervalStart").text), float(gv.find("intervalEnd").text)) if gv is not None else None
+
+    # start lanelets: polygons (left bound + reversed right bound) containing the initial position, best heading match first
+    starts = []
+    for lid, ll in lanelets.items():
+        if _inside(np.vstack([ll["left"], ll["right"][::-1]]), init[0], init[1]):
+            c = ll["center"]
+            k = int(np.argmin(np.hypot(c[:, 0] - init[0], c[:, 1] - init[1])))
+            k = min(k, len(c) - 2)
+            heading = np.arctan2(c[k + 1, 1] - c[k, 1], c[k + 1, 0] - c[k, 0])
+            dev = abs((heading - init[2] + np.pi) % (2 * np.pi) - np.pi)
+            starts.append((dev, lid))
+    if not starts:
+        raise ValueError("initial position is not on any lanelet")
+    route = None
+    for _, s in sorted(starts):
+        prev = {s: None}
+        dq = deque([s])
+        while dq and goal_lanelet not in prev:
+            u = dq.popleft()
+            for v in lanelets[u]["succ"]:
+                if v not in prev and v in lanelets:
+                    prev[v] = u
+                    dq.append(v)
+        if goal_lanelet in prev:
+            route = [goal_lanelet]
+            while prev[route[-1]] is not None:
+                route.append(prev[route[-1]])
+            route.reverse()
+            break
+    if route is None:
+        raise ValueError("no successor-only route from the initial lanelet to the goal lanelet")
+    lanes = list(route)
+    if lanelets[route[-1]]["succ"]:
+        lanes.append(lanelets[route[-1]]["succ"][0])
+    cc = np.concatenate([lanelets[i]["center"] for i in lanes])
+    _, first = np.unique(cc, return_index=True, axis=0)
+    centerline = cc[np.sort(first)]
+    gc = lanelets[goal_lanelet]["center"]
+    goal_center = gc[int((gc.shape[0] - 1) / 2)]
+
+    obs, T = [], 0
+    for ob in root.findall("dynamicObstacle"):
+        rect = ob.find("shape/rectangle")
+        if rect is None:
+            raise ValueError("only rectangle obstacles are supported (all demo scenarios use rectangles)")
+        states = {}
+        for st in [ob.find("initialState")] + ob.find("trajectory").findall("state"):
+            states[int(st.find("time/exact").text)] = (float(st.find("position/point/x").text), float(st.find("position/point/y").text),
+                                                       float(st.find("orientation/exact").text))
+        obs.append((float(rect.find("length").text), float(rect.find("width").text), states))
+        T = max(T, max(states) + 1)
+    if not obs:
+        raise ValueError("scenario has no dynamic obstacle (the reference reads dynamic_obstacles[0], planning.py:70)")
+    pose = np.zeros((T, len(obs), 4))
+    dims = np.zeros((len(obs), 2))
+    for j, (l, w, states) in enumerate(obs):
+        dims[j] = (l, w)
+        for t, (x, y, yaw) in states.items():
+            pose[t, j] = (x, y, yaw, 1.0)
+    fts = max(obs[0][2])  # dynamic_obstacles[0].prediction.final_time_step
+    return Scenario(root.get("benchmarkID"), float(root.get("timeStepSize")), route, centerline,
+                    ObstacleTable(pose[:max(fts, 1)], dims, fts), init, goal_lanelet, np.asarray(goal_center), goal_speed)
