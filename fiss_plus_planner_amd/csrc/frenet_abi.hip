@@ -501,6 +501,78 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
     return FP_OK;
 }
 
+int fp_frames_build(fp_ctx* ctx, int32_t F, int32_t NX, const int32_t* n, const double* points, double* knots, double* coef, int mem,
+                    void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    if (F < 0 || NX < 2 || NX > FP_MAX_KNOTS) return fail(FP_EINVAL, "bad sizes F=%d NX=%d", F, NX);
+    if (!n || !points || !knots || !coef) return fail(FP_EINVAL, "NULL array");
+    if (F == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (mem == FP_MEM_DEVICE) {
+        hipError_t e = fp::launch_frames_build(F, NX, n, points, knots, coef, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "frame build launch failed: %s", hipGetErrorString(e));
+        return FP_OK;
+    }
+    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+    for (int f = 0; f < F; ++f)
+        if (n[f] < 2 || n[f] > NX) return fail(FP_EINVAL, "n[%d]=%d out of range", f, n[f]);
+    const size_t fn = (size_t)F * NX;
+    int rc;
+    if ((rc = ctx->arena.reserve(Arena::padded(sizeof(int32_t) * F) + Arena::padded(sizeof(double) * fn * 2) + Arena::padded(sizeof(double) * fn) +
+                                 Arena::padded(sizeof(double) * fn * 8))) != FP_OK)
+        return rc;
+    ctx->arena.reset();
+    const int32_t* d_n = nullptr; const double* d_pts = nullptr;
+    if ((rc = push(ctx, n, (size_t)F, &d_n)) != FP_OK) return rc;
+    if ((rc = push(ctx, points, fn * 2, &d_pts)) != FP_OK) return rc;
+    double* d_k = (double*)ctx->arena.take(sizeof(double) * fn);
+    double* d_c = (double*)ctx->arena.take(sizeof(double) * fn * 8);
+    hipError_t e = fp::launch_frames_build(F, NX, d_n, d_pts, d_k, d_c, ctx->stream);
+    if (e != hipSuccess) return fail(FP_EHIP, "frame build launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(knots, d_k, sizeof(double) * fn, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(coef, d_c, sizeof(double) * fn * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FP_OK;
+}
+
+int fp_from_state(fp_ctx* ctx, const fp_batch* batch, const double* states, double* ego, int mem, void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    if (!batch || !states || !ego) return fail(FP_EINVAL, "NULL argument");
+    if (batch->B < 0 || batch->F < 1 || batch->NX < 2 || batch->NX > FP_MAX_KNOTS) return fail(FP_EINVAL, "bad batch sizes");
+    if (!batch->frame_of || !batch->nx || !batch->knots || !batch->coef) return fail(FP_EINVAL, "batch frame arrays must not be NULL");
+    if (batch->B == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (mem == FP_MEM_DEVICE) {
+        hipError_t e = fp::launch_from_state(*batch, states, ego, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(FP_EHIP, "from_state launch failed: %s", hipGetErrorString(e));
+        return FP_OK;
+    }
+    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+    const size_t B = (size_t)batch->B, fn = (size_t)batch->F * batch->NX;
+    for (size_t i = 0; i < B; ++i)
+        if (batch->frame_of[i] < 0 || batch->frame_of[i] >= batch->F) return fail(FP_EINVAL, "frame_of[%zu] out of range", i);
+    int rc;
+    if ((rc = ctx->arena.reserve(Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(int32_t) * batch->F) + Arena::padded(sizeof(double) * fn) +
+                                 Arena::padded(sizeof(double) * fn * 8) + Arena::padded(sizeof(double) * B * 4) + Arena::padded(sizeof(double) * B * 6))) != FP_OK)
+        return rc;
+    ctx->arena.reset();
+    fp_batch db = *batch;
+    if ((rc = push(ctx, batch->frame_of, B, &db.frame_of)) != FP_OK) return rc;
+    if ((rc = push(ctx, batch->nx, (size_t)batch->F, &db.nx)) != FP_OK) return rc;
+    if ((rc = push(ctx, batch->knots, fn, &db.knots)) != FP_OK) return rc;
+    if ((rc = push(ctx, batch->coef, fn * 8, &db.coef)) != FP_OK) return rc;
+    const double* d_states = nullptr;
+    if ((rc = push(ctx, states, B * 4, &d_states)) != FP_OK) return rc;
+    double* d_ego = (double*)ctx->arena.take(sizeof(double) * B * 6);
+    hipError_t e = fp::launch_from_state(db, d_states, d_ego, ctx->stream);
+    if (e != hipSuccess) return fail(FP_EHIP, "from_state launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(ego, d_ego, sizeof(double) * B * 6, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FP_OK;
+}
+
 int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states, double* cost,
                   uint32_t* flags, double* traj, int32_t stride, int mem, void* stream)
 {

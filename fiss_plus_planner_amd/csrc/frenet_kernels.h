@@ -38,6 +38,9 @@ hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which);
 // Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
 // end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);
+// Frenet frame construction / Cartesian -> Frenet projection (frenet_frame.hip).
+hipError_t launch_frames_build(int F, int NX, const int32_t* n, const double* points, double* knots, double* coef, hipStream_t stream);
+hipError_t launch_from_state(const fp_batch& bt, const double* states, double* ego, hipStream_t stream);
 // Closed-loop bookkeeping between two plan cycles (one lane per ego).
 hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const double* end_state, const fp_loop_io& io, hipStream_t stream);
 hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,

@@ -158,6 +158,29 @@ class FrenetEngine:
         _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(p), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_HOST, None))
         return out
 
+    def build_frames(self, points: np.ndarray, n: np.ndarray | None = None):
+        """CubicSpline2D construction for F centerlines on the GPU (fp_frames_build): points [F,NX,2] -> knots [F,NX], coef [F,8,NX]."""
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        if pts.ndim == 2:
+            pts = pts[None]
+        F, NX, _ = pts.shape
+        n = np.full(F, NX, dtype=np.int32) if n is None else np.ascontiguousarray(n, dtype=np.int32)
+        knots = np.empty((F, NX)); coef = np.empty((F, 8, NX))
+        _abi.check(self._lib.fp_frames_build(self._ctx, F, NX, n.ctypes.data, pts.ctypes.data, knots.ctypes.data, coef.ctypes.data, _abi.FP_MEM_HOST, None))
+        return knots, coef
+
+    def from_state(self, knots: np.ndarray, coef: np.ndarray, nx: np.ndarray, frame_of: np.ndarray, states: np.ndarray) -> np.ndarray:
+        """FrenetState.from_state for B Cartesian states [B,4] = x, y, yaw, v (fp_from_state) -> ego [B,6]."""
+        st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 4)
+        knots = np.ascontiguousarray(knots, dtype=np.float64); coef = np.ascontiguousarray(coef, dtype=np.float64)
+        nx = np.ascontiguousarray(nx, dtype=np.int32); fo = np.ascontiguousarray(frame_of, dtype=np.int32)
+        fb = _abi.FpBatch()
+        fb.B, fb.F, fb.NX = st.shape[0], knots.shape[0], knots.shape[1]
+        fb.frame_of, fb.nx, fb.knots, fb.coef = fo.ctypes.data, nx.ctypes.data, knots.ctypes.data, coef.ctypes.data
+        ego = np.empty((st.shape[0], 6))
+        _abi.check(self._lib.fp_from_state(self._ctx, C.byref(fb), st.ctypes.data, ego.ctypes.data, _abi.FP_MEM_HOST, None))
+        return ego
+
     # ------------------------------------------------------------------ resident device memory
     def plan_dense_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_cost: int, stats: int = 0,
                           cost_tbl: int = 0, flag_tbl: int = 0, stream: int = 0, best_flags: int = 0, best_traj: int = 0):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 4
+#define FP_ABI_VERSION 5
 
 /* error codes */
 #define FP_OK 0
@@ -189,6 +189,21 @@ typedef struct {
 /* In FP_MEM_DEVICE mode the ctx grows an internal scratch arena (dense tables, B*C*12 bytes) on first use. */
 int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io,
                  int mem, void* stream);
+
+/* ---- Frenet frame construction on the device ------------------------------------------------------------------
+ * fp_frames_build = CubicSpline2D.__init__ for F centerlines at once (common/geometry/cubic_spline.py:157-168 arclength
+ * knots, :19-43 natural cubic spline per axis; the reference solves the dense system with np.linalg.solve, here a
+ * tridiagonal Thomas sweep - same solution to ~1e-12).
+ * points [F][NX][2] (rows >= n[f] ignored), n [F]  ->  knots [F][NX] (+inf padded), coef [F][8][NX]. */
+int fp_frames_build(fp_ctx* ctx, int32_t F, int32_t NX, const int32_t* n, const double* points, double* knots, double* coef, int mem,
+                    void* stream);
+
+/* fp_from_state = FrenetState.from_state (common/scenario/frenet.py:32-99) for B egos: projection of a Cartesian state
+ * (x, y, yaw, v) on the 0.1 m-resampled reference line of its frame (generate_frenet_frame, frenet_optimal_planner.py:272-278):
+ * nearest point (first minimum), next-waypoint rule by heading, projection on the segment, sign from `wp_yaw <= x_yaw`,
+ * s = polyline length up to the previous waypoint.  states [B][4]  ->  ego [B][6] = s, s_d, 0, d, d_d, 0.
+ * Uses batch->F, NX, nx, knots, coef, frame_of (the other batch fields may be NULL). */
+int fp_from_state(fp_ctx* ctx, const fp_batch* batch, const double* states, double* ego, int mem, void* stream);
 
 /* ---- closed-loop stepping on the device ---------------------------------------------------------------------
  * fp_advance = the bookkeeping between two plan() calls of the reference's simulation loop
