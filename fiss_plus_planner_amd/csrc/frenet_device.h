@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/frenet_gpu.h"
+
 namespace fp {
 
 constexpr int kWave = 64;
@@ -81,6 +83,87 @@ __device__ __forceinline__ void quartic_eval(const Quartic& q, double t, double&
     v = fma(fma(fma(4.0 * q.a4, t, 3.0 * q.a3), t, 2.0 * q.a2), t, q.a1);
     a = fma(fma(12.0 * q.a4, t, 6.0 * q.a3), t, 2.0 * q.a2);
     j = fma(24.0 * q.a4, t, 6.0 * q.a3);
+}
+
+// ---------------------------------------------------------------------------
+// Cost sums in closed form.  Every summand of CostFunction.cost_total (cost_function.py:29-50) is the square of a
+// polynomial in t, so  sum_i p(t_i)^2 = sum_k (p * p)_k S_k  with the power sums S_k = sum_{i<N} t_i^k, k = 0..10.
+//   lon[3] = sum (s_d - v_target)^2, sum s_dd^2, sum s_ddd^2      lat[3] = sum d_dd^2, sum d_ddd^2, sum d^2
+// Even in the lateral boundary data: mirrored candidates give bit-identical sums.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lon_cost_sums(const Quartic& q, double target_speed, const double* S, double* lon)
+{
+    const double e0 = q.a1 - target_speed, e1 = 2.0 * q.a2, e2 = 3.0 * q.a3, e3 = 4.0 * q.a4;
+    const double g0 = 2.0 * q.a2, g1 = 6.0 * q.a3, g2 = 12.0 * q.a4;
+    const double h0 = 6.0 * q.a3, h1 = 24.0 * q.a4;
+    double sv = e0 * e0 * S[0];
+    sv = fma(2.0 * e0 * e1, S[1], sv);
+    sv = fma(fma(2.0 * e0, e2, e1 * e1), S[2], sv);
+    sv = fma(2.0 * fma(e0, e3, e1 * e2), S[3], sv);
+    sv = fma(fma(2.0 * e1, e3, e2 * e2), S[4], sv);
+    sv = fma(2.0 * e2 * e3, S[5], sv);
+    sv = fma(e3 * e3, S[6], sv);
+    double sa = g0 * g0 * S[0];
+    sa = fma(2.0 * g0 * g1, S[1], sa);
+    sa = fma(fma(2.0 * g0, g2, g1 * g1), S[2], sa);
+    sa = fma(2.0 * g1 * g2, S[3], sa);
+    sa = fma(g2 * g2, S[4], sa);
+    double sj = h0 * h0 * S[0];
+    sj = fma(2.0 * h0 * h1, S[1], sj);
+    sj = fma(h1 * h1, S[2], sj);
+    lon[0] = sv; lon[1] = sa; lon[2] = sj;
+}
+
+__device__ __forceinline__ void lat_cost_sums(const Quintic& q, const double* S, double* lat)
+{
+    const double c[6] = {q.a0, q.a1, q.a2, q.a3, q.a4, q.a5};
+    double sd = 0.0;
+#pragma unroll
+    for (int kk = 0; kk <= 10; ++kk) {
+        double ck = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 <= 5; ++a2) {
+            const int b2 = kk - a2;
+            if (b2 >= 0 && b2 <= 5) ck = fma(c[a2], c[b2], ck);
+        }
+        sd = fma(ck, S[kk], sd);
+    }
+    const double g[4] = {2.0 * q.a2, 6.0 * q.a3, 12.0 * q.a4, 20.0 * q.a5};  // d_dd
+    double sa = 0.0;
+#pragma unroll
+    for (int kk = 0; kk <= 6; ++kk) {
+        double ck = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 <= 3; ++a2) {
+            const int b2 = kk - a2;
+            if (b2 >= 0 && b2 <= 3) ck = fma(g[a2], g[b2], ck);
+        }
+        sa = fma(ck, S[kk], sa);
+    }
+    const double h[3] = {6.0 * q.a3, 24.0 * q.a4, 60.0 * q.a5};  // d_ddd
+    double sj = 0.0;
+#pragma unroll
+    for (int kk = 0; kk <= 4; ++kk) {
+        double ck = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 <= 2; ++a2) {
+            const int b2 = kk - a2;
+            if (b2 >= 0 && b2 <= 2) ck = fma(h[a2], h[b2], ck);
+        }
+        sj = fma(ck, S[kk], sj);
+    }
+    lat[0] = sa; lat[1] = sj; lat[2] = sd;
+}
+
+// cost_total with the reference's grouping (cost_function.py:41-50)
+__device__ __forceinline__ double combine_cost(const fp_params& p, int N, const double* lon, const double* lat)
+{
+    const double cost_time = p.cost_horizon - (double)(N - 1) * p.tick_t;
+    const double cost_speed = p.w_speed * lon[0];
+    const double cost_accel = p.w_accel * lon[1] + p.w_accel * lat[0];
+    const double cost_jerk = p.w_jerk * lon[2] + p.w_jerk * lat[1];
+    const double cost_offset = p.w_offset * lat[2];
+    return (cost_time + 0.0 + cost_speed + cost_accel + cost_jerk + cost_offset) / (double)N;
 }
 
 // len(np.arange(0, T, tick)) = ceil(T / tick) evaluated in double

@@ -23,7 +23,6 @@ constexpr uint8_t kGen = 1, kInQ = 2;
 
 struct Walk {
     const double* J;
-    const double* E;
     const uint8_t* F;
     uint8_t* st;
     double* keyQ;   // J where "in queue", +inf elsewhere      -> queue head = argmin
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         return;
     }
     double* J = (double*)smem;
-    double* E = J + C;
-    double* keyQ = E + C;
+    double* keyQ = J + C;
     double* keyF = keyQ + C;
     double* keyG = keyF + C;
     uint8_t* F = (uint8_t*)(keyG + C);
@@ -147,7 +145,6 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
             const int a = i - p0, bb = j - p1, c = k - p2;
             est += fa.opts.w_heuristic * (double)(a * a + bb * bb + c * c) / max_sqr_dist;
         }
-        E[q] = est;
         keyQ[q] = __builtin_inf();
         keyF[q] = __builtin_inf();
         keyG[q] = est <= __builtin_inf() ? est : __builtin_inf();  // a NaN estimate can never satisfy `<=`
@@ -180,7 +177,7 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         }
     }
 
-    Walk w{J, E, F, st, keyQ, keyF, keyG, nd, nv, nt, C, lane, 0, 0, 0, 0};
+    Walk w{J, F, st, keyQ, keyF, keyG, nd, nv, nt, C, lane, 0, 0, 0, 0};
     const int sizes[3] = {nd, nv, nt};
     int best = -1;
     const bool plus = fa.opts.kind == FP_FISS_PLUS;
@@ -223,24 +220,36 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
                 }
             }
         } else {
-            // explore_neighbors + frontier (fiss_plus_planner.py:30-59, :106-116)
+            // explore_neighbors + frontier (fiss_plus_planner.py:30-59, :106-116).  The centre is generated first (wave-uniform);
+            // its up-to-six axis neighbours are distinct cells, so lanes 0..5 generate them in parallel (one LDS round trip
+            // instead of six dependent ones); the bookkeeping counts are order-independent.
+            int frontier_size = 0;  // wave-uniform number of frontier entries
             for (;;) {
                 w.generate(w.raster(idx[0], idx[1], idx[2]), cost_center);
-#pragma unroll
-                for (int dim = 0; dim < 3; ++dim) {
-#pragma unroll
-                    for (int step = -1; step <= 1; step += 2) {
-                        const int n = idx[dim] + step;
-                        if (n < 0 || n > sizes[dim] - 1) continue;
-                        int nb[3] = {idx[0], idx[1], idx[2]};
-                        nb[dim] = n;
+                bool is_new = false, to_frontier = false;
+                if (lane < 6) {
+                    const int dim = lane >> 1, step = (lane & 1) ? +1 : -1;
+                    int nb[3] = {idx[0], idx[1], idx[2]};
+                    nb[dim] += step;
+                    if (nb[dim] >= 0 && nb[dim] <= sizes[dim] - 1) {
                         const int nq = w.raster(nb[0], nb[1], nb[2]);
-                        if (w.generate(nq, cost) && cost <= cost_center) keyF[nq] = cost;  // frontier_idxs.put((cost, idx))
+                        const double c = J[nq];
+                        const uint8_t s = st[nq];
+                        if (!(s & kGen)) {
+                            is_new = true;
+                            st[nq] = s | kGen | kInQ;
+                            keyQ[nq] = c;
+                            keyG[nq] = __builtin_inf();
+                            if (c <= cost_center) { keyF[nq] = c; to_frontier = true; }  // frontier_idxs.put((cost, idx))
+                        }
                     }
                 }
+                w.num_generated += __popcll(__ballot(is_new));
+                frontier_size += __popcll(__ballot(to_frontier));
+                if (frontier_size == 0) break;
                 const int nq = w.head_frontier();
-                if (nq < 0) break;
                 keyF[nq] = __builtin_inf();
+                --frontier_size;
                 idx[0] = nq / (nt * nv); idx[1] = (nq / nt) % nv; idx[2] = nq % nt;
             }
         }
@@ -271,10 +280,279 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
     }
 }
 
+// ---------------------------------------------------------------------------
+// FISS+ refinement (fiss_plus_planner.py:207-326), one wavefront per ego.
+//   * costs in closed form: a table S_k(N) = sum_{i<N} t_i^k for every N <= 128 is built once per workgroup (11 lanes, one
+//     running sum each), then the cost of ANY end state is O(1) (lon_cost_sums / lat_cost_sums): per round lanes 0..5 price the
+//     six probes clip(x -/+ res_dim e_dim) (:213-232), the finite-difference gradient and the decayed step are wave-uniform
+//     arithmetic on shuffled lane values (:262-271), lane 0 prices the trajectory at the new x.  The coarse winner is priced by
+//     the same function, so a probe clipped back onto x ties with it exactly (`cost > coarse cost` ends the loop, :303-304).
+//   * validation is lazy and in cost order like refined_trajs.get() (:301-323); each popped trajectory is checked by the WHOLE
+//     wavefront: lane = time point for the masks / truncation / Cartesian points, then lane = obstacle for every checked pose
+//     (coalesced 32-byte pose reads straight from the scene table, exact circle + separating-axis test), ballot early exit.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct RefineLds {
+    double* S;      // [FP_MAX_POINTS + 1][11]
+    double2* xy;    // [FP_MAX_POINTS]
+    double* knots;  // [nx]
+    double* coef;   // [8][nx]
+};
+
+__device__ __forceinline__ double analytic_cost(const fp_params& p, const double* eg, double target_speed, const double* x, const double* Stab)
+{
+    const double T = x[2];
+    const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
+    if (N <= 0 || N > FP_MAX_POINTS) return __builtin_nan("");
+    const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], x[1], 0.0, T);
+    const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
+    double ls[3], ds[3];
+    lon_cost_sums(lon, target_speed, Stab + N * 11, ls);
+    lat_cost_sums(lat, Stab + N * 11, ds);
+    return combine_cost(p, N, ls, ds);
+}
+
+// constraint + collision flags of ONE trajectory, computed by the whole wavefront (all arguments wave-uniform)
+__device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane)
+{
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
+    const double T = x[2];
+    const int N = arange_len(T, p.tick_t);
+    const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], x[1], 0.0, T);
+    const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
+    SplineLds sp{L.knots, L.coef, nx, nx};
+    const double knot0 = L.knots[0], knot_last = L.knots[nx - 1];
+    unsigned long long off_lo = 0, off_hi = 0;
+    bool bad_speed = false, bad_accel = false;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int i = lane + half * kWave;
+        bool off = false;
+        if (i < N) {
+            const double t = (double)i * p.tick_t;
+            double s, s_d, s_dd, s_ddd;
+            quartic_eval(lon, t, s, s_d, s_dd, s_ddd);
+            bad_speed |= s_d > p.max_speed;
+            bad_accel |= fabs(s_dd) > p.max_accel;
+            off = !(s >= knot0) || !(s < knot_last);
+            if (!off) {
+                const double d = fma(fma(fma(fma(fma(lat.a5, t, lat.a4), t, lat.a3), t, lat.a2), t, lat.a1), t, lat.a0);
+                const int seg = spline_segment(sp, s, -1);
+                double px, py, tx, ty, cx, cy;
+                spline_frame(sp, seg, s - L.knots[seg], px, py, tx, ty);
+                frenet_to_cartesian(px, py, tx, ty, d, cx, cy);
+                L.xy[i] = make_double2(cx, cy);
+            }
+        }
+        const unsigned long long m = __ballot(off);
+        if (half == 0) off_lo = m; else off_hi = m;
+    }
+    uint32_t flags = 0;
+    if (__ballot(bad_speed)) flags |= FP_FLAG_SPEED;
+    if (__ballot(bad_accel)) flags |= FP_FLAG_ACCEL;
+    const int M = off_lo ? __ffsll((long long)off_lo) - 1 : (off_hi ? kWave + __ffsll((long long)off_hi) - 1 : N);
+    if (M < N) flags |= FP_FLAG_TRUNCATED;
+    flags |= ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+    // collision (frenet_optimal_planner.py:168-195)
+    const int sc = bt.scene_of[b];
+    const int n_obs = sc >= 0 ? bt.n_obs : 0;
+    if (n_obs <= 0) return flags;
+    const int t_now = bt.t_now[b];
+    const int horizon_cap = bt.final_time_step[sc] - t_now;
+    if (M == 1 && horizon_cap >= 1) return flags | FP_FLAG_COLLISION;  // traj.yaw is empty -> IndexError -> collision (:178-182)
+    if (M < 2) return flags;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double* scene = bt.obs_pose + (size_t)sc * bt.T_obs * n_obs * 4;
+    const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
+    const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
+    const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
+    const int k_end = M < horizon_cap ? M : horizon_cap;
+    for (int k = 0; k < k_end; k += p.check_stride) {
+        const int ts = k + t_now;
+        if (ts >= bt.T_obs) break;  // beyond the table: state_at_time() is None for every obstacle
+        const int a = (k + 1 < M) ? k : k - 1;  // heading: forward difference, previous one for the last point (:127-129)
+        const double2 pa = L.xy[a], pb = L.xy[a + 1], pc = L.xy[k];
+        Obb ego;
+        step_heading(pb.x - pa.x, pb.y - pa.y, ego.c, ego.s);
+        ego.x = pc.x; ego.y = pc.y; ego.hl = veh_hl; ego.hw = veh_hw;
+        const bool broken = !(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c);
+        bool hit = false;
+        for (int j0 = 0; j0 < n_obs; j0 += kWave) {
+            const int j = j0 + lane;
+            if (j < n_obs) {
+                const double4 ps = *(const double4*)(scene + ((size_t)ts * n_obs + j) * 4);
+                if (ps.w != 0.0) {
+                    const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
+                    const double R = (r_ego + sqrt(fma(hl, hl, hw * hw))) * (1.0 + 1e-12);
+                    const double dx = ps.x - ego.x, dy = ps.y - ego.y;
+                    if (broken) {
+                        hit = true;  // polygon construction fails in the reference -> collision (:178-182)
+                    } else if (fma(dx, dx, dy * dy) <= R * R) {
+                        double oc, os;
+                        sincos(ps.z, &os, &oc);
+                        hit = obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
+                    }
+                }
+            }
+            if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
+        }
+        if (broken) return flags | FP_FLAG_COLLISION;  // the ego polygon is built (and fails) before the obstacle loop
+    }
+    return flags;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kWave) void fiss_refine_kernel(FissArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const KernelArgs& ka = fa.ka;
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int32_t* ijk = fa.io.best_ijk + (size_t)b * 3;
+    const int R = fa.opts.max_refine_iters;
+    if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None
+    const int f = bt.frame_of[b];
+    const int nx = bt.nx[f];
+    RefineLds L;
+    L.S = (double*)smem;
+    L.xy = (double2*)(L.S + (FP_MAX_POINTS + 1) * 11);
+    L.knots = (double*)(L.xy + FP_MAX_POINTS);
+    L.coef = L.knots + nx;
+    {
+        const double* gk = bt.knots + (size_t)f * bt.NX;
+        const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
+        for (int i = lane; i < nx; i += kWave) L.knots[i] = gk[i];
+        for (int i = lane; i < 8 * nx; i += kWave) {
+            const int r = i / nx, c = i - r * nx;
+            L.coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
+        }
+        if (lane < 11) {  // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane
+            double acc = 0.0;
+            L.S[lane] = 0.0;
+            for (int i = 0; i < FP_MAX_POINTS; ++i) {
+                const double t = (double)i * p.tick_t;
+                double tk = 1.0;
+                for (int m = 0; m < lane; ++m) tk *= t;
+                acc += tk;
+                L.S[(i + 1) * 11 + lane] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    const double nan = __builtin_nan("");
+    double eg[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) eg[m] = bt.ego[(size_t)b * 6 + m];
+    const double target_speed = bt.target_speed[b];
+    double x[3], res[3], lo[3], hi[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        x[m] = fa.io.end_state[(size_t)b * 3 + m];
+        res[m] = fa.io.samp_res[(size_t)b * 3 + m];
+        lo[m] = fa.io.samp_min[(size_t)b * 3 + m];
+        hi[m] = fa.io.samp_max[(size_t)b * 3 + m];
+    }
+    const double coarse_cost = analytic_cost(p, eg, target_speed, x, L.S);
+
+    double my_x[3] = {nan, nan, nan}, my_cost = nan;  // lane c = refinement trajectory c (generation order)
+    int ncand = 0;
+    for (int r = 0; r < R; ++r) {
+        const int dim = lane >> 1;
+        double xp[3] = {x[0], x[1], x[2]};
+        if (lane < 6) xp[dim] += (lane & 1) ? res[dim] : -res[dim];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) xp[m] = fmin(fmax(xp[m], lo[m]), hi[m]);  // np.clip
+        const bool bad = lane < 6 && (!(xp[0] == xp[0]) || !(xp[1] == xp[1]) || !(xp[2] == xp[2]));
+        if (__ballot(bad)) break;
+        const double cp = analytic_cost(p, eg, target_speed, xp, L.S);  // lanes >= 6 price x itself (unused)
+        for (int k = 0; k < 6; ++k) {  // hand probe k to lane ncand + k
+            const double c = __shfl(cp, k, kWave), a0 = __shfl(xp[0], k, kWave), a1 = __shfl(xp[1], k, kWave), a2 = __shfl(xp[2], k, kWave);
+            if (lane == ncand + k) { my_cost = c; my_x[0] = a0; my_x[1] = a1; my_x[2] = a2; }
+        }
+        ncand += 6;
+        double g[3], nrm2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const double Jl = __shfl(cp, 2 * m, kWave), Jr = __shfl(cp, 2 * m + 1, kWave);
+            const double xl = __shfl(xp[m], 2 * m, kWave), xr = __shfl(xp[m], 2 * m + 1, kWave);
+            g[m] = (Jr - Jl) / (xr - xl);
+            nrm2 += g[m] * g[m];
+        }
+        const double nrm = sqrt(nrm2);
+        double xn[3];
+        bool nan_step = false;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            res[m] *= fa.opts.decaying_factor;  // decays in place, like the reference's aliasing of sampling_res (:282)
+            xn[m] = x[m] - res[m] * g[m] / nrm;
+            xn[m] = fmin(fmax(xn[m], lo[m]), hi[m]);
+            nan_step |= !(xn[m] == xn[m]);
+        }
+        if (nan_step) break;  // zero gradient: the reference raises inside np.arange(nan); refinement stops here
+        const double cn = analytic_cost(p, eg, target_speed, xn, L.S);
+        if (lane == ncand) { my_cost = cn; my_x[0] = xn[0]; my_x[1] = xn[1]; my_x[2] = xn[2]; }
+        ncand += 1;
+        x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
+    }
+    // refined_trajs.get() in cost order (ties: generation order), :301-323 - each popped trajectory checked by the whole wave
+    int validated = 0, checks = 0, winner = -1;
+    bool alive = lane < ncand;
+    for (int it = 0; it < ncand; ++it) {
+        double bc = alive ? my_cost : __builtin_inf();
+        int bl = alive ? lane : kWave;
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const double oc = __shfl_xor(bc, off, kWave);
+            const int ol = __shfl_xor(bl, off, kWave);
+            if (ol < kWave && (bl >= kWave || oc < bc || (oc == bc && ol < bl))) { bc = oc; bl = ol; }
+        }
+        if (bl >= kWave) break;
+        if (bc > coarse_cost) break;
+        if (lane == bl) alive = false;
+        ++validated;
+        const double cx[3] = {__shfl(my_x[0], bl, kWave), __shfl(my_x[1], bl, kWave), __shfl(my_x[2], bl, kWave)};
+        const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane);
+        if (fl & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) continue;
+        ++checks;
+        if (!(fl & FP_FLAG_COLLISION)) { winner = bl; break; }
+    }
+    if (fa.io.trace && lane < R * 7) {
+        double* tr = fa.io.trace + ((size_t)b * R * 7 + lane) * 4;
+        const bool have = lane < ncand;
+        tr[0] = have ? my_x[0] : nan; tr[1] = have ? my_x[1] : nan; tr[2] = have ? my_x[2] : nan; tr[3] = have ? my_cost : nan;
+    }
+    if (lane == 0) {
+        int32_t* s4 = fa.io.stats + (size_t)b * 4;
+        s4[1] += ncand;
+        s4[2] += validated;
+        s4[3] += checks;
+        fa.io.best_cost[b] = coarse_cost;  // same evaluator as the refined costs
+    }
+    if (winner >= 0 && lane == winner) {
+        fa.io.refined[b] = 1;
+        fa.io.best_cost[b] = my_cost;
+        double* es = fa.io.end_state + (size_t)b * 3;
+        es[0] = my_x[0]; es[1] = my_x[1]; es[2] = my_x[2];
+    }
+}
+
+hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream)
+{
+    const int bytes = (int)sizeof(double) * ((FP_MAX_POINTS + 1) * 11 + 2 * FP_MAX_POINTS + 9 * fa.ka.b.NX) + 32;
+    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa);
+    return hipGetLastError();
+}
+
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
 {
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
-    const int bytes = C * (5 * 8 + 1 + 1) + 16;
+    const int bytes = C * (4 * 8 + 1 + 1) + 16;
     hipLaunchKernelGGL(fiss_search_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa);
     return hipGetLastError();
 }

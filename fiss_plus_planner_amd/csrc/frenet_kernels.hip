@@ -467,142 +467,6 @@ hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream)
 
 
 // ---------------------------------------------------------------------------
-// FISS+ refinement (fiss_plus_planner.py:207-326), one wavefront per ego.
-//   per round: lanes 0..5 evaluate the six probe trajectories clip(x -/+ res_dim e_dim) (:213-232), the finite
-//   difference gradient and the decayed step are wave-uniform arithmetic on shuffled lane values (:262-271), lane 0
-//   evaluates the trajectory at the new x.  Afterwards lane c holds refinement trajectory c: the ones that can be
-//   popped (cost <= coarse cost) get their constraint + collision flags in parallel, and the cost-ordered validation
-//   loop (:301-323) is replayed with the reference's Stats bookkeeping.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void fiss_refine_kernel(FissArgs fa, int lds_doubles)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const KernelArgs& ka = fa.ka;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int32_t* ijk = fa.io.best_ijk + (size_t)b * 3;
-    const int R = fa.opts.max_refine_iters;
-    if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None (block-uniform exit)
-    EgoCtx e;
-    stage_ego(ka, b, lds, e, lds_doubles);
-    const double nan = __builtin_nan("");
-    double x[3], res[3], lo[3], hi[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        x[m] = fa.io.end_state[(size_t)b * 3 + m];
-        res[m] = fa.io.samp_res[(size_t)b * 3 + m];
-        lo[m] = fa.io.samp_min[(size_t)b * 3 + m];
-        hi[m] = fa.io.samp_max[(size_t)b * 3 + m];
-    }
-    // the coarse winner through the same evaluator as the refined ones: a probe clipped back onto x must tie exactly
-    double coarse_cost = 0.0;
-    if (lane == 6) coarse_cost = traj_eval<false>(ka, e, x[0], x[1], x[2], false, nullptr, 0).cost;
-    coarse_cost = __shfl(coarse_cost, 6, kWave);
-
-    double my_x[3] = {nan, nan, nan}, my_cost = nan;  // lane c = refinement trajectory c (generation order)
-    int ncand = 0;
-    for (int r = 0; r < R; ++r) {
-        const int dim = lane >> 1;
-        double xp[3] = {x[0], x[1], x[2]};
-        if (lane < 6) xp[dim] += (lane & 1) ? res[dim] : -res[dim];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) xp[m] = fmin(fmax(xp[m], lo[m]), hi[m]);  // np.clip
-        const bool bad = lane < 6 && (!(xp[0] == xp[0]) || !(xp[1] == xp[1]) || !(xp[2] == xp[2]));
-        if (__ballot(bad)) break;
-        double cp = 0.0;
-        if (lane < 6) cp = traj_eval<false>(ka, e, xp[0], xp[1], xp[2], false, nullptr, 0).cost;
-        // hand probe k to lane ncand + k
-        for (int k = 0; k < 6; ++k) {
-            const double c = __shfl(cp, k, kWave), a0 = __shfl(xp[0], k, kWave), a1 = __shfl(xp[1], k, kWave), a2 = __shfl(xp[2], k, kWave);
-            if (lane == ncand + k) { my_cost = c; my_x[0] = a0; my_x[1] = a1; my_x[2] = a2; }
-        }
-        ncand += 6;
-        double g[3], nrm2 = 0.0;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const double Jl = __shfl(cp, 2 * m, kWave), Jr = __shfl(cp, 2 * m + 1, kWave);
-            const double xl = __shfl(xp[m], 2 * m, kWave), xr = __shfl(xp[m], 2 * m + 1, kWave);
-            g[m] = (Jr - Jl) / (xr - xl);
-            nrm2 += g[m] * g[m];
-        }
-        const double nrm = sqrt(nrm2);
-        double xn[3];
-        bool nan_step = false;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            res[m] *= fa.opts.decaying_factor;  // decays in place, like the reference's aliasing of sampling_res (:282)
-            xn[m] = x[m] - res[m] * g[m] / nrm;
-            xn[m] = fmin(fmax(xn[m], lo[m]), hi[m]);
-            nan_step |= !(xn[m] == xn[m]);
-        }
-        if (nan_step) break;  // zero gradient: the reference raises inside np.arange(nan); refinement stops here
-        double cn = 0.0;
-        if (lane == 0) cn = traj_eval<false>(ka, e, xn[0], xn[1], xn[2], false, nullptr, 0).cost;
-        cn = __shfl(cn, 0, kWave);
-        if (lane == ncand) { my_cost = cn; my_x[0] = xn[0]; my_x[1] = xn[1]; my_x[2] = xn[2]; }
-        ncand += 1;
-        x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
-    }
-    // constraint + collision flags of every refinement trajectory that can be popped before the loop stops
-    const bool poppable = lane < ncand && !(my_cost > coarse_cost);
-    uint32_t my_flags = 0;
-    if (poppable) my_flags = traj_eval<false>(ka, e, my_x[0], my_x[1], my_x[2], true, nullptr, 0).flags;
-    // refined_trajs.get() in cost order (ties: generation order), :301-323
-    int validated = 0, checks = 0, winner = -1;
-    bool alive = lane < ncand;
-    for (int it = 0; it < ncand; ++it) {
-        // minimum cost among alive lanes
-        double bc = alive ? my_cost : __builtin_inf();
-        int bl = alive ? lane : kWave;
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            const double oc = __shfl_xor(bc, off, kWave);
-            const int ol = __shfl_xor(bl, off, kWave);
-            if (ol < kWave && (bl >= kWave || oc < bc || (oc == bc && ol < bl))) { bc = oc; bl = ol; }
-        }
-        if (bl >= kWave) break;
-        if (bc > coarse_cost) break;
-        if (lane == bl) alive = false;
-        ++validated;
-        const uint32_t f = (uint32_t)__shfl((int)my_flags, bl, kWave);
-        if (f & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) continue;
-        ++checks;
-        if (!(f & FP_FLAG_COLLISION)) { winner = bl; break; }
-    }
-    if (fa.io.trace && lane < R * 7) {
-        double* tr = fa.io.trace + ((size_t)b * R * 7 + lane) * 4;
-        const bool have = lane < ncand;
-        tr[0] = have ? my_x[0] : nan; tr[1] = have ? my_x[1] : nan; tr[2] = have ? my_x[2] : nan; tr[3] = have ? my_cost : nan;
-    }
-    if (lane == 0) {
-        int32_t* s4 = fa.io.stats + (size_t)b * 4;
-        s4[1] += ncand;
-        s4[2] += validated;
-        s4[3] += checks;
-        fa.io.best_cost[b] = coarse_cost;  // same evaluator as the refined costs and as the trajectory dump
-    }
-    if (winner >= 0 && lane == winner) {
-        fa.io.refined[b] = 1;
-        fa.io.best_cost[b] = my_cost;
-        double* es = fa.io.end_state + (size_t)b * 3;
-        es[0] = my_x[0]; es[1] = my_x[1]; es[2] = my_x[2];
-    }
-}
-
-hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream)
-{
-    int lds_doubles = 0;
-    const int bytes = ego_lds_bytes(fa.ka.p, fa.ka.b, 150 * 1024, &lds_doubles);
-    static int configured = -1;
-    if (bytes > configured) {
-        hipError_t err = hipFuncSetAttribute((const void*)fiss_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (err != hipSuccess) return err;
-        configured = bytes;
-    }
-    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa, lds_doubles);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // closed-loop bookkeeping (planners/benchmark/planning.py:131-162), one lane per ego
 // ---------------------------------------------------------------------------
 __global__ void advance_kernel(KernelArgs ka, const int32_t* best_idx, const double* end_state, fp_loop_io io)

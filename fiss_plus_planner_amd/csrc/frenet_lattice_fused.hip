@@ -301,68 +301,17 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const double* S = s_pows + it * 11;
         if (sub < nv) {
             const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[sub], 0.0, T);
-            // e(t) = s_d - v_target = e0 + e1 t + e2 t^2 + e3 t^3 ; a(t) = s_dd = g0 + g1 t + g2 t^2 ; j(t) = s_ddd = h0 + h1 t
-            const double e0 = q.a1 - target_speed, e1 = 2.0 * q.a2, e2 = 3.0 * q.a3, e3 = 4.0 * q.a4;
-            const double g0 = 2.0 * q.a2, g1 = 6.0 * q.a3, g2 = 12.0 * q.a4;
-            const double h0 = 6.0 * q.a3, h1 = 24.0 * q.a4;
-            double sv = e0 * e0 * S[0];
-            sv = fma(2.0 * e0 * e1, S[1], sv);
-            sv = fma(fma(2.0 * e0, e2, e1 * e1), S[2], sv);
-            sv = fma(2.0 * fma(e0, e3, e1 * e2), S[3], sv);
-            sv = fma(fma(2.0 * e1, e3, e2 * e2), S[4], sv);
-            sv = fma(2.0 * e2 * e3, S[5], sv);
-            sv = fma(e3 * e3, S[6], sv);
-            double sa = g0 * g0 * S[0];
-            sa = fma(2.0 * g0 * g1, S[1], sa);
-            sa = fma(fma(2.0 * g0, g2, g1 * g1), S[2], sa);
-            sa = fma(2.0 * g1 * g2, S[3], sa);
-            sa = fma(g2 * g2, S[4], sa);
-            double sj = h0 * h0 * S[0];
-            sj = fma(2.0 * h0 * h1, S[1], sj);
-            sj = fma(h1 * h1, S[2], sj);
+            double lon[3];
+            lon_cost_sums(q, target_speed, S, lon);
             double* o = s_lon_sum + 3 * (it * nv + sub);
-            o[0] = sv; o[1] = sa; o[2] = sj;
+            o[0] = lon[0]; o[1] = lon[1]; o[2] = lon[2];
         } else {
             const int id = sub - nv;
             const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, T);
-            const double c[6] = {q.a0, q.a1, q.a2, q.a3, q.a4, q.a5};
-            double sd = 0.0;  // sum d^2 = sum_k (c (*) c)_k S_k, degree 10
-#pragma unroll
-            for (int kk = 0; kk <= 10; ++kk) {
-                double ck = 0.0;
-#pragma unroll
-                for (int a2 = 0; a2 <= 5; ++a2) {
-                    const int b2 = kk - a2;
-                    if (b2 >= 0 && b2 <= 5) ck = fma(c[a2], c[b2], ck);
-                }
-                sd = fma(ck, S[kk], sd);
-            }
-            const double g[4] = {2.0 * q.a2, 6.0 * q.a3, 12.0 * q.a4, 20.0 * q.a5};  // d_dd
-            double sa = 0.0;
-#pragma unroll
-            for (int kk = 0; kk <= 6; ++kk) {
-                double ck = 0.0;
-#pragma unroll
-                for (int a2 = 0; a2 <= 3; ++a2) {
-                    const int b2 = kk - a2;
-                    if (b2 >= 0 && b2 <= 3) ck = fma(g[a2], g[b2], ck);
-                }
-                sa = fma(ck, S[kk], sa);
-            }
-            const double h[3] = {6.0 * q.a3, 24.0 * q.a4, 60.0 * q.a5};  // d_ddd
-            double sj = 0.0;
-#pragma unroll
-            for (int kk = 0; kk <= 4; ++kk) {
-                double ck = 0.0;
-#pragma unroll
-                for (int a2 = 0; a2 <= 2; ++a2) {
-                    const int b2 = kk - a2;
-                    if (b2 >= 0 && b2 <= 2) ck = fma(h[a2], h[b2], ck);
-                }
-                sj = fma(ck, S[kk], sj);
-            }
+            double lat[3];
+            lat_cost_sums(q, S, lat);
             double* o = s_lat_sum + 3 * (id * nt + it);
-            o[0] = sa; o[1] = sj; o[2] = sd;
+            o[0] = lat[0]; o[1] = lat[1]; o[2] = lat[2];
         }
     }
     __syncthreads();  // the final assembly reads the sums (with no obstacles there is no other barrier in between)
@@ -608,13 +557,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         if (n_obs > 0 && M == 1 && horizon_cap >= 1) hit = true;  // traj.yaw is empty -> IndexError -> collision (:178-182)
         if (hit) flags |= FP_FLAG_COLLISION;
         if (M < N) flags |= FP_FLAG_TRUNCATED;
-        // cost_function.py:41-50, same grouping as the reference
-        const double cost_time = p.cost_horizon - (double)(N - 1) * tick;
-        const double cost_speed = p.w_speed * ls[0];
-        const double cost_accel = p.w_accel * ls[1] + p.w_accel * ds[0];
-        const double cost_jerk = p.w_jerk * ls[2] + p.w_jerk * ds[1];
-        const double cost_offset = p.w_offset * ds[2];
-        const double cost = (cost_time + 0.0 + cost_speed + cost_accel + cost_jerk + cost_offset) / (double)N;
+        const double cost = combine_cost(p, N, ls, ds);  // cost_function.py:41-50, same grouping as the reference
         if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = cost;
         if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
         if (!(flags & FP_FLAG_INFEASIBLE) && cost == cost) mine = best_merge(mine, Best{cost, c});
