@@ -1,0 +1,96 @@
+"""GPU: limits, fallbacks and error behaviour of the C ABI.
+
+* problems that do not fit the fused kernel (obstacle table larger than its LDS budget, more lateral samples than lanes)
+  fall back to the lane-per-candidate kernel and still match the oracle;
+* invalid arguments produce error codes + messages, never a crash and never a silent CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fiss_plus_planner_amd import _abi, synth
+from fiss_plus_planner_amd.engine import _host_batch, make_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_vs_oracle(oracle, engine, batch):
+    out = engine.plan_dense(batch)
+    for e, p in enumerate(oracle.problems_from_batch(batch)):
+        r = p.fop_plan()
+        np.testing.assert_allclose(out.cost[e], r.cost, rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(out.flags[e], r.flags)
+        assert out.best_idx[e] == r.best_idx
+    return out
+
+
+def test_obstacle_table_larger_than_lds_falls_back(oracle, engine):
+    batch = synth.make_batch(3, 5, 5, 5, 150, 100, True, 71)  # 50 rows x 150 obstacles x 32 B = 240 KB > LDS
+    engine.set_option("lattice_kernel", 2)
+    with pytest.raises(_abi.FrenetGpuError):  # the fused kernel alone refuses it ...
+        engine.plan_dense(batch)
+    engine.set_option("lattice_kernel", 0)    # ... auto mode uses the lane-per-candidate kernel (rows read through L2)
+    out = _check_vs_oracle(oracle, engine, batch)
+    assert ((out.flags & 4) != 0).any()
+
+
+def test_more_lateral_samples_than_lanes_falls_back(oracle, engine):
+    batch = synth.make_batch(2, 70, 2, 2, 6, 40, True, 72)
+    _check_vs_oracle(oracle, engine, batch)
+
+
+def test_largest_lattice(oracle, engine):
+    batch = synth.make_batch(1, 16, 16, 16, 12, 50, True, 73)  # C = 4096 = FP_MAX_CAND
+    _check_vs_oracle(oracle, engine, batch)
+
+
+def _call(engine, batch, mutate):
+    p = make_params(batch)
+    fb = _host_batch(batch)
+    B = batch.B
+    bi = np.empty(B, dtype=np.int32); bc = np.empty(B)
+    res = _abi.FpResult()
+    res.best_idx, res.best_cost = bi.ctypes.data, bc.ctypes.data
+    mutate(p, fb, res)
+    rc = engine._lib.fp_plan_dense(engine._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None)
+    return rc, engine._lib.fp_last_error().decode()
+
+
+def test_error_codes(engine):
+    batch = synth.make_batch(2, 3, 3, 2, 4, 20, False, 74)
+
+    rc, msg = _call(engine, batch, lambda p, fb, r: setattr(fb, "ego", None))
+    assert rc == -1 and "NULL" in msg
+    rc, msg = _call(engine, batch, lambda p, fb, r: setattr(r, "best_idx", None))
+    assert rc == -1
+    rc, msg = _call(engine, batch, lambda p, fb, r: setattr(p, "nd", 4097))
+    assert rc == -4 and "FP_MAX_CAND" in msg
+    rc, msg = _call(engine, batch, lambda p, fb, r: setattr(p, "tick_t", 0.01))  # 10 s / 0.01 = 1000 points > FP_MAX_POINTS
+    assert rc == -4 and "FP_MAX_POINTS" in msg
+    rc, msg = _call(engine, batch, lambda p, fb, r: setattr(p, "check_stride", 0))
+    assert rc == -1
+
+    bad = synth.make_batch(2, 3, 3, 2, 4, 20, False, 74)
+    bad.frame_of[1] = 7
+    rc, msg = _call(engine, bad, lambda p, fb, r: None)
+    assert rc == -1 and "frame_of" in msg
+    bad = synth.make_batch(2, 3, 3, 2, 4, 20, False, 74)
+    bad.t_now[0] = -3
+    rc, msg = _call(engine, bad, lambda p, fb, r: None)
+    assert rc == -1 and "t_now" in msg
+    # the ctx survives every failed call
+    assert engine.plan_dense(batch).best_idx.shape == (2,)
+
+
+def test_empty_batch_is_a_noop(engine):
+    batch = synth.make_batch(2, 3, 3, 2, 0, 0, False, 75)
+    rc, _ = _call(engine, batch, lambda p, fb, r: setattr(fb, "B", 0))
+    assert rc == 0
+
+
+def test_unknown_option_is_rejected(engine):
+    with pytest.raises(_abi.FrenetGpuError):
+        engine.set_option("no_such_knob", 1)
+    with pytest.raises(_abi.FrenetGpuError):
+        engine.set_option("lattice_kernel", 9)
