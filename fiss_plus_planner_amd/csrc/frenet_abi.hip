@@ -1,13 +1,18 @@
 // frenet_abi.hip - the C ABI of libfrenetgpu.so (include/frenet_gpu.h).
 //
-// Host-side responsibilities only: argument validation, the per-ctx device staging
-// arena used by FP_MEM_HOST calls, error strings.  No planning arithmetic happens on
-// the host: if there is no usable GPU every entry point fails with FP_ENODEV/FP_EHIP.
+// Host-side responsibilities only: argument validation, the per-ctx staging used by FP_MEM_HOST calls, error
+// strings.  No planning arithmetic happens on the host: if there is no usable GPU every entry point fails with
+// FP_ENODEV / FP_EHIP.
+//
+// FP_MEM_HOST staging (latency matters for the B = 1 drop-in planners): small arrays are packed into ONE pinned host
+// block that mirrors the head of the device arena, so a call costs one H2D copy, the kernels, one D2H copy - instead of
+// one transfer per array.  Arrays above kSmallMax bytes are copied directly (no extra host pass over big batches).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -33,11 +38,27 @@ int fail(int code, const char* fmt, ...)
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) return fail(FP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));     \
     } while (0)
+#define FP_TRY(expr)                  \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != FP_OK) return _rc; \
+    } while (0)
+#define LAUNCH_TRY(expr, what)                                                                          \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(FP_EHIP, what " launch failed: %s", hipGetErrorString(_e));   \
+    } while (0)
 
-// A grow-only device arena; host-memory calls carve their staging copies out of it.
-struct Arena {
+constexpr size_t kAlign = 256;
+constexpr size_t kSmallRegion = 4u << 20;  // device bytes mirrored by the pinned host block
+constexpr size_t kSmallMax = 64u << 10;    // arrays up to this size travel through the pinned block
+
+inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+// grow-only device buffer
+struct DeviceBuf {
     char* base = nullptr;
-    size_t cap = 0, used = 0;
+    size_t cap = 0;
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return FP_OK;
@@ -47,20 +68,12 @@ struct Arena {
             cap = 0;
             if (e != hipSuccess) return fail(FP_EHIP, "hipFree failed: %s", hipGetErrorString(e));
         }
-        size_t want = bytes + bytes / 4 + (1u << 20);
+        const size_t want = bytes + bytes / 4 + (1u << 20);
         hipError_t e = hipMalloc((void**)&base, want);
         if (e != hipSuccess) return fail(FP_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         cap = want;
         return FP_OK;
     }
-    void reset() { used = 0; }
-    void* take(size_t bytes)
-    {
-        size_t off = (used + 255) & ~size_t(255);
-        used = off + bytes;
-        return base + off;
-    }
-    static size_t padded(size_t bytes) { return ((bytes + 255) & ~size_t(255)) + 256; }
 };
 
 }  // namespace
@@ -68,12 +81,115 @@ struct Arena {
 struct fp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // used by FP_MEM_HOST calls
-    Arena arena;                   // staging copies of FP_MEM_HOST calls
-    Arena scratch;                 // intermediate tables of multi-kernel entry points (fp_plan_fiss)
+    DeviceBuf arena;               // [ small region (kSmallRegion) | large region ] staging of FP_MEM_HOST calls
+    char* pinned = nullptr;        // kSmallRegion bytes of pinned host memory mirroring the small region
+    DeviceBuf scratch;             // intermediate tables of multi-kernel entry points (fp_plan_fiss)
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
 };
 
 namespace {
+
+// One FP_MEM_HOST call: reserve(), in()/in_mut() for every input, flush_in(), out() for every output, launch kernels,
+// fetch_out().
+class HostStage {
+  public:
+    explicit HostStage(fp_ctx* ctx) : ctx_(ctx) {}
+
+    int reserve(size_t large_bytes)
+    {
+        FP_TRY(ctx_->arena.reserve(kSmallRegion + large_bytes + kAlign));
+        small_ = 0;
+        large_ = kSmallRegion;
+        outs_.clear();
+        small_out_lo_ = small_out_hi_ = 0;
+        return FP_OK;
+    }
+    // bytes a `count`-element array may add to the large region
+    template <typename T>
+    static size_t need(size_t count) { return align_up(sizeof(T) * count) + kAlign; }
+
+    template <typename T>
+    int in(const T* host, size_t count, const T** dev)
+    {
+        const size_t bytes = sizeof(T) * count;
+        if (count == 0) { *dev = (const T*)(ctx_->arena.base + large_); return FP_OK; }
+        if (bytes <= kSmallMax && align_up(small_) + bytes <= kSmallRegion) {
+            small_ = align_up(small_);
+            memcpy(ctx_->pinned + small_, host, bytes);
+            *dev = (const T*)(ctx_->arena.base + small_);
+            small_ += bytes;
+            return FP_OK;
+        }
+        large_ = align_up(large_);
+        T* d = (T*)(ctx_->arena.base + large_);
+        large_ += bytes;
+        HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx_->stream));
+        *dev = d;
+        return FP_OK;
+    }
+    template <typename T>
+    int in_mut(T* host, size_t count, T** dev)  // in/out array: staged in, copied straight back by fetch_out
+    {
+        const T* c = nullptr;
+        FP_TRY(in((const T*)host, count, &c));
+        *dev = const_cast<T*>(c);
+        outs_.push_back({host, (char*)*dev, sizeof(T) * count, false});
+        return FP_OK;
+    }
+    int flush_in()  // the output window of the small region starts after the inputs
+    {
+        if (small_ > 0) HIP_TRY(hipMemcpyAsync(ctx_->arena.base, ctx_->pinned, small_, hipMemcpyHostToDevice, ctx_->stream));
+        small_out_lo_ = small_out_hi_ = align_up(small_);
+        return FP_OK;
+    }
+    template <typename T>
+    T* out(T* host, size_t count)
+    {
+        const size_t bytes = sizeof(T) * count;
+        if (!host || count == 0) return nullptr;
+        if (bytes <= kSmallMax && align_up(small_out_hi_) + bytes <= kSmallRegion) {
+            small_out_hi_ = align_up(small_out_hi_);
+            T* d = (T*)(ctx_->arena.base + small_out_hi_);
+            outs_.push_back({host, (char*)d, bytes, true});
+            small_out_hi_ += bytes;
+            return d;
+        }
+        T* d = temp<T>(count);
+        outs_.push_back({host, (char*)d, bytes, false});
+        return d;
+    }
+    template <typename T>
+    T* temp(size_t count)  // device-only scratch inside the arena
+    {
+        large_ = align_up(large_);
+        T* d = (T*)(ctx_->arena.base + large_);
+        large_ += sizeof(T) * count;
+        return d;
+    }
+    int fetch_out()
+    {
+        if (small_out_hi_ > small_out_lo_)
+            HIP_TRY(hipMemcpyAsync(ctx_->pinned + small_out_lo_, ctx_->arena.base + small_out_lo_, small_out_hi_ - small_out_lo_,
+                                   hipMemcpyDeviceToHost, ctx_->stream));
+        for (const Out& o : outs_)
+            if (!o.via_pinned) HIP_TRY(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx_->stream));
+        HIP_TRY(hipStreamSynchronize(ctx_->stream));
+        for (const Out& o : outs_)
+            if (o.via_pinned) memcpy(o.host, ctx_->pinned + (o.dev - ctx_->arena.base), o.bytes);
+        return FP_OK;
+    }
+
+  private:
+    struct Out {
+        void* host;
+        char* dev;
+        size_t bytes;
+        bool via_pinned;
+    };
+    fp_ctx* ctx_;
+    size_t small_ = 0, large_ = 0, small_out_lo_ = 0, small_out_hi_ = 0;
+    std::vector<Out> outs_;
+};
 
 int check_params(const fp_params* p)
 {
@@ -115,38 +231,19 @@ int check_batch_host(const fp_params* p, const fp_batch* b)
     return FP_OK;
 }
 
-struct Staged {
-    fp_batch dev;
-    size_t bytes = 0;
-};
-
-size_t batch_bytes(const fp_params* p, const fp_batch* b)
+size_t batch_need(const fp_params* p, const fp_batch* b)
 {
-    size_t n = 0;
-    n += Arena::padded(sizeof(double) * p->nd) + Arena::padded(sizeof(double) * p->nt);
-    n += Arena::padded(sizeof(double) * (size_t)b->B * p->nv) + Arena::padded(sizeof(double) * b->B);
-    n += Arena::padded(sizeof(double) * (size_t)b->B * 6) + 3 * Arena::padded(sizeof(int32_t) * b->B);
-    n += Arena::padded(sizeof(int32_t) * b->F) + Arena::padded(sizeof(double) * (size_t)b->F * b->NX) +
-         Arena::padded(sizeof(double) * (size_t)b->F * 8 * b->NX);
-    n += Arena::padded(sizeof(double) * (size_t)b->S * b->T_obs * b->n_obs * 4) + Arena::padded(sizeof(double) * (size_t)b->S * b->n_obs * 2) +
-         Arena::padded(sizeof(int32_t) * (b->S > 0 ? b->S : 1)) + Arena::padded(sizeof(int32_t) * b->B);
-    return n;
+    const size_t B = (size_t)b->B, fn = (size_t)b->F * b->NX, so = (size_t)b->S * b->n_obs;
+    return HostStage::need<double>(p->nd) + HostStage::need<double>(p->nt) + HostStage::need<double>(B * p->nv) + HostStage::need<double>(B) +
+           HostStage::need<double>(B * 6) + 4 * HostStage::need<int32_t>(B) + HostStage::need<int32_t>(b->F) + HostStage::need<double>(fn) +
+           HostStage::need<double>(fn * 8) + HostStage::need<double>(so * b->T_obs * 4) + HostStage::need<double>(so * 2) +
+           HostStage::need<int32_t>(b->S);
 }
 
-template <typename T>
-int push(fp_ctx* ctx, const T* host, size_t count, const T** dev_out)
-{
-    T* d = (T*)ctx->arena.take(sizeof(T) * (count ? count : 1));
-    if (count) HIP_TRY(hipMemcpyAsync(d, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
-    *dev_out = d;
-    return FP_OK;
-}
-
-int stage_batch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, fp_batch* dev)
+int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* dev)
 {
     *dev = *b;
-    int rc;
-#define PUSH(field, count) if ((rc = push(ctx, b->field, (size_t)(count), &dev->field)) != FP_OK) return rc
+#define PUSH(field, count) FP_TRY(hs.in(b->field, (size_t)(count), &dev->field))
     PUSH(d_samples, p->nd);
     PUSH(t_samples, p->nt);
     PUSH(v_samples, (size_t)b->B * p->nv);
@@ -162,9 +259,20 @@ int stage_batch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, fp_batch* de
     PUSH(obs_pose, has_obs ? (size_t)b->S * b->T_obs * b->n_obs * 4 : 0);
     PUSH(obs_dims, has_obs ? (size_t)b->S * b->n_obs * 2 : 0);
     PUSH(final_time_step, has_obs ? b->S : 0);
-    if (b->skip) { PUSH(skip, b->B); }
+    if (b->skip) PUSH(skip, b->B);
 #undef PUSH
     if (!has_obs) dev->n_obs = 0;
+    return FP_OK;
+}
+
+fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
+
+int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    FP_TRY(check_params(params));
+    FP_TRY(check_batch(batch));
+    if (mem != FP_MEM_HOST && mem != FP_MEM_DEVICE) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
     return FP_OK;
 }
 
@@ -211,9 +319,11 @@ int fp_ctx_create(int device, fp_ctx** out)
     if (!ctx) return fail(FP_ENOMEM, "out of host memory");
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->pinned, kSmallRegion, hipHostMallocDefault);
     if (e != hipSuccess) {
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
-        return fail(FP_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        return fail(FP_EHIP, "ctx resources: %s", hipGetErrorString(e));
     }
     *out = ctx;
     return FP_OK;
@@ -226,6 +336,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
     return FP_OK;
 }
@@ -243,119 +354,82 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
 
 int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
 {
-    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
-    int rc;
-    if ((rc = check_params(params)) != FP_OK) return rc;
-    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    FP_TRY(common_checks(ctx, params, batch, mem));
     if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");
     if (result->best_traj && !result->best_flags) return fail(FP_EINVAL, "result.best_traj requires result.best_flags");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t C = (size_t)params->nd * params->nv * params->nt;
-    const size_t B = (size_t)batch->B;
+    const size_t C = (size_t)params->nd * params->nv * params->nt, B = (size_t)batch->B;
     fp::KernelArgs ka;
     ka.p = *params;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
-        hipError_t e = fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel);
-        if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
-        if (result->best_traj) {
-            e = fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream);
-            if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
-        }
+        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel), "lattice kernel");
+        if (result->best_traj) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
     }
-    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
-    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
-    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(double) * B) +
-                  Arena::padded(sizeof(int32_t) * B * 4);
-    if (result->cost_tbl) need += Arena::padded(sizeof(double) * B * C);
-    if (result->flag_tbl) need += Arena::padded(sizeof(uint32_t) * B * C);
+    FP_TRY(check_batch_host(params, batch));
     const size_t traj_doubles = result->best_traj ? B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS : 0;
-    need += Arena::padded(sizeof(uint32_t) * B) + Arena::padded(sizeof(double) * traj_doubles);
-    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
-    ctx->arena.reset();
-    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
-    ka.r.best_idx = (int32_t*)ctx->arena.take(sizeof(int32_t) * B);
-    ka.r.best_cost = (double*)ctx->arena.take(sizeof(double) * B);
-    ka.r.stats = result->stats ? (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 4) : nullptr;
-    ka.r.cost_tbl = result->cost_tbl ? (double*)ctx->arena.take(sizeof(double) * B * C) : nullptr;
-    ka.r.flag_tbl = result->flag_tbl ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B * C) : nullptr;
-    ka.r.best_flags = result->best_flags ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B) : nullptr;
-    ka.r.best_traj = result->best_traj ? (double*)ctx->arena.take(sizeof(double) * traj_doubles) : nullptr;
-    hipError_t e = fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel);
-    if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
-    if (result->best_traj) {
-        e = fp::launch_winner_traj(ka, nullptr, ctx->stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
-        HIP_TRY(hipMemcpyAsync(result->best_traj, ka.r.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(result->best_flags, ka.r.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(result->best_idx, ka.r.best_idx, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(result->best_cost, ka.r.best_cost, sizeof(double) * B, hipMemcpyDeviceToHost, ctx->stream));
-    if (result->stats) HIP_TRY(hipMemcpyAsync(result->stats, ka.r.stats, sizeof(int32_t) * B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (result->cost_tbl) HIP_TRY(hipMemcpyAsync(result->cost_tbl, ka.r.cost_tbl, sizeof(double) * B * C, hipMemcpyDeviceToHost, ctx->stream));
-    if (result->flag_tbl) HIP_TRY(hipMemcpyAsync(result->flag_tbl, ka.r.flag_tbl, sizeof(uint32_t) * B * C, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return FP_OK;
+    HostStage hs(ctx);
+    FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<int32_t>(B * 4) + 2 * HostStage::need<double>(B) + HostStage::need<int32_t>(B) +
+                      HostStage::need<double>(B * C) + HostStage::need<uint32_t>(B * C) + HostStage::need<uint32_t>(B) +
+                      HostStage::need<double>(traj_doubles)));
+    FP_TRY(stage_batch(hs, params, batch, &ka.b));
+    FP_TRY(hs.flush_in());
+    ka.r.best_idx = hs.out(result->best_idx, B);
+    ka.r.best_cost = hs.out(result->best_cost, B);
+    ka.r.stats = hs.out(result->stats, B * 4);
+    ka.r.cost_tbl = hs.out(result->cost_tbl, B * C);
+    ka.r.flag_tbl = hs.out(result->flag_tbl, B * C);
+    ka.r.best_flags = hs.out(result->best_flags, B);
+    ka.r.best_traj = hs.out(result->best_traj, traj_doubles);
+    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel), "lattice kernel");
+    if (result->best_traj) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
+    return hs.fetch_out();
 }
 
 int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
                     double* best_traj, int mem, void* stream)
 {
-    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
-    int rc;
-    if ((rc = check_params(params)) != FP_OK) return rc;
-    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    FP_TRY(common_checks(ctx, params, batch, mem));
     if (!best_idx || !best_flags || !best_traj) return fail(FP_EINVAL, "best_idx/best_flags/best_traj must not be NULL");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t B = (size_t)batch->B;
-    const size_t traj_doubles = B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS;
+    const size_t B = (size_t)batch->B, traj_doubles = B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS;
     fp::KernelArgs ka;
     ka.p = *params;
-    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ka.r = no_result();
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         ka.r.best_idx = const_cast<int32_t*>(best_idx);
         ka.r.best_flags = best_flags;
         ka.r.best_traj = best_traj;
-        hipError_t e = fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
+        LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
     }
-    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
-    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
+    FP_TRY(check_batch_host(params, batch));
     const int C = params->nd * params->nv * params->nt;
     for (size_t i = 0; i < B; ++i)
         if (best_idx[i] >= C) return fail(FP_EINVAL, "best_idx[%zu]=%d out of range", i, best_idx[i]);
-    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(uint32_t) * B) +
-                  Arena::padded(sizeof(double) * traj_doubles);
-    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
-    ctx->arena.reset();
-    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
+    HostStage hs(ctx);
+    FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<int32_t>(B) + HostStage::need<uint32_t>(B) + HostStage::need<double>(traj_doubles)));
+    FP_TRY(stage_batch(hs, params, batch, &ka.b));
     const int32_t* d_idx = nullptr;
-    if ((rc = push(ctx, best_idx, B, &d_idx)) != FP_OK) return rc;
+    FP_TRY(hs.in(best_idx, B, &d_idx));
+    FP_TRY(hs.flush_in());
     ka.r.best_idx = const_cast<int32_t*>(d_idx);
-    ka.r.best_flags = (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B);
-    ka.r.best_traj = (double*)ctx->arena.take(sizeof(double) * traj_doubles);
-    hipError_t e = fp::launch_winner_traj(ka, nullptr, ctx->stream);
-    if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(best_traj, ka.r.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(best_flags, ka.r.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return FP_OK;
+    ka.r.best_flags = hs.out(best_flags, B);
+    ka.r.best_traj = hs.out(best_traj, traj_doubles);
+    LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
+    return hs.fetch_out();
 }
 
 int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, int mem,
                  void* stream_v)
 {
-    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
-    int rc;
-    if ((rc = check_params(params)) != FP_OK) return rc;
-    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    FP_TRY(common_checks(ctx, params, batch, mem));
     if (!opts || !io) return fail(FP_EINVAL, "opts/io is NULL");
     if (opts->kind != FP_FISS && opts->kind != FP_FISS_PLUS) return fail(FP_EINVAL, "opts.kind must be FP_FISS or FP_FISS_PLUS");
     if (opts->max_refine_iters < 0 || opts->max_refine_iters * 7 > 64) return fail(FP_ELIMIT, "max_refine_iters must be in 0..9");
@@ -368,94 +442,72 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     const size_t B = (size_t)batch->B, C = (size_t)params->nd * params->nv * params->nt;
     const int R = opts->kind == FP_FISS_PLUS ? opts->max_refine_iters : 0;
     hipStream_t stream = mem == FP_MEM_DEVICE ? (hipStream_t)stream_v : ctx->stream;
-    if (mem != FP_MEM_DEVICE && mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
 
-    // dense tables + per-ego dense results live in the scratch arena in both modes
-    const size_t scratch_need = Arena::padded(sizeof(double) * B * C) + Arena::padded(sizeof(uint32_t) * B * C) +
-                                Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(double) * B);
-    if (scratch_need > ctx->scratch.cap) HIP_TRY(hipStreamSynchronize(stream));  // the arena may be reallocated: drain its users
-    if ((rc = ctx->scratch.reserve(scratch_need)) != FP_OK) return rc;
-    ctx->scratch.reset();
+    // dense tables + per-ego dense results live in the scratch buffer in both modes
+    const size_t scratch_need = align_up(sizeof(double) * B * C) + align_up(sizeof(uint32_t) * B * C) + align_up(sizeof(int32_t) * B) +
+                                align_up(sizeof(double) * B) + 4 * kAlign;
+    if (scratch_need > ctx->scratch.cap) HIP_TRY(hipStreamSynchronize(stream));  // the buffer may be reallocated: drain its users
+    FP_TRY(ctx->scratch.reserve(scratch_need));
+    char* sp = ctx->scratch.base;
     fp::FissArgs fa;
     fa.ka.p = *params;
     fa.opts = *opts;
     fa.opts.max_refine_iters = R;
-    fa.ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    fa.ka.r.cost_tbl = (double*)ctx->scratch.take(sizeof(double) * B * C);
-    fa.ka.r.flag_tbl = (uint32_t*)ctx->scratch.take(sizeof(uint32_t) * B * C);
-    fa.ka.r.best_idx = (int32_t*)ctx->scratch.take(sizeof(int32_t) * B);
-    fa.ka.r.best_cost = (double*)ctx->scratch.take(sizeof(double) * B);
+    fa.ka.r = no_result();
+    fa.ka.r.cost_tbl = (double*)sp;
+    sp += align_up(sizeof(double) * B * C);
+    fa.ka.r.flag_tbl = (uint32_t*)sp;
+    sp += align_up(sizeof(uint32_t) * B * C);
+    fa.ka.r.best_idx = (int32_t*)sp;
+    sp += align_up(sizeof(int32_t) * B);
+    fa.ka.r.best_cost = (double*)sp;
     fa.cost_tbl = fa.ka.r.cost_tbl;
     fa.flag_tbl = fa.ka.r.flag_tbl;
     const size_t traj_doubles = io->best_traj ? B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS : 0;
     const size_t trace_doubles = (io->trace && R > 0) ? B * (size_t)R * 7 * 4 : 0;
+    HostStage hs(ctx);
     if (mem == FP_MEM_DEVICE) {
         fa.ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) fa.ka.b.n_obs = 0;
         fa.io = *io;
+        if (!trace_doubles) fa.io.trace = nullptr;
     } else {
-        if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
-        size_t need = batch_bytes(params, batch) + 3 * Arena::padded(sizeof(double) * B * 3) + 2 * Arena::padded(sizeof(int32_t) * B * 3) +
-                      Arena::padded(sizeof(double) * B) + Arena::padded(sizeof(double) * B * 3) + Arena::padded(sizeof(int32_t) * B) +
-                      Arena::padded(sizeof(int32_t) * B * 4) + Arena::padded(sizeof(double) * trace_doubles) +
-                      Arena::padded(sizeof(uint32_t) * B) + Arena::padded(sizeof(double) * traj_doubles);
-        if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
-        ctx->arena.reset();
-        if ((rc = stage_batch(ctx, params, batch, &fa.ka.b)) != FP_OK) return rc;
+        FP_TRY(check_batch_host(params, batch));
+        FP_TRY(hs.reserve(batch_need(params, batch) + 4 * HostStage::need<double>(B * 3) + 2 * HostStage::need<int32_t>(B * 3) +
+                          HostStage::need<double>(B) + 2 * HostStage::need<int32_t>(B * 4) + HostStage::need<uint32_t>(B) +
+                          HostStage::need<double>(trace_doubles) + HostStage::need<double>(traj_doubles)));
+        FP_TRY(stage_batch(hs, params, batch, &fa.ka.b));
         fa.io = *io;
-        if ((rc = push(ctx, io->samp_min, B * 3, &fa.io.samp_min)) != FP_OK) return rc;
-        if ((rc = push(ctx, io->samp_max, B * 3, &fa.io.samp_max)) != FP_OK) return rc;
-        if ((rc = push(ctx, io->samp_res, B * 3, &fa.io.samp_res)) != FP_OK) return rc;
-        const int32_t* d_prev = nullptr;
-        if ((rc = push(ctx, (const int32_t*)io->prev_best_idx, B * 3, &d_prev)) != FP_OK) return rc;
-        fa.io.prev_best_idx = const_cast<int32_t*>(d_prev);
-        fa.io.best_ijk = (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 3);
-        fa.io.best_cost = (double*)ctx->arena.take(sizeof(double) * B);
-        fa.io.end_state = (double*)ctx->arena.take(sizeof(double) * B * 3);
-        fa.io.refined = (int32_t*)ctx->arena.take(sizeof(int32_t) * B);
-        fa.io.stats = (int32_t*)ctx->arena.take(sizeof(int32_t) * B * 4);
-        fa.io.trace = trace_doubles ? (double*)ctx->arena.take(sizeof(double) * trace_doubles) : nullptr;
-        fa.io.best_flags = io->best_flags ? (uint32_t*)ctx->arena.take(sizeof(uint32_t) * B) : nullptr;
-        fa.io.best_traj = io->best_traj ? (double*)ctx->arena.take(sizeof(double) * traj_doubles) : nullptr;
+        FP_TRY(hs.in(io->samp_min, B * 3, &fa.io.samp_min));
+        FP_TRY(hs.in(io->samp_max, B * 3, &fa.io.samp_max));
+        FP_TRY(hs.in(io->samp_res, B * 3, &fa.io.samp_res));
+        FP_TRY(hs.in_mut(io->prev_best_idx, B * 3, &fa.io.prev_best_idx));
+        FP_TRY(hs.flush_in());
+        fa.io.best_ijk = hs.out(io->best_ijk, B * 3);
+        fa.io.best_cost = hs.out(io->best_cost, B);
+        fa.io.end_state = hs.out(io->end_state, B * 3);
+        fa.io.refined = hs.out(io->refined, B);
+        fa.io.stats = hs.out(io->stats, B * 4);
+        fa.io.trace = trace_doubles ? hs.out(io->trace, trace_doubles) : nullptr;
+        fa.io.best_flags = hs.out(io->best_flags, B);
+        fa.io.best_traj = hs.out(io->best_traj, traj_doubles);
     }
-    if (!(io->trace && R > 0)) fa.io.trace = nullptr;
-    hipError_t e = fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel);
-    if (e != hipSuccess) return fail(FP_EHIP, "lattice kernel launch failed: %s", hipGetErrorString(e));
-    e = fp::launch_fiss_search(fa, stream);
-    if (e != hipSuccess) return fail(FP_EHIP, "search kernel launch failed: %s", hipGetErrorString(e));
-    if (R > 0) {
-        e = fp::launch_fiss_refine(fa, stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "refinement kernel launch failed: %s", hipGetErrorString(e));
-    }
+    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel), "lattice kernel");
+    LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
+    if (R > 0) LAUNCH_TRY(fp::launch_fiss_refine(fa, stream), "refinement kernel");
     if (fa.io.best_traj) {
         fp::KernelArgs kw = fa.ka;
         kw.r.best_flags = fa.io.best_flags;
         kw.r.best_traj = fa.io.best_traj;
-        e = fp::launch_winner_traj(kw, fa.io.end_state, stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "winner epilogue launch failed: %s", hipGetErrorString(e));
+        LAUNCH_TRY(fp::launch_winner_traj(kw, fa.io.end_state, stream), "winner epilogue");
     }
-    if (mem == FP_MEM_HOST) {
-        HIP_TRY(hipMemcpyAsync(io->prev_best_idx, fa.io.prev_best_idx, sizeof(int32_t) * B * 3, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(io->best_ijk, fa.io.best_ijk, sizeof(int32_t) * B * 3, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(io->best_cost, fa.io.best_cost, sizeof(double) * B, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(io->end_state, fa.io.end_state, sizeof(double) * B * 3, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(io->refined, fa.io.refined, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(io->stats, fa.io.stats, sizeof(int32_t) * B * 4, hipMemcpyDeviceToHost, stream));
-        if (trace_doubles) HIP_TRY(hipMemcpyAsync(io->trace, fa.io.trace, sizeof(double) * trace_doubles, hipMemcpyDeviceToHost, stream));
-        if (io->best_flags) HIP_TRY(hipMemcpyAsync(io->best_flags, fa.io.best_flags, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, stream));
-        if (io->best_traj) HIP_TRY(hipMemcpyAsync(io->best_traj, fa.io.best_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    }
-    return FP_OK;
+    return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;
 }
 
 int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, const double* end_state,
                const fp_loop_io* io, int mem, void* stream)
 {
-    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
-    int rc;
-    if ((rc = check_params(params)) != FP_OK) return rc;
-    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    FP_TRY(common_checks(ctx, params, batch, mem));
     if ((best_idx == nullptr) == (end_state == nullptr)) return fail(FP_EINVAL, "exactly one of best_idx / end_state must be given");
     if (!io || !io->ego || !io->t_now || !io->done || !io->cycles || !io->goal_xy) return fail(FP_EINVAL, "fp_loop_io has a NULL mandatory array");
     if (batch->B == 0) return FP_OK;
@@ -463,42 +515,32 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
     const size_t B = (size_t)batch->B;
     fp::KernelArgs ka;
     ka.p = *params;
-    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ka.r = no_result();
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
-        hipError_t e = fp::launch_advance(ka, best_idx, end_state, *io, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "advance kernel launch failed: %s", hipGetErrorString(e));
+        LAUNCH_TRY(fp::launch_advance(ka, best_idx, end_state, *io, (hipStream_t)stream), "advance kernel");
         return FP_OK;
     }
-    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
-    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
-    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(double) * B * 6) + 3 * Arena::padded(sizeof(int32_t) * B) +
-                  Arena::padded(sizeof(double) * B * 2) + 2 * Arena::padded(sizeof(double) * B * 3) + Arena::padded(sizeof(int32_t) * B);
-    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
-    ctx->arena.reset();
-    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
+    FP_TRY(check_batch_host(params, batch));
+    HostStage hs(ctx);
+    FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<double>(B * 6) + 4 * HostStage::need<int32_t>(B) + HostStage::need<double>(B * 2) +
+                      2 * HostStage::need<double>(B * 3)));
+    FP_TRY(stage_batch(hs, params, batch, &ka.b));
     fp_loop_io dio = *io;
-    const double* c_ego = nullptr; const int32_t *c_tn = nullptr, *c_done = nullptr, *c_cyc = nullptr, *c_idx = nullptr; const double* c_es = nullptr;
-    if ((rc = push(ctx, (const double*)io->ego, B * 6, &c_ego)) != FP_OK) return rc;
-    if ((rc = push(ctx, (const int32_t*)io->t_now, B, &c_tn)) != FP_OK) return rc;
-    if ((rc = push(ctx, (const int32_t*)io->done, B, &c_done)) != FP_OK) return rc;
-    if ((rc = push(ctx, (const int32_t*)io->cycles, B, &c_cyc)) != FP_OK) return rc;
-    if ((rc = push(ctx, io->goal_xy, B * 2, &dio.goal_xy)) != FP_OK) return rc;
-    if (best_idx && (rc = push(ctx, best_idx, B, &c_idx)) != FP_OK) return rc;
-    if (end_state && (rc = push(ctx, end_state, B * 3, &c_es)) != FP_OK) return rc;
-    dio.ego = const_cast<double*>(c_ego); dio.t_now = const_cast<int32_t*>(c_tn);
-    dio.done = const_cast<int32_t*>(c_done); dio.cycles = const_cast<int32_t*>(c_cyc);
-    dio.cart_state = io->cart_state ? (double*)ctx->arena.take(sizeof(double) * B * 3) : nullptr;
+    FP_TRY(hs.in_mut(io->ego, B * 6, &dio.ego));
+    FP_TRY(hs.in_mut(io->t_now, B, &dio.t_now));
+    FP_TRY(hs.in_mut(io->done, B, &dio.done));
+    FP_TRY(hs.in_mut(io->cycles, B, &dio.cycles));
+    FP_TRY(hs.in(io->goal_xy, B * 2, &dio.goal_xy));
+    const int32_t* d_idx = nullptr;
+    const double* d_es = nullptr;
+    if (best_idx) FP_TRY(hs.in(best_idx, B, &d_idx));
+    if (end_state) FP_TRY(hs.in(end_state, B * 3, &d_es));
+    FP_TRY(hs.flush_in());
+    dio.cart_state = hs.out(io->cart_state, B * 3);
     if (dio.cart_state) HIP_TRY(hipMemsetAsync(dio.cart_state, 0xFF, sizeof(double) * B * 3, ctx->stream));  // NaN for egos that do not move
-    hipError_t e = fp::launch_advance(ka, c_idx, c_es, dio, ctx->stream);
-    if (e != hipSuccess) return fail(FP_EHIP, "advance kernel launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(io->ego, dio.ego, sizeof(double) * B * 6, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(io->t_now, dio.t_now, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(io->done, dio.done, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(io->cycles, dio.cycles, sizeof(int32_t) * B, hipMemcpyDeviceToHost, ctx->stream));
-    if (io->cart_state) HIP_TRY(hipMemcpyAsync(io->cart_state, dio.cart_state, sizeof(double) * B * 3, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return FP_OK;
+    LAUNCH_TRY(fp::launch_advance(ka, d_idx, d_es, dio, ctx->stream), "advance kernel");
+    return hs.fetch_out();
 }
 
 int fp_frames_build(fp_ctx* ctx, int32_t F, int32_t NX, const int32_t* n, const double* points, double* knots, double* coef, int mem,
@@ -507,33 +549,27 @@ int fp_frames_build(fp_ctx* ctx, int32_t F, int32_t NX, const int32_t* n, const 
     if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
     if (F < 0 || NX < 2 || NX > FP_MAX_KNOTS) return fail(FP_EINVAL, "bad sizes F=%d NX=%d", F, NX);
     if (!n || !points || !knots || !coef) return fail(FP_EINVAL, "NULL array");
+    if (mem != FP_MEM_HOST && mem != FP_MEM_DEVICE) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
     if (F == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (mem == FP_MEM_DEVICE) {
-        hipError_t e = fp::launch_frames_build(F, NX, n, points, knots, coef, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "frame build launch failed: %s", hipGetErrorString(e));
+        LAUNCH_TRY(fp::launch_frames_build(F, NX, n, points, knots, coef, (hipStream_t)stream), "frame build");
         return FP_OK;
     }
-    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
     for (int f = 0; f < F; ++f)
         if (n[f] < 2 || n[f] > NX) return fail(FP_EINVAL, "n[%d]=%d out of range", f, n[f]);
     const size_t fn = (size_t)F * NX;
-    int rc;
-    if ((rc = ctx->arena.reserve(Arena::padded(sizeof(int32_t) * F) + Arena::padded(sizeof(double) * fn * 2) + Arena::padded(sizeof(double) * fn) +
-                                 Arena::padded(sizeof(double) * fn * 8))) != FP_OK)
-        return rc;
-    ctx->arena.reset();
-    const int32_t* d_n = nullptr; const double* d_pts = nullptr;
-    if ((rc = push(ctx, n, (size_t)F, &d_n)) != FP_OK) return rc;
-    if ((rc = push(ctx, points, fn * 2, &d_pts)) != FP_OK) return rc;
-    double* d_k = (double*)ctx->arena.take(sizeof(double) * fn);
-    double* d_c = (double*)ctx->arena.take(sizeof(double) * fn * 8);
-    hipError_t e = fp::launch_frames_build(F, NX, d_n, d_pts, d_k, d_c, ctx->stream);
-    if (e != hipSuccess) return fail(FP_EHIP, "frame build launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(knots, d_k, sizeof(double) * fn, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(coef, d_c, sizeof(double) * fn * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return FP_OK;
+    HostStage hs(ctx);
+    FP_TRY(hs.reserve(HostStage::need<int32_t>(F) + HostStage::need<double>(fn * 2) + HostStage::need<double>(fn) + HostStage::need<double>(fn * 8)));
+    const int32_t* d_n = nullptr;
+    const double* d_pts = nullptr;
+    FP_TRY(hs.in(n, (size_t)F, &d_n));
+    FP_TRY(hs.in(points, fn * 2, &d_pts));
+    FP_TRY(hs.flush_in());
+    double* d_k = hs.out(knots, fn);
+    double* d_c = hs.out(coef, fn * 8);
+    LAUNCH_TRY(fp::launch_frames_build(F, NX, d_n, d_pts, d_k, d_c, ctx->stream), "frame build");
+    return hs.fetch_out();
 }
 
 int fp_from_state(fp_ctx* ctx, const fp_batch* batch, const double* states, double* ego, int mem, void* stream)
@@ -542,44 +578,36 @@ int fp_from_state(fp_ctx* ctx, const fp_batch* batch, const double* states, doub
     if (!batch || !states || !ego) return fail(FP_EINVAL, "NULL argument");
     if (batch->B < 0 || batch->F < 1 || batch->NX < 2 || batch->NX > FP_MAX_KNOTS) return fail(FP_EINVAL, "bad batch sizes");
     if (!batch->frame_of || !batch->nx || !batch->knots || !batch->coef) return fail(FP_EINVAL, "batch frame arrays must not be NULL");
+    if (mem != FP_MEM_HOST && mem != FP_MEM_DEVICE) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (mem == FP_MEM_DEVICE) {
-        hipError_t e = fp::launch_from_state(*batch, states, ego, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "from_state launch failed: %s", hipGetErrorString(e));
+        LAUNCH_TRY(fp::launch_from_state(*batch, states, ego, (hipStream_t)stream), "from_state");
         return FP_OK;
     }
-    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
     const size_t B = (size_t)batch->B, fn = (size_t)batch->F * batch->NX;
     for (size_t i = 0; i < B; ++i)
         if (batch->frame_of[i] < 0 || batch->frame_of[i] >= batch->F) return fail(FP_EINVAL, "frame_of[%zu] out of range", i);
-    int rc;
-    if ((rc = ctx->arena.reserve(Arena::padded(sizeof(int32_t) * B) + Arena::padded(sizeof(int32_t) * batch->F) + Arena::padded(sizeof(double) * fn) +
-                                 Arena::padded(sizeof(double) * fn * 8) + Arena::padded(sizeof(double) * B * 4) + Arena::padded(sizeof(double) * B * 6))) != FP_OK)
-        return rc;
-    ctx->arena.reset();
+    HostStage hs(ctx);
+    FP_TRY(hs.reserve(HostStage::need<int32_t>(B) + HostStage::need<int32_t>(batch->F) + HostStage::need<double>(fn) + HostStage::need<double>(fn * 8) +
+                      HostStage::need<double>(B * 4) + HostStage::need<double>(B * 6)));
     fp_batch db = *batch;
-    if ((rc = push(ctx, batch->frame_of, B, &db.frame_of)) != FP_OK) return rc;
-    if ((rc = push(ctx, batch->nx, (size_t)batch->F, &db.nx)) != FP_OK) return rc;
-    if ((rc = push(ctx, batch->knots, fn, &db.knots)) != FP_OK) return rc;
-    if ((rc = push(ctx, batch->coef, fn * 8, &db.coef)) != FP_OK) return rc;
+    FP_TRY(hs.in(batch->frame_of, B, &db.frame_of));
+    FP_TRY(hs.in(batch->nx, (size_t)batch->F, &db.nx));
+    FP_TRY(hs.in(batch->knots, fn, &db.knots));
+    FP_TRY(hs.in(batch->coef, fn * 8, &db.coef));
     const double* d_states = nullptr;
-    if ((rc = push(ctx, states, B * 4, &d_states)) != FP_OK) return rc;
-    double* d_ego = (double*)ctx->arena.take(sizeof(double) * B * 6);
-    hipError_t e = fp::launch_from_state(db, d_states, d_ego, ctx->stream);
-    if (e != hipSuccess) return fail(FP_EHIP, "from_state launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(ego, d_ego, sizeof(double) * B * 6, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return FP_OK;
+    FP_TRY(hs.in(states, B * 4, &d_states));
+    FP_TRY(hs.flush_in());
+    double* d_ego = hs.out(ego, B * 6);
+    LAUNCH_TRY(fp::launch_from_state(db, d_states, d_ego, ctx->stream), "from_state");
+    return hs.fetch_out();
 }
 
 int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states, double* cost,
                   uint32_t* flags, double* traj, int32_t stride, int mem, void* stream)
 {
-    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
-    int rc;
-    if ((rc = check_params(params)) != FP_OK) return rc;
-    if ((rc = check_batch(batch)) != FP_OK) return rc;
+    FP_TRY(common_checks(ctx, params, batch, mem));
     if (K < 1 || !end_states) return fail(FP_EINVAL, "K must be >= 1 and end_states non-NULL");
     if (traj && stride < FP_MAX_POINTS) return fail(FP_EINVAL, "traj stride must be >= FP_MAX_POINTS (%d)", FP_MAX_POINTS);
     if (batch->B == 0) return FP_OK;
@@ -587,39 +615,32 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
     const size_t BK = (size_t)batch->B * K;
     fp::KernelArgs ka;
     ka.p = *params;
-    ka.r = fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ka.r = no_result();
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
-        hipError_t e = fp::launch_eval_trajs(ka, K, end_states, cost, flags, traj, stride, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(FP_EHIP, "eval kernel launch failed: %s", hipGetErrorString(e));
+        LAUNCH_TRY(fp::launch_eval_trajs(ka, K, end_states, cost, flags, traj, stride, (hipStream_t)stream), "eval kernel");
         return FP_OK;
     }
-    if (mem != FP_MEM_HOST) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
-    if ((rc = check_batch_host(params, batch)) != FP_OK) return rc;
+    FP_TRY(check_batch_host(params, batch));
     for (size_t i = 0; i < BK; ++i) {
         const double n = end_states[3 * i + 2] / params->tick_t;
         if (n != n) continue;  // NaN end state = "no trajectory": the kernels emit NaN cost / all-NaN series
         if (!(n > 0) || n > FP_MAX_POINTS) return fail(FP_ELIMIT, "end_states[%zu].T=%g needs 1..FP_MAX_POINTS points", i, end_states[3 * i + 2]);
     }
     const size_t traj_doubles = traj ? BK * FP_ARR_COUNT * (size_t)stride : 0;
-    size_t need = batch_bytes(params, batch) + Arena::padded(sizeof(double) * BK * 3) + Arena::padded(sizeof(double) * BK) +
-                  Arena::padded(sizeof(uint32_t) * BK) + Arena::padded(sizeof(double) * traj_doubles);
-    if ((rc = ctx->arena.reserve(need)) != FP_OK) return rc;
-    ctx->arena.reset();
-    if ((rc = stage_batch(ctx, params, batch, &ka.b)) != FP_OK) return rc;
+    HostStage hs(ctx);
+    FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<double>(BK * 3) + HostStage::need<double>(BK) + HostStage::need<uint32_t>(BK) +
+                      HostStage::need<double>(traj_doubles)));
+    FP_TRY(stage_batch(hs, params, batch, &ka.b));
     const double* d_end = nullptr;
-    if ((rc = push(ctx, end_states, BK * 3, &d_end)) != FP_OK) return rc;
-    double* d_cost = (double*)ctx->arena.take(sizeof(double) * BK);
-    uint32_t* d_flags = (uint32_t*)ctx->arena.take(sizeof(uint32_t) * BK);
-    double* d_traj = traj ? (double*)ctx->arena.take(sizeof(double) * traj_doubles) : nullptr;
-    hipError_t e = fp::launch_eval_trajs(ka, K, d_end, d_cost, d_flags, d_traj, stride, ctx->stream);
-    if (e != hipSuccess) return fail(FP_EHIP, "eval kernel launch failed: %s", hipGetErrorString(e));
-    if (cost) HIP_TRY(hipMemcpyAsync(cost, d_cost, sizeof(double) * BK, hipMemcpyDeviceToHost, ctx->stream));
-    if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, sizeof(uint32_t) * BK, hipMemcpyDeviceToHost, ctx->stream));
-    if (traj) HIP_TRY(hipMemcpyAsync(traj, d_traj, sizeof(double) * traj_doubles, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return FP_OK;
+    FP_TRY(hs.in(end_states, BK * 3, &d_end));
+    FP_TRY(hs.flush_in());
+    double* d_cost = cost ? hs.out(cost, BK) : hs.temp<double>(BK);
+    uint32_t* d_flags = flags ? hs.out(flags, BK) : hs.temp<uint32_t>(BK);
+    double* d_traj = hs.out(traj, traj_doubles);
+    LAUNCH_TRY(fp::launch_eval_trajs(ka, K, d_end, d_cost, d_flags, d_traj, stride, ctx->stream), "eval kernel");
+    return hs.fetch_out();
 }
 
 }  // extern "C"
