@@ -545,6 +545,9 @@ __global__ __launch_bounds__(kWave) void fiss_refine_kernel(FissArgs fa)
 hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream)
 {
     const int bytes = (int)sizeof(double) * ((FP_MAX_POINTS + 1) * 11 + 2 * FP_MAX_POINTS + 9 * fa.ka.b.NX) + 32;
+    FP_LDS_SLOTS(configured);
+    hipError_t e = ensure_dynamic_lds((const void*)fiss_refine_kernel, bytes, configured);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa);
     return hipGetLastError();
 }
@@ -553,6 +556,9 @@ hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
 {
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
     const int bytes = C * (4 * 8 + 1 + 1) + 16;
+    FP_LDS_SLOTS(configured);
+    hipError_t e = ensure_dynamic_lds((const void*)fiss_search_kernel, bytes, configured);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fiss_search_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa);
     return hipGetLastError();
 }

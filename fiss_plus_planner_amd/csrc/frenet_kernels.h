@@ -7,6 +7,24 @@
 
 namespace fp {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and not free: remember the largest size configured per
+// (kernel, device).  `slot` is a function-local static array of kMaxDevices ints initialised to -1.
+constexpr int kMaxDevices = 64;
+inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes, int* slot)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (bytes > slot[dev]) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        slot[dev] = bytes;
+    }
+    return hipSuccess;
+}
+#define FP_LDS_SLOTS(name) static int name[fp::kMaxDevices] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}
+
 // Everything a kernel needs, passed by value as the kernel argument block.
 // All pointers are device addresses.
 struct KernelArgs {

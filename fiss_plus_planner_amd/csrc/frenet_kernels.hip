@@ -455,12 +455,9 @@ hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream)
     if (threads > 1024) threads = 1024;
     int lds_doubles = 0;
     const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
-    static int configured = -1;
-    if (bytes > configured) {
-        hipError_t err = hipFuncSetAttribute((const void*)lattice_percand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (err != hipSuccess) return err;
-        configured = bytes;
-    }
+    FP_LDS_SLOTS(configured);
+    hipError_t err = ensure_dynamic_lds((const void*)lattice_percand_kernel, bytes, configured);
+    if (err != hipSuccess) return err;
     hipLaunchKernelGGL(lattice_percand_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, lds_doubles);
     return hipGetLastError();
 }
@@ -568,12 +565,9 @@ hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_stat
     if (threads > 256) threads = 256;
     int lds_doubles = 0;
     const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
-    static int configured = -1;
-    if (bytes > configured) {
-        hipError_t err = hipFuncSetAttribute((const void*)eval_trajs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (err != hipSuccess) return err;
-        configured = bytes;
-    }
+    FP_LDS_SLOTS(configured);
+    hipError_t err = ensure_dynamic_lds((const void*)eval_trajs_kernel, bytes, configured);
+    if (err != hipSuccess) return err;
     hipLaunchKernelGGL(eval_trajs_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, K, end_states, cost, flags, traj, stride,
                        lds_doubles);
     return hipGetLastError();

@@ -596,12 +596,9 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream)
     }
     const Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt);
     if (L.total > 150 * 1024) return hipErrorInvalidValue;
-    static int configured_bytes = -1;
-    if (L.total > configured_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)lattice_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-        if (e != hipSuccess) return e;
-        configured_bytes = L.total;
-    }
+    FP_LDS_SLOTS(configured);
+    hipError_t e = ensure_dynamic_lds((const void*)lattice_fused_kernel, L.total, configured);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B), dim3(kThreads), L.total, stream, ka, rows, hp);
     return hipGetLastError();
 }

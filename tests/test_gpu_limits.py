@@ -45,6 +45,18 @@ def test_largest_lattice(oracle, engine):
     _check_vs_oracle(oracle, engine, batch)
 
 
+def test_largest_lattice_fiss_pipeline(oracle, engine):
+    """C = 4096 needs 139 KB of LDS in the search kernel (above the 64 KB default dynamic limit)."""
+    batch = synth.make_batch(2, 16, 16, 16, 12, 50, True, 76, kind="FISS+")
+    out = engine.plan_fiss(batch, "FISS+")
+    for e, p in enumerate(oracle.problems_from_batch(batch)):
+        r = p.fissplus_plan()
+        np.testing.assert_array_equal(out.stats[e], r.stats)
+        assert (not np.isnan(out.best_cost[e])) == (not np.isnan(r.best_cost))
+        if not np.isnan(r.best_cost):
+            assert abs(out.best_cost[e] - r.best_cost) < 1e-6
+
+
 def _call(engine, batch, mutate):
     p = make_params(batch)
     fb = _host_batch(batch)
