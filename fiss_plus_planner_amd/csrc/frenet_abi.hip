@@ -84,7 +84,9 @@ struct fp_ctx {
     DeviceBuf arena;               // [ small region (kSmallRegion) | large region ] staging of FP_MEM_HOST calls
     char* pinned = nullptr;        // kSmallRegion bytes of pinned host memory mirroring the small region
     DeviceBuf scratch;             // intermediate tables of multi-kernel entry points (fp_plan_fiss)
+    DeviceBuf parts;               // partial argmins of the latency-mode lattice launch
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
+    int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
 };
 
 namespace {
@@ -265,6 +267,22 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
     return FP_OK;
 }
 
+// Latency mode: a small batch cannot fill 256 CUs with one workgroup per ego, so the time-horizon slices of every ego are
+// spread over nt workgroups.  Returns the split factor and makes sure the partial-argmin buffer exists.
+int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, int* nsplit, void** parts)
+{
+    *nsplit = 1;
+    *parts = nullptr;
+    const bool want = ctx->lattice_split == 2 || (ctx->lattice_split == 0 && (long)b->B * p->nt <= 1024);
+    if (!want || p->nt < 2) return FP_OK;
+    const size_t need = (size_t)b->B * p->nt * 16 + kAlign;
+    if (need > ctx->parts.cap) HIP_TRY(hipStreamSynchronize(stream));  // the buffer may be reallocated: drain its users
+    FP_TRY(ctx->parts.reserve(need));
+    *nsplit = p->nt;
+    *parts = ctx->parts.base;
+    return FP_OK;
+}
+
 fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
 
 int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem)
@@ -336,6 +354,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
+    if (ctx->parts.base) (void)hipFree(ctx->parts.base);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
     return FP_OK;
@@ -347,6 +366,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
     if (strcmp(name, "lattice_kernel") == 0) {
         if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_kernel must be 0 (auto), 1 (per-candidate) or 2 (fused)");
         ctx->lattice_kernel = value;
+        return FP_OK;
+    }
+    if (strcmp(name, "lattice_split") == 0) {
+        if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_split must be 0 (auto), 1 (never) or 2 (always)");
+        ctx->lattice_split = value;
         return FP_OK;
     }
     return fail(FP_EINVAL, "unknown option '%s'", name);
@@ -366,7 +390,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
-        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel), "lattice kernel");
+        int nsplit; void* parts;
+        FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
+        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit), "lattice kernel");
         if (result->best_traj) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
     }
@@ -385,7 +411,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     ka.r.flag_tbl = hs.out(result->flag_tbl, B * C);
     ka.r.best_flags = hs.out(result->best_flags, B);
     ka.r.best_traj = hs.out(result->best_traj, traj_doubles);
-    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel), "lattice kernel");
+    int nsplit; void* parts;
+    FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts));
+    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel, parts, nsplit), "lattice kernel");
     if (result->best_traj) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     return hs.fetch_out();
 }
@@ -492,7 +520,9 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         fa.io.best_flags = hs.out(io->best_flags, B);
         fa.io.best_traj = hs.out(io->best_traj, traj_doubles);
     }
-    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel), "lattice kernel");
+    int nsplit; void* parts;
+    FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
+    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit), "lattice kernel");
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
     if (R > 0) LAUNCH_TRY(fp::launch_fiss_refine(fa, stream), "refinement kernel");
     if (fa.io.best_traj) {

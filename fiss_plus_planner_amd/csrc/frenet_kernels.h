@@ -49,10 +49,11 @@ hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream);
 // One wavefront per ego: FISS+ refinement rounds + cost-ordered validation of the refined trajectories.
 hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream);
 
-hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream);
+// part_scratch: device buffer of B * nsplit * 16 bytes (partial argmins) or nullptr; nsplit > 1 = latency mode.
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
-hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which);
+hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit);
 // Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
 // end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);

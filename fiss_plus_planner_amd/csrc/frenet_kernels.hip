@@ -547,10 +547,10 @@ hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const d
     return hipGetLastError();
 }
 
-hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which)
+hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit)
 {
     if (which == 1) return launch_lattice_percand(ka, stream);
-    hipError_t e = launch_lattice_fused(ka, stream);
+    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit);
     if (e == hipErrorInvalidValue && which != 2) {
         (void)hipGetLastError();
         return launch_lattice_percand(ka, stream);

@@ -110,17 +110,21 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
     return seg;
 }
 
-__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max)
+// nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
+// writes its partial argmin to part_best[ego * nsplit + part]; merge_best_kernel combines them.
+__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
     const int nd = p.nd, nv = p.nv, nt = p.nt;
     const int C = nd * nv * nt;
+    const int it_lo = part * nt / nsplit, it_hi = (part + 1) * nt / nsplit;  // this workgroup's slices
+    const int n_it = it_hi - it_lo;
     const int stride = p.check_stride;
     const double tick = p.tick_t;
 
@@ -149,7 +153,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     Best* s_best = (Best*)(smem + L.best);
 
     if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch (block-uniform exit)
-        if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
+        if (tid == 0) {
+            if (nsplit == 1) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
+            else part_best[blockIdx.x] = Best{0.0, -1};
+        }
         return;
     }
     // ---------------------------------------------------------------- stage: ego, spline, obstacle rows
@@ -243,8 +250,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     //     sum_i p(t_i)^2 = sum_k c_k S_k with c = p (*) p (coefficient convolution) - no per-point work and no reductions.
     //     Conditioning is benign on t in [0, 10] (terms ~1e2..1e4 against sums ~1e1..1e3: ~1e-12 absolute), far inside the
     //     1e-6 cost bar, and the expressions are even in the lateral boundary data, so mirrored candidates still tie bit-exactly.
-    for (int task = wave; task < nt * (nv + 1); task += kWaves) {
-        const int it = task / (nv + 1), iv = task - it * (nv + 1);
+    for (int task = wave; task < n_it * (nv + 1); task += kWaves) {
+        const int it = it_lo + task / (nv + 1), iv = task % (nv + 1);
         const double T = s_ts[it];
         const int N = arange_len(T, tick);
         if (iv < nv) {
@@ -295,8 +302,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
     }
     __syncthreads();
-    for (int e = tid; e < nt * (nv + nd); e += kThreads) {
-        const int it = e / (nv + nd), sub = e - it * (nv + nd);
+    for (int e = tid; e < n_it * (nv + nd); e += kThreads) {
+        const int it = it_lo + e / (nv + nd), sub = e % (nv + nd);
         const double T = s_ts[it];
         const double* S = s_pows + it * 11;
         if (sub < nv) {
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     }
     __syncthreads();  // the final assembly reads the sums (with no obstacles there is no other barrier in between)
 
-    for (int it = 0; n_obs > 0 && hp > 0 && it < nt; ++it) {
+    for (int it = it_lo; n_obs > 0 && hp > 0 && it < it_hi; ++it) {
         const double T = s_ts[it];
         const int N = arange_len(T, tick);
         float* s_dmax = s_dmax2 + (it & 1) * hp_max;    // this slice's buffers (zeroed during the previous slice)
@@ -546,6 +553,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     Best mine{0.0, -1};
     for (int c = tid; c < C; c += kThreads) {
         const int iv = c % nv, it = (c / nv) % nt, id = c / (nv * nt);
+        if (it < it_lo || it >= it_hi) continue;  // another workgroup's slice (latency mode)
         const double T = s_ts[it];
         const int N = arange_len(T, tick);
         const double* ls = s_lon_sum + 3 * (it * nv + iv);
@@ -568,6 +576,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     if (tid == 0) {
         Best r = s_best[0];
         for (int w = 1; w < kWaves; ++w) r = best_merge(r, s_best[w]);
+        if (nsplit > 1) {
+            part_best[blockIdx.x] = r;
+            return;
+        }
         ka.r.best_idx[b] = r.idx;
         ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
         if (ka.r.stats) {
@@ -577,9 +589,24 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     }
 }
 
+__global__ void merge_best_kernel(KernelArgs ka, int nsplit, const Best* part_best)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= ka.b.B) return;
+    Best r = part_best[(size_t)b * nsplit];
+    for (int k = 1; k < nsplit; ++k) r = best_merge(r, part_best[(size_t)b * nsplit + k]);
+    ka.r.best_idx[b] = r.idx;
+    ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
+    if (ka.r.stats) {
+        const int C = ka.p.nd * ka.p.nv * ka.p.nt;
+        int32_t* st = ka.r.stats + (size_t)b * 4;
+        st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
+    }
+}
+
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the
 // lane-per-candidate kernel, which keeps oversized obstacle tables in HBM/L2).
-hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream)
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit)
 {
     const fp_params& p = ka.p;
     const fp_batch& b = ka.b;
@@ -599,7 +626,10 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream)
     FP_LDS_SLOTS(configured);
     hipError_t e = ensure_dynamic_lds((const void*)lattice_fused_kernel, L.total, configured);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B), dim3(kThreads), L.total, stream, ka, rows, hp);
+    if (!part_scratch || nsplit < 1) nsplit = 1;
+    if (nsplit > p.nt) nsplit = p.nt;
+    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, (Best*)part_scratch);
+    if (nsplit > 1) hipLaunchKernelGGL(merge_best_kernel, dim3((b.B + 63) / 64), dim3(64), 0, stream, ka, nsplit, (const Best*)part_scratch);
     return hipGetLastError();
 }
 
