@@ -140,27 +140,46 @@ class FrenetOptimalPlanner:
         return self.settings.max_road_width - self.vehicle.w + (0.3 if self.KIND in FISS_KINDS else 0.0)
 
     def _make_batch(self, frenet_state: FrenetState, obstacles, time_step_now: int) -> ProblemBatch:
+        """The B = 1 problem batch of this plan() call.  Everything that does not change between cycles (lattice grids, spline
+        table, obstacle table) is built once and reused; per cycle only the start state, t_now and - when max_target_speed
+        changed - the speed samples are rewritten in place."""
         if self.cubic_spline is None:
             raise RuntimeError("generate_frenet_frame() must be called before plan()")
         st = self.settings
-        sw = self._sampling_width()
-        d, rd = np.linspace(-sw / 2, sw / 2, st.num_width, retstep=True)
-        t, rt = np.linspace(st.min_t, st.max_t, st.num_t, retstep=True)
-        v, rv = np.linspace(st.lowest_speed, st.highest_speed, st.num_speed, retstep=True)
         tab = self._obstacle_table(obstacles)
         sp = self.cubic_spline
-        if tab is None:
-            pose, dims, fts, scene = np.zeros((0, 1, 0, 4)), np.zeros((0, 0, 2)), np.zeros(0, dtype=np.int32), -1
-        else:
-            pose, dims, fts, scene = tab.pose[None], tab.dims[None], np.array([tab.final_time_step], dtype=np.int32), 0
-        return ProblemBatch(
-            d_samples=d, t_samples=t, v_samples=v[None], target_speed=np.array([st.highest_speed]),
-            ego=frenet_state.as_start_vector()[None], frame_of=[0], scene_of=[scene], t_now=[time_step_now],
-            nx=[len(sp.knots)], knots=sp.knots[None], coef=sp.coef[None], obs_pose=pose, obs_dims=dims, final_time_step=fts,
-            veh_l=self.vehicle.l, veh_w=self.vehicle.w, max_speed=self.vehicle.max_speed, max_accel=self.vehicle.max_accel,
-            tick_t=st.tick_t, check_stride=2,
-            samp_min=np.array([[-sw / 2, st.lowest_speed, st.min_t]]), samp_max=np.array([[sw / 2, st.highest_speed, st.max_t]]),
-            samp_res=np.array([[rd, rv, rt]]))
+        key = (id(sp), id(tab), st.num_width, st.num_speed, st.num_t, st.min_t, st.max_t, st.tick_t, st.max_road_width, st.lowest_speed,
+               self.vehicle.l, self.vehicle.w, self.vehicle.max_speed, self.vehicle.max_accel)
+        cache = getattr(self, "_batch_cache", None)
+        if cache is None or cache[0] != key:
+            sw = self._sampling_width()
+            d, rd = np.linspace(-sw / 2, sw / 2, st.num_width, retstep=True)
+            t, rt = np.linspace(st.min_t, st.max_t, st.num_t, retstep=True)
+            if tab is None:
+                pose, dims, fts, scene = np.zeros((0, 1, 0, 4)), np.zeros((0, 0, 2)), np.zeros(0, dtype=np.int32), -1
+            else:
+                pose, dims, fts, scene = tab.pose[None], tab.dims[None], np.array([tab.final_time_step], dtype=np.int32), 0
+            batch = ProblemBatch(
+                d_samples=d, t_samples=t, v_samples=np.zeros((1, st.num_speed)), target_speed=np.zeros(1), ego=np.zeros((1, 6)),
+                frame_of=[0], scene_of=[scene], t_now=[0], nx=[len(sp.knots)], knots=sp.knots[None], coef=sp.coef[None],
+                obs_pose=pose, obs_dims=dims, final_time_step=fts, veh_l=self.vehicle.l, veh_w=self.vehicle.w,
+                max_speed=self.vehicle.max_speed, max_accel=self.vehicle.max_accel, tick_t=st.tick_t, check_stride=2,
+                samp_min=np.array([[-sw / 2, st.lowest_speed, st.min_t]]), samp_max=np.array([[sw / 2, 0.0, st.max_t]]),
+                samp_res=np.array([[rd, 0.0, rt]]))
+            cache = [key, batch, None, sp, tab]  # sp / tab kept alive so their ids cannot be recycled
+            self._batch_cache = cache
+        batch = cache[1]
+        if cache[2] != st.highest_speed:
+            v, rv = np.linspace(st.lowest_speed, st.highest_speed, st.num_speed, retstep=True)
+            batch.v_samples[0] = v
+            batch.target_speed[0] = st.highest_speed
+            batch.samp_max[0, 1] = st.highest_speed
+            batch.samp_res[0, 1] = rv
+            cache[2] = st.highest_speed
+        fs = frenet_state
+        batch.ego[0] = (fs.s, fs.s_d, fs.s_dd, fs.d, fs.d_d, fs.d_dd)
+        batch.t_now[0] = time_step_now
+        return batch
 
     def _materialize(self, batch: ProblemBatch, end_states: np.ndarray, idxs=None):
         """end_states [K,3] -> list of FrenetTrajectory (full series from the GPU dump)."""
