@@ -91,6 +91,27 @@ class ClosedLoopRunner:
             _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), None, self.end_state.data_ptr(), C.byref(self.io),
                                       _abi.FP_MEM_DEVICE, stream or None))
 
+    def run_graph(self, max_cycles: int):
+        """The same loop as run(), but one [plan -> advance] cycle is captured into a HIP graph once and replayed: the cycle is
+        launch-bound for small batches (2-5 short kernels), and every pointer it touches is fixed (state lives in HBM and is
+        updated in place), so a replay needs no host work beyond hipGraphLaunch."""
+        torch = self.db.torch
+        self.step(torch.cuda.current_stream(self.db.dev).cuda_stream)  # warm-up outside capture: first-use allocations, LDS attributes
+        torch.cuda.synchronize(self.db.dev)
+        side = torch.cuda.Stream(self.db.dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            self.step(side.cuda_stream)
+        torch.cuda.synchronize(self.db.dev)
+        import time
+        t0 = time.perf_counter()
+        for _ in range(max_cycles - 1):
+            graph.replay()
+        torch.cuda.synchronize(self.db.dev)
+        self.replay_seconds = time.perf_counter() - t0  # capture / instantiation excluded
+        return SimpleNamespace(done=self.done.cpu().numpy(), cycles=self.cycles.cpu().numpy(), ego=self.db.t["ego"].cpu().numpy(),
+                               t_now=self.db.t["t_now"].cpu().numpy(), cart=self.cart.cpu().numpy(), trace=[])
+
     def run(self, max_cycles: int, trace: bool = False):
         torch = self.db.torch
         stream = torch.cuda.current_stream(self.db.dev).cuda_stream

@@ -92,3 +92,25 @@ def test_device_closed_loop_batch_no_host_sync(engine):
     np.testing.assert_array_equal(dev.t_now, hb.t_now)
     np.testing.assert_allclose(dev.ego, hb.ego, rtol=0, atol=1e-12)
     assert (dev.cycles > 0).any()
+
+
+@pytest.mark.parametrize("kind", ["FOP", "FISS+"])
+def test_hip_graph_replay_equals_eager_loop(engine, kind):
+    """One captured [plan -> advance] cycle replayed from a HIP graph gives the same final states as the eager loop."""
+    from fiss_plus_planner_amd import synth
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+
+    cycles = 9
+    goal = None
+    outs = []
+    for use_graph in (False, True):
+        batch = synth.make_batch(48, 5, 5, 5, 10, 100, False, 62, kind=kind)
+        goal = np.stack([batch.coef[:, 0, 30], batch.coef[:, 4, 30]], axis=1)
+        run = ClosedLoopRunner(engine, DeviceBatch(batch, 0), goal, kind)
+        outs.append(run.run_graph(cycles) if use_graph else run.run(cycles))
+    a, b = outs
+    np.testing.assert_array_equal(a.done, b.done)
+    np.testing.assert_array_equal(a.cycles, b.cycles)
+    np.testing.assert_array_equal(a.t_now, b.t_now)
+    np.testing.assert_array_equal(a.ego, b.ego)
+    assert (a.cycles > 0).any()
