@@ -83,3 +83,14 @@ def test_two_rank_gloo_shards_match_single_process(tmp_path, oracle):
                           "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "SHARD_OK" in out.stdout
+
+
+def test_generator_is_pinned_by_digest():
+    """The synthetic configs are bit-reproducible: SHA-256 over every array of the first 8 egos of BASELINE configs 2-5
+    (the GPU box regenerates them; bench.py prints the digest of what it ran on)."""
+    want = {2: "4ba11b9bb86f1b4a9501f7307a2ad131a74a055cfdf6c376f5c02d985a259e17",
+            3: "1e0a80bd9f1e2360c4e40097ac85ad614f8090686a7620c8edc9450151861c6a",
+            4: "4a7cce28e5bbe33fe1cf30d744f1efd942397e2309b21afea50c4ce5e124aa71",
+            5: "458ad8ea57d41c9e16f06a8bfb473bbf7fbecce0ccac978c93b9fa18ff43ee5f"}
+    for cfg, digest in want.items():
+        assert synth.make_config(cfg, B=8).digest() == digest, cfg
