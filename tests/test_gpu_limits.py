@@ -106,3 +106,26 @@ def test_unknown_option_is_rejected(engine):
         engine.set_option("no_such_knob", 1)
     with pytest.raises(_abi.FrenetGpuError):
         engine.set_option("lattice_kernel", 9)
+
+
+def test_long_reference_line(oracle, engine):
+    """400-knot centerlines (2 km): larger spline tables in LDS, 16-bit bucket LUT, egos far along the line."""
+    from fiss_plus_planner_amd.batch import ProblemBatch
+    from fiss_plus_planner_amd.spline import build_frames
+
+    base = synth.make_batch(3, 5, 5, 5, 8, 60, True, 77)
+    NX = 400
+    x = np.linspace(0, 2000, NX)
+    pts = np.stack([np.stack([x, a * np.sin(x / lam)], axis=1) for a, lam in ((5, 60), (2, 35), (9, 140))])
+    knots, coef = build_frames(pts)
+    ego = base.ego.copy()
+    ego[:, 0] = [20.0, 1500.0, 1985.0]  # the last one runs off the end (truncation)
+    b = ProblemBatch(d_samples=base.d_samples, t_samples=base.t_samples, v_samples=base.v_samples, target_speed=base.target_speed, ego=ego,
+                     frame_of=[0, 1, 2], scene_of=base.scene_of, t_now=base.t_now, nx=[NX] * 3, knots=knots, coef=coef, obs_pose=base.obs_pose,
+                     obs_dims=base.obs_dims, final_time_step=base.final_time_step, veh_l=base.veh_l, veh_w=base.veh_w,
+                     max_speed=base.max_speed, max_accel=base.max_accel)
+    for split in (1, 2):
+        engine.set_option("lattice_split", split)
+        out = _check_vs_oracle(oracle, engine, b)
+    engine.set_option("lattice_split", 0)
+    assert ((out.flags[2] & 8) != 0).any()
