@@ -231,6 +231,32 @@ def main():
             ms = res.plan_seconds * 1e3
             plan_cycle[kind] = {"p50": float(np.median(ms)), "p90": float(np.percentile(ms, 90)), "cycles": len(ms)}
 
+    # ---- materialise mode (rank 0, N=1): the one HBM-bound mode of the path - every candidate's full series written out
+    # (fp_materialize_all = the reference's all_trajs payload).  256 egos of the same batch: 2.4 GB per launch.
+    materialize = None
+    if rank == 0 and world == 1 and not args.no_latency and not fiss:
+        Bm = min(B, 256)
+        fbm = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in dten.items()})
+        fbm.B = Bm
+        m_traj = torch.empty((Bm * C, 16, 128), dtype=torch.float64, device=dev)
+        m_flags = torch.empty(Bm * C, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            eng.materialize_all_device(params, fbm, m_flags.data_ptr(), m_traj.data_ptr(), stream=stream.cuda_stream)
+        mev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b_ in mev:
+            a.record(stream)
+            eng.materialize_all_device(params, fbm, m_flags.data_ptr(), m_traj.data_ptr(), stream=stream.cuda_stream)
+            b_.record(stream)
+        torch.cuda.synchronize(dev)
+        m_ms = float(np.median([a.elapsed_time(b_) for a, b_ in mev]))
+        n_mean = float(batch.points_per_candidate().mean())
+        written = Bm * C * (16 * 128 * 8 + 4)
+        materialize = {"kernel": "winner_traj_kernel (all candidates)", "egos": Bm, "kernel_ms": m_ms, "candidates_per_s": Bm * C / (m_ms * 1e-3),
+                       "bound": "hbm", "bytes_written_per_launch": written, "achieved_GBps": written / (m_ms * 1e-3) / 1e9,
+                       "algorithmic_GBps": Bm * C * 16 * 8 * n_mean / (m_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                       "frac": written / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del m_traj, m_flags
+
     if rank == 0:
         total_cand = world * B * (C + (21 if fiss else 0)) * args.steps  # config 4 counts the 21 refinement trajectories too
         value = total_cand / elapsed
@@ -266,6 +292,7 @@ def main():
                                   "counts from rocprofv3 PMC are in DESIGN.md"},
             "cpu_baseline": cpu_baseline,
             "plan_cycle_latency": plan_cycle,
+            "materialize_mode": materialize,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 5
+FP_ABI_VERSION = 6
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
@@ -24,7 +24,7 @@ _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option",
-                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_frames_build", "fp_from_state")
+                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_frames_build", "fp_from_state", "fp_materialize_all")
 
 
 class FpParams(C.Structure):
@@ -104,6 +104,7 @@ def load() -> C.CDLL:
     L.fp_advance.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.POINTER(FpLoopIo), C.c_int, C.c_void_p]
     L.fp_frames_build.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fp_from_state.argtypes = [C.c_void_p, C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.fp_materialize_all.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     if L.fp_abi_version() != FP_ABI_VERSION:
         raise ImportError(f"libfrenetgpu ABI {L.fp_abi_version()} != binding {FP_ABI_VERSION}: rebuild")
     _lib = L

@@ -454,6 +454,35 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
     return hs.fetch_out();
 }
 
+int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, uint32_t* flags, double* traj, int mem, void* stream)
+{
+    FP_TRY(common_checks(ctx, params, batch, mem));
+    if (!flags || !traj) return fail(FP_EINVAL, "flags/traj must not be NULL");
+    if (batch->B == 0) return FP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t BC = (size_t)batch->B * params->nd * params->nv * params->nt, traj_doubles = BC * FP_ARR_COUNT * (size_t)FP_MAX_POINTS;
+    if (BC > 0x7fffffffu) return fail(FP_ELIMIT, "B*C = %zu exceeds the grid size limit", BC);
+    fp::KernelArgs ka;
+    ka.p = *params;
+    ka.r = no_result();
+    if (mem == FP_MEM_DEVICE) {
+        ka.b = *batch;
+        ka.r.best_flags = flags;
+        ka.r.best_traj = traj;
+        LAUNCH_TRY(fp::launch_materialize_all(ka, (hipStream_t)stream), "materialise kernel");
+        return FP_OK;
+    }
+    FP_TRY(check_batch_host(params, batch));
+    HostStage hs(ctx);
+    FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<uint32_t>(BC) + HostStage::need<double>(traj_doubles)));
+    FP_TRY(stage_batch(hs, params, batch, &ka.b));
+    FP_TRY(hs.flush_in());
+    ka.r.best_flags = hs.out(flags, BC);
+    ka.r.best_traj = hs.out(traj, traj_doubles);
+    LAUNCH_TRY(fp::launch_materialize_all(ka, ctx->stream), "materialise kernel");
+    return hs.fetch_out();
+}
+
 int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, int mem,
                  void* stream_v)
 {

@@ -331,17 +331,19 @@ __global__ void eval_trajs_kernel(KernelArgs ka, int K, const double* end_states
 // winner epilogue: one workgroup per ego, one lane per time point (no LDS staging of tables: a single
 // trajectory touches ~100 spline segments, read straight through L2)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs ka, const double* end_states)
+// all_C > 0: materialise EVERY lattice candidate (workgroup = (ego, candidate), output slot = blockIdx.x): the all_trajs payload.
+__global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C)
 {
     __shared__ double sx[FP_MAX_POINTS + 1], sy[FP_MAX_POINTS + 1], syaw[FP_MAX_POINTS + 1], sds[FP_MAX_POINTS + 1], sc[FP_MAX_POINTS + 1],
         scd[FP_MAX_POINTS + 1];
     __shared__ int sM;
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
-    const int b = blockIdx.x, i = threadIdx.x;
+    const int slot = blockIdx.x, i = threadIdx.x;
+    const int b = all_C > 0 ? slot / all_C : slot;
     const double nan = __builtin_nan("");
-    double* out = ka.r.best_traj + (size_t)b * FP_ARR_COUNT * FP_MAX_POINTS;
-    const int best = end_states ? 0 : ka.r.best_idx[b];
+    double* out = ka.r.best_traj + (size_t)slot * FP_ARR_COUNT * FP_MAX_POINTS;
+    const int best = all_C > 0 ? slot - b * all_C : (end_states ? 0 : ka.r.best_idx[b]);
     double d_end = nan, v_end = nan, T = nan;
     if (end_states) {
         d_end = end_states[(size_t)b * 3]; v_end = end_states[(size_t)b * 3 + 1]; T = end_states[(size_t)b * 3 + 2];
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs k
     if (best < 0 || N <= 0 || N > FP_MAX_POINTS || !(d_end == d_end) || !(v_end == v_end)) {
 #pragma unroll
         for (int r = 0; r < FP_ARR_COUNT; ++r) out[r * FP_MAX_POINTS + i] = nan;
-        if (i == 0 && ka.r.best_flags) ka.r.best_flags[b] = 0u;
+        if (i == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
         return;
     }
     const double* eg = bt.ego + (size_t)b * 6;
@@ -417,11 +419,11 @@ __global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs k
         row[FP_ARR_DS] = ds; row[FP_ARR_C] = c; row[FP_ARR_C_D] = c_d; row[FP_ARR_C_DD] = c_dd;
     }
 #pragma unroll
-    for (int r = 0; r < FP_ARR_COUNT; ++r) out[r * FP_MAX_POINTS + i] = row[r];
+    for (int r = 0; r < FP_ARR_COUNT; ++r) __builtin_nontemporal_store(row[r], &out[r * FP_MAX_POINTS + i]);  // write-once stream
     if (i == 0 && ka.r.best_flags) {
         uint32_t fl = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
         if (M < N) fl |= FP_FLAG_TRUNCATED;
-        ka.r.best_flags[b] = fl;
+        ka.r.best_flags[slot] = fl;
     }
 }
 
@@ -430,7 +432,14 @@ __global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs k
 // ---------------------------------------------------------------------------
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream)
 {
-    hipLaunchKernelGGL(winner_traj_kernel, dim3(ka.b.B), dim3(FP_MAX_POINTS), 0, stream, ka, end_states);
+    hipLaunchKernelGGL(winner_traj_kernel, dim3(ka.b.B), dim3(FP_MAX_POINTS), 0, stream, ka, end_states, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
+{
+    const int C = ka.p.nd * ka.p.nv * ka.p.nt;
+    hipLaunchKernelGGL(winner_traj_kernel, dim3((unsigned)ka.b.B * (unsigned)C), dim3(FP_MAX_POINTS), 0, stream, ka, nullptr, C);
     return hipGetLastError();
 }
 

@@ -158,6 +158,18 @@ class FrenetEngine:
         _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(p), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_HOST, None))
         return out
 
+    def materialize_all(self, batch: ProblemBatch):
+        """Full series of every lattice candidate (fp_materialize_all): traj [B,C,16,128], flags [B,C] (N, M, truncated)."""
+        B, Cn = batch.B, batch.C
+        traj = np.empty((B, Cn, 16, TRAJ_STRIDE)); flags = np.empty((B, Cn), dtype=np.uint32)
+        p = make_params(batch)
+        fb = _host_batch(batch)
+        _abi.check(self._lib.fp_materialize_all(self._ctx, C.byref(p), C.byref(fb), flags.ctypes.data, traj.ctypes.data, _abi.FP_MEM_HOST, None))
+        return SimpleNamespace(traj=traj, flags=flags)
+
+    def materialize_all_device(self, params: _abi.FpParams, fb: _abi.FpBatch, flags: int, traj: int, stream: int = 0):
+        _abi.check(self._lib.fp_materialize_all(self._ctx, C.byref(params), C.byref(fb), flags, traj, _abi.FP_MEM_DEVICE, stream or None))
+
     def build_frames(self, points: np.ndarray, n: np.ndarray | None = None):
         """CubicSpline2D construction for F centerlines on the GPU (fp_frames_build): points [F,NX,2] -> knots [F,NX], coef [F,8,NX]."""
         pts = np.ascontiguousarray(points, dtype=np.float64)

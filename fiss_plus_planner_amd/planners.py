@@ -201,10 +201,11 @@ class FrenetOptimalPlanner:
     def _dense(self, batch: ProblemBatch, winner: bool = False):
         out = self._engine.plan_dense(batch, tables=True, winner=winner)
         self.last_tables = (out.cost[0], out.flags[0])
-        if self.materialize_all:
-            es = np.array([self._end_state_of_flat(batch, c)[0] for c in range(batch.C)])
-            trajs, _ = self._materialize(batch, es)
-            self.all_trajs.append(trajs)
+        if self.materialize_all:  # visualisation payload (reference :102): every candidate's series in one launch
+            m = self._engine.materialize_all(batch)
+            _, N, M = unpack_flags(m.flags[0])
+            self.all_trajs.append([FrenetTrajectory.from_dump(m.traj[0, c], int(N[c]), int(M[c]), float(out.cost[0, c]))
+                                   for c in range(batch.C)])
         else:
             self.all_trajs.append([])
         return out

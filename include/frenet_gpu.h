@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 5
+#define FP_ABI_VERSION 6
 
 /* error codes */
 #define FP_OK 0
@@ -143,6 +143,14 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
  * caller can time / schedule the two kernels independently.  Replaces the object hand-back of plan() (:264-270). */
 int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
                     double* best_traj, int mem, void* stream);
+
+/* Materialise the whole lattice: the full series of EVERY candidate of every ego, in FOP order
+ *   traj [B][C][16][FP_MAX_POINTS] (NaN padded), flags [B][C] (N << 8 | M << 20 | FP_FLAG_TRUNCATED; the feasibility bits
+ *   come from fp_plan_dense's flag_tbl).
+ * = what calc_frenet_paths + calc_global_paths leave in `all_trajs` for the visualisation (frenet_optimal_planner.py:102,
+ * planners/benchmark/planning.py:336-357).  This is the one mode of the path that is HBM bound: 16 KiB written per candidate. */
+int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, uint32_t* flags, double* traj, int mem,
+                       void* stream);
 
 /* Explicit end states: K trajectories per ego with end state (d_end, v_end, T_end)
  *   = generate_trajectory_by_end_state (fiss_plus_planner.py:172-205) / generate_trajectory
