@@ -42,9 +42,14 @@ class ClosedLoopResult:
 
 def run_closed_loop(planner, centerline: np.ndarray, init_state, obstacles: ObstacleTable, goal_center, max_speed: float = 13.5,
                     max_cycles: int | None = None) -> ClosedLoopResult:
-    _, ref = planner.generate_frenet_frame(centerline)
+    sp, ref = planner.generate_frenet_frame(centerline)
     cur = FrenetState()
-    cur.from_state(State(t=0.0, x=init_state[0], y=init_state[1], yaw=init_state[2], v=init_state[3], a=0.0), ref)
+    if getattr(planner, "frame_on", "host") == "device":
+        # Cartesian -> Frenet projection on the GPU (fp_from_state), same rules as FrenetState.from_state
+        e = planner._engine.from_state(sp.knots[None], sp.coef[None], [len(sp.knots)], [0], np.asarray(init_state, dtype=np.float64)[None, :4])[0]
+        cur = FrenetState(t=0.0, s=e[0], s_d=e[1], s_dd=e[2], d=e[3], d_d=e[4], d_dd=e[5])
+    else:
+        cur.from_state(State(t=0.0, x=init_state[0], y=init_state[1], yaw=init_state[2], v=init_state[3], a=0.0), ref)
     res = ClosedLoopResult()
     n_cycles = obstacles.final_time_step if max_cycles is None else min(max_cycles, obstacles.final_time_step)
     half_len = planner.vehicle.l / 2

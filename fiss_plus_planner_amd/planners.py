@@ -104,7 +104,7 @@ class FrenetOptimalPlanner:
     KIND = "FOP"
 
     def __init__(self, planner_settings: FrenetOptimalPlannerSettings, ego_vehicle: Vehicle, scenario=None, *,
-                 device: int = 0, engine: FrenetEngine | None = None, materialize_all: bool = False):
+                 device: int = 0, engine: FrenetEngine | None = None, materialize_all: bool = False, frame_on: str = "device"):
         self.settings = planner_settings
         self.vehicle = ego_vehicle
         self.cubic_spline = None
@@ -112,6 +112,8 @@ class FrenetOptimalPlanner:
         self.all_trajs = []
         self.stats = Stats()
         self.materialize_all = materialize_all  # fill all_trajs with every candidate (visualisation payload)
+        assert frame_on in ("device", "host")
+        self.frame_on = frame_on  # where generate_frenet_frame() solves the spline system (fp_frames_build or numpy)
         self._engine = engine if engine is not None else _engine_for(device)
         self._obs_cache = (None, None)
         self.last_tables = None  # (cost [C], flags [C]) of the last dense pass, flat FOP order
@@ -120,7 +122,11 @@ class FrenetOptimalPlanner:
     def generate_frenet_frame(self, centerline_pts: np.ndarray):
         """reference :272-278 -> (CubicSpline2D, [n', 4] = x, y, yaw, kappa every 0.1 m)."""
         pts = np.asarray(centerline_pts, dtype=np.float64)
-        self.cubic_spline = CubicSpline2D(pts[:, 0], pts[:, 1])
+        tables = None
+        if self.frame_on == "device" and 2 <= len(pts) <= 512:
+            knots, coef = self._engine.build_frames(pts[None, :, :2])  # fp_frames_build: Thomas sweep on the GPU
+            tables = (knots[0], coef[0])
+        self.cubic_spline = CubicSpline2D(pts[:, 0], pts[:, 1], tables)
         s = np.arange(0, self.cubic_spline.s[-1], 0.1)
         x, y, yaw, kappa = self.cubic_spline.sample(s)
         return self.cubic_spline, np.column_stack((x, y, yaw, kappa))

@@ -132,11 +132,14 @@ class _Spline1D:
 class CubicSpline2D:
     """Reference line through centerline vertices, parameterised by chord length."""
 
-    def __init__(self, x, y):
-        pts = np.column_stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)])
-        knots, coef = build_frames(pts[None])
-        self.knots = knots[0]
-        self.coef = coef[0]  # [8, nx]
+    def __init__(self, x, y, tables=None):
+        """tables = (knots [nx], coef [8, nx]) built elsewhere (e.g. on the GPU by fp_frames_build); default: host build."""
+        if tables is None:
+            pts = np.column_stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)])
+            knots, coef = build_frames(pts[None])
+            tables = (knots[0], coef[0])
+        self.knots = np.ascontiguousarray(tables[0], dtype=np.float64)
+        self.coef = np.ascontiguousarray(tables[1], dtype=np.float64)  # [8, nx]
         self.s = list(self.knots)
         self.ds = np.diff(self.knots)
         self.sx = _Spline1D(self.knots, self.coef[0:4])

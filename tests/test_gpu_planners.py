@@ -115,7 +115,7 @@ def test_history_heuristic_and_refinement(engine, kind, search_on):
             np.testing.assert_array_equal(pl.prev_best_idx, g[f"{kind}_prev_out"][e])
 
 
-def _closed_loop(kind, g, engine, search_on="device"):
+def _closed_loop(kind, g, engine, search_on="device", frame_on="device"):
     """planners/benchmark/planning.py:101-162 on the Flensburg fixture inputs."""
     from fiss_plus_planner_amd import planners as P
     from fiss_plus_planner_amd.closed_loop import run_closed_loop
@@ -125,7 +125,7 @@ def _closed_loop(kind, g, engine, search_on="device"):
     cls, st = {"FOP": (P.FrenetOptimalPlanner, P.FrenetOptimalPlannerSettings), "FOP+": (P.FopPlusPlanner, P.FrenetOptimalPlannerSettings),
                "FISS": (P.FissPlanner, P.FissPlannerSettings), "FISS+": (P.FissPlusPlanner, P.FissPlusPlannerSettings)}[kind]
     kw = {"search_on": search_on} if kind in ("FISS", "FISS+") else {}
-    pl = cls(st(5, 5, 5), Vehicle(), None, engine=engine, **kw)
+    pl = cls(st(5, 5, 5), Vehicle(), None, engine=engine, frame_on=frame_on, **kw)
     fts = int(g["final_time_step"])
     res = run_closed_loop(pl, g["centerline"], g["init_state"], ObstacleTable(g["obs_pose"][:fts], g["obs_dims"], fts), g["goal_center"])
     return res.cycles, np.array(res.states)
@@ -139,7 +139,8 @@ def test_flensburg_closed_loop(engine, kind, search_on):
     if kind in ("FOP", "FOP+") and search_on == "host":
         pytest.skip("FOP/FOP+ have a single code path")
     want = g[f"{kind}_rows"]
-    rows, states = _closed_loop(kind, g, engine, search_on)
+    # device search runs with the device-built frame + device projection, the host walk with the numpy ones
+    rows, states = _closed_loop(kind, g, engine, search_on, frame_on=search_on)
     assert len(rows) == len(want)
     for i, (r, w) in enumerate(zip(rows, want)):
         np.testing.assert_allclose(r.start, w[0:6], rtol=0, atol=1e-7, err_msg=f"cycle {i} start state")
