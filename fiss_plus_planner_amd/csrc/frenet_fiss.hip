@@ -298,6 +298,8 @@ struct RefineLds {
     double2* xy;    // [FP_MAX_POINTS]
     double* knots;  // [nx]
     double* coef;   // [8][nx]
+    double2* cs;    // [rows][n_obs] cos/sin of the obstacle yaw at every checked row (nullptr: computed per pair)
+    int cs_rows;
 };
 
 __device__ __forceinline__ double analytic_cost(const fp_params& p, const double* eg, double target_speed, const double* x, const double* Stab)
@@ -371,74 +373,144 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
     const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
     const int k_end = M < horizon_cap ? M : horizon_cap;
-    for (int k = 0; k < k_end; k += p.check_stride) {
-        const int ts = k + t_now;
-        if (ts >= bt.T_obs) break;  // beyond the table: state_at_time() is None for every obstacle
-        const int a = (k + 1 < M) ? k : k - 1;  // heading: forward difference, previous one for the last point (:127-129)
-        const double2 pa = L.xy[a], pb = L.xy[a + 1], pc = L.xy[k];
-        Obb ego;
-        step_heading(pb.x - pa.x, pb.y - pa.y, ego.c, ego.s);
-        ego.x = pc.x; ego.y = pc.y; ego.hl = veh_hl; ego.hw = veh_hw;
-        const bool broken = !(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c);
+    const int stride = p.check_stride;
+    // a non-finite checked pose makes the reference's polygon construction fail -> "collision" (:178-182)
+    {
+        bool broken = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int i = lane + half * kWave;
+            if (i < k_end && (i % stride) == 0) {
+                const double2 q = L.xy[i];
+                broken |= !(q.x == q.x) || !(q.y == q.y);
+            }
+        }
+        if (__ballot(broken)) return flags | FP_FLAG_COLLISION;
+    }
+    // every (checked pose, obstacle) pair is independent: lanes run over the flattened pairs (coalesced 32-byte pose reads
+    // straight from the scene table), four loads in flight per lane, one ballot per group of 256 pairs for the early exit
+    const int in_table = bt.T_obs - t_now;
+    const int k_lim = k_end < in_table ? k_end : in_table;  // beyond the table state_at_time() is None for every obstacle
+    const int n_poses = k_lim > 0 ? (k_lim + stride - 1) / stride : 0;
+    const int P = n_poses * n_obs;
+    constexpr int kInFlight = 4;   // pose reads in flight per lane (the table is read from L2 / HBM: ~1-2 us per round trip)
+    for (int e0 = 0; e0 < P; e0 += kInFlight * kWave) {
         bool hit = false;
-        for (int j0 = 0; j0 < n_obs; j0 += kWave) {
-            const int j = j0 + lane;
-            if (j < n_obs) {
-                const double4 ps = *(const double4*)(scene + ((size_t)ts * n_obs + j) * 4);
+        double4 pq[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const int e = e0 + u * kWave + lane;
+            pq[u] = make_double4(0.0, 0.0, 0.0, 0.0);
+            if (e < P) {
+                const int r = e / n_obs, j = e - r * n_obs;
+                pq[u] = *(const double4*)(scene + ((size_t)(r * stride + t_now) * n_obs + j) * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const int e = e0 + u * kWave + lane;
+            if (e < P) {
+                const int r = e / n_obs, j = e - r * n_obs;
+                const int kk = r * stride;
+                const double4 ps = pq[u];
                 if (ps.w != 0.0) {
                     const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
                     const double R = (r_ego + sqrt(fma(hl, hl, hw * hw))) * (1.0 + 1e-12);
-                    const double dx = ps.x - ego.x, dy = ps.y - ego.y;
-                    if (broken) {
-                        hit = true;  // polygon construction fails in the reference -> collision (:178-182)
-                    } else if (fma(dx, dx, dy * dy) <= R * R) {
+                    const double2 pc = L.xy[kk];
+                    const double dx = ps.x - pc.x, dy = ps.y - pc.y;
+                    if (fma(dx, dx, dy * dy) <= R * R) {
+                        const int a2 = (kk + 1 < M) ? kk : kk - 1;  // heading: forward difference, previous one for the last point (:127-129)
+                        const double2 pa = L.xy[a2], pb = L.xy[a2 + 1];
+                        Obb ego;
+                        step_heading(pb.x - pa.x, pb.y - pa.y, ego.c, ego.s);
+                        ego.x = pc.x; ego.y = pc.y; ego.hl = veh_hl; ego.hw = veh_hw;
                         double oc, os;
-                        sincos(ps.z, &os, &oc);
-                        hit = obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
+                        if (L.cs && r < L.cs_rows) {
+                            const double2 q = L.cs[r * n_obs + j];
+                            oc = q.x; os = q.y;
+                        } else {
+                            sincos(ps.z, &os, &oc);
+                        }
+                        hit |= obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
                     }
                 }
             }
-            if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
         }
-        if (broken) return flags | FP_FLAG_COLLISION;  // the ego polygon is built (and fails) before the obstacle loop
+        if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
     }
     return flags;
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(kWave) void fiss_refine_kernel(FissArgs fa)
+constexpr int kRefineWaves = 4;  // trajectories validated speculatively side by side (one wavefront each)
+
+// LDS layout of the refinement kernel, in doubles (every double2 region starts 16-byte aligned):
+//   [0, kRefineS) power-sum table | kRefineWaves Cartesian scratch rows | knots + coef (9 NX, padded even) | cos/sin table | verdicts
+constexpr int kRefineS = ((FP_MAX_POINTS + 1) * 11 + 1) & ~1;
+__host__ __device__ constexpr int refine_spline_off() { return kRefineS + 2 * FP_MAX_POINTS * kRefineWaves; }
+__host__ __device__ constexpr int refine_cs_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
+__host__ __device__ constexpr int refine_lds_bytes(int NX, int cs_entries)
+{
+    return (int)sizeof(double) * (refine_cs_off(NX) + 2 * cs_entries) + 32;
+}
+
+__global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissArgs fa, int cs_rows_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const KernelArgs& ka = fa.ka;
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    constexpr int kThreads = kWave * kRefineWaves;
     const int32_t* ijk = fa.io.best_ijk + (size_t)b * 3;
     const int R = fa.opts.max_refine_iters;
     if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None
     const int f = bt.frame_of[b];
     const int nx = bt.nx[f];
+    const int verdict_off = refine_lds_bytes(bt.NX, cs_rows_max * bt.n_obs) - 32;
     RefineLds L;
     L.S = (double*)smem;
-    L.xy = (double2*)(L.S + (FP_MAX_POINTS + 1) * 11);
-    L.knots = (double*)(L.xy + FP_MAX_POINTS);
+    L.xy = (double2*)(L.S + kRefineS) + wave * FP_MAX_POINTS;  // one Cartesian scratch row per wavefront
+    L.knots = L.S + refine_spline_off();
     L.coef = L.knots + nx;
     {
         const double* gk = bt.knots + (size_t)f * bt.NX;
         const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
-        for (int i = lane; i < nx; i += kWave) L.knots[i] = gk[i];
-        for (int i = lane; i < 8 * nx; i += kWave) {
+        for (int i = tid; i < nx; i += kThreads) L.knots[i] = gk[i];
+        for (int i = tid; i < 8 * nx; i += kThreads) {
             const int r = i / nx, c = i - r * nx;
             L.coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
         }
-        if (lane < 11) {  // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane
+        // cos/sin of every obstacle yaw the collision horizon can touch, once per ego: the validation loop may visit the same
+        // (row, obstacle) pair for up to 21 trajectories and fp64 sincos is the most expensive thing it would do
+        L.cs = nullptr;
+        L.cs_rows = 0;
+        const int sc0 = bt.scene_of[b];
+        if (sc0 >= 0 && bt.n_obs > 0 && cs_rows_max > 0) {
+            const int t0 = bt.t_now[b];
+            int h = bt.final_time_step[sc0] - t0;
+            if (h > FP_MAX_POINTS) h = FP_MAX_POINTS;
+            if (h > bt.T_obs - t0) h = bt.T_obs - t0;
+            int rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;
+            if (rows > cs_rows_max) rows = cs_rows_max;
+            L.cs = (double2*)(L.S + refine_cs_off(bt.NX));
+            L.cs_rows = rows;
+            const double* scene = bt.obs_pose + (size_t)sc0 * bt.T_obs * bt.n_obs * 4;
+            for (int e = tid; e < rows * bt.n_obs; e += kThreads) {
+                const int r = e / bt.n_obs, j = e - r * bt.n_obs;
+                double sn, cn;
+                sincos(scene[((size_t)(r * p.check_stride + t0) * bt.n_obs + j) * 4 + 2], &sn, &cn);
+                L.cs[e] = make_double2(cn, sn);
+            }
+        }
+        if (tid < 11) {  // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane
             double acc = 0.0;
             L.S[lane] = 0.0;
             for (int i = 0; i < FP_MAX_POINTS; ++i) {
                 const double t = (double)i * p.tick_t;
-                double tk = 1.0;
-                for (int m = 0; m < lane; ++m) tk *= t;
+                const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;  // t^lane by binary exponentiation (lane <= 10), no inner loop
+                const double tk = ((lane & 1) ? t : 1.0) * ((lane & 2) ? t2 : 1.0) * ((lane & 4) ? t4 : 1.0) * ((lane & 8) ? t8 : 1.0);
                 acc += tk;
                 L.S[(i + 1) * 11 + lane] = acc;
             }
@@ -500,28 +572,54 @@ __global__ __launch_bounds__(kWave) void fiss_refine_kernel(FissArgs fa)
         ncand += 1;
         x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
     }
-    // refined_trajs.get() in cost order (ties: generation order), :301-323 - each popped trajectory checked by the whole wave
+    // refined_trajs.get() in cost order (ties: generation order), :301-323.  Every wavefront holds the same candidate list (the
+    // rounds above are replicated, bit-identical); the next kRefineWaves trajectories in pop order are checked SPECULATIVELY side
+    // by side, one whole wavefront each, and the verdicts are then consumed in pop order exactly like the sequential loop -
+    // validated / checks count only what the reference would have popped before its first collision-free trajectory.
+    uint32_t* verdict = (uint32_t*)(smem + verdict_off);  // [2][kRefineWaves], double-buffered across groups
     int validated = 0, checks = 0, winner = -1;
     bool alive = lane < ncand;
-    for (int it = 0; it < ncand; ++it) {
-        double bc = alive ? my_cost : __builtin_inf();
-        int bl = alive ? lane : kWave;
+    for (int grp = 0; winner < 0; ++grp) {
+        int pop[kRefineWaves];
 #pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            const double oc = __shfl_xor(bc, off, kWave);
-            const int ol = __shfl_xor(bl, off, kWave);
-            if (ol < kWave && (bl >= kWave || oc < bc || (oc == bc && ol < bl))) { bc = oc; bl = ol; }
+        for (int u = 0; u < kRefineWaves; ++u) {
+            double bc = alive ? my_cost : __builtin_inf();
+            int bl = alive ? lane : kWave;
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                const double oc = __shfl_xor(bc, off, kWave);
+                const int ol = __shfl_xor(bl, off, kWave);
+                if (ol < kWave && (bl >= kWave || oc < bc || (oc == bc && ol < bl))) { bc = oc; bl = ol; }
+            }
+            if (bl >= kWave || bc > coarse_cost) bl = -1;  // queue empty / `cost > coarse cost` ends the loop (:303-304)
+            pop[u] = bl;
+            if (bl < 0) alive = false;  // nothing further is ever popped
+            if (lane == bl) alive = false;
         }
-        if (bl >= kWave) break;
-        if (bc > coarse_cost) break;
-        if (lane == bl) alive = false;
-        ++validated;
-        const double cx[3] = {__shfl(my_x[0], bl, kWave), __shfl(my_x[1], bl, kWave), __shfl(my_x[2], bl, kWave)};
-        const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane);
-        if (fl & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) continue;
-        ++checks;
-        if (!(fl & FP_FLAG_COLLISION)) { winner = bl; break; }
+        if (pop[0] < 0) break;
+        int mine = pop[0];
+#pragma unroll
+        for (int u = 1; u < kRefineWaves; ++u) mine = (wave == u) ? pop[u] : mine;
+        if (mine >= 0) {
+            const double cx[3] = {__shfl(my_x[0], mine, kWave), __shfl(my_x[1], mine, kWave), __shfl(my_x[2], mine, kWave)};
+            const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane);
+            if (lane == 0) verdict[(grp & 1) * kRefineWaves + wave] = fl;
+        }
+        __syncthreads();
+        bool done = false;
+#pragma unroll
+        for (int u = 0; u < kRefineWaves; ++u) {
+            if (done) continue;
+            if (pop[u] < 0) { done = true; continue; }
+            const uint32_t fl = verdict[(grp & 1) * kRefineWaves + u];
+            ++validated;
+            if (fl & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) continue;
+            ++checks;
+            if (!(fl & FP_FLAG_COLLISION)) { winner = pop[u]; done = true; }
+        }
+        if (done) break;
     }
+    if (wave != 0) return;
     if (fa.io.trace && lane < R * 7) {
         double* tr = fa.io.trace + ((size_t)b * R * 7 + lane) * 4;
         const bool have = lane < ncand;
@@ -544,11 +642,20 @@ __global__ __launch_bounds__(kWave) void fiss_refine_kernel(FissArgs fa)
 
 hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream)
 {
-    const int bytes = (int)sizeof(double) * ((FP_MAX_POINTS + 1) * 11 + 2 * FP_MAX_POINTS + 9 * fa.ka.b.NX) + 32;
+    // cos/sin table of the checked obstacle rows when it fits in a modest LDS budget (keeps >= 4 workgroups per CU)
+    int cs_rows = 0;
+    if (fa.ka.b.n_obs > 0) {
+        const int stride = fa.ka.p.check_stride;
+        int rows = (FP_MAX_POINTS + stride - 1) / stride;
+        const int rows_tab = (fa.ka.b.T_obs + stride - 1) / stride;
+        if (rows_tab < rows) rows = rows_tab;
+        if ((long)rows * fa.ka.b.n_obs * 16 <= 24 * 1024) cs_rows = rows;
+    }
+    const int bytes = refine_lds_bytes(fa.ka.b.NX, cs_rows * fa.ka.b.n_obs);
     FP_LDS_SLOTS(configured);
     hipError_t e = ensure_dynamic_lds((const void*)fiss_refine_kernel, bytes, configured);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa);
+    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, cs_rows);
     return hipGetLastError();
 }
 
