@@ -87,6 +87,7 @@ struct fp_ctx {
     DeviceBuf parts;               // partial argmins of the latency-mode lattice launch
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
+    int refine_table_kb = 24;      // fp_ctx_set_option("refine_table_kb")
 };
 
 namespace {
@@ -368,6 +369,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->lattice_kernel = value;
         return FP_OK;
     }
+    if (strcmp(name, "refine_table_kb") == 0) {
+        if (value < 0 || value > 96) return fail(FP_EINVAL, "refine_table_kb must be in [0, 96]");
+        ctx->refine_table_kb = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_split") == 0) {
         if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_split must be 0 (auto), 1 (never) or 2 (always)");
         ctx->lattice_split = value;
@@ -553,7 +559,7 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
     LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit), "lattice kernel");
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
-    if (R > 0) LAUNCH_TRY(fp::launch_fiss_refine(fa, stream), "refinement kernel");
+    if (R > 0) LAUNCH_TRY(fp::launch_fiss_refine(fa, stream, ctx->refine_table_kb), "refinement kernel");
     if (fa.io.best_traj) {
         fp::KernelArgs kw = fa.ka;
         kw.r.best_flags = fa.io.best_flags;

@@ -298,8 +298,11 @@ struct RefineLds {
     double2* xy;    // [FP_MAX_POINTS]
     double* knots;  // [nx]
     double* coef;   // [8][nx]
-    double2* cs;    // [rows][n_obs] cos/sin of the obstacle yaw at every checked row (nullptr: computed per pair)
-    int cs_rows;
+    // conservative fp32 broad phase, staged once per ego (nullptr: table over the LDS budget, pairs are read from the scene table)
+    float4* pt;     // [rows][n_obs] {x - ox, y - oy, (padded bounding-circle sum)^2 or -1 when absent, row as int bits}
+    float2* xyf;    // [FP_MAX_POINTS] this wavefront's poses relative to (ox, oy), fp32
+    uint16_t* queue;  // [2 * kWave] this wavefront's broad-phase survivors (pair table indices)
+    double ox, oy;  // first knot of the reference line: keeps the fp32 coordinates small
 };
 
 __device__ __forceinline__ double analytic_cost(const fp_params& p, const double* eg, double target_speed, const double* x, const double* Stab)
@@ -316,8 +319,17 @@ __device__ __forceinline__ double analytic_cost(const fp_params& p, const double
 }
 
 // constraint + collision flags of ONE trajectory, computed by the whole wavefront (all arguments wave-uniform)
-__device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane)
+#ifdef REFINE_TIMING
+__device__ long long g_tphase[4];
+#define TPH(i) do { long long now_ = wall_clock64(); tph[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define TPH(i)
+#endif
+__device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane, long long* tph = nullptr)
 {
+#ifdef REFINE_TIMING
+    long long tlast = wall_clock64();
+#endif
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const double T = x[2];
@@ -326,6 +338,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
     SplineLds sp{L.knots, L.coef, nx, nx};
     const double knot0 = L.knots[0], knot_last = L.knots[nx - 1];
+    TPH(0);
     unsigned long long off_lo = 0, off_hi = 0;
     bool bad_speed = false, bad_accel = false;
 #pragma unroll
@@ -346,11 +359,13 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
                 spline_frame(sp, seg, s - L.knots[seg], px, py, tx, ty);
                 frenet_to_cartesian(px, py, tx, ty, d, cx, cy);
                 L.xy[i] = make_double2(cx, cy);
+                if (L.pt) L.xyf[i] = make_float2((float)(cx - L.ox), (float)(cy - L.oy));
             }
         }
         const unsigned long long m = __ballot(off);
         if (half == 0) off_lo = m; else off_hi = m;
     }
+    TPH(1);
     uint32_t flags = 0;
     if (__ballot(bad_speed)) flags |= FP_FLAG_SPEED;
     if (__ballot(bad_accel)) flags |= FP_FLAG_ACCEL;
@@ -387,13 +402,76 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
         }
         if (__ballot(broken)) return flags | FP_FLAG_COLLISION;
     }
-    // every (checked pose, obstacle) pair is independent: lanes run over the flattened pairs (coalesced 32-byte pose reads
-    // straight from the scene table), four loads in flight per lane, one ballot per group of 256 pairs for the early exit
     const int in_table = bt.T_obs - t_now;
     const int k_lim = k_end < in_table ? k_end : in_table;  // beyond the table state_at_time() is None for every obstacle
     const int n_poses = k_lim > 0 ? (k_lim + stride - 1) / stride : 0;
     const int P = n_poses * n_obs;
-    constexpr int kInFlight = 4;   // pose reads in flight per lane (the table is read from L2 / HBM: ~1-2 us per round trip)
+    // exact test of pair (checked row r, obstacle j): bounding circles, then the separating-axis test
+    auto pair_hits = [&](int r, int j, const double4& ps) -> bool {
+        if (ps.w == 0.0) return false;
+        const int kk = r * stride;
+        const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
+        const double R = (r_ego + sqrt(fma(hl, hl, hw * hw))) * (1.0 + 1e-12);
+        const double2 pc = L.xy[kk];
+        const double dx = ps.x - pc.x, dy = ps.y - pc.y;
+        if (!(fma(dx, dx, dy * dy) <= R * R)) return false;
+        const int a2 = (kk + 1 < M) ? kk : kk - 1;  // heading: forward difference, previous one for the last point (:127-129)
+        const double2 pa = L.xy[a2], pb = L.xy[a2 + 1];
+        Obb ego;
+        step_heading(pb.x - pa.x, pb.y - pa.y, ego.c, ego.s);
+        ego.x = pc.x; ego.y = pc.y; ego.hl = veh_hl; ego.hw = veh_hw;
+        double oc, os;
+        sincos(ps.z, &os, &oc);
+        return obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
+    };
+    TPH(2);
+    if (L.pt) {
+        // every (checked pose, obstacle) pair is independent: lanes run over the flattened pair table; the fp32 circle test is
+        // conservative (radius padded far beyond the fp32 rounding).  Survivors are compacted into this wavefront's queue and
+        // take the exact fp64 test one per lane, so their pose reads (L2 / HBM, ~1-2 us) are all in flight together
+        int qn = 0;
+        bool hit = false;
+        auto drain = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int slot = u * kWave + lane;
+                if (slot < qn) {
+                    const int e = L.queue[slot];
+                    const int r = __float_as_int(L.pt[e].w), j = e - r * n_obs;
+                    hit |= pair_hits(r, j, *(const double4*)(scene + ((size_t)(r * stride + t_now) * n_obs + j) * 4));
+                }
+            }
+            qn = 0;
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int e0 = 0; e0 < P; e0 += kWave) {
+            const int e = e0 + lane;
+            bool pass = false;
+            if (e < P) {
+                const float4 q = L.pt[e];
+                const float2 c = L.xyf[__float_as_int(q.w) * stride];
+                const float dx = q.x - c.x, dy = q.y - c.y;
+                pass = dx * dx + dy * dy <= q.z;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                if (pass) L.queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
+                qn += __popcll(m);
+                if (qn > kWave) {
+                    drain();
+                    if (__ballot(hit)) { TPH(3); return flags | FP_FLAG_COLLISION; }
+                }
+            }
+        }
+        if (qn > 0) drain();
+        TPH(3);
+        return __ballot(hit) ? (flags | FP_FLAG_COLLISION) : flags;
+    }
+    // no table: coalesced 32-byte pose reads straight from the scene table, four in flight per lane
+    constexpr int kInFlight = 4;
     for (int e0 = 0; e0 < P; e0 += kInFlight * kWave) {
         bool hit = false;
         double4 pq[kInFlight];
@@ -411,29 +489,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
             const int e = e0 + u * kWave + lane;
             if (e < P) {
                 const int r = e / n_obs, j = e - r * n_obs;
-                const int kk = r * stride;
-                const double4 ps = pq[u];
-                if (ps.w != 0.0) {
-                    const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
-                    const double R = (r_ego + sqrt(fma(hl, hl, hw * hw))) * (1.0 + 1e-12);
-                    const double2 pc = L.xy[kk];
-                    const double dx = ps.x - pc.x, dy = ps.y - pc.y;
-                    if (fma(dx, dx, dy * dy) <= R * R) {
-                        const int a2 = (kk + 1 < M) ? kk : kk - 1;  // heading: forward difference, previous one for the last point (:127-129)
-                        const double2 pa = L.xy[a2], pb = L.xy[a2 + 1];
-                        Obb ego;
-                        step_heading(pb.x - pa.x, pb.y - pa.y, ego.c, ego.s);
-                        ego.x = pc.x; ego.y = pc.y; ego.hl = veh_hl; ego.hw = veh_hw;
-                        double oc, os;
-                        if (L.cs && r < L.cs_rows) {
-                            const double2 q = L.cs[r * n_obs + j];
-                            oc = q.x; os = q.y;
-                        } else {
-                            sincos(ps.z, &os, &oc);
-                        }
-                        hit |= obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
-                    }
-                }
+                hit |= pair_hits(r, j, pq[u]);
             }
         }
         if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
@@ -443,19 +499,26 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
 
 }  // namespace
 
-constexpr int kRefineWaves = 4;  // trajectories validated speculatively side by side (one wavefront each)
+#ifndef REFINE_WAVES
+#define REFINE_WAVES 4
+#endif
+#ifndef REFINE_MIN_WAVES
+#define REFINE_MIN_WAVES 2
+#endif
+constexpr int kRefineWaves = REFINE_WAVES;  // trajectories validated speculatively side by side (one wavefront each)
 
 // LDS layout of the refinement kernel, in doubles (every double2 region starts 16-byte aligned):
-//   [0, kRefineS) power-sum table | kRefineWaves Cartesian scratch rows | knots + coef (9 NX, padded even) | cos/sin table | verdicts
+//   [0, kRefineS) power-sum table | kRefineWaves x (fp64 poses, fp32 relative poses) | knots + coef (9 NX, padded even)
+//   | pair table (float4 per entry) | verdicts (32 B) | kRefineWaves survivor queues
 constexpr int kRefineS = ((FP_MAX_POINTS + 1) * 11 + 1) & ~1;
-__host__ __device__ constexpr int refine_spline_off() { return kRefineS + 2 * FP_MAX_POINTS * kRefineWaves; }
-__host__ __device__ constexpr int refine_cs_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
-__host__ __device__ constexpr int refine_lds_bytes(int NX, int cs_entries)
+__host__ __device__ constexpr int refine_spline_off() { return kRefineS + 3 * FP_MAX_POINTS * kRefineWaves; }
+__host__ __device__ constexpr int refine_pt_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
+__host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
 {
-    return (int)sizeof(double) * (refine_cs_off(NX) + 2 * cs_entries) + 32;
+    return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 4 * kWave;
 }
 
-__global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissArgs fa, int cs_rows_max)
+__global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_refine_kernel(FissArgs fa, int pt_rows_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const KernelArgs& ka = fa.ka;
@@ -468,11 +531,16 @@ __global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissA
     if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None
     const int f = bt.frame_of[b];
     const int nx = bt.nx[f];
-    const int verdict_off = refine_lds_bytes(bt.NX, cs_rows_max * bt.n_obs) - 32;
+#ifdef REFINE_TIMING
+    const long long tm0 = wall_clock64();
+#endif
+    const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 4 * kWave;
     RefineLds L;
     L.S = (double*)smem;
     L.xy = (double2*)(L.S + kRefineS) + wave * FP_MAX_POINTS;  // one Cartesian scratch row per wavefront
+    L.xyf = (float2*)(L.S + kRefineS + 2 * FP_MAX_POINTS * kRefineWaves) + wave * FP_MAX_POINTS;
     L.knots = L.S + refine_spline_off();
+    L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * 2 * kWave;
     L.coef = L.knots + nx;
     {
         const double* gk = bt.knots + (size_t)f * bt.NX;
@@ -482,32 +550,41 @@ __global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissA
             const int r = i / nx, c = i - r * nx;
             L.coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
         }
-        // cos/sin of every obstacle yaw the collision horizon can touch, once per ego: the validation loop may visit the same
-        // (row, obstacle) pair for up to 21 trajectories and fp64 sincos is the most expensive thing it would do
-        L.cs = nullptr;
-        L.cs_rows = 0;
+        // fp32 broad-phase table of every (checked row, obstacle) pair the collision horizon can touch, once per ego: the
+        // validation loop may visit the same pair for up to 21 trajectories
+        L.pt = nullptr;
+        L.ox = gc[0];                       // x, y of the first knot
+        L.oy = gc[(size_t)4 * bt.NX];
         const int sc0 = bt.scene_of[b];
-        if (sc0 >= 0 && bt.n_obs > 0 && cs_rows_max > 0) {
+        if (sc0 >= 0 && bt.n_obs > 0 && pt_rows_max > 0) {
             const int t0 = bt.t_now[b];
             int h = bt.final_time_step[sc0] - t0;
             if (h > FP_MAX_POINTS) h = FP_MAX_POINTS;
             if (h > bt.T_obs - t0) h = bt.T_obs - t0;
-            int rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;
-            if (rows > cs_rows_max) rows = cs_rows_max;
-            L.cs = (double2*)(L.S + refine_cs_off(bt.NX));
-            L.cs_rows = rows;
+            const int rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;  // <= pt_rows_max by construction
+            L.pt = (float4*)(L.S + refine_pt_off(bt.NX));
             const double* scene = bt.obs_pose + (size_t)sc0 * bt.T_obs * bt.n_obs * 4;
+            const double* gd = bt.obs_dims + (size_t)sc0 * bt.n_obs * 2;
+            const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
+            const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
             for (int e = tid; e < rows * bt.n_obs; e += kThreads) {
                 const int r = e / bt.n_obs, j = e - r * bt.n_obs;
-                double sn, cn;
-                sincos(scene[((size_t)(r * p.check_stride + t0) * bt.n_obs + j) * 4 + 2], &sn, &cn);
-                L.cs[e] = make_double2(cn, sn);
+                const double4 ps = *(const double4*)(scene + ((size_t)(r * p.check_stride + t0) * bt.n_obs + j) * 4);
+                const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
+                const double rx = ps.x - L.ox, ry = ps.y - L.oy;
+                // padding: 1 cm + 2e-6 of the coordinate magnitude dwarfs the fp32 rounding of rx, ry, the pose and the sum
+                const double R = r_ego + sqrt(fma(hl, hl, hw * hw)) + 1e-2 + 2e-6 * (fabs(rx) + fabs(ry));
+                float R2 = (float)(R * R * (1.0 + 1e-5));
+                if (ps.w == 0.0 || !(R2 >= 0.0f)) R2 = -1.0f;  // absent at this step (or NaN size): never passes
+                L.pt[e] = make_float4((float)rx, (float)ry, R2, __int_as_float(r));
             }
         }
-        if (tid < 11) {  // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane
+        // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane, the 128 steps split into one chunk per wavefront
+        constexpr int kChunk = FP_MAX_POINTS / kRefineWaves;
+        if (lane < 11) {
             double acc = 0.0;
-            L.S[lane] = 0.0;
-            for (int i = 0; i < FP_MAX_POINTS; ++i) {
+            if (wave == 0) L.S[lane] = 0.0;
+            for (int i = wave * kChunk; i < (wave + 1) * kChunk; ++i) {
                 const double t = (double)i * p.tick_t;
                 const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;  // t^lane by binary exponentiation (lane <= 10), no inner loop
                 const double tk = ((lane & 1) ? t : 1.0) * ((lane & 2) ? t2 : 1.0) * ((lane & 4) ? t4 : 1.0) * ((lane & 8) ? t8 : 1.0);
@@ -517,6 +594,22 @@ __global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissA
         }
     }
     __syncthreads();
+    {   // chunk w adds the totals of chunks < w (read before anyone overwrites them: barrier in between)
+        constexpr int kChunk = FP_MAX_POINTS / kRefineWaves;
+        double base = 0.0;
+        if (lane < 11)
+            for (int w = 1; w <= wave; ++w) base += L.S[(w * kChunk) * 11 + lane];
+        __syncthreads();
+        if (wave > 0)
+            for (int e = lane; e < kChunk * 11; e += kWave) {
+                const int k11 = e % 11;
+                L.S[(wave * kChunk + 1) * 11 + e] += __shfl(base, k11, kWave);
+            }
+    }
+    __syncthreads();
+#ifdef REFINE_TIMING
+    const long long tm1 = wall_clock64();
+#endif
     const double nan = __builtin_nan("");
     double eg[6];
 #pragma unroll
@@ -576,6 +669,11 @@ __global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissA
     // rounds above are replicated, bit-identical); the next kRefineWaves trajectories in pop order are checked SPECULATIVELY side
     // by side, one whole wavefront each, and the verdicts are then consumed in pop order exactly like the sequential loop -
     // validated / checks count only what the reference would have popped before its first collision-free trajectory.
+#ifdef REFINE_TIMING
+    const long long tm2 = wall_clock64();
+    long long tmv = 0; int ngrp = 0;
+    long long tph[4] = {0, 0, 0, 0};
+#endif
     uint32_t* verdict = (uint32_t*)(smem + verdict_off);  // [2][kRefineWaves], double-buffered across groups
     int validated = 0, checks = 0, winner = -1;
     bool alive = lane < ncand;
@@ -602,7 +700,17 @@ __global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissA
         for (int u = 1; u < kRefineWaves; ++u) mine = (wave == u) ? pop[u] : mine;
         if (mine >= 0) {
             const double cx[3] = {__shfl(my_x[0], mine, kWave), __shfl(my_x[1], mine, kWave), __shfl(my_x[2], mine, kWave)};
+#ifdef REFINE_TIMING
+            const long long ta = wall_clock64();
+#endif
+#ifdef REFINE_TIMING
+            const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane, tph);
+#else
             const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane);
+#endif
+#ifdef REFINE_TIMING
+            tmv += wall_clock64() - ta; ++ngrp;
+#endif
             if (lane == 0) verdict[(grp & 1) * kRefineWaves + wave] = fl;
         }
         __syncthreads();
@@ -620,6 +728,16 @@ __global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissA
         if (done) break;
     }
     if (wave != 0) return;
+#ifdef REFINE_TIMING
+    if (fa.io.trace && lane == 0) {
+        double* tr = fa.io.trace + ((size_t)b * R * 7) * 4;
+        const long long tm3 = wall_clock64();
+        tr[0] = (double)(tm1 - tm0); tr[1] = (double)(tm2 - tm1); tr[2] = (double)(tm3 - tm2); tr[3] = (double)tmv;
+        tr[4] = (double)ngrp; tr[5] = (double)validated; tr[6] = (double)tm0; tr[7] = (double)tm3;
+        tr[8] = (double)tph[0]; tr[9] = (double)tph[1]; tr[10] = (double)tph[2]; tr[11] = (double)tph[3];
+    }
+    return;
+#endif
     if (fa.io.trace && lane < R * 7) {
         double* tr = fa.io.trace + ((size_t)b * R * 7 + lane) * 4;
         const bool have = lane < ncand;
@@ -640,22 +758,22 @@ __global__ __launch_bounds__(kWave * kRefineWaves) void fiss_refine_kernel(FissA
     }
 }
 
-hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream)
+hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb)
 {
-    // cos/sin table of the checked obstacle rows when it fits in a modest LDS budget (keeps >= 4 workgroups per CU)
-    int cs_rows = 0;
+    // pair table of the checked obstacle rows when it fits in a modest LDS budget (keeps >= 3 workgroups per CU)
+    int pt_rows = 0;
     if (fa.ka.b.n_obs > 0) {
         const int stride = fa.ka.p.check_stride;
         int rows = (FP_MAX_POINTS + stride - 1) / stride;
         const int rows_tab = (fa.ka.b.T_obs + stride - 1) / stride;
         if (rows_tab < rows) rows = rows_tab;
-        if ((long)rows * fa.ka.b.n_obs * 16 <= 24 * 1024) cs_rows = rows;
+        if ((long)rows * fa.ka.b.n_obs * 16 <= (long)table_kb * 1024) pt_rows = rows;
     }
-    const int bytes = refine_lds_bytes(fa.ka.b.NX, cs_rows * fa.ka.b.n_obs);
+    const int bytes = refine_lds_bytes(fa.ka.b.NX, pt_rows * fa.ka.b.n_obs);
     FP_LDS_SLOTS(configured);
     hipError_t e = ensure_dynamic_lds((const void*)fiss_refine_kernel, bytes, configured);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, cs_rows);
+    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, pt_rows);
     return hipGetLastError();
 }
 

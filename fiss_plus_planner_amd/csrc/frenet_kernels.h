@@ -46,8 +46,9 @@ struct FissArgs {
 
 // One wavefront per ego: coarse FISS / FISS+ search over the dense tables.
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream);
-// One wavefront per ego: FISS+ refinement rounds + cost-ordered validation of the refined trajectories.
-hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream);
+// One workgroup per ego: FISS+ refinement rounds + cost-ordered validation of the refined trajectories.  table_kb = LDS budget
+// of the per-ego fp32 pose-obstacle pair table (0: no table, pairs are read from the scene table).
+hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb);
 
 // part_scratch: device buffer of B * nsplit * 16 bytes (partial argmins) or nullptr; nsplit > 1 = latency mode.
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit);

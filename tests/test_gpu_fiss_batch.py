@@ -102,3 +102,33 @@ def test_batch_pipeline_vs_oracle(oracle, engine, cfg, kind):
             np.testing.assert_allclose(out.end_state[e], r.end_state, rtol=0, atol=1e-9)
             n = int((~np.isnan(r.trace.reshape(-1, 4)[:, 0])).sum())
             np.testing.assert_allclose(out.trace[e, :n], r.trace.reshape(-1, 4)[:n], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("table_kb", [0, 24])
+@pytest.mark.parametrize("shift", [(0.0, 0.0), (4.0e4, -7.5e4)], ids=["origin", "far"])
+def test_refinement_collision_paths_match_oracle(oracle, engine, table_kb, shift):
+    """The refinement kernel's two collision paths (per-ego fp32 pair table + exact survivors / pairs straight from the scene
+    table) give the oracle's verdicts, also when the map sits tens of kilometres from the origin (the table's coordinates are
+    taken relative to the first knot so that fp32 stays conservative)."""
+    b = synth.make_batch(48, 9, 9, 7, 50, 50, True, 77, kind="FISS+")
+    b.coef[:, 0, :] += shift[0]
+    b.coef[:, 4, :] += shift[1]
+    b.obs_pose[..., 0] += shift[0]
+    b.obs_pose[..., 1] += shift[1]
+    engine.set_option("refine_table_kb", table_kb)
+    try:
+        out = engine.plan_fiss(b, "FISS+", trace=True)
+    finally:
+        engine.set_option("refine_table_kb", 24)
+    n_refined = 0
+    for e, p in enumerate(oracle.problems_from_batch(b)):
+        r = p.fissplus_plan(None)
+        np.testing.assert_array_equal(out.stats[e], r.stats, err_msg=f"ego {e}")
+        found = not np.isnan(r.best_cost)
+        assert (not np.isnan(out.best_cost[e])) == found
+        if found:
+            assert abs(out.best_cost[e] - r.best_cost) < TOL
+            assert bool(out.refined[e]) == r.refined
+            n_refined += int(r.refined)
+            np.testing.assert_allclose(out.end_state[e], r.end_state, rtol=0, atol=1e-9)
+    assert n_refined > 0
