@@ -281,17 +281,25 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
 }
 
 // ---------------------------------------------------------------------------
-// FISS+ refinement (fiss_plus_planner.py:207-326), one wavefront per ego.
-//   * costs in closed form: a table S_k(N) = sum_{i<N} t_i^k for every N <= 128 is built once per workgroup (11 lanes, one
-//     running sum each), then the cost of ANY end state is O(1) (lon_cost_sums / lat_cost_sums): per round lanes 0..5 price the
-//     six probes clip(x -/+ res_dim e_dim) (:213-232), the finite-difference gradient and the decayed step are wave-uniform
-//     arithmetic on shuffled lane values (:262-271), lane 0 prices the trajectory at the new x.  The coarse winner is priced by
-//     the same function, so a probe clipped back onto x ties with it exactly (`cost > coarse cost` ends the loop, :303-304).
-//   * validation is lazy and in cost order like refined_trajs.get() (:301-323); each popped trajectory is checked by the WHOLE
-//     wavefront: lane = time point for the masks / truncation / Cartesian points, then lane = obstacle for every checked pose
-//     (coalesced 32-byte pose reads straight from the scene table, exact circle + separating-axis test), ballot early exit.
+// FISS+ refinement (fiss_plus_planner.py:207-326), one workgroup of kRefineWaves wavefronts per ego.
+//   * costs in closed form: a table S_k(N) = sum_{i<N} t_i^k for every N <= 128 is built once per workgroup, then the cost of ANY
+//     end state is O(1) (lon_cost_sums / lat_cost_sums): per round lanes 0..5 price the six probes clip(x -/+ res_dim e_dim)
+//     (:213-232), the finite-difference gradient and the decayed step are wave-uniform arithmetic on shuffled lane values
+//     (:262-271), lane 0 prices the trajectory at the new x.  The coarse winner is priced by the same function, so a probe clipped
+//     back onto x ties with it exactly (`cost > coarse cost` ends the loop, :303-304).  Every wavefront runs the rounds
+//     redundantly (bit-identical), so all of them hold the same candidate list.
+//   * validation is lazy and in cost order like refined_trajs.get() (:301-323): the next kRefineWaves trajectories in pop order
+//     are checked speculatively side by side, one whole wavefront each (lane = time point for the masks / truncation / Cartesian
+//     points, then lane = (checked pose, obstacle) pair), and the verdicts are consumed in pop order.
+//   * collision checks never wait on L2 / HBM per pair: the obstacle rows the horizon can touch are staged once per ego as an
+//     fp32 table relative to the first knot; a conservative fp32 circle test (branch-free, four table reads in flight per lane)
+//     feeds a per-wavefront survivor queue, survivors take the exact fp64 circle + separating-axis test one per lane.
+//   The kernel is instruction-issue bound at low occupancy (160+ VGPRs): 3 workgroups per CU need <= 168 VGPRs and <= 53 KB of
+//   LDS, which is what sizes the survivor queues.
 // ---------------------------------------------------------------------------
 namespace {
+
+constexpr int kQueue = 5 * kWave;  // survivor queue entries per wavefront (refinement kernel): drained above kWave, filled 4 kWave at a time
 
 struct RefineLds {
     double* S;      // [FP_MAX_POINTS + 1][11]
@@ -299,10 +307,11 @@ struct RefineLds {
     double* knots;  // [nx]
     double* coef;   // [8][nx]
     // conservative fp32 broad phase, staged once per ego (nullptr: table over the LDS budget, pairs are read from the scene table)
-    float4* pt;     // [rows][n_obs] {x - ox, y - oy, (padded bounding-circle sum)^2 or -1 when absent, row as int bits}
+    float4* pt;     // [rows][n_obs] {x - ox, y - oy, (padded bounding-circle sum)^2 or -1 when absent, (step | obstacle << 8) as int bits}
     float2* xyf;    // [FP_MAX_POINTS] this wavefront's poses relative to (ox, oy), fp32
-    uint16_t* queue;  // [2 * kWave] this wavefront's broad-phase survivors (pair table indices)
+    uint16_t* queue;  // [kQueue] this wavefront's broad-phase survivors (pair table indices)
     double ox, oy;  // first knot of the reference line: keeps the fp32 coordinates small
+    int scene, t_now, horizon_cap;  // per-ego scene facts read once (scene < 0: none; horizon_cap = final_time_step - t_now)
 };
 
 __device__ __forceinline__ double analytic_cost(const fp_params& p, const double* eg, double target_speed, const double* x, const double* Stab)
@@ -319,17 +328,8 @@ __device__ __forceinline__ double analytic_cost(const fp_params& p, const double
 }
 
 // constraint + collision flags of ONE trajectory, computed by the whole wavefront (all arguments wave-uniform)
-#ifdef REFINE_TIMING
-__device__ long long g_tphase[4];
-#define TPH(i) do { long long now_ = wall_clock64(); tph[i] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define TPH(i)
-#endif
-__device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane, long long* tph = nullptr)
+__device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane)
 {
-#ifdef REFINE_TIMING
-    long long tlast = wall_clock64();
-#endif
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const double T = x[2];
@@ -338,7 +338,6 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
     SplineLds sp{L.knots, L.coef, nx, nx};
     const double knot0 = L.knots[0], knot_last = L.knots[nx - 1];
-    TPH(0);
     unsigned long long off_lo = 0, off_hi = 0;
     bool bad_speed = false, bad_accel = false;
 #pragma unroll
@@ -365,7 +364,6 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
         const unsigned long long m = __ballot(off);
         if (half == 0) off_lo = m; else off_hi = m;
     }
-    TPH(1);
     uint32_t flags = 0;
     if (__ballot(bad_speed)) flags |= FP_FLAG_SPEED;
     if (__ballot(bad_accel)) flags |= FP_FLAG_ACCEL;
@@ -373,11 +371,11 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     if (M < N) flags |= FP_FLAG_TRUNCATED;
     flags |= ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
     // collision (frenet_optimal_planner.py:168-195)
-    const int sc = bt.scene_of[b];
+    const int sc = L.scene;
     const int n_obs = sc >= 0 ? bt.n_obs : 0;
     if (n_obs <= 0) return flags;
-    const int t_now = bt.t_now[b];
-    const int horizon_cap = bt.final_time_step[sc] - t_now;
+    const int t_now = L.t_now;
+    const int horizon_cap = L.horizon_cap;
     if (M == 1 && horizon_cap >= 1) return flags | FP_FLAG_COLLISION;  // traj.yaw is empty -> IndexError -> collision (:178-182)
     if (M < 2) return flags;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -407,9 +405,8 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const int n_poses = k_lim > 0 ? (k_lim + stride - 1) / stride : 0;
     const int P = n_poses * n_obs;
     // exact test of pair (checked row r, obstacle j): bounding circles, then the separating-axis test
-    auto pair_hits = [&](int r, int j, const double4& ps) -> bool {
+    auto pair_hits = [&](int kk, int j, const double4& ps) -> bool {  // kk = checked time step
         if (ps.w == 0.0) return false;
-        const int kk = r * stride;
         const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
         const double R = (r_ego + sqrt(fma(hl, hl, hw * hw))) * (1.0 + 1e-12);
         const double2 pc = L.xy[kk];
@@ -424,51 +421,49 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
         sincos(ps.z, &os, &oc);
         return obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
     };
-    TPH(2);
     if (L.pt) {
         // every (checked pose, obstacle) pair is independent: lanes run over the flattened pair table; the fp32 circle test is
         // conservative (radius padded far beyond the fp32 rounding).  Survivors are compacted into this wavefront's queue and
         // take the exact fp64 test one per lane, so their pose reads (L2 / HBM, ~1-2 us) are all in flight together
+        constexpr int kU = 4;  // table reads in flight per lane: branch-free (clamped index) so the LDS latencies overlap
         int qn = 0;
-        bool hit = false;
-        auto drain = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e0 = 0; e0 < P + kU * kWave; e0 += kU * kWave) {  // one extra trip drains what is left: the (large) exact test
+            if (e0 < P) {                                            // is inlined once
+                float4 q[kU];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int slot = u * kWave + lane;
-                if (slot < qn) {
-                    const int e = L.queue[slot];
-                    const int r = __float_as_int(L.pt[e].w), j = e - r * n_obs;
-                    hit |= pair_hits(r, j, *(const double4*)(scene + ((size_t)(r * stride + t_now) * n_obs + j) * 4));
+                for (int u = 0; u < kU; ++u) {
+                    const int e = e0 + u * kWave + lane;
+                    q[u] = L.pt[e < P ? e : P - 1];
+                }
+                float2 c[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) c[u] = L.xyf[__float_as_int(q[u].w) & 0xFF];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const float dx = q[u].x - c[u].x, dy = q[u].y - c[u].y;
+                    const bool pass = (dx * dx + dy * dy <= q[u].z) && (e0 + u * kWave + lane < P);
+                    const unsigned long long m = __ballot(pass);
+                    const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (pass) L.queue[qn + below] = (uint16_t)(e0 + u * kWave + lane);
+                    qn += __popcll(m);
                 }
             }
-            qn = 0;
-            __builtin_amdgcn_wave_barrier();
-        };
-        for (int e0 = 0; e0 < P; e0 += kWave) {
-            const int e = e0 + lane;
-            bool pass = false;
-            if (e < P) {
-                const float4 q = L.pt[e];
-                const float2 c = L.xyf[__float_as_int(q.w) * stride];
-                const float dx = q.x - c.x, dy = q.y - c.y;
-                pass = dx * dx + dy * dy <= q.z;
-            }
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                if (pass) L.queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
-                qn += __popcll(m);
-                if (qn > kWave) {
-                    drain();
-                    if (__ballot(hit)) { TPH(3); return flags | FP_FLAG_COLLISION; }
+            if (qn > kQueue - kU * kWave || (e0 >= P && qn > 0)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                bool hit = false;
+                for (int slot = lane; slot < qn; slot += kWave) {  // survivors: exact fp64 test, their pose reads in flight together
+                    const uint32_t kj = (uint32_t)__float_as_int(L.pt[L.queue[slot]].w);
+                    const int kk = kj & 0xFF, j = kj >> 8;
+                    hit |= pair_hits(kk, j, *(const double4*)(scene + ((size_t)(kk + t_now) * n_obs + j) * 4));
                 }
+                qn = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
             }
         }
-        if (qn > 0) drain();
-        TPH(3);
-        return __ballot(hit) ? (flags | FP_FLAG_COLLISION) : flags;
+        return flags;
     }
     // no table: coalesced 32-byte pose reads straight from the scene table, four in flight per lane
     constexpr int kInFlight = 4;
@@ -489,7 +484,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
             const int e = e0 + u * kWave + lane;
             if (e < P) {
                 const int r = e / n_obs, j = e - r * n_obs;
-                hit |= pair_hits(r, j, pq[u]);
+                hit |= pair_hits(r * stride, j, pq[u]);
             }
         }
         if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
@@ -499,13 +494,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
 
 }  // namespace
 
-#ifndef REFINE_WAVES
-#define REFINE_WAVES 4
-#endif
-#ifndef REFINE_MIN_WAVES
-#define REFINE_MIN_WAVES 2
-#endif
-constexpr int kRefineWaves = REFINE_WAVES;  // trajectories validated speculatively side by side (one wavefront each)
+constexpr int kRefineWaves = 4;  // trajectories validated speculatively side by side (one wavefront each)
 
 // LDS layout of the refinement kernel, in doubles (every double2 region starts 16-byte aligned):
 //   [0, kRefineS) power-sum table | kRefineWaves x (fp64 poses, fp32 relative poses) | knots + coef (9 NX, padded even)
@@ -515,10 +504,10 @@ __host__ __device__ constexpr int refine_spline_off() { return kRefineS + 3 * FP
 __host__ __device__ constexpr int refine_pt_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
 __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
 {
-    return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 4 * kWave;
+    return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 2 * kQueue;
 }
 
-__global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_refine_kernel(FissArgs fa, int pt_rows_max)
+__global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(FissArgs fa, int pt_rows_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const KernelArgs& ka = fa.ka;
@@ -531,16 +520,13 @@ __global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_r
     if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None
     const int f = bt.frame_of[b];
     const int nx = bt.nx[f];
-#ifdef REFINE_TIMING
-    const long long tm0 = wall_clock64();
-#endif
-    const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 4 * kWave;
+    const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 2 * kQueue;
     RefineLds L;
     L.S = (double*)smem;
     L.xy = (double2*)(L.S + kRefineS) + wave * FP_MAX_POINTS;  // one Cartesian scratch row per wavefront
     L.xyf = (float2*)(L.S + kRefineS + 2 * FP_MAX_POINTS * kRefineWaves) + wave * FP_MAX_POINTS;
     L.knots = L.S + refine_spline_off();
-    L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * 2 * kWave;
+    L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * kQueue;
     L.coef = L.knots + nx;
     {
         const double* gk = bt.knots + (size_t)f * bt.NX;
@@ -556,9 +542,12 @@ __global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_r
         L.ox = gc[0];                       // x, y of the first knot
         L.oy = gc[(size_t)4 * bt.NX];
         const int sc0 = bt.scene_of[b];
+        L.scene = sc0;
+        L.t_now = bt.t_now[b];
+        L.horizon_cap = sc0 >= 0 ? bt.final_time_step[sc0] - L.t_now : 0;
         if (sc0 >= 0 && bt.n_obs > 0 && pt_rows_max > 0) {
-            const int t0 = bt.t_now[b];
-            int h = bt.final_time_step[sc0] - t0;
+            const int t0 = L.t_now;
+            int h = L.horizon_cap;
             if (h > FP_MAX_POINTS) h = FP_MAX_POINTS;
             if (h > bt.T_obs - t0) h = bt.T_obs - t0;
             const int rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;  // <= pt_rows_max by construction
@@ -576,7 +565,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_r
                 const double R = r_ego + sqrt(fma(hl, hl, hw * hw)) + 1e-2 + 2e-6 * (fabs(rx) + fabs(ry));
                 float R2 = (float)(R * R * (1.0 + 1e-5));
                 if (ps.w == 0.0 || !(R2 >= 0.0f)) R2 = -1.0f;  // absent at this step (or NaN size): never passes
-                L.pt[e] = make_float4((float)rx, (float)ry, R2, __int_as_float(r));
+                L.pt[e] = make_float4((float)rx, (float)ry, R2, __int_as_float((r * p.check_stride) | (j << 8)));
             }
         }
         // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane, the 128 steps split into one chunk per wavefront
@@ -607,9 +596,6 @@ __global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_r
             }
     }
     __syncthreads();
-#ifdef REFINE_TIMING
-    const long long tm1 = wall_clock64();
-#endif
     const double nan = __builtin_nan("");
     double eg[6];
 #pragma unroll
@@ -669,11 +655,6 @@ __global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_r
     // rounds above are replicated, bit-identical); the next kRefineWaves trajectories in pop order are checked SPECULATIVELY side
     // by side, one whole wavefront each, and the verdicts are then consumed in pop order exactly like the sequential loop -
     // validated / checks count only what the reference would have popped before its first collision-free trajectory.
-#ifdef REFINE_TIMING
-    const long long tm2 = wall_clock64();
-    long long tmv = 0; int ngrp = 0;
-    long long tph[4] = {0, 0, 0, 0};
-#endif
     uint32_t* verdict = (uint32_t*)(smem + verdict_off);  // [2][kRefineWaves], double-buffered across groups
     int validated = 0, checks = 0, winner = -1;
     bool alive = lane < ncand;
@@ -700,17 +681,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_r
         for (int u = 1; u < kRefineWaves; ++u) mine = (wave == u) ? pop[u] : mine;
         if (mine >= 0) {
             const double cx[3] = {__shfl(my_x[0], mine, kWave), __shfl(my_x[1], mine, kWave), __shfl(my_x[2], mine, kWave)};
-#ifdef REFINE_TIMING
-            const long long ta = wall_clock64();
-#endif
-#ifdef REFINE_TIMING
-            const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane, tph);
-#else
             const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane);
-#endif
-#ifdef REFINE_TIMING
-            tmv += wall_clock64() - ta; ++ngrp;
-#endif
             if (lane == 0) verdict[(grp & 1) * kRefineWaves + wave] = fl;
         }
         __syncthreads();
@@ -728,16 +699,6 @@ __global__ __launch_bounds__(kWave * kRefineWaves, REFINE_MIN_WAVES) void fiss_r
         if (done) break;
     }
     if (wave != 0) return;
-#ifdef REFINE_TIMING
-    if (fa.io.trace && lane == 0) {
-        double* tr = fa.io.trace + ((size_t)b * R * 7) * 4;
-        const long long tm3 = wall_clock64();
-        tr[0] = (double)(tm1 - tm0); tr[1] = (double)(tm2 - tm1); tr[2] = (double)(tm3 - tm2); tr[3] = (double)tmv;
-        tr[4] = (double)ngrp; tr[5] = (double)validated; tr[6] = (double)tm0; tr[7] = (double)tm3;
-        tr[8] = (double)tph[0]; tr[9] = (double)tph[1]; tr[10] = (double)tph[2]; tr[11] = (double)tph[3];
-    }
-    return;
-#endif
     if (fa.io.trace && lane < R * 7) {
         double* tr = fa.io.trace + ((size_t)b * R * 7 + lane) * 4;
         const bool have = lane < ncand;
@@ -767,7 +728,7 @@ hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_
         int rows = (FP_MAX_POINTS + stride - 1) / stride;
         const int rows_tab = (fa.ka.b.T_obs + stride - 1) / stride;
         if (rows_tab < rows) rows = rows_tab;
-        if ((long)rows * fa.ka.b.n_obs * 16 <= (long)table_kb * 1024) pt_rows = rows;
+        if (fa.ka.b.n_obs < (1 << 23) && (long)rows * fa.ka.b.n_obs * 16 <= (long)table_kb * 1024) pt_rows = rows;
     }
     const int bytes = refine_lds_bytes(fa.ka.b.NX, pt_rows * fa.ka.b.n_obs);
     FP_LDS_SLOTS(configured);
