@@ -4,11 +4,13 @@
 // its constraint / collision outcome and its cost_est are pure functions of its index, so the walk
 // can run over tables the lattice kernel already produced:  J = cost_final,  F = flag word,  E = cost_est.
 // The walk itself is sequential and data dependent; it is kept wave-uniform (every lane follows the same control
-// flow, scalar state lives in uniform registers) and only its two search primitives use the 64 lanes:
+// flow, scalar state lives in uniform registers) and only its search primitives use the 64 lanes:
 //     queue head    = argmin of J over "in queue" entries          (fiss_planner.py:207 / :229, heapq order)
-//     initial guess = argmin of E over not-yet-generated entries, LAST minimum  (fiss_planner.py:140-150)
 //     frontier pop  = argmin of J over frontier entries            (fiss_plus_planner.py:113)
-// each a strided scan over an LDS key array (+inf = absent) + a DPP wave minimum + ballot for the owner.
+//     initial guess = argmin of E over not-yet-generated entries, LAST minimum  (fiss_planner.py:140-150)
+// The first two are two-level minima (BlockMin: per-lane cached block minima over an LDS key array, +inf = absent), the last -
+// needed only when the queue runs dry - a strided scan + DPP wave minimum.  A walk through a blocked scene pops hundreds of
+// candidates one after the other, so the cost of one pop (argmin + removal) is what bounds the kernel.
 //
 // Restated: fiss_planner.py:33-99 (cost_est), :101-138 (generate_trajectory -> table lookup), :140-188, :190-270;
 //           fiss_plus_planner.py:30-59, :80-148.
@@ -21,13 +23,59 @@ namespace {
 
 constexpr uint8_t kGen = 1, kInQ = 2;
 
+// Two-level minimum over an LDS key array (+inf = absent).  The array is cut into blocks of 64 consecutive raster indices;
+// lane L keeps the minimum of block L and its raster index in registers.  Insert = one compare on the owning lane, removal of a
+// block's cached minimum = one parallel rescan of that block (one LDS read per lane + a DPP wave minimum), argmin = a DPP wave
+// minimum over the cached values - no scan of the whole array anywhere (C <= FP_MAX_CAND = 4096 -> at most 64 blocks).
+// Exact ties resolve to the LOWEST raster index (documented divergence from the reference's ValueError on tied heap entries).
+struct BlockMin {
+    double* key;
+    double bmin;  // lane L: minimum of key[64 L .. 64 L + 63]
+    int barg;     // its raster index, -1 when the block is empty
+
+    __device__ __forceinline__ void reset(double* k) { key = k; bmin = __builtin_inf(); barg = -1; }
+    // register side of an insert (the key itself is already in LDS); q, c wave-uniform
+    __device__ __forceinline__ void note(int q, double c, int lane)
+    {
+        if (lane == (q >> 6) && (c < bmin || (c == bmin && q < barg))) { bmin = c; barg = q; }
+    }
+    __device__ __forceinline__ void insert(int q, double c, int lane)
+    {
+        key[q] = c;
+        note(q, c, lane);
+    }
+    __device__ __forceinline__ void remove(int q, int lane, int C)
+    {
+        key[q] = __builtin_inf();
+        const int blk = q >> 6;
+        if (__builtin_amdgcn_readlane(barg, blk) != q) return;  // the block's minimum is untouched
+        const int at = blk * kWave + lane;
+        double v = at < C ? key[at] : __builtin_inf();
+        v = v < __builtin_inf() ? v : __builtin_inf();  // NaN keys are never popped
+        const double m = wave_min_f64(v);
+        const unsigned long long owners = __ballot(v == m && m < __builtin_inf());
+        if (lane == blk) {
+            bmin = m;
+            barg = owners ? blk * kWave + __ffsll((long long)owners) - 1 : -1;
+        }
+    }
+    __device__ __forceinline__ int argmin() const
+    {
+        const double m = wave_min_f64(bmin);
+        if (!(m < __builtin_inf())) return -1;
+        const unsigned long long owners = __ballot(bmin == m);
+        return __builtin_amdgcn_readlane(barg, __ffsll((long long)owners) - 1);
+    }
+};
+
 struct Walk {
     const double* J;
     const uint8_t* F;
     uint8_t* st;
-    double* keyQ;   // J where "in queue", +inf elsewhere      -> queue head = argmin
-    double* keyF;   // J where "on the frontier", +inf elsewhere
-    double* keyG;   // E where not yet generated, +inf elsewhere -> initial guess = LAST argmin
+    BlockMin Q;     // J where "in queue"        -> queue head = argmin   (fiss_planner.py:207 / :229, heapq order)
+    BlockMin Fr;    // J where "on the frontier" -> frontier pop = argmin (fiss_plus_planner.py:113)
+    double* keyG;   // E where not yet generated, +inf elsewhere -> initial guess = LAST argmin (needed only when the queue runs dry)
+    const uint16_t* ijk;  // raster index -> i | j << sh_j | k << sh_k (bit fields sized for nd, nv, nt: at most 15 bits in all)
     int nd, nv, nt, C, lane;
     int num_iter, num_generated, num_validated, num_checks;
 
@@ -40,49 +88,39 @@ struct Walk {
         const uint8_t s = st[q];
         if (s & kGen) return false;
         st[q] = s | kGen | kInQ;  // candidate_trajs.put((cost_final, idx))
-        keyQ[q] = cost;
+        Q.insert(q, cost, lane);
         keyG[q] = __builtin_inf();
         ++num_generated;
         return true;
     }
 
-    // argmin over a key array (+inf = absent).  The scan issues all of a lane's loads before comparing (independent LDS
-    // reads), the wave minimum uses DPP, the owner is found with a ballot.  Exact ties: lowest raster index
-    // (PREFER_HIGH = false; documented divergence from the reference's ValueError) or highest (find_initial_guess).
-    template <bool PREFER_HIGH>
-    __device__ __forceinline__ int argmin_key(const double* key) const
+    // find_initial_guess (fiss_planner.py:140-150): `cost_est <= min_cost` keeps the LAST minimum.  A strided scan of the whole
+    // array (independent LDS reads), DPP wave minimum, ballot for the owner; exact ties across lanes -> highest raster index.
+    __device__ __forceinline__ int initial_guess() const
     {
         double best = __builtin_inf();
         int bq = -1;
 #pragma unroll 4
         for (int q = lane; q < C; q += kWave) {
-            const double v = key[q];
-            if (PREFER_HIGH ? (v <= best && v < __builtin_inf()) : (v < best)) { best = v; bq = q; }
+            const double v = keyG[q];
+            if (v <= best && v < __builtin_inf()) { best = v; bq = q; }
         }
         const double m = wave_min_f64(best);
         if (!(m < __builtin_inf())) return -1;
-        const unsigned long long owners = __ballot(best == m && bq >= 0);
-        if (__popcll(owners) == 1) return __builtin_amdgcn_readlane(bq, __ffsll((long long)owners) - 1);
-        // exact tie across lanes: integer min / max of the candidates' raster indices
-        int cand = (best == m && bq >= 0) ? bq : (PREFER_HIGH ? -1 : 0x7fffffff);
+        int cand = (best == m && bq >= 0) ? bq : -1;
 #pragma unroll
         for (int off = kWave / 2; off > 0; off >>= 1) {
             const int o = __shfl_xor(cand, off, kWave);
-            cand = PREFER_HIGH ? (o > cand ? o : cand) : (o < cand ? o : cand);
+            cand = o > cand ? o : cand;
         }
         return cand;
     }
-
-    __device__ __forceinline__ int head_queue() const { return argmin_key<false>(keyQ); }
-    __device__ __forceinline__ int head_frontier() const { return argmin_key<false>(keyF); }
-    // find_initial_guess (fiss_planner.py:140-150): `cost_est <= min_cost` keeps the LAST minimum
-    __device__ __forceinline__ int initial_guess() const { return argmin_key<true>(keyG); }
 
     // validation of the queue head (fiss_planner.py:229-258): returns 1 = answer, 0 = rejected
     __device__ __forceinline__ int validate(int q)
     {
         st[q] &= (uint8_t)~kInQ;
-        keyQ[q] = __builtin_inf();
+        Q.remove(q, lane, C);
         ++num_validated;
         const uint8_t f = F[q];
         if (f & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) return 0;
@@ -117,7 +155,12 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
     double* keyQ = J + C;
     double* keyF = keyQ + C;
     double* keyG = keyF + C;
-    uint8_t* F = (uint8_t*)(keyG + C);
+    uint16_t* ijk = (uint16_t*)(keyG + C);
+    uint8_t* F = (uint8_t*)(ijk + C);
+    // bit fields of the packed index: ceil(log2 nd) + ceil(log2 nv) + ceil(log2 nt) <= log2(FP_MAX_CAND) + 3 = 15
+    const int sh_j = nd > 1 ? 32 - __clz(nd - 1) : 0;
+    const int sh_k = sh_j + (nv > 1 ? 32 - __clz(nv - 1) : 0);
+    const uint32_t mask_i = (1u << sh_j) - 1u, mask_j = (1u << (sh_k - sh_j)) - 1u;
     uint8_t* st = F + C;
 
     // ---- tables: FOP flat order (i_d, i_T, i_v) -> FISS raster (i_d, i_v, i_t); cost_est (fiss_planner.py:33-99)
@@ -135,6 +178,7 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         J[q] = fa.cost_tbl[flat];
         F[q] = (uint8_t)(fa.flag_tbl[flat] & 0xFFu);
         st[q] = 0;
+        ijk[q] = (uint16_t)((uint32_t)i | ((uint32_t)j << sh_j) | ((uint32_t)k << sh_k));
         const double d = bt.d_samples[i], v = vs[j], t = bt.t_samples[k];
         const double ev = smax[1] - v;
         const double est_lat = (d * d) / lat_norm;
@@ -177,20 +221,23 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         }
     }
 
-    Walk w{J, F, st, keyQ, keyF, keyG, nd, nv, nt, C, lane, 0, 0, 0, 0};
+    Walk w{J, F, st, {}, {}, keyG, ijk, nd, nv, nt, C, lane, 0, 0, 0, 0};
+    w.Q.reset(keyQ);
+    w.Fr.reset(keyF);
     const int sizes[3] = {nd, nv, nt};
     int best = -1;
     const bool plus = fa.opts.kind == FP_FISS_PLUS;
     for (;;) {
         ++w.num_iter;
-        int q = w.head_queue();
+        int q = w.Q.argmin();
         const int generated_before = w.num_generated;
         const int head_before = q;
         if (q < 0) {
             q = w.initial_guess();
             if (q < 0) break;  // every sample searched, nothing feasible (:203-206)
         }
-        int idx[3] = {q / (nt * nv), (q / nt) % nv, q % nt};
+        const uint32_t packed = ijk[q];
+        int idx[3] = {(int)(packed & mask_i), (int)((packed >> sh_j) & mask_j), (int)(packed >> sh_k)};
         double cost_center, cost;
         if (!plus) {
             // explore_next_sample (:174-188) until it lands on a generated sample
@@ -224,16 +271,18 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
             // its up-to-six axis neighbours are distinct cells, so lanes 0..5 generate them in parallel (one LDS round trip
             // instead of six dependent ones); the bookkeeping counts are order-independent.
             int frontier_size = 0;  // wave-uniform number of frontier entries
+            int cq = q;             // raster index of the centre
             for (;;) {
-                w.generate(w.raster(idx[0], idx[1], idx[2]), cost_center);
+                w.generate(cq, cost_center);
                 bool is_new = false, to_frontier = false;
+                int nq = 0;
+                double c = 0.0;
                 if (lane < 6) {
                     const int dim = lane >> 1, step = (lane & 1) ? +1 : -1;
-                    int nb[3] = {idx[0], idx[1], idx[2]};
-                    nb[dim] += step;
-                    if (nb[dim] >= 0 && nb[dim] <= sizes[dim] - 1) {
-                        const int nq = w.raster(nb[0], nb[1], nb[2]);
-                        const double c = J[nq];
+                    const int at = idx[dim] + step;
+                    if (at >= 0 && at <= sizes[dim] - 1) {
+                        nq = cq + step * (dim == 0 ? nv * nt : (dim == 1 ? nt : 1));
+                        c = J[nq];
                         const uint8_t s = st[nq];
                         if (!(s & kGen)) {
                             is_new = true;
@@ -244,17 +293,28 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
                         }
                     }
                 }
-                w.num_generated += __popcll(__ballot(is_new));
-                frontier_size += __popcll(__ballot(to_frontier));
+                unsigned long long fresh = __ballot(is_new);
+                const unsigned long long front = __ballot(to_frontier);
+                w.num_generated += __popcll(fresh);
+                frontier_size += __popcll(front);
+                while (fresh) {  // register side of the (at most six) inserts
+                    const int l = __ffsll((long long)fresh) - 1;
+                    fresh &= fresh - 1;
+                    const int uq = __builtin_amdgcn_readlane(nq, l);
+                    const double uc = lane_value(c, l);
+                    w.Q.note(uq, uc, lane);
+                    if ((front >> l) & 1ull) w.Fr.note(uq, uc, lane);
+                }
                 if (frontier_size == 0) break;
-                const int nq = w.head_frontier();
-                keyF[nq] = __builtin_inf();
+                cq = w.Fr.argmin();
+                w.Fr.remove(cq, lane, C);
                 --frontier_size;
-                idx[0] = nq / (nt * nv); idx[1] = (nq / nt) % nv; idx[2] = nq % nt;
+                const uint32_t pk = ijk[cq];
+                idx[0] = (int)(pk & mask_i); idx[1] = (int)((pk >> sh_j) & mask_j); idx[2] = (int)(pk >> sh_k);
             }
         }
         // the queue head only changes when the exploration generated something
-        q = (head_before >= 0 && w.num_generated == generated_before) ? head_before : w.head_queue();
+        q = (head_before >= 0 && w.num_generated == generated_before) ? head_before : w.Q.argmin();
         if (q < 0) break;
         if (w.validate(q)) { best = q; break; }
     }
@@ -262,7 +322,8 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         int32_t* out = fa.io.best_ijk + (size_t)b * 3;
         int32_t* pv = fa.io.prev_best_idx + (size_t)b * 3;
         if (best >= 0) {
-            const int i = best / (nt * nv), j = (best / nt) % nv, k = best % nt;
+            const uint32_t pk = ijk[best];
+            const int i = (int)(pk & mask_i), j = (int)((pk >> sh_j) & mask_j), k = (int)(pk >> sh_k);
             out[0] = i; out[1] = j; out[2] = k;
             pv[0] = i; pv[1] = j; pv[2] = k;  // prev_best_idx persists across cycles (:252 / :140)
             fa.io.best_cost[b] = J[best];
@@ -741,7 +802,7 @@ hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
 {
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
-    const int bytes = C * (4 * 8 + 1 + 1) + 16;
+    const int bytes = C * (4 * 8 + 2 + 1 + 1) + 16;
     FP_LDS_SLOTS(configured);
     hipError_t e = ensure_dynamic_lds((const void*)fiss_search_kernel, bytes, configured);
     if (e != hipSuccess) return e;
