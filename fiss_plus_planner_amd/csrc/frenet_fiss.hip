@@ -32,8 +32,9 @@ struct BlockMin {
     double* key;
     double bmin;  // lane L: minimum of key[64 L .. 64 L + 63]
     int barg;     // its raster index, -1 when the block is empty
+    bool few;     // C <= 1024
 
-    __device__ __forceinline__ void reset(double* k) { key = k; bmin = __builtin_inf(); barg = -1; }
+    __device__ __forceinline__ void reset(double* k, int C) { key = k; bmin = __builtin_inf(); barg = -1; few = C <= 16 * kWave; }
     // register side of an insert (the key itself is already in LDS); q, c wave-uniform
     __device__ __forceinline__ void note(int q, double c, int lane)
     {
@@ -61,7 +62,8 @@ struct BlockMin {
     }
     __device__ __forceinline__ int argmin() const
     {
-        const double m = wave_min_f64(bmin);
+        // at most 16 blocks (C <= 1024): the cached minima sit in the first DPP row
+        const double m = few ? lane_value(row16_min(bmin), 0) : wave_min_f64(bmin);
         if (!(m < __builtin_inf())) return -1;
         const unsigned long long owners = __ballot(bmin == m);
         return __builtin_amdgcn_readlane(barg, __ffsll((long long)owners) - 1);
@@ -78,6 +80,15 @@ struct Walk {
     const uint16_t* ijk;  // raster index -> i | j << sh_j | k << sh_k (bit fields sized for nd, nv, nt: at most 15 bits in all)
     int nd, nv, nt, C, lane;
     int num_iter, num_generated, num_validated, num_checks;
+    // the queue head (lexicographic minimum of (J, raster index) over the queue), kept incrementally: inserts compare against
+    // it, the only removal is the pop of the head itself (pop_head recomputes it).  Wave-uniform.
+    int head;
+    double head_c;
+
+    __device__ __forceinline__ void offer_head(int q, double c)
+    {
+        if (c < head_c || (c == head_c && q < head)) { head_c = c; head = q; }
+    }
 
     __device__ __forceinline__ int raster(int i, int j, int k) const { return (i * nv + j) * nt + k; }
 
@@ -89,6 +100,7 @@ struct Walk {
         if (s & kGen) return false;
         st[q] = s | kGen | kInQ;  // candidate_trajs.put((cost_final, idx))
         Q.insert(q, cost, lane);
+        offer_head(q, cost);
         keyG[q] = __builtin_inf();
         ++num_generated;
         return true;
@@ -113,16 +125,34 @@ struct Walk {
             const int o = __shfl_xor(cand, off, kWave);
             cand = o > cand ? o : cand;
         }
-        return cand;
+        return __builtin_amdgcn_readfirstlane(cand);
     }
 
-    // validation of the queue head (fiss_planner.py:229-258): returns 1 = answer, 0 = rejected
-    __device__ __forceinline__ int validate(int q)
+    // validation of the queue head (fiss_planner.py:229-258): pops it, returns 1 = answer, 0 = rejected, and leaves the NEXT head
+    // in (head, head_c).  The popped cell is its block's cached minimum, so that block is rescanned (one LDS read per lane + a
+    // wave minimum); the minimum over the other blocks' cached values does not depend on that read and overlaps its latency.
+    __device__ __forceinline__ int pop_head()
     {
+        const int q = head;
         st[q] &= (uint8_t)~kInQ;
-        Q.remove(q, lane, C);
-        ++num_validated;
+        Q.key[q] = __builtin_inf();
+        const int blk = q >> 6;
+        const int at = blk * kWave + lane;
+        double v = at < C ? Q.key[at] : __builtin_inf();
         const uint8_t f = F[q];
+        const double o = lane == blk ? __builtin_inf() : Q.bmin;
+        const double mo = Q.few ? lane_value(row16_min(o), 0) : wave_min_f64(o);
+        int ao = -1;
+        if (mo < __builtin_inf()) ao = __builtin_amdgcn_readlane(Q.barg, __ffsll((long long)__ballot(o == mo)) - 1);
+        v = v < __builtin_inf() ? v : __builtin_inf();  // NaN keys are never popped
+        const double mb = wave_min_f64(v);
+        const unsigned long long owners = __ballot(v == mb && mb < __builtin_inf());
+        const int ab = owners ? blk * kWave + __ffsll((long long)owners) - 1 : -1;
+        if (lane == blk) { Q.bmin = mb; Q.barg = ab; }
+        const bool take_b = ab >= 0 && (ao < 0 || mb < mo || (mb == mo && ab < ao));
+        head = take_b ? ab : ao;
+        head_c = take_b ? mb : mo;  // +inf when the queue is empty (head = -1)
+        ++num_validated;
         if (f & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) return 0;
         ++num_checks;
         return (f & FP_FLAG_COLLISION) ? 0 : 1;
@@ -221,25 +251,28 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         }
     }
 
-    Walk w{J, F, st, {}, {}, keyG, ijk, nd, nv, nt, C, lane, 0, 0, 0, 0};
-    w.Q.reset(keyQ);
-    w.Fr.reset(keyF);
+    Walk w{J, F, st, {}, {}, keyG, ijk, nd, nv, nt, C, lane, 0, 0, 0, 0, -1, __builtin_inf()};
+    w.Q.reset(keyQ, C);
+    w.Fr.reset(keyF, C);
     const int sizes[3] = {nd, nv, nt};
     int best = -1;
     const bool plus = fa.opts.kind == FP_FISS_PLUS;
+    // lane l < 6 owns the neighbour along axis l / 2 in direction +-1 (FISS+ exploration)
+    const int my_dim = lane >> 1, my_step = (lane & 1) ? +1 : -1;
+    const int my_stride = my_step * (my_dim == 0 ? nv * nt : (my_dim == 1 ? nt : 1));
+    const int my_size = my_dim == 0 ? nd : (my_dim == 1 ? nv : nt);
     for (;;) {
         ++w.num_iter;
-        int q = w.Q.argmin();
-        const int generated_before = w.num_generated;
-        const int head_before = q;
+        int q = w.head;
         if (q < 0) {
             q = w.initial_guess();
             if (q < 0) break;  // every sample searched, nothing feasible (:203-206)
         }
-        const uint32_t packed = ijk[q];
-        int idx[3] = {(int)(packed & mask_i), (int)((packed >> sh_j) & mask_j), (int)(packed >> sh_k)};
-        double cost_center, cost;
+        q = __builtin_amdgcn_readfirstlane(q);  // wave-uniform: scalar addressing and branches from here on
         if (!plus) {
+            const uint32_t packed = __builtin_amdgcn_readfirstlane((int)ijk[q]);
+            int idx[3] = {(int)(packed & mask_i), (int)((packed >> sh_j) & mask_j), (int)(packed >> sh_k)};
+            double cost_center, cost;
             // explore_next_sample (:174-188) until it lands on a generated sample
             while (!(st[w.raster(idx[0], idx[1], idx[2])] & kGen)) {
                 w.generate(w.raster(idx[0], idx[1], idx[2]), cost_center);  // find_gradients (:152-172)
@@ -267,31 +300,35 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
                 }
             }
         } else {
-            // explore_neighbors + frontier (fiss_plus_planner.py:30-59, :106-116).  The centre is generated first (wave-uniform);
-            // its up-to-six axis neighbours are distinct cells, so lanes 0..5 generate them in parallel (one LDS round trip
-            // instead of six dependent ones); the bookkeeping counts are order-independent.
+            // explore_neighbors + frontier (fiss_plus_planner.py:30-59, :106-116).  One LDS round trip per centre: its packed
+            // index, state and cost together with the state and cost of the six axis neighbours (distinct cells, lanes 0..5,
+            // addresses clamped - the range check needs the unpacked index and is applied afterwards).  The centre is generated
+            // first (wave-uniform); the bookkeeping counts are order-independent.
             int frontier_size = 0;  // wave-uniform number of frontier entries
             int cq = q;             // raster index of the centre
             for (;;) {
-                w.generate(cq, cost_center);
-                bool is_new = false, to_frontier = false;
-                int nq = 0;
-                double c = 0.0;
-                if (lane < 6) {
-                    const int dim = lane >> 1, step = (lane & 1) ? +1 : -1;
-                    const int at = idx[dim] + step;
-                    if (at >= 0 && at <= sizes[dim] - 1) {
-                        nq = cq + step * (dim == 0 ? nv * nt : (dim == 1 ? nt : 1));
-                        c = J[nq];
-                        const uint8_t s = st[nq];
-                        if (!(s & kGen)) {
-                            is_new = true;
-                            st[nq] = s | kGen | kInQ;
-                            keyQ[nq] = c;
-                            keyG[nq] = __builtin_inf();
-                            if (c <= cost_center) { keyF[nq] = c; to_frontier = true; }  // frontier_idxs.put((cost, idx))
-                        }
-                    }
+                int nq = cq + my_stride;
+                nq = nq < 0 ? 0 : (nq > C - 1 ? C - 1 : nq);
+                const uint32_t pk = ijk[cq];
+                const uint8_t cs = st[cq];
+                const double cost_center = J[cq];
+                const uint8_t s = st[nq];
+                const double c = J[nq];
+                if (!(cs & kGen)) {  // generate_trajectory of the centre
+                    st[cq] = cs | kGen | kInQ;
+                    w.Q.insert(cq, cost_center, lane);
+                    w.offer_head(cq, cost_center);
+                    keyG[cq] = __builtin_inf();
+                    ++w.num_generated;
+                }
+                const int at = (int)(my_dim == 0 ? (pk & mask_i) : (my_dim == 1 ? ((pk >> sh_j) & mask_j) : (pk >> sh_k))) + my_step;
+                const bool is_new = lane < 6 && at >= 0 && at < my_size && !(s & kGen);
+                const bool to_frontier = is_new && c <= cost_center;  // frontier_idxs.put((cost, idx))
+                if (is_new) {
+                    st[nq] = s | kGen | kInQ;
+                    keyQ[nq] = c;
+                    keyG[nq] = __builtin_inf();
+                    if (to_frontier) keyF[nq] = c;
                 }
                 unsigned long long fresh = __ballot(is_new);
                 const unsigned long long front = __ballot(to_frontier);
@@ -303,20 +340,18 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
                     const int uq = __builtin_amdgcn_readlane(nq, l);
                     const double uc = lane_value(c, l);
                     w.Q.note(uq, uc, lane);
+                    w.offer_head(uq, uc);
                     if ((front >> l) & 1ull) w.Fr.note(uq, uc, lane);
                 }
                 if (frontier_size == 0) break;
                 cq = w.Fr.argmin();
                 w.Fr.remove(cq, lane, C);
                 --frontier_size;
-                const uint32_t pk = ijk[cq];
-                idx[0] = (int)(pk & mask_i); idx[1] = (int)((pk >> sh_j) & mask_j); idx[2] = (int)(pk >> sh_k);
             }
         }
-        // the queue head only changes when the exploration generated something
-        q = (head_before >= 0 && w.num_generated == generated_before) ? head_before : w.Q.argmin();
-        if (q < 0) break;
-        if (w.validate(q)) { best = q; break; }
+        if (w.head < 0) break;
+        const int popped = w.head;
+        if (w.pop_head()) { best = popped; break; }
     }
     if (lane == 0) {
         int32_t* out = fa.io.best_ijk + (size_t)b * 3;
