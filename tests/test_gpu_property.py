@@ -86,3 +86,44 @@ def test_random_settings_vs_oracle(oracle, engine, seed):
             assert np.array_equal(np.isnan(a), np.isnan(w))
             m = ~np.isnan(w)
             np.testing.assert_allclose(a[:11][m[:11]], w[:11][m[:11]], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("kind", ["FISS", "FISS+"])
+@pytest.mark.parametrize("seed", range(30))
+def test_random_settings_search_vs_oracle(oracle, engine, seed, kind):
+    """The device-side search walk + refinement on the same randomised settings (lattice axes of at least two samples):
+    Stats, selected index / refined end state and history index exactly as the oracle's restatement of the planners."""
+    rng = np.random.default_rng(5000 + seed)
+    b = None
+    for attempt in range(50):  # draw until every lattice axis has >= 2 samples
+        b = random_batch(int(rng.integers(1, 10**6)))
+        if min(b.nd, b.nv, b.nt) >= 2:
+            break
+    assert min(b.nd, b.nv, b.nt) >= 2
+    b.samp_min = np.column_stack([np.full(b.B, b.d_samples[0]), b.v_samples[:, 0], np.full(b.B, b.t_samples[0])])
+    b.samp_max = np.column_stack([np.full(b.B, b.d_samples[-1]), b.v_samples[:, -1], np.full(b.B, b.t_samples[-1])])
+    b.samp_res = np.column_stack([np.full(b.B, b.d_samples[1] - b.d_samples[0]), b.v_samples[:, 1] - b.v_samples[:, 0],
+                                  np.full(b.B, b.t_samples[1] - b.t_samples[0])])
+    prev = np.where(rng.uniform(size=(b.B, 1)) < 0.5, -1, np.column_stack([rng.integers(0, b.nd, b.B), rng.integers(0, b.nv, b.B),
+                                                                          rng.integers(0, b.nt, b.B)])).astype(np.int32)
+    for table_kb in ((24, 0) if kind == "FISS+" else (24,)):
+        engine.set_option("refine_table_kb", table_kb)
+        try:
+            out = engine.plan_fiss(b, kind, prev_best_idx=prev, trace=True)
+        finally:
+            engine.set_option("refine_table_kb", 24)
+        for e, p in enumerate(oracle.problems_from_batch(b)):
+            pv = None if prev[e, 0] < 0 else prev[e]
+            r = p.fiss_plan(pv) if kind == "FISS" else p.fissplus_plan(pv)
+            np.testing.assert_array_equal(out.stats[e], r.stats, err_msg=f"seed {seed} ego {e}")
+            found = not np.isnan(r.best_cost)
+            assert (not np.isnan(out.best_cost[e])) == found
+            np.testing.assert_array_equal(out.prev_best_idx[e], r.prev_best_idx)
+            if not found:
+                continue
+            assert abs(out.best_cost[e] - r.best_cost) < 1e-6
+            if kind == "FISS":
+                np.testing.assert_array_equal(out.best_ijk[e], r.best_ijk)
+            else:
+                assert bool(out.refined[e]) == r.refined
+                np.testing.assert_allclose(out.end_state[e], r.end_state, rtol=0, atol=1e-9)
