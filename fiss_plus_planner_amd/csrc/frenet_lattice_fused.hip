@@ -60,7 +60,7 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, coll, queue, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, coll, queue, best, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -81,13 +81,16 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.wfat = o;     o = align16(o + 4 * nv * hp);  // float, rounded up
     L.grp = o;      o = align16(o + 32 * (rows > 0 ? rows : 1));       // per checked pose row: circle enclosing all lon profiles' points
     L.iqueue = o;   o = align16(o + 2 * kItemCap * kWaves);                  // per-wave queue of (row, obstacle) items that pass the group test
-    L.pows = o;     o = align16(o + 8 * 11 * nt);    // power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per time-horizon slice
     L.samples = o;  o = align16(o + 8 * (nt + nv + nd));  // t / v / d sample grids (read all over the kernel: keep them out of HBM latency)
     L.lon_sum = o;  o = align16(o + 24 * nt * nv);   // sum_v, sum_as, sum_js
     L.lat_sum = o;  o = align16(o + 24 * nd * nt);   // sum_ad, sum_jd, sum_d
     L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
+    L.qlon = o;     o = align16(o + 16 * nt * nv);   // a3, a4 of every lon profile (a0..a2 are the ego state)
+    L.qlat = o;     o = align16(o + 24 * nd);        // a3, a4, a5 of the CURRENT slice's lat profiles
     L.coll = o;     o = align16(o + nd * nv * nt);
-    L.queue = o;    o = align16(o + 4 * kQueueCap * kWaves);
+    // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
+    L.queue = o;    L.pows = o;
+    o = align16(o + (4 * kQueueCap * kWaves > 88 * nt ? 4 * kQueueCap * kWaves : 88 * nt));
     L.best = o;     o = align16(o + 16 * kWaves);
     L.total = o;
     return L;
@@ -148,6 +151,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     double* s_lon_sum = (double*)(smem + L.lon_sum);
     double* s_lat_sum = (double*)(smem + L.lat_sum);
     int2* s_lon_meta = (int2*)(smem + L.lon_meta);
+    double* s_qlon = (double*)(smem + L.qlon);  // [nt][nv][2]
+    double* s_qlat = (double*)(smem + L.qlat);  // [nd][3]
     unsigned char* s_coll = smem + L.coll;
     uint32_t* s_queue = (uint32_t*)(smem + L.queue) + wave * kQueueCap;
     Best* s_best = (Best*)(smem + L.best);
@@ -242,45 +247,29 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     int qlen = 0;  // wave-uniform length of this wave's hit queue
 
     // ---------------------------------------------------------------- phase A0 (once): masks / M / cost sums of every profile
-    // (1) wave tasks: per lon profile, one lane per time point (N <= 128 = 2 points per lane): speed / acceleration masks and
-    //     the truncation index M (first point off the spline, a pure range test) by ballot; per slice, the power sums
-    //     S_k = sum_{i<N} t_i^k (k = 0..10) by DPP tree sums.
+    // (0) lane per lon profile: the boundary-value solve (two divisions), kept for the whole kernel; meta = {N, no flags}.
+    // (1) lane per (lon profile, time point): speed / acceleration masks by LDS atomic OR, the truncation index M (first point
+    //     off the spline, a pure range test) by LDS atomic MIN - the same brute force over every point as the reference, with
+    //     every lane busy (a wavefront per profile would idle a third of its lanes and all of its second half);
+    //     wave tasks: per slice, the power sums S_k = sum_{i<N} t_i^k (k = 0..10) by DPP tree sums.
     // (2) lane per profile: the six cost sums in closed form.  Each summand is the square of a polynomial in t
     //     (s_d - v_target: cubic, s_dd: quadratic, s_ddd: linear, d: quintic, d_dd: cubic, d_ddd: quadratic), so
     //     sum_i p(t_i)^2 = sum_k c_k S_k with c = p (*) p (coefficient convolution) - no per-point work and no reductions.
     //     Conditioning is benign on t in [0, 10] (terms ~1e2..1e4 against sums ~1e1..1e3: ~1e-12 absolute), far inside the
     //     1e-6 cost bar, and the expressions are even in the lateral boundary data, so mirrored candidates still tie bit-exactly.
-    for (int task = wave; task < n_it * (nv + 1); task += kWaves) {
-        const int it = it_lo + task / (nv + 1), iv = task % (nv + 1);
+    for (int e = tid; e < n_it * nv; e += kThreads) {
+        const int it = it_lo + e / nv, iv = e % nv;
         const double T = s_ts[it];
-        const int N = arange_len(T, tick);
-        if (iv < nv) {
-            const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
-            unsigned long long off_lo = 0, off_hi = 0;
-            bool bad_speed = false, bad_accel = false;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int i = lane + half * kWave;
-                bool off = false;
-                if (i < N) {
-                    const double t = (double)i * tick;
-                    const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
-                    const double s_d = fma(fma(fma(4.0 * q.a4, t, 3.0 * q.a3), t, 2.0 * q.a2), t, q.a1);
-                    const double s_dd = fma(fma(12.0 * q.a4, t, 6.0 * q.a3), t, 2.0 * q.a2);
-                    bad_speed |= s_d > p.max_speed;
-                    bad_accel |= fabs(s_dd) > p.max_accel;
-                    off = !(s >= knot0) || !(s < knot_last);  // calc_position -> None (cubic_spline.py:56-59)
-                }
-                const unsigned long long m = __ballot(off);
-                if (half == 0) off_lo = m; else off_hi = m;
-            }
-            const bool any_speed = __ballot(bad_speed) != 0ull;
-            const bool any_accel = __ballot(bad_accel) != 0ull;
-            if (lane == 0) {
-                const int M = off_lo ? __ffsll((long long)off_lo) - 1 : (off_hi ? kWave + __ffsll((long long)off_hi) - 1 : N);
-                s_lon_meta[it * nv + iv] = make_int2(M, (any_speed ? FP_FLAG_SPEED : 0) | (any_accel ? FP_FLAG_ACCEL : 0));
-            }
-        } else {
+        const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
+        s_qlon[2 * (it * nv + iv)] = q.a3;
+        s_qlon[2 * (it * nv + iv) + 1] = q.a4;
+        s_lon_meta[it * nv + iv] = make_int2(arange_len(T, tick), 0);
+    }
+    __syncthreads();
+    if (wave < n_it) {  // power sums: one wavefront per slice (n_it <= 8 workgroup waves in practice; loop otherwise)
+        for (int task = wave; task < n_it; task += kWaves) {
+            const int it = it_lo + task;
+            const int N = arange_len(s_ts[it], tick);
             double pw[11];
 #pragma unroll
             for (int kk = 0; kk < 11; ++kk) pw[kk] = 0.0;
@@ -301,13 +290,31 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             }
         }
     }
+    for (int it = it_lo; it < it_hi; ++it) {
+        const int N = arange_len(s_ts[it], tick);
+        const float inv_n = 1.0f / (float)N;
+        for (int e = tid; e < nv * N; e += kThreads) {
+            int iv = (int)(((float)e + 0.5f) * inv_n);  // e / N for e < 2^15 (N <= 128)
+            int i = e - iv * N;
+            if (i < 0) { --iv; i += N; } else if (i >= N) { ++iv; i -= N; }
+            const double a3 = s_qlon[2 * (it * nv + iv)], a4 = s_qlon[2 * (it * nv + iv) + 1];
+            const double a2 = s_dd0 * 0.5;
+            const double t = (double)i * tick;
+            const double s = fma(fma(fma(fma(a4, t, a3), t, a2), t, s_d0), t, s0);
+            const double s_d = fma(fma(fma(4.0 * a4, t, 3.0 * a3), t, 2.0 * a2), t, s_d0);
+            const double s_dd = fma(fma(12.0 * a4, t, 6.0 * a3), t, 2.0 * a2);
+            const uint32_t bad = (s_d > p.max_speed ? FP_FLAG_SPEED : 0u) | (fabs(s_dd) > p.max_accel ? FP_FLAG_ACCEL : 0u);
+            if (bad) atomicOr((unsigned int*)&s_lon_meta[it * nv + iv].y, bad);
+            if (!(s >= knot0) || !(s < knot_last)) atomicMin(&s_lon_meta[it * nv + iv].x, i);  // calc_position -> None (cubic_spline.py:56-59)
+        }
+    }
     __syncthreads();
     for (int e = tid; e < n_it * (nv + nd); e += kThreads) {
         const int it = it_lo + e / (nv + nd), sub = e % (nv + nd);
         const double T = s_ts[it];
         const double* S = s_pows + it * 11;
         if (sub < nv) {
-            const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[sub], 0.0, T);
+            const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (it * nv + sub)], s_qlon[2 * (it * nv + sub) + 1]};
             double lon[3];
             lon_cost_sums(q, target_speed, S, lon);
             double* o = s_lon_sum + 3 * (it * nv + sub);
@@ -321,6 +328,16 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             o[0] = lat[0]; o[1] = lat[1]; o[2] = lat[2];
         }
     }
+    // lat polynomial coefficients of one slice (a boundary-value solve costs two divisions): nd threads per slice instead of once
+    // per trajectory point
+    auto fill_slice_lat = [&](int it) {
+        const int id = kThreads - 1 - tid;  // the last threads: they have the least prep work
+        if (id < nd && it < it_hi) {
+            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, s_ts[it]);
+            s_qlat[3 * id] = q.a3; s_qlat[3 * id + 1] = q.a4; s_qlat[3 * id + 2] = q.a5;
+        }
+    };
+    fill_slice_lat(it_lo);
     __syncthreads();  // the final assembly reads the sums (with no obstacles there is no other barrier in between)
 
     for (int it = it_lo; n_obs > 0 && hp > 0 && it < it_hi; ++it) {
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         for (int e = tid; e < nv * np; e += kThreads) {
             const int iv = e / np, i = e - iv * np;
             if (i < s_lon_meta[it * nv + iv].x) {  // i < M: the point is on the spline
-                const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
+                const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (it * nv + iv)], s_qlon[2 * (it * nv + iv) + 1]};
                 const double t = (double)i * tick;
                 const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
                 const int seg = lut_segment(s_knots, s_lut, nx, s, knot0, inv_bucket_w, n_buckets);
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
         for (int e = tid; e < nd * np; e += kThreads) {
             const int id = e / np, i = e - id * np;
-            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, T);
+            const Quintic q{d0, d_d0, d_dd0 * 0.5, s_qlat[3 * id], s_qlat[3 * id + 1], s_qlat[3 * id + 2]};
             const double t = (double)i * tick;
             const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
             s_lat[id * hp_max + i] = d;
@@ -374,6 +391,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 float* z_dmax = s_dmax2 + ((it + 1) & 1) * hp_max;   // zero the other parity for the next slice
                 float* z_ddmax = s_ddmax2 + ((it + 1) & 1) * hp_max;
                 for (int i = tid; i < hp_max; i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
+                fill_slice_lat(it + 1);  // phase A of this slice is done with the table (barrier above)
                 const int sub = tid & 15;
                 for (int r = tid >> 4; r < rows; r += kThreads >> 4) {
                     const int k = r * stride;
