@@ -34,6 +34,10 @@ namespace fp {
 
 namespace {
 
+// fp64 -> fp32 that never rounds below the argument (x >= 0): to nearest, then one part in 2^22 up.  Replaces the software
+// emulation of the directed-rounding conversion (~15 instructions) where only a conservative bound is needed.
+__device__ __forceinline__ float float_above(double x) { return (float)x * 1.00000024f; }
+
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
 constexpr int kQueueCap = 128;   // per-wave hit queue: < 64 pending + one full push of 64
@@ -367,12 +371,12 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
             s_lat[id * hp_max + i] = d;
             // fan half-width max|d| and largest lateral step max|d(i+1) - d(i)| over the lateral samples: LDS atomic max on
-            // the bit patterns (non-negative floats order like unsigned integers); rounded UP to float
-            atomicMax((unsigned int*)&s_dmax[i], __float_as_uint(__double2float_ru(fabs(d))));
+            // the bit patterns (non-negative floats order like unsigned integers); float_above: never below the fp64 value
+            atomicMax((unsigned int*)&s_dmax[i], __float_as_uint(float_above(fabs(d))));
             if (i + 1 < np) {
                 const double tn = (double)(i + 1) * tick;
                 const double dn = fma(fma(fma(fma(fma(q.a5, tn, q.a4), tn, q.a3), tn, q.a2), tn, q.a1), tn, q.a0);
-                atomicMax((unsigned int*)&s_ddmax[i], __float_as_uint(__double2float_ru(fabs(dn - d))));
+                atomicMax((unsigned int*)&s_ddmax[i], __float_as_uint(float_above(fabs(dn - d))));
             }
         }
         __syncthreads();
@@ -392,19 +396,27 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 float* z_ddmax = s_ddmax2 + ((it + 1) & 1) * hp_max;
                 for (int i = tid; i < hp_max; i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
                 fill_slice_lat(it + 1);  // phase A of this slice is done with the table (barrier above)
+                // Both products are conservative bounds, so they are computed in fp32 with outward rounding (coordinates relative
+                // to the first knot keep fp32 at ~1e-4 m over kilometres of road): the box is four single-instruction DPP
+                // reductions per step, the ratio a reciprocal instead of an fp64 division, the radius one v_sqrt_f32.
                 const int sub = tid & 15;
+                const double org_x = s_coef[0], org_y = s_coef[4 * nx];
+                const float r_ego_f = float_above(r_ego), hl_f = float_above(veh_hl), hw_f = float_above(veh_hw);
                 for (int r = tid >> 4; r < rows; r += kThreads >> 4) {
                     const int k = r * stride;
-                    double minx = __builtin_inf(), maxx = -__builtin_inf(), miny = __builtin_inf(), maxy = -__builtin_inf();
+                    float minx = __builtin_inff(), maxx = -__builtin_inff(), miny = __builtin_inff(), maxy = -__builtin_inff();
                     const bool row_ok = k < N && k < hp;
+                    const float dmk = s_dmax[k];
                     for (int iv = sub; iv < nv; iv += 16) {
                         const int M = s_lon_meta[it * nv + iv].x;
-                        double wl = r_ego;
+                        float wl = r_ego_f;
                         const Frame f0 = s_frames[iv * hp_max + k];
                         if (row_ok && k < M && M >= 2) {
-                            minx = fmin(minx, f0.px); maxx = fmax(maxx, f0.px);
-                            miny = fmin(miny, f0.py); maxy = fmax(maxy, f0.py);
-                            if (!(f0.px == f0.px)) { minx = -__builtin_inf(); maxx = __builtin_inf(); }  // NaN pose: keep everything
+                            const double rx = f0.px - org_x, ry = f0.py - org_y;
+                            const float fx = (float)rx, fy = (float)ry;  // to nearest; the box is widened once, below
+                            minx = vmin_f32(minx, fx); maxx = vmax_f32(maxx, fx);
+                            miny = vmin_f32(miny, fy); maxy = vmax_f32(maxy, fy);
+                            if (!(rx == rx) || !(ry == ry)) { minx = -__builtin_inff(); maxx = __builtin_inff(); }  // NaN pose: keep everything
                         }
                         if (k + 1 < M && k + 1 < hp && k + 1 < N) {
                             const Frame f1 = s_frames[iv * hp_max + k + 1];
@@ -414,22 +426,24 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty);   // n_{k+1} . n_k
                             const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
                             const double dm1 = (double)s_dmax[k + 1];
-                            const double num = fabs(a_n) + (double)s_ddmax[k] + dm1 * fabs(1.0 - nn);
-                            const double den = fabs(a_t) - dm1 * fabs(nt_);
-                            if (den > 0.0) {
-                                const double sigma = fmin(1.0, num / den * (1.0 + 1e-9) + 1e-12);
-                                wl = fmin(r_ego, fma(veh_hl, sigma, veh_hw));
+                            const float num = (float)(fabs(a_n) + (double)s_ddmax[k] + dm1 * fabs(1.0 - nn));
+                            const float den = (float)(fabs(a_t) - dm1 * fabs(nt_));
+                            if (den > 1e-30f) {  // v_rcp_f32: 1 ulp; the factor covers it and the two roundings to nearest
+                                const float sigma = vmin_f32(1.0f, num * __builtin_amdgcn_rcpf(den) * (1.0f + 4e-6f) + 1e-9f);
+                                wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
                             }
                         }
-                        s_wfat[iv * hp_max + k] = row_ok ? __double2float_ru(((double)s_dmax[k] + wl) * (1.0 + 1e-12) + 1e-12) : 0.0f;
+                        s_wfat[iv * hp_max + k] = row_ok ? (dmk + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
                     }
-                    minx = row16_min(minx); maxx = row16_max(maxx); miny = row16_min(miny); maxy = row16_max(maxy);
+                    minx = row16_min_f32(minx); maxx = row16_max_f32(maxx); miny = row16_min_f32(miny); maxy = row16_max_f32(maxy);
                     if (sub == 0) {
-                        const double hx = 0.5 * (maxx - minx), hy = 0.5 * (maxy - miny);
+                        const float hx = 0.5f * (maxx - minx), hy = 0.5f * (maxy - miny);
                         // empty row (no valid pose): radius -1 rejects every obstacle; an infinite box keeps every obstacle
                         double rad = -1.0;
-                        if (maxx >= minx) rad = (sqrt(fma(hx, hx, hy * hy)) + r_ego + (double)s_dmax[k]) * (1.0 + 1e-9) + 1e-9;
-                        s_grp[r] = ObsDim{0.5 * (maxx + minx), 0.5 * (maxy + miny), rad, 0.0};
+                        // v_sqrt_f32: 1 ulp; the corners were rounded to nearest: half an ulp of each coordinate, covered by slack
+                        const float slack = (fabsf(maxx) + fabsf(minx) + fabsf(maxy) + fabsf(miny)) * 2.4e-7f + 1e-6f;
+                        if (maxx >= minx) rad = ((double)(__builtin_amdgcn_sqrtf(hx * hx + hy * hy) * (1.0f + 4e-6f) + slack) + r_ego + (double)dmk) * (1.0 + 1e-9) + 1e-9;
+                        s_grp[r] = ObsDim{org_x + 0.5 * ((double)maxx + (double)minx), org_y + 0.5 * ((double)maxy + (double)miny), rad, 0.0};
                     }
                 }
             }
