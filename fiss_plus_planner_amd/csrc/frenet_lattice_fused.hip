@@ -38,6 +38,15 @@ namespace {
 // emulation of the directed-rounding conversion (~15 instructions) where only a conservative bound is needed.
 __device__ __forceinline__ float float_above(double x) { return (float)x * 1.00000024f; }
 
+// monotone map fp32 -> uint32 (and back), so that LDS integer atomic min / max order floats of either sign
+__device__ __forceinline__ uint32_t f32_ordered(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_ordered(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+constexpr uint32_t kOrdPosInf = 0xFF800000u, kOrdNegInf = 0x007FFFFFu;  // f32_ordered(+inf), f32_ordered(-inf)
+
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
 constexpr int kQueueCap = 128;   // per-wave hit queue: < 64 pending + one full push of 64
@@ -64,7 +73,7 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, coll, queue, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, best, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -91,6 +100,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
     L.qlon = o;     o = align16(o + 16 * nt * nv);   // a3, a4 of every lon profile (a0..a2 are the ego state)
     L.qlat = o;     o = align16(o + 24 * nd);        // a3, a4, a5 of the CURRENT slice's lat profiles
+    L.box = o;      o = align16(o + 16 * (rows > 0 ? rows : 1));  // per checked pose row: bounding box of the slice's reference points (ordered-uint fp32)
     L.coll = o;     o = align16(o + nd * nv * nt);
     // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
     L.queue = o;    L.pows = o;
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     int2* s_lon_meta = (int2*)(smem + L.lon_meta);
     double* s_qlon = (double*)(smem + L.qlon);  // [nt][nv][2]
     double* s_qlat = (double*)(smem + L.qlat);  // [nd][3]
+    uint4* s_box = (uint4*)(smem + L.box);      // [rows] {min x, max x, min y, max y} relative to the first knot
     unsigned char* s_coll = smem + L.coll;
     uint32_t* s_queue = (uint32_t*)(smem + L.queue) + wave * kQueueCap;
     Best* s_best = (Best*)(smem + L.best);
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
             s_dim[j] = ObsDim{hl, hw, sqrt(fma(hl, hl, hw * hw)), 0.0};
         }
+    // [section STAGE]
         const double* gp = bt.obs_pose + (size_t)sc * bt.T_obs * n_obs * 4;
         for (int i = tid; i < rows * n_obs; i += kThreads) {
             const int r = i / n_obs, j = i - r * n_obs;
@@ -236,8 +248,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             }
             s_pose[i] = o;
         }
+    // [/section STAGE]
     }
     for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
+    for (int r = tid; r < rows; r += kThreads) s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);  // empty
     for (int i = tid; i < 2 * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
     // points whose frame the collision stage can touch: 0 .. hp-1 (pose k needs point k+1 for its heading)
     const int pose_limit = rows * stride < horizon_cap ? rows * stride : horizon_cap;  // poses k < pose_limit (and k < M)
@@ -248,6 +262,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     __syncthreads();
 
     const double* v_samples = s_vs;
+    const double org_x = s_coef[0], org_y = s_coef[4 * nx];  // first knot: origin of the fp32 bounding boxes
     int qlen = 0;  // wave-uniform length of this wave's hit queue
 
     // ---------------------------------------------------------------- phase A0 (once): masks / M / cost sums of every profile
@@ -270,6 +285,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         s_lon_meta[it * nv + iv] = make_int2(arange_len(T, tick), 0);
     }
     __syncthreads();
+    // [section POWS]
     if (wave < n_it) {  // power sums: one wavefront per slice (n_it <= 8 workgroup waves in practice; loop otherwise)
         for (int task = wave; task < n_it; task += kWaves) {
             const int it = it_lo + task;
@@ -294,6 +310,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             }
         }
     }
+    // [/section POWS]
+    // [section MASKS]
     for (int it = it_lo; it < it_hi; ++it) {
         const int N = arange_len(s_ts[it], tick);
         const float inv_n = 1.0f / (float)N;
@@ -312,6 +330,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             if (!(s >= knot0) || !(s < knot_last)) atomicMin(&s_lon_meta[it * nv + iv].x, i);  // calc_position -> None (cubic_spline.py:56-59)
         }
     }
+    // [/section MASKS]
     __syncthreads();
     for (int e = tid; e < n_it * (nv + nd); e += kThreads) {
         const int it = it_lo + e / (nv + nd), sub = e % (nv + nd);
@@ -352,9 +371,11 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         // ------------------------------------------------------------ phase A (per slice): one lane per (profile, point)
         // reference-line frames of the points the collision horizon can touch (i < hp), lateral offsets, fan bounds
         const int np = hp < N ? hp : N;
+    // [section FRAMES]
         for (int e = tid; e < nv * np; e += kThreads) {
             const int iv = e / np, i = e - iv * np;
-            if (i < s_lon_meta[it * nv + iv].x) {  // i < M: the point is on the spline
+            const int M = s_lon_meta[it * nv + iv].x;
+            if (i < M) {  // the point is on the spline
                 const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (it * nv + iv)], s_qlon[2 * (it * nv + iv) + 1]};
                 const double t = (double)i * tick;
                 const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
@@ -362,8 +383,24 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 Frame fr;
                 spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
                 s_frames[iv * hp_max + i] = fr;
+                // bounding box of the row's reference points over the lon profiles (fp32 to nearest, relative to the first knot;
+                // prep widens it): LDS atomic min / max on order-preserving bit patterns
+                const int r = i / stride;
+                if (r * stride == i && r < rows && M >= 2) {
+                    const double rx = fr.px - org_x, ry = fr.py - org_y;
+                    uint32_t* bx = (uint32_t*)&s_box[r];
+                    if (rx == rx && ry == ry) {
+                        const uint32_t ux = f32_ordered((float)rx), uy = f32_ordered((float)ry);
+                        atomicMin(bx + 0, ux); atomicMax(bx + 1, ux);
+                        atomicMin(bx + 2, uy); atomicMax(bx + 3, uy);
+                    } else {  // NaN pose: keep everything
+                        atomicMin(bx + 0, kOrdNegInf); atomicMax(bx + 1, kOrdPosInf);
+                    }
+                }
             }
         }
+    // [/section FRAMES]
+    // [section LAT]
         for (int e = tid; e < nd * np; e += kThreads) {
             const int id = e / np, i = e - id * np;
             const Quintic q{d0, d_d0, d_dd0 * 0.5, s_qlat[3 * id], s_qlat[3 * id + 1], s_qlat[3 * id + 2]};
@@ -379,6 +416,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 atomicMax((unsigned int*)&s_ddmax[i], __float_as_uint(float_above(fabs(dn - d))));
             }
         }
+    // [/section LAT]
         __syncthreads();
         if (n_obs > 0 && hp > 0) {
             // ---- prep (one stage): per checked pose (row r, lon profile iv)
@@ -390,59 +428,56 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             //      |h| >= |h.t_k| >= |dP.t_k| - max|d_{k+1}| |n_{k+1}.t_k|.   n_k then serves as a (conservative) separating axis.
             //  * grp = circle around the bounding box of the valid reference points of ALL lon profiles in the row: one test
             //      per (row, obstacle) item prunes the item for every profile at once.
-            // 16 lanes (one DPP row) per pose row, lane = lon profile; the box is a DPP row reduction.
+            //      The box itself was accumulated by phase A (LDS atomic min / max).
             {
                 float* z_dmax = s_dmax2 + ((it + 1) & 1) * hp_max;   // zero the other parity for the next slice
                 float* z_ddmax = s_ddmax2 + ((it + 1) & 1) * hp_max;
                 for (int i = tid; i < hp_max; i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
                 fill_slice_lat(it + 1);  // phase A of this slice is done with the table (barrier above)
-                // Both products are conservative bounds, so they are computed in fp32 with outward rounding (coordinates relative
-                // to the first knot keep fp32 at ~1e-4 m over kilometres of road): the box is four single-instruction DPP
-                // reductions per step, the ratio a reciprocal instead of an fp64 division, the radius one v_sqrt_f32.
-                const int sub = tid & 15;
-                const double org_x = s_coef[0], org_y = s_coef[4 * nx];
+                // Both products are conservative bounds, so they are computed in fp32 (coordinates relative to the first knot keep
+                // fp32 at ~1e-4 m over kilometres of road): the ratio is a reciprocal instead of an fp64 division, the radius one
+                // v_sqrt_f32.  One lane per (row, lon profile) pair for wfat; the last `rows` threads turn the boxes phase A
+                // accumulated into circles and empty them for the next slice.
                 const float r_ego_f = float_above(r_ego), hl_f = float_above(veh_hl), hw_f = float_above(veh_hw);
-                for (int r = tid >> 4; r < rows; r += kThreads >> 4) {
+                const float inv_nv = 1.0f / (float)nv;
+    // [section PREP]
+                for (int e = tid; e < rows * nv; e += kThreads) {
+                    const int r = (int)(((float)e + 0.5f) * inv_nv), iv = e - r * nv;  // e / nv for e < 2^15
                     const int k = r * stride;
-                    float minx = __builtin_inff(), maxx = -__builtin_inff(), miny = __builtin_inff(), maxy = -__builtin_inff();
                     const bool row_ok = k < N && k < hp;
-                    const float dmk = s_dmax[k];
-                    for (int iv = sub; iv < nv; iv += 16) {
-                        const int M = s_lon_meta[it * nv + iv].x;
-                        float wl = r_ego_f;
-                        const Frame f0 = s_frames[iv * hp_max + k];
-                        if (row_ok && k < M && M >= 2) {
-                            const double rx = f0.px - org_x, ry = f0.py - org_y;
-                            const float fx = (float)rx, fy = (float)ry;  // to nearest; the box is widened once, below
-                            minx = vmin_f32(minx, fx); maxx = vmax_f32(maxx, fx);
-                            miny = vmin_f32(miny, fy); maxy = vmax_f32(maxy, fy);
-                            if (!(rx == rx) || !(ry == ry)) { minx = -__builtin_inff(); maxx = __builtin_inff(); }  // NaN pose: keep everything
+                    const int M = s_lon_meta[it * nv + iv].x;
+                    float wl = r_ego_f;
+                    if (k + 1 < M && k + 1 < hp && k + 1 < N) {
+                        const Frame f0 = s_frames[iv * hp_max + k], f1 = s_frames[iv * hp_max + k + 1];
+                        const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
+                        const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
+                        const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
+                        const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty);   // n_{k+1} . n_k
+                        const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
+                        const double dm1 = (double)s_dmax[k + 1];
+                        const float num = (float)(fabs(a_n) + (double)s_ddmax[k] + dm1 * fabs(1.0 - nn));
+                        const float den = (float)(fabs(a_t) - dm1 * fabs(nt_));
+                        if (den > 1e-30f) {  // v_rcp_f32: 1 ulp; the factor covers it and the two roundings to nearest
+                            const float sigma = vmin_f32(1.0f, num * __builtin_amdgcn_rcpf(den) * (1.0f + 4e-6f) + 1e-9f);
+                            wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
                         }
-                        if (k + 1 < M && k + 1 < hp && k + 1 < N) {
-                            const Frame f1 = s_frames[iv * hp_max + k + 1];
-                            const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
-                            const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
-                            const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
-                            const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty);   // n_{k+1} . n_k
-                            const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
-                            const double dm1 = (double)s_dmax[k + 1];
-                            const float num = (float)(fabs(a_n) + (double)s_ddmax[k] + dm1 * fabs(1.0 - nn));
-                            const float den = (float)(fabs(a_t) - dm1 * fabs(nt_));
-                            if (den > 1e-30f) {  // v_rcp_f32: 1 ulp; the factor covers it and the two roundings to nearest
-                                const float sigma = vmin_f32(1.0f, num * __builtin_amdgcn_rcpf(den) * (1.0f + 4e-6f) + 1e-9f);
-                                wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
-                            }
-                        }
-                        s_wfat[iv * hp_max + k] = row_ok ? (dmk + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
                     }
-                    minx = row16_min_f32(minx); maxx = row16_max_f32(maxx); miny = row16_min_f32(miny); maxy = row16_max_f32(maxy);
-                    if (sub == 0) {
+                    s_wfat[iv * hp_max + k] = row_ok ? (s_dmax[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
+                }
+    // [/section PREP]
+                {
+                    const int r = kThreads - 1 - tid;
+                    if (r < rows) {
+                        const uint4 bx = s_box[r];
+                        s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);
+                        const float minx = f32_from_ordered(bx.x), maxx = f32_from_ordered(bx.y);
+                        const float miny = f32_from_ordered(bx.z), maxy = f32_from_ordered(bx.w);
                         const float hx = 0.5f * (maxx - minx), hy = 0.5f * (maxy - miny);
                         // empty row (no valid pose): radius -1 rejects every obstacle; an infinite box keeps every obstacle
                         double rad = -1.0;
                         // v_sqrt_f32: 1 ulp; the corners were rounded to nearest: half an ulp of each coordinate, covered by slack
                         const float slack = (fabsf(maxx) + fabsf(minx) + fabsf(maxy) + fabsf(miny)) * 2.4e-7f + 1e-6f;
-                        if (maxx >= minx) rad = ((double)(__builtin_amdgcn_sqrtf(hx * hx + hy * hy) * (1.0f + 4e-6f) + slack) + r_ego + (double)dmk) * (1.0 + 1e-9) + 1e-9;
+                        if (maxx >= minx) rad = ((double)(__builtin_amdgcn_sqrtf(hx * hx + hy * hy) * (1.0f + 4e-6f) + slack) + r_ego + (double)s_dmax[r * stride]) * (1.0 + 1e-9) + 1e-9;
                         s_grp[r] = ObsDim{org_x + 0.5 * ((double)maxx + (double)minx), org_y + 0.5 * ((double)maxy + (double)miny), rad, 0.0};
                     }
                 }
@@ -543,6 +578,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 }
             };
 
+    // [section COLL]
             for (int e0 = wave * kWave; e0 < n_items; e0 += kThreads) {
                 const int e = e0 + lane;
                 bool keep = false;
@@ -578,11 +614,13 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 qlen = 0;
             }
         }
+    // [/section COLL]
         __syncthreads();  // frames / lat / dmax are rewritten by the next slice
     }
 
     // ---------------------------------------------------------------- per-candidate assembly + argmin
     Best mine{0.0, -1};
+    // [section ASM]
     for (int c = tid; c < C; c += kThreads) {
         const int iv = c % nv, it = (c / nv) % nt, id = c / (nv * nt);
         if (it < it_lo || it >= it_hi) continue;  // another workgroup's slice (latency mode)
@@ -602,6 +640,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
         if (!(flags & FP_FLAG_INFEASIBLE) && cost == cost) mine = best_merge(mine, Best{cost, c});
     }
+    // [/section ASM]
     mine = wave_best(mine);
     if (lane == 0) s_best[wave] = mine;
     __syncthreads();
