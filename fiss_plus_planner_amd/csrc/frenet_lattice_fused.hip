@@ -12,12 +12,11 @@
 //   phase A  one wavefront per profile, one lane per time point: quartic/quintic evaluation, ballot for the
 //            speed/accel masks and for the truncation index M (first point off the spline), DPP tree sums
 //            for the cost terms, spline frames of the points the collision horizon can touch -> LDS
-//   phase B  broad phase: every (checked pose of a lon profile) x (obstacle at that time step) pair is tested
-//            with a circle fattened by the largest lateral offset of the slice; lanes run over the contiguous
-//            [time][obstacle] table (conflict-free LDS reads), survivors are compacted with ballot/popcount
-//            into a per-wave LDS queue
-//            narrow phase: the queue is drained 64 lanes at a time, lane = (hit, lateral sample): exact ego
-//            centre + heading, exact circle test, 4-axis separating-axis test (closed: touching collides)
+//   phase B  three block-wide stages, every lane busy in each: G  (row, obstacle) items against the circle that encloses the
+//            row's reference points of ALL lon profiles; B  (surviving item, lon profile) pairs against a circle fattened by
+//            the largest lateral offset of the slice and a separating axis along the reference normal; N  (hit, lateral
+//            sample) pairs: exact ego centre + heading, exact circle test, 4-axis separating-axis test (closed: touching
+//            collides).  Survivors are appended to block-wide LDS lists with ballot/popcount + one atomic per wavefront.
 // Finally one lane per candidate assembles cost + flag word and a wave/LDS argmin with FOP's
 // "last minimum wins" rule picks the winner.
 //
@@ -49,8 +48,8 @@ constexpr uint32_t kOrdPosInf = 0xFF800000u, kOrdNegInf = 0x007FFFFFu;  // f32_o
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kQueueCap = 128;   // per-wave hit queue: < 64 pending + one full push of 64
-constexpr int kItemCap = 128;    // per-wave item queue: < 64 pending + one full push of 64
+constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass
+constexpr int kItemCap = 1024;   // block-wide list of (row, obstacle) items that pass the group test
 
 struct __attribute__((aligned(16))) Frame {  // reference-line frame of one lon-profile point
     double px, py, tx, ty;
@@ -73,7 +72,7 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, best, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -93,7 +92,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.ddmax = o;    o = align16(o + 2 * 4 * hp);
     L.wfat = o;     o = align16(o + 4 * nv * hp);  // float, rounded up
     L.grp = o;      o = align16(o + 32 * (rows > 0 ? rows : 1));       // per checked pose row: circle enclosing all lon profiles' points
-    L.iqueue = o;   o = align16(o + 2 * kItemCap * kWaves);                  // per-wave queue of (row, obstacle) items that pass the group test
+    L.iqueue = o;   o = align16(o + 2 * kItemCap);                           // (row, obstacle) items that pass the group test
     L.samples = o;  o = align16(o + 8 * (nt + nv + nd));  // t / v / d sample grids (read all over the kernel: keep them out of HBM latency)
     L.lon_sum = o;  o = align16(o + 24 * nt * nv);   // sum_v, sum_as, sum_js
     L.lat_sum = o;  o = align16(o + 24 * nd * nt);   // sum_ad, sum_jd, sum_d
@@ -104,7 +103,8 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.coll = o;     o = align16(o + nd * nv * nt);
     // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
     L.queue = o;    L.pows = o;
-    o = align16(o + (4 * kQueueCap * kWaves > 88 * nt ? 4 * kQueueCap * kWaves : 88 * nt));
+    o = align16(o + (4 * kHitCap > 88 * nt ? 4 * kHitCap : 88 * nt));
+    L.cnt = o;      o = align16(o + 8);  // list counters (monotone)
     L.best = o;     o = align16(o + 16 * kWaves);
     L.total = o;
     return L;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     float* s_ddmax2 = (float*)(smem + L.ddmax);  // [2][hp_max]
     float* s_wfat = (float*)(smem + L.wfat);
     ObsDim* s_grp = (ObsDim*)(smem + L.grp);  // reused as {cx, cy, radius, -}
-    unsigned short* s_iqueue = (unsigned short*)(smem + L.iqueue) + wave * kItemCap;  // item index r * n_obs + j
+    unsigned short* s_items = (unsigned short*)(smem + L.iqueue);  // item index r * n_obs + j
     double* s_pows = (double*)(smem + L.pows);
     double* s_ts = (double*)(smem + L.samples);
     double* s_vs = s_ts + nt;
@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     double* s_qlat = (double*)(smem + L.qlat);  // [nd][3]
     uint4* s_box = (uint4*)(smem + L.box);      // [rows] {min x, max x, min y, max y} relative to the first knot
     unsigned char* s_coll = smem + L.coll;
-    uint32_t* s_queue = (uint32_t*)(smem + L.queue) + wave * kQueueCap;
+    uint32_t* s_hits = (uint32_t*)(smem + L.queue);
+    int* s_cnt = (int*)(smem + L.cnt);
     Best* s_best = (Best*)(smem + L.best);
 
     if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch (block-uniform exit)
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // [/section STAGE]
     }
     for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
+    if (tid < 2) s_cnt[tid] = 0;
     for (int r = tid; r < rows; r += kThreads) s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);  // empty
     for (int i = tid; i < 2 * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
     // points whose frame the collision stage can touch: 0 .. hp-1 (pose k needs point k+1 for its heading)
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 
     const double* v_samples = s_vs;
     const double org_x = s_coef[0], org_y = s_coef[4 * nx];  // first knot: origin of the fp32 bounding boxes
-    int qlen = 0;  // wave-uniform length of this wave's hit queue
+    int item_base = 0, hit_base = 0;  // list counters at the start of the current stage (block-uniform)
 
     // ---------------------------------------------------------------- phase A0 (once): masks / M / cost sums of every profile
     // (0) lane per lon profile: the boundary-value solve (two divisions), kept for the whole kernel; meta = {N, no flags}.
@@ -485,15 +487,98 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             __syncthreads();
 
             // -------------------------------------------------------- phase B: collision of this slice
-            // exact narrow phase on up to 64 (hit, lateral sample) pairs taken from the queue tail
-            const uint32_t inv_nd = (65536u + (uint32_t)nd - 1u) / (uint32_t)nd;  // e / nd == (e * inv_nd) >> 16 for e < 128
-            auto narrow = [&](int n_hits) {
-                const int items = n_hits * nd;
-                for (int base = 0; base < items; base += kWave) {
-                    const int e = base + lane;
-                    if (e < items) {
-                        const int h = (int)(((uint32_t)e * inv_nd) >> 16), id = e - h * nd;
-                        const uint32_t code = s_queue[qlen - n_hits + h];
+            // Three block-wide stages, every lane busy in each of them (the survivors of one stage are a few percent of its
+            // input, so per-wavefront queues would run the next stage at a fraction of a wavefront):
+            //   G  lane = (row, obstacle) item: group circle of the row                      -> s_items
+            //   B  lane = (surviving item, lon profile): fattened circle + separating axis n_k -> s_hits
+            //   N  lane = (hit, lateral sample): exact circle + 4-axis separating-axis test    -> s_coll
+            // Lists are appended with one LDS atomic per wavefront (ballot + popcount); the two counters only ever grow, each
+            // stage works on [base, counter) and every thread tracks the bases itself, so nothing is reset between stages.
+            // Capacity: the item list is filled optimistically by the whole table; if the survivors do not fit (rare) the
+            // range is redone in chunks of kItemCap items; the pair range of B is cut into passes of kHitCap pairs.
+            const int n_items = rows * n_obs;
+            const float inv_nobs = 1.0f / (float)n_obs, inv_nvf = 1.0f / (float)nv, inv_ndf = 1.0f / (float)nd;
+            int chunk = n_items;
+            for (int i0 = 0; i0 < n_items;) {
+                // ---- G
+                const int i1 = i0 + chunk < n_items ? i0 + chunk : n_items;
+                for (int e0 = i0 + wave * kWave; e0 < i1; e0 += kThreads) {
+                    const int e = e0 + lane;
+                    bool keep = false;
+                    if (e < i1) {
+                        int r = (int)(((float)e + 0.5f) * inv_nobs), j = e - r * n_obs;
+                        if (j < 0) { --r; j += n_obs; } else if (j >= n_obs) { ++r; j -= n_obs; }
+                        const int k = r * stride;
+                        const double2 oxy = *(const double2*)&s_pose[e];
+                        const ObsDim g = s_grp[r];
+                        const double dx = oxy.x - g.hl, dy = oxy.y - g.hw, R = g.r + s_dim[j].r;
+                        keep = k < N && k < pose_limit && (oxy.x == oxy.x) && g.r >= 0.0 && !(fma(dx, dx, dy * dy) > R * R);
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {
+                        const int first = __ffsll((long long)m) - 1;
+                        int base = 0;
+                        if (lane == first) base = atomicAdd(&s_cnt[0], __popcll(m));
+                        const int pos = __builtin_amdgcn_readlane(base, first) - item_base + __popcll(m & ((1ull << lane) - 1ull));
+                        if (keep && pos < kItemCap) s_items[pos] = (unsigned short)e;
+                    }
+                }
+                __syncthreads();
+                const int item_end = s_cnt[0];
+                const int n_surv = item_end - item_base;
+                item_base = item_end;
+                if (n_surv > kItemCap) {  // block-uniform: does not fit, redo [i0, ...) in chunks whose survivors always fit
+                    chunk = kItemCap;
+                    continue;
+                }
+                // ---- B / N passes over the (survivor, lon profile) pairs
+                const int n_pairs = n_surv * nv;
+                for (int p0 = 0; p0 < n_pairs; p0 += kHitCap) {
+                    const int p1 = p0 + kHitCap < n_pairs ? p0 + kHitCap : n_pairs;
+                    for (int q0 = p0 + wave * kWave; q0 < p1; q0 += kThreads) {
+                        const int pr = q0 + lane;
+                        bool pass = false;
+                        uint32_t code = 0;
+                        if (pr < p1) {
+                            int si = (int)(((float)pr + 0.5f) * inv_nvf), iv = pr - si * nv;
+                            if (iv < 0) { --si; iv += nv; } else if (iv >= nv) { ++si; iv -= nv; }
+                            const int item = s_items[si];
+                            int r = (int)(((float)item + 0.5f) * inv_nobs), j = item - r * n_obs;
+                            if (j < 0) { --r; j += n_obs; } else if (j >= n_obs) { ++r; j -= n_obs; }
+                            const int k = r * stride;
+                            const ObsPose op = s_pose[item];
+                            const ObsDim od = s_dim[j];
+                            const Frame fr = s_frames[iv * hp_max + k];
+                            // Poses beyond a profile's M hold stale frames: they may pass here and are rejected by the narrow
+                            // phase (k < M is tested there).
+                            const double fat = (r_ego + od.r + (double)s_dmax[k]) * (1.0 + 1e-12);
+                            const double dx = op.x - fr.px, dy = op.y - fr.py;
+                            // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre
+                            // vs the fan half-width + the obstacle's own reach along n_k.  A NaN pose passes both (-> "collision").
+                            const double w = fma(dy, fr.tx, -dx * fr.ty);
+                            const double reach = fma(od.hl, fabs(fma(op.s, fr.tx, -op.c * fr.ty)), od.hw * fabs(fma(op.c, fr.tx, op.s * fr.ty)));
+                            pass = !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[iv * hp_max + k] + reach);
+                            code = ((uint32_t)iv << 24) | ((uint32_t)r << 12) | (uint32_t)j;
+                        }
+                        const unsigned long long m = __ballot(pass);
+                        if (m) {
+                            const int first = __ffsll((long long)m) - 1;
+                            int base = 0;
+                            if (lane == first) base = atomicAdd(&s_cnt[1], __popcll(m));
+                            const int pos = __builtin_amdgcn_readlane(base, first) - hit_base + __popcll(m & ((1ull << lane) - 1ull));
+                            if (pass) s_hits[pos] = code;  // at most kHitCap pairs per pass: always fits
+                        }
+                    }
+                    __syncthreads();
+                    const int hit_end = s_cnt[1];
+                    const int n_hits = hit_end - hit_base;
+                    hit_base = hit_end;
+                    // ---- N: exact narrow phase
+                    const int n_exact = n_hits * nd;
+                    for (int x = tid; x < n_exact; x += kThreads) {
+                        int h = (int)(((float)x + 0.5f) * inv_ndf), id = x - h * nd;
+                        if (id < 0) { --h; id += nd; } else if (id >= nd) { ++h; id -= nd; }
+                        const uint32_t code = s_hits[h];
                         const int iv = code >> 24, r = (code >> 12) & 0xFFF, j = code & 0xFFF;
                         const int cand = (id * nt + it) * nv + iv;
                         const int k = r * stride;
@@ -525,96 +610,12 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             if (hit) s_coll[cand] = 1;
                         }
                     }
+                    if (p1 < n_pairs) __syncthreads();  // the next pass overwrites the hit list
                 }
-            };
-
-            const int hits_per_round = kWave / nd > 0 ? kWave / nd : 1;
-            const int n_items = rows * n_obs;
-            int iqlen = 0;  // wave-uniform length of this wave's item queue
-
-            // broad phase proper on up to 64 queued (row, obstacle) items: loop over the lon profiles
-            auto broad = [&](int n_take) {
-                const bool live = lane < n_take;
-                int r = 0, j = 0;
-                double ox = __builtin_nan(""), oy = 0.0, oc = 1.0, os = 0.0, orad = 0.0, ohl = 0.0, ohw = 0.0;
-                if (live) {
-                    const int item = s_iqueue[iqlen - n_take + lane];
-                    r = item / n_obs;
-                    j = item - r * n_obs;
-                    const ObsPose op = s_pose[item];
-                    ox = op.x; oy = op.y; oc = op.c; os = op.s;
-                    const ObsDim od = s_dim[j];
-                    orad = od.r; ohl = od.hl; ohw = od.hw;
-                }
-                const int k = r * stride;
-                // Poses beyond a profile's M hold stale frames: they may pass here and are rejected by the narrow phase
-                // (k < M is tested there), which keeps the per-profile M out of this loop.
-                double fat2 = -1.0;
-                if (live) {
-                    const double fat = (r_ego + orad + (double)s_dmax[k]) * (1.0 + 1e-12);
-                    fat2 = fat * fat;
-                }
-                for (int iv = 0; iv < nv; ++iv) {
-                    const Frame fr = s_frames[iv * hp_max + k];
-                    const double dx = ox - fr.px, dy = oy - fr.py;
-                    // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre vs the
-                    // fan half-width + the obstacle's own reach along n_k.  A NaN pose passes both (-> "collision" downstream).
-                    const double w = fma(dy, fr.tx, -dx * fr.ty);
-                    const double reach = fma(ohl, fabs(fma(os, fr.tx, -oc * fr.ty)), ohw * fabs(fma(oc, fr.tx, os * fr.ty)));
-                    const bool pass = live && !(fma(dx, dx, dy * dy) > fat2) && !(fabs(w) > (double)s_wfat[iv * hp_max + k] + reach);
-                    const unsigned long long m = __ballot(pass);
-                    if (m) {
-                        if (pass) {
-                            const int off = __popcll(m & ((1ull << lane) - 1ull));
-                            s_queue[qlen + off] = ((uint32_t)iv << 24) | ((uint32_t)r << 12) | (uint32_t)j;
-                        }
-                        qlen += __popcll(m);
-                        lds_wave_sync();
-                        while (qlen >= hits_per_round) {
-                            narrow(hits_per_round);
-                            qlen -= hits_per_round;
-                        }
-                    }
-                }
-            };
-
-    // [section COLL]
-            for (int e0 = wave * kWave; e0 < n_items; e0 += kThreads) {
-                const int e = e0 + lane;
-                bool keep = false;
-                int r = 0, j = 0;
-                if (e < n_items) {
-                    r = e / n_obs;
-                    j = e - r * n_obs;
-                    const int k = r * stride;
-                    const double2 oxy = *(const double2*)&s_pose[e];
-                    const ObsDim g = s_grp[r];
-                    const double dx = oxy.x - g.hl, dy = oxy.y - g.hw, R = g.r + s_dim[j].r;
-                    keep = k < N && k < pose_limit && (oxy.x == oxy.x) && g.r >= 0.0 && !(fma(dx, dx, dy * dy) > R * R);
-                }
-                const unsigned long long m = __ballot(keep);
-                if (m) {
-                    if (keep) s_iqueue[iqlen + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
-                    iqlen += __popcll(m);
-                    lds_wave_sync();
-                    if (iqlen >= kWave) {
-                        broad(kWave);
-                        iqlen -= kWave;
-                    }
-                }
-            }
-            if (iqlen > 0) {
-                lds_wave_sync();
-                broad(iqlen);
-                iqlen = 0;
-            }
-            if (qlen > 0) {
-                lds_wave_sync();
-                narrow(qlen);
-                qlen = 0;
+                i0 = i1;
+                if (i0 < n_items) __syncthreads();  // the next chunk overwrites the item list
             }
         }
-    // [/section COLL]
         __syncthreads();  // frames / lat / dmax are rewritten by the next slice
     }
 
