@@ -72,7 +72,7 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, nslice, best, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -105,6 +105,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.queue = o;    L.pows = o;
     o = align16(o + (4 * kHitCap > 88 * nt ? 4 * kHitCap : 88 * nt));
     L.cnt = o;      o = align16(o + 8);  // list counters (monotone)
+    L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * kWaves);
     L.total = o;
     return L;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     unsigned char* s_coll = smem + L.coll;
     uint32_t* s_hits = (uint32_t*)(smem + L.queue);
     int* s_cnt = (int*)(smem + L.cnt);
+    int* s_nslice = (int*)(smem + L.nslice);
     Best* s_best = (Best*)(smem + L.best);
 
     if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch (block-uniform exit)
@@ -238,16 +240,32 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
     // [section STAGE]
         const double* gp = bt.obs_pose + (size_t)sc * bt.T_obs * n_obs * 4;
-        for (int i = tid; i < rows * n_obs; i += kThreads) {
-            const int r = i / n_obs, j = i - r * n_obs;
-            const double* ps = gp + ((size_t)(r * stride + t_now) * n_obs + j) * 4;
-            ObsPose o{__builtin_nan(""), 0.0, 1.0, 0.0};  // x = NaN: no state at this step (state_at_time -> None)
-            if (ps[3] != 0.0) {
-                o.x = ps[0];
-                o.y = ps[1];
-                sincos(ps[2], &o.s, &o.c);
+        const float inv_nobs_s = 1.0f / (float)n_obs;
+        for (int i0 = 0; i0 < rows * n_obs; i0 += 4 * kThreads) {  // four pose reads in flight per lane before any sincos
+            double4 ps[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kThreads + tid;
+                ps[u] = make_double4(0.0, 0.0, 0.0, 0.0);
+                if (i < rows * n_obs) {
+                    int r = (int)(((float)i + 0.5f) * inv_nobs_s), j = i - r * n_obs;
+                    if (j < 0) { --r; j += n_obs; } else if (j >= n_obs) { ++r; j -= n_obs; }
+                    ps[u] = *(const double4*)(gp + ((size_t)(r * stride + t_now) * n_obs + j) * 4);
+                }
             }
-            s_pose[i] = o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kThreads + tid;
+                if (i < rows * n_obs) {
+                    ObsPose o{__builtin_nan(""), 0.0, 1.0, 0.0};  // x = NaN: no state at this step (state_at_time -> None)
+                    if (ps[u].w != 0.0) {
+                        o.x = ps[u].x;
+                        o.y = ps[u].y;
+                        sincos(ps[u].z, &o.s, &o.c);
+                    }
+                    s_pose[i] = o;
+                }
+            }
         }
     // [/section STAGE]
     }
@@ -284,7 +302,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
         s_qlon[2 * (it * nv + iv)] = q.a3;
         s_qlon[2 * (it * nv + iv) + 1] = q.a4;
-        s_lon_meta[it * nv + iv] = make_int2(arange_len(T, tick), 0);
+        const int N = arange_len(T, tick);
+        s_lon_meta[it * nv + iv] = make_int2(N, 0);
+        if (iv == 0) s_nslice[it] = N;
     }
     __syncthreads();
     // [section POWS]
@@ -622,11 +642,15 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // ---------------------------------------------------------------- per-candidate assembly + argmin
     Best mine{0.0, -1};
     // [section ASM]
+    const float inv_nv_a = 1.0f / (float)nv, inv_nt_a = 1.0f / (float)nt;
     for (int c = tid; c < C; c += kThreads) {
-        const int iv = c % nv, it = (c / nv) % nt, id = c / (nv * nt);
+        // c = (id * nt + it) * nv + iv, c < 4096: quotients by fp32 reciprocal + one correction step
+        int q1 = (int)(((float)c + 0.5f) * inv_nv_a), iv = c - q1 * nv;
+        if (iv < 0) { --q1; iv += nv; } else if (iv >= nv) { ++q1; iv -= nv; }
+        int id = (int)(((float)q1 + 0.5f) * inv_nt_a), it = q1 - id * nt;
+        if (it < 0) { --id; it += nt; } else if (it >= nt) { ++id; it -= nt; }
         if (it < it_lo || it >= it_hi) continue;  // another workgroup's slice (latency mode)
-        const double T = s_ts[it];
-        const int N = arange_len(T, tick);
+        const int N = s_nslice[it];
         const double* ls = s_lon_sum + 3 * (it * nv + iv);
         const double* ds = s_lat_sum + 3 * (id * nt + it);
         const int2 meta = s_lon_meta[it * nv + iv];
