@@ -46,6 +46,12 @@ __device__ __forceinline__ uint32_t f32_ordered(float f)
 __device__ __forceinline__ float f32_from_ordered(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 constexpr uint32_t kOrdPosInf = 0xFF800000u, kOrdNegInf = 0x007FFFFFu;  // f32_ordered(+inf), f32_ordered(-inf)
 
+// e / d for 0 <= e, e + d < 2^22 with inv_d = 1.0f / d: (e + 0.5) / d lies at least 0.5 / d away from an integer and the two fp32
+// roundings move it by less than (e / d + 1) 2^-23, so the truncation is exact.  Four full-rate instructions instead of the
+// ~20 of an integer division; the remainder uses the 24-bit multiplier (full rate; v_mul_lo_u32 is quarter rate).
+__device__ __forceinline__ int div_small(int e, float inv_d) { return (int)(((float)e + 0.5f) * inv_d); }
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
 constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     float* s_ddmax2 = (float*)(smem + L.ddmax);  // [2][hp_max]
     float* s_wfat = (float*)(smem + L.wfat);
     ObsDim* s_grp = (ObsDim*)(smem + L.grp);  // reused as {cx, cy, radius, -}
-    unsigned short* s_items = (unsigned short*)(smem + L.iqueue);  // item index r * n_obs + j
+    unsigned short* s_items = (unsigned short*)(smem + L.iqueue);  // item index mul24(r, n_obs) + j
     double* s_pows = (double*)(smem + L.pows);
     double* s_ts = (double*)(smem + L.samples);
     double* s_vs = s_ts + nt;
@@ -248,9 +254,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 const int i = i0 + u * kThreads + tid;
                 ps[u] = make_double4(0.0, 0.0, 0.0, 0.0);
                 if (i < rows * n_obs) {
-                    int r = (int)(((float)i + 0.5f) * inv_nobs_s), j = i - r * n_obs;
-                    if (j < 0) { --r; j += n_obs; } else if (j >= n_obs) { ++r; j -= n_obs; }
-                    ps[u] = *(const double4*)(gp + ((size_t)(r * stride + t_now) * n_obs + j) * 4);
+                    const int r = div_small(i, inv_nobs_s), j = i - mul24(r, n_obs);
+                    ps[u] = *(const double4*)(gp + ((size_t)(mul24(r, stride) + t_now) * n_obs + j) * 4);
                 }
             }
 #pragma unroll
@@ -300,10 +305,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const int it = it_lo + e / nv, iv = e % nv;
         const double T = s_ts[it];
         const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
-        s_qlon[2 * (it * nv + iv)] = q.a3;
-        s_qlon[2 * (it * nv + iv) + 1] = q.a4;
+        s_qlon[2 * (mul24(it, nv) + iv)] = q.a3;
+        s_qlon[2 * (mul24(it, nv) + iv) + 1] = q.a4;
         const int N = arange_len(T, tick);
-        s_lon_meta[it * nv + iv] = make_int2(N, 0);
+        s_lon_meta[mul24(it, nv) + iv] = make_int2(N, 0);
         if (iv == 0) s_nslice[it] = N;
     }
     __syncthreads();
@@ -338,18 +343,16 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const int N = arange_len(s_ts[it], tick);
         const float inv_n = 1.0f / (float)N;
         for (int e = tid; e < nv * N; e += kThreads) {
-            int iv = (int)(((float)e + 0.5f) * inv_n);  // e / N for e < 2^15 (N <= 128)
-            int i = e - iv * N;
-            if (i < 0) { --iv; i += N; } else if (i >= N) { ++iv; i -= N; }
-            const double a3 = s_qlon[2 * (it * nv + iv)], a4 = s_qlon[2 * (it * nv + iv) + 1];
+            const int iv = div_small(e, inv_n), i = e - mul24(iv, N);
+            const double a3 = s_qlon[2 * (mul24(it, nv) + iv)], a4 = s_qlon[2 * (mul24(it, nv) + iv) + 1];
             const double a2 = s_dd0 * 0.5;
             const double t = (double)i * tick;
             const double s = fma(fma(fma(fma(a4, t, a3), t, a2), t, s_d0), t, s0);
             const double s_d = fma(fma(fma(4.0 * a4, t, 3.0 * a3), t, 2.0 * a2), t, s_d0);
             const double s_dd = fma(fma(12.0 * a4, t, 6.0 * a3), t, 2.0 * a2);
             const uint32_t bad = (s_d > p.max_speed ? FP_FLAG_SPEED : 0u) | (fabs(s_dd) > p.max_accel ? FP_FLAG_ACCEL : 0u);
-            if (bad) atomicOr((unsigned int*)&s_lon_meta[it * nv + iv].y, bad);
-            if (!(s >= knot0) || !(s < knot_last)) atomicMin(&s_lon_meta[it * nv + iv].x, i);  // calc_position -> None (cubic_spline.py:56-59)
+            if (bad) atomicOr((unsigned int*)&s_lon_meta[mul24(it, nv) + iv].y, bad);
+            if (!(s >= knot0) || !(s < knot_last)) atomicMin(&s_lon_meta[mul24(it, nv) + iv].x, i);  // calc_position -> None (cubic_spline.py:56-59)
         }
     }
     // [/section MASKS]
@@ -359,17 +362,17 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const double T = s_ts[it];
         const double* S = s_pows + it * 11;
         if (sub < nv) {
-            const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (it * nv + sub)], s_qlon[2 * (it * nv + sub) + 1]};
+            const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + sub)], s_qlon[2 * (mul24(it, nv) + sub) + 1]};
             double lon[3];
             lon_cost_sums(q, target_speed, S, lon);
-            double* o = s_lon_sum + 3 * (it * nv + sub);
+            double* o = s_lon_sum + 3 * (mul24(it, nv) + sub);
             o[0] = lon[0]; o[1] = lon[1]; o[2] = lon[2];
         } else {
             const int id = sub - nv;
             const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, T);
             double lat[3];
             lat_cost_sums(q, S, lat);
-            double* o = s_lat_sum + 3 * (id * nt + it);
+            double* o = s_lat_sum + 3 * (mul24(id, nt) + it);
             o[0] = lat[0]; o[1] = lat[1]; o[2] = lat[2];
         }
     }
@@ -393,22 +396,23 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         // ------------------------------------------------------------ phase A (per slice): one lane per (profile, point)
         // reference-line frames of the points the collision horizon can touch (i < hp), lateral offsets, fan bounds
         const int np = hp < N ? hp : N;
+        const float inv_np = 1.0f / (float)np;
     // [section FRAMES]
         for (int e = tid; e < nv * np; e += kThreads) {
-            const int iv = e / np, i = e - iv * np;
-            const int M = s_lon_meta[it * nv + iv].x;
+            const int iv = div_small(e, inv_np), i = e - mul24(iv, np);
+            const int M = s_lon_meta[mul24(it, nv) + iv].x;
             if (i < M) {  // the point is on the spline
-                const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (it * nv + iv)], s_qlon[2 * (it * nv + iv) + 1]};
+                const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + iv)], s_qlon[2 * (mul24(it, nv) + iv) + 1]};
                 const double t = (double)i * tick;
                 const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
                 const int seg = lut_segment(s_knots, s_lut, nx, s, knot0, inv_bucket_w, n_buckets);
                 Frame fr;
                 spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
-                s_frames[iv * hp_max + i] = fr;
+                s_frames[mul24(iv, hp_max) + i] = fr;
                 // bounding box of the row's reference points over the lon profiles (fp32 to nearest, relative to the first knot;
                 // prep widens it): LDS atomic min / max on order-preserving bit patterns
                 const int r = i / stride;
-                if (r * stride == i && r < rows && M >= 2) {
+                if (mul24(r, stride) == i && r < rows && M >= 2) {
                     const double rx = fr.px - org_x, ry = fr.py - org_y;
                     uint32_t* bx = (uint32_t*)&s_box[r];
                     if (rx == rx && ry == ry) {
@@ -424,11 +428,11 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // [/section FRAMES]
     // [section LAT]
         for (int e = tid; e < nd * np; e += kThreads) {
-            const int id = e / np, i = e - id * np;
+            const int id = div_small(e, inv_np), i = e - mul24(id, np);
             const Quintic q{d0, d_d0, d_dd0 * 0.5, s_qlat[3 * id], s_qlat[3 * id + 1], s_qlat[3 * id + 2]};
             const double t = (double)i * tick;
             const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
-            s_lat[id * hp_max + i] = d;
+            s_lat[mul24(id, hp_max) + i] = d;
             // fan half-width max|d| and largest lateral step max|d(i+1) - d(i)| over the lateral samples: LDS atomic max on
             // the bit patterns (non-negative floats order like unsigned integers); float_above: never below the fp64 value
             atomicMax((unsigned int*)&s_dmax[i], __float_as_uint(float_above(fabs(d))));
@@ -464,13 +468,13 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 const float inv_nv = 1.0f / (float)nv;
     // [section PREP]
                 for (int e = tid; e < rows * nv; e += kThreads) {
-                    const int r = (int)(((float)e + 0.5f) * inv_nv), iv = e - r * nv;  // e / nv for e < 2^15
-                    const int k = r * stride;
+                    const int r = div_small(e, inv_nv), iv = e - mul24(r, nv);
+                    const int k = mul24(r, stride);
                     const bool row_ok = k < N && k < hp;
-                    const int M = s_lon_meta[it * nv + iv].x;
+                    const int M = s_lon_meta[mul24(it, nv) + iv].x;
                     float wl = r_ego_f;
                     if (k + 1 < M && k + 1 < hp && k + 1 < N) {
-                        const Frame f0 = s_frames[iv * hp_max + k], f1 = s_frames[iv * hp_max + k + 1];
+                        const Frame f0 = s_frames[mul24(iv, hp_max) + k], f1 = s_frames[mul24(iv, hp_max) + k + 1];
                         const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
                         const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
                         const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
                         }
                     }
-                    s_wfat[iv * hp_max + k] = row_ok ? (s_dmax[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
+                    s_wfat[mul24(iv, hp_max) + k] = row_ok ? (s_dmax[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
                 }
     // [/section PREP]
                 {
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                         double rad = -1.0;
                         // v_sqrt_f32: 1 ulp; the corners were rounded to nearest: half an ulp of each coordinate, covered by slack
                         const float slack = (fabsf(maxx) + fabsf(minx) + fabsf(maxy) + fabsf(miny)) * 2.4e-7f + 1e-6f;
-                        if (maxx >= minx) rad = ((double)(__builtin_amdgcn_sqrtf(hx * hx + hy * hy) * (1.0f + 4e-6f) + slack) + r_ego + (double)s_dmax[r * stride]) * (1.0 + 1e-9) + 1e-9;
+                        if (maxx >= minx) rad = ((double)(__builtin_amdgcn_sqrtf(hx * hx + hy * hy) * (1.0f + 4e-6f) + slack) + r_ego + (double)s_dmax[mul24(r, stride)]) * (1.0 + 1e-9) + 1e-9;
                         s_grp[r] = ObsDim{org_x + 0.5 * ((double)maxx + (double)minx), org_y + 0.5 * ((double)maxy + (double)miny), rad, 0.0};
                     }
                 }
@@ -526,9 +530,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     const int e = e0 + lane;
                     bool keep = false;
                     if (e < i1) {
-                        int r = (int)(((float)e + 0.5f) * inv_nobs), j = e - r * n_obs;
-                        if (j < 0) { --r; j += n_obs; } else if (j >= n_obs) { ++r; j -= n_obs; }
-                        const int k = r * stride;
+                        const int r = div_small(e, inv_nobs), j = e - mul24(r, n_obs);
+                        const int k = mul24(r, stride);
                         const double2 oxy = *(const double2*)&s_pose[e];
                         const ObsDim g = s_grp[r];
                         const double dx = oxy.x - g.hl, dy = oxy.y - g.hw, R = g.r + s_dim[j].r;
@@ -560,15 +563,13 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                         bool pass = false;
                         uint32_t code = 0;
                         if (pr < p1) {
-                            int si = (int)(((float)pr + 0.5f) * inv_nvf), iv = pr - si * nv;
-                            if (iv < 0) { --si; iv += nv; } else if (iv >= nv) { ++si; iv -= nv; }
+                            const int si = div_small(pr, inv_nvf), iv = pr - mul24(si, nv);
                             const int item = s_items[si];
-                            int r = (int)(((float)item + 0.5f) * inv_nobs), j = item - r * n_obs;
-                            if (j < 0) { --r; j += n_obs; } else if (j >= n_obs) { ++r; j -= n_obs; }
-                            const int k = r * stride;
+                            const int r = div_small(item, inv_nobs), j = item - mul24(r, n_obs);
+                            const int k = mul24(r, stride);
                             const ObsPose op = s_pose[item];
                             const ObsDim od = s_dim[j];
-                            const Frame fr = s_frames[iv * hp_max + k];
+                            const Frame fr = s_frames[mul24(iv, hp_max) + k];
                             // Poses beyond a profile's M hold stale frames: they may pass here and are rejected by the narrow
                             // phase (k < M is tested there).
                             const double fat = (r_ego + od.r + (double)s_dmax[k]) * (1.0 + 1e-12);
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             // vs the fan half-width + the obstacle's own reach along n_k.  A NaN pose passes both (-> "collision").
                             const double w = fma(dy, fr.tx, -dx * fr.ty);
                             const double reach = fma(od.hl, fabs(fma(op.s, fr.tx, -op.c * fr.ty)), od.hw * fabs(fma(op.c, fr.tx, op.s * fr.ty)));
-                            pass = !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[iv * hp_max + k] + reach);
+                            pass = !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach);
                             code = ((uint32_t)iv << 24) | ((uint32_t)r << 12) | (uint32_t)j;
                         }
                         const unsigned long long m = __ballot(pass);
@@ -596,18 +597,17 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     // ---- N: exact narrow phase
                     const int n_exact = n_hits * nd;
                     for (int x = tid; x < n_exact; x += kThreads) {
-                        int h = (int)(((float)x + 0.5f) * inv_ndf), id = x - h * nd;
-                        if (id < 0) { --h; id += nd; } else if (id >= nd) { ++h; id -= nd; }
+                        const int h = div_small(x, inv_ndf), id = x - mul24(h, nd);
                         const uint32_t code = s_hits[h];
                         const int iv = code >> 24, r = (code >> 12) & 0xFFF, j = code & 0xFFF;
-                        const int cand = (id * nt + it) * nv + iv;
-                        const int k = r * stride;
-                        const int M = s_lon_meta[it * nv + iv].x;
+                        const int cand = mul24(mul24(id, nt) + it, nv) + iv;
+                        const int k = mul24(r, stride);
+                        const int M = s_lon_meta[mul24(it, nv) + iv].x;
                         if (k < M && M >= 2 && !s_coll[cand]) {
                             // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                             const int ka_ = (k + 1 < M) ? k : k - 1;
-                            const Frame f0 = s_frames[iv * hp_max + ka_], f1 = s_frames[iv * hp_max + ka_ + 1];
-                            const double da = s_lat[id * hp_max + ka_], db = s_lat[id * hp_max + ka_ + 1];
+                            const Frame f0 = s_frames[mul24(iv, hp_max) + ka_], f1 = s_frames[mul24(iv, hp_max) + ka_ + 1];
+                            const double da = s_lat[mul24(id, hp_max) + ka_], db = s_lat[mul24(id, hp_max) + ka_ + 1];
                             double xa, ya, xb, yb;
                             frenet_to_cartesian(f0.px, f0.py, f0.tx, f0.ty, da, xa, ya);
                             frenet_to_cartesian(f1.px, f1.py, f1.tx, f1.ty, db, xb, yb);
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             ego.y = (ka_ == k) ? ya : yb;
                             ego.hl = veh_hl;
                             ego.hw = veh_hw;
-                            const ObsPose op = s_pose[r * n_obs + j];
+                            const ObsPose op = s_pose[mul24(r, n_obs) + j];
                             const ObsDim od = s_dim[j];
                             bool hit;
                             if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
@@ -644,16 +644,14 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // [section ASM]
     const float inv_nv_a = 1.0f / (float)nv, inv_nt_a = 1.0f / (float)nt;
     for (int c = tid; c < C; c += kThreads) {
-        // c = (id * nt + it) * nv + iv, c < 4096: quotients by fp32 reciprocal + one correction step
-        int q1 = (int)(((float)c + 0.5f) * inv_nv_a), iv = c - q1 * nv;
-        if (iv < 0) { --q1; iv += nv; } else if (iv >= nv) { ++q1; iv -= nv; }
-        int id = (int)(((float)q1 + 0.5f) * inv_nt_a), it = q1 - id * nt;
-        if (it < 0) { --id; it += nt; } else if (it >= nt) { ++id; it -= nt; }
+        // c = mul24(mul24(id, nt) + it, nv) + iv
+        const int q1 = div_small(c, inv_nv_a), iv = c - mul24(q1, nv);
+        const int id = div_small(q1, inv_nt_a), it = q1 - mul24(id, nt);
         if (it < it_lo || it >= it_hi) continue;  // another workgroup's slice (latency mode)
         const int N = s_nslice[it];
-        const double* ls = s_lon_sum + 3 * (it * nv + iv);
-        const double* ds = s_lat_sum + 3 * (id * nt + it);
-        const int2 meta = s_lon_meta[it * nv + iv];
+        const double* ls = s_lon_sum + 3 * (mul24(it, nv) + iv);
+        const double* ds = s_lat_sum + 3 * (mul24(id, nt) + it);
+        const int2 meta = s_lon_meta[mul24(it, nv) + iv];
         const int M = meta.x;
         uint32_t flags = (uint32_t)meta.y;
         bool hit = s_coll[c] != 0;
