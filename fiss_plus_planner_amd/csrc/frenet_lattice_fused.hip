@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         // ------------------------------------------------------------ phase A (per slice): one lane per (profile, point)
         // reference-line frames of the points the collision horizon can touch (i < hp), lateral offsets, fan bounds
         const int np = hp < N ? hp : N;
-        const float inv_np = 1.0f / (float)np;
+        const float inv_np = 1.0f / (float)np, inv_stride = 1.0f / (float)stride;
     // [section FRAMES]
         for (int e = tid; e < nv * np; e += kThreads) {
             const int iv = div_small(e, inv_np), i = e - mul24(iv, np);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 s_frames[mul24(iv, hp_max) + i] = fr;
                 // bounding box of the row's reference points over the lon profiles (fp32 to nearest, relative to the first knot;
                 // prep widens it): LDS atomic min / max on order-preserving bit patterns
-                const int r = i / stride;
+                const int r = div_small(i, inv_stride);
                 if (mul24(r, stride) == i && r < rows && M >= 2) {
                     const double rx = fr.px - org_x, ry = fr.py - org_y;
                     uint32_t* bx = (uint32_t*)&s_box[r];
@@ -429,7 +429,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // [section LAT]
         for (int e = tid; e < nd * np; e += kThreads) {
             const int id = div_small(e, inv_np), i = e - mul24(id, np);
-            const Quintic q{d0, d_d0, d_dd0 * 0.5, s_qlat[3 * id], s_qlat[3 * id + 1], s_qlat[3 * id + 2]};
+            const double* ql = s_qlat + mul24(id, 3);
+            const Quintic q{d0, d_d0, d_dd0 * 0.5, ql[0], ql[1], ql[2]};
             const double t = (double)i * tick;
             const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
             s_lat[mul24(id, hp_max) + i] = d;
@@ -649,8 +650,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const int id = div_small(q1, inv_nt_a), it = q1 - mul24(id, nt);
         if (it < it_lo || it >= it_hi) continue;  // another workgroup's slice (latency mode)
         const int N = s_nslice[it];
-        const double* ls = s_lon_sum + 3 * (mul24(it, nv) + iv);
-        const double* ds = s_lat_sum + 3 * (mul24(id, nt) + it);
+        const double* ls = s_lon_sum + mul24(3, mul24(it, nv) + iv);
+        const double* ds = s_lat_sum + mul24(3, mul24(id, nt) + it);
         const int2 meta = s_lon_meta[mul24(it, nv) + iv];
         const int M = meta.x;
         uint32_t flags = (uint32_t)meta.y;
