@@ -110,7 +110,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
     L.queue = o;    L.pows = o;
     o = align16(o + (4 * kHitCap > 88 * nt ? 4 * kHitCap : 88 * nt));
-    L.cnt = o;      o = align16(o + 8);  // list counters (monotone)
+    L.cnt = o;      o = align16(o + 16);  // list counters (monotone) + scan mask
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * kWaves);
     L.total = o;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // [/section STAGE]
     }
     for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
-    if (tid < 2) s_cnt[tid] = 0;
+    if (tid < 4) s_cnt[tid] = 0;  // [0], [1]: list counters; [2]: slices whose lon profiles need the point-by-point scan
     for (int r = tid; r < rows; r += kThreads) s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);  // empty
     for (int i = tid; i < 2 * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
     // points whose frame the collision stage can touch: 0 .. hp-1 (pose k needs point k+1 for its heading)
@@ -310,6 +310,35 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const int N = arange_len(T, tick);
         s_lon_meta[mul24(it, nv) + iv] = make_int2(N, 0);
         if (iv == 0) s_nslice[it] = N;
+        // Proof that the profile violates nothing, from the extrema of the polynomials over the continuous interval [0, t_last]
+        // (a superset of the grid): |s_dd| (quadratic: ends + vertex), s_d (cubic: ends + the roots of s_dd), and s inside the
+        // spline's range (s_d >= 0 makes s monotone: its ends suffice).  Margins of 1e-9 dwarf the rounding of the Horner
+        // evaluations the point-by-point scan would do; anything not proven (including NaNs) falls back to that scan, so the
+        // outcome is the scan's outcome either way.
+        if (N > 0) {
+            const double a2 = s_dd0 * 0.5, tl = (double)(N - 1) * tick;
+            auto acc = [&](double t) { return fma(fma(12.0 * q.a4, t, 6.0 * q.a3), t, 2.0 * a2); };
+            auto vel = [&](double t) { return fma(fma(fma(4.0 * q.a4, t, 3.0 * q.a3), t, 2.0 * a2), t, s_d0); };
+            const double qa = 12.0 * q.a4, qb = 6.0 * q.a3, qc = 2.0 * a2;  // s_dd = qa t^2 + qb t + qc
+            double amax = fmax(fabs(acc(0.0)), fabs(acc(tl)));
+            const double tv = -qb / (2.0 * qa);
+            if (tv > 0.0 && tv < tl) amax = fmax(amax, fabs(acc(tv)));
+            bool proven = amax <= p.max_accel * (1.0 - 1e-9) - 1e-12;
+            double vmax = fmax(vel(0.0), vel(tl)), vmin = fmin(vel(0.0), vel(tl));
+            const double disc = fma(qb, qb, -4.0 * qa * qc);
+            if (disc >= 0.0) {  // stable quadratic roots; a root that is NaN / inf / outside (0, t_last) is not an interior extremum
+                const double sq = sqrt(disc), qq = -0.5 * (qb + (qb >= 0.0 ? sq : -sq));
+                const double r1 = qq / qa, r2 = qc / qq;
+                if (r1 > 0.0 && r1 < tl) { vmax = fmax(vmax, vel(r1)); vmin = fmin(vmin, vel(r1)); }
+                if (r2 > 0.0 && r2 < tl) { vmax = fmax(vmax, vel(r2)); vmin = fmin(vmin, vel(r2)); }
+            } else if (!(disc < 0.0)) proven = false;  // NaN
+            const double pad = amax * 1e-6;  // |s_d(t) - s_d(r)| <= max|s_dd| |t - r|: covers a root off by a microsecond
+            proven = proven && vmax + pad <= p.max_speed * (1.0 - 1e-9) - 1e-12 && vmin - pad >= 0.0;
+            const double s_end = fma(fma(fma(fma(q.a4, tl, q.a3), tl, a2), tl, s_d0), tl, s0);
+            const double eps = 1e-9 * (1.0 + fabs(knot_last) + fabs(knot0));
+            proven = proven && s0 >= knot0 + eps && s_end < knot_last - eps;
+            if (!proven) atomicOr((unsigned int*)&s_cnt[2], 1u << ((it - it_lo) & 31));
+        }
     }
     __syncthreads();
     // [section POWS]
@@ -339,7 +368,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     }
     // [/section POWS]
     // [section MASKS]
+    const uint32_t scan_mask = (uint32_t)s_cnt[2];
     for (int it = it_lo; it < it_hi; ++it) {
+        if (!((scan_mask >> ((it - it_lo) & 31)) & 1u)) continue;  // every lon profile of the slice is proven clean
         const int N = arange_len(s_ts[it], tick);
         const float inv_n = 1.0f / (float)N;
         for (int e = tid; e < nv * N; e += kThreads) {
