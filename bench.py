@@ -101,15 +101,18 @@ def main():
     fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in dten.items()})
     params = make_params(batch)
     B, C = batch.B, batch.C
-    best_idx = torch.empty(B, dtype=torch.int32, device=dev)
-    best_cost = torch.empty(B, dtype=torch.float64, device=dev)
+    # per-ego results, packed in one device buffer [cost f64 x B | index i32 x B] so that one async copy brings both to the host
+    packed = torch.empty(12 * B, dtype=torch.uint8, device=dev)
+    best_cost = packed[:8 * B].view(torch.float64)
+    best_idx = packed[8 * B:].view(torch.int32)
     stats = torch.empty((B, 4), dtype=torch.int32, device=dev)
     cost_tbl = torch.empty((B, C), dtype=torch.float64, device=dev) if args.tables else None
     flag_tbl = torch.empty((B, C), dtype=torch.int32, device=dev) if args.tables else None
     best_flags = torch.empty(B, dtype=torch.int32, device=dev)
     best_traj = torch.empty((B, 16, 128), dtype=torch.float64, device=dev)   # winner epilogue output, stays in HBM
-    h_idx = torch.empty(B, dtype=torch.int32).pin_memory()
-    h_cost = torch.empty(B, dtype=torch.float64).pin_memory()
+    h_packed = torch.empty(12 * B, dtype=torch.uint8).pin_memory()
+    h_cost = h_packed[:8 * B].view(torch.float64)
+    h_idx = h_packed[8 * B:].view(torch.int32)
     eng = FrenetEngine(local_rank)
     stream = torch.cuda.current_stream(dev)
 
@@ -121,7 +124,7 @@ def main():
         prev = torch.full((B, 3), -1, dtype=torch.int32, device=dev)
         ijk = torch.empty((B, 3), dtype=torch.int32, device=dev)
         end_state = torch.empty((B, 3), dtype=torch.float64, device=dev)
-        refined = torch.empty(B, dtype=torch.int32, device=dev)
+        refined = best_idx  # the per-ego int result of this mode (refined yes/no) rides in the packed buffer
         opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS, 3, 10.0, 0.5)
         io = _abi.FpFissIo()
         io.samp_min, io.samp_max, io.samp_res = (f_t[k].data_ptr() for k in ("samp_min", "samp_max", "samp_res"))
@@ -146,8 +149,7 @@ def main():
         eng.winner_trajs_device(params, fb, best_idx.data_ptr(), best_flags.data_ptr(), best_traj.data_ptr(), stream=stream.cuda_stream)
 
     def fetch():
-        h_idx.copy_(refined if fiss else best_idx, non_blocking=True)
-        h_cost.copy_(best_cost, non_blocking=True)
+        h_packed.copy_(packed, non_blocking=True)
 
     def barrier():
         torch.cuda.synchronize(dev)
