@@ -11,6 +11,7 @@
 // (x, y, cos, sin) so that the per-pose test does no trigonometry.
 #include "frenet_device.h"
 #include "frenet_kernels.h"
+#include "frenet_winner.h"
 
 namespace fp {
 
@@ -334,15 +335,12 @@ __global__ void eval_trajs_kernel(KernelArgs ka, int K, const double* end_states
 // all_C > 0: materialise EVERY lattice candidate (workgroup = (ego, candidate), output slot = blockIdx.x): the all_trajs payload.
 __global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C)
 {
-    __shared__ double sx[FP_MAX_POINTS + 1], sy[FP_MAX_POINTS + 1], syaw[FP_MAX_POINTS + 1], sds[FP_MAX_POINTS + 1], sc[FP_MAX_POINTS + 1],
-        scd[FP_MAX_POINTS + 1];
-    __shared__ int sM;
+    __shared__ double scratch[kWinnerScratchDoubles];
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const int slot = blockIdx.x, i = threadIdx.x;
     const int b = all_C > 0 ? slot / all_C : slot;
     const double nan = __builtin_nan("");
-    double* out = ka.r.best_traj + (size_t)slot * FP_ARR_COUNT * FP_MAX_POINTS;
     const int best = all_C > 0 ? slot - b * all_C : (end_states ? 0 : ka.r.best_idx[b]);
     double d_end = nan, v_end = nan, T = nan;
     if (end_states) {
@@ -351,80 +349,9 @@ __global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs k
         const int iv = best % p.nv, it = (best / p.nv) % p.nt, id = best / (p.nv * p.nt);
         d_end = bt.d_samples[id]; v_end = bt.v_samples[(size_t)b * p.nv + iv]; T = bt.t_samples[it];
     }
-    const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
-    double row[FP_ARR_COUNT];
-#pragma unroll
-    for (int r = 0; r < FP_ARR_COUNT; ++r) row[r] = nan;
-    if (best < 0 || N <= 0 || N > FP_MAX_POINTS || !(d_end == d_end) || !(v_end == v_end)) {
-#pragma unroll
-        for (int r = 0; r < FP_ARR_COUNT; ++r) out[r * FP_MAX_POINTS + i] = nan;
-        if (i == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
-        return;
-    }
-    const double* eg = bt.ego + (size_t)b * 6;
-    const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
-    const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], v_end, 0.0, T);
     const int f = bt.frame_of[b];
-    const int nx = bt.nx[f];
-    const double* knots = bt.knots + (size_t)f * bt.NX;
-    const double* coef = bt.coef + (size_t)f * 8 * bt.NX;
-    if (i == 0) sM = N;
-    __syncthreads();
-    bool on = false;
-    double x = nan, y = nan;
-    if (i < N) {
-        const double t = (double)i * p.tick_t;
-        row[FP_ARR_T] = t;
-        quartic_eval(lon, t, row[FP_ARR_S], row[FP_ARR_S_D], row[FP_ARR_S_DD], row[FP_ARR_S_DDD]);
-        quintic_eval(lat, t, row[FP_ARR_D], row[FP_ARR_D_D], row[FP_ARR_D_DD], row[FP_ARR_D_DDD]);
-        SplineLds sp{knots, coef, nx, bt.NX};
-        const int seg = spline_segment(sp, row[FP_ARR_S], -1);
-        if (seg < 0) {
-            atomicMin(&sM, i);  // first point off the spline truncates the Cartesian series (:112-113)
-        } else {
-            double px, py, tx, ty;
-            spline_frame(sp, seg, row[FP_ARR_S] - knots[seg], px, py, tx, ty);
-            frenet_to_cartesian(px, py, tx, ty, row[FP_ARR_D], x, y);
-            on = true;
-        }
-    }
-    sx[i] = x;
-    sy[i] = y;
-    __syncthreads();
-    const int M = sM;
-    on = on && i < M;
-    if (on) { row[FP_ARR_X] = x; row[FP_ARR_Y] = y; }
-    // yaw / ds / c / c_d / c_dd exactly as np.arctan2 / hypot / diff chains (:121-134); only when M >= 2
-    double yaw = nan, ds = nan;
-    if (M >= 2 && i < M - 1) {
-        const double ddx = sx[i + 1] - x, ddy = sy[i + 1] - y;
-        yaw = atan2(ddy, ddx);
-        ds = hypot(ddx, ddy);
-    }
-    syaw[i] = yaw;
-    sds[i] = ds;
-    __syncthreads();
-    if (M >= 2 && i == M - 1) { yaw = syaw[M - 2]; syaw[i] = yaw; }
-    __syncthreads();
-    double c = nan, c_d = nan, c_dd = nan;
-    if (M >= 2 && i < M - 1) c = (syaw[i + 1] - syaw[i]) / sds[i];
-    sc[i] = c;
-    __syncthreads();
-    if (M >= 2 && i < M - 2) c_d = (sc[i + 1] - sc[i]) / p.tick_t;
-    scd[i] = c_d;
-    __syncthreads();
-    if (M >= 2 && i < M - 3) c_dd = (scd[i + 1] - scd[i]) / p.tick_t;
-    if (M >= 2) {
-        if (i < M) row[FP_ARR_YAW] = yaw;
-        row[FP_ARR_DS] = ds; row[FP_ARR_C] = c; row[FP_ARR_C_D] = c_d; row[FP_ARR_C_DD] = c_dd;
-    }
-#pragma unroll
-    for (int r = 0; r < FP_ARR_COUNT; ++r) __builtin_nontemporal_store(row[r], &out[r * FP_MAX_POINTS + i]);  // write-once stream
-    if (i == 0 && ka.r.best_flags) {
-        uint32_t fl = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
-        if (M < N) fl |= FP_FLAG_TRUNCATED;
-        ka.r.best_flags[slot] = fl;
-    }
+    const SplineLds sp{bt.knots + (size_t)f * bt.NX, bt.coef + (size_t)f * 8 * bt.NX, bt.nx[f], bt.NX};
+    winner_series(ka, b, slot, best >= 0, d_end, v_end, T, i, sp, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -556,12 +483,14 @@ hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const d
     return hipGetLastError();
 }
 
-hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit)
+hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done)
 {
+    if (winner_done) *winner_done = false;
     if (which == 1) return launch_lattice_percand(ka, stream);
-    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit);
+    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done);
     if (e == hipErrorInvalidValue && which != 2) {
         (void)hipGetLastError();
+        if (winner_done) *winner_done = false;
         return launch_lattice_percand(ka, stream);
     }
     return e;

@@ -28,6 +28,7 @@
 //   argmin              planners/frenet_optimal_planner.py:263-268
 #include "frenet_device.h"
 #include "frenet_kernels.h"
+#include "frenet_winner.h"
 
 namespace fp {
 
@@ -113,6 +114,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.cnt = o;      o = align16(o + 16);  // list counters (monotone) + scan mask
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * kWaves);
+    if (o < L.dim + 8 * kWinnerScratchDoubles) o = align16(L.dim + 8 * kWinnerScratchDoubles);  // the winner epilogue reuses [dim, ...)
     L.total = o;
     return L;
 }
@@ -704,15 +706,31 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         for (int w = 1; w < kWaves; ++w) r = best_merge(r, s_best[w]);
         if (nsplit > 1) {
             part_best[blockIdx.x] = r;
-            return;
-        }
-        ka.r.best_idx[b] = r.idx;
-        ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
-        if (ka.r.stats) {
-            int32_t* st = ka.r.stats + (size_t)b * 4;
-            st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
+        } else {
+            ka.r.best_idx[b] = r.idx;
+            ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
+            if (ka.r.stats) {
+                int32_t* st = ka.r.stats + (size_t)b * 4;
+                st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
+            }
+            s_best[0] = r;
         }
     }
+    // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
+    // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
+    // 16 KB of stores per ego hide behind the other workgroups' arithmetic.  (Latency mode: merge_best_kernel picks the winner,
+    // the standalone winner_traj_kernel follows.)
+    if (nsplit > 1 || !ka.r.best_traj) return;
+    __syncthreads();
+    const int win = s_best[0].idx;
+    double d_end = __builtin_nan(""), v_end = d_end, T_end = d_end;
+    if (win >= 0) {
+        const int q1 = div_small(win, inv_nv_a), iv = win - mul24(q1, nv);
+        const int id = div_small(q1, inv_nt_a), it = q1 - mul24(id, nt);
+        d_end = s_ds[id]; v_end = s_vs[iv]; T_end = s_ts[it];
+    }
+    __syncthreads();  // everything behind the spline tables is dead now: the epilogue's scratch lives there
+    winner_series(ka, b, b, win >= 0, d_end, v_end, T_end, tid, sp, (double*)(smem + L.dim));
 }
 
 __global__ void merge_best_kernel(KernelArgs ka, int nsplit, const Best* part_best)
@@ -732,8 +750,9 @@ __global__ void merge_best_kernel(KernelArgs ka, int nsplit, const Best* part_be
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the
 // lane-per-candidate kernel, which keeps oversized obstacle tables in HBM/L2).
-hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit)
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done)
 {
+    if (winner_done) *winner_done = false;
     const fp_params& p = ka.p;
     const fp_batch& b = ka.b;
     if (p.nd > kWave || p.nv > 255 || b.n_obs > 4095) return hipErrorInvalidValue;
@@ -755,6 +774,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     if (!part_scratch || nsplit < 1) nsplit = 1;
     if (nsplit > p.nt) nsplit = p.nt;
     hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, (Best*)part_scratch);
+    if (winner_done) *winner_done = nsplit == 1 && ka.r.best_traj != nullptr;
     if (nsplit > 1) hipLaunchKernelGGL(merge_best_kernel, dim3((b.B + 63) / 64), dim3(64), 0, stream, ka, nsplit, (const Best*)part_scratch);
     return hipGetLastError();
 }
