@@ -84,7 +84,7 @@ struct fp_ctx {
     DeviceBuf arena;               // [ small region (kSmallRegion) | large region ] staging of FP_MEM_HOST calls
     char* pinned = nullptr;        // kSmallRegion bytes of pinned host memory mirroring the small region
     DeviceBuf scratch;             // intermediate tables of multi-kernel entry points (fp_plan_fiss)
-    DeviceBuf parts;               // partial argmins of the latency-mode lattice launch
+    DeviceBuf parts;               // latency-mode lattice launch: [ticket counters, fixed-size region][partial argmins]
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
     int refine_table_kb = 24;      // fp_ctx_set_option("refine_table_kb")
@@ -276,9 +276,16 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
     *parts = nullptr;
     const bool want = ctx->lattice_split == 2 || (ctx->lattice_split == 0 && (long)b->B * p->nt <= 1024);
     if (!want || p->nt < 2) return FP_OK;
-    const size_t need = (size_t)b->B * p->nt * 16 + kAlign;
-    if (need > ctx->parts.cap) HIP_TRY(hipStreamSynchronize(stream));  // the buffer may be reallocated: drain its users
-    FP_TRY(ctx->parts.reserve(need));
+    // want implies B * nt <= 1024 or an explicit request: the counters get a fixed region in front (kTicketBytes) so that they
+    // never share bytes with the partial argmins of a call with another B
+    if ((size_t)b->B * 4 > fp::kTicketBytes) return FP_OK;  // (an explicitly requested split of a huge batch: not worth it)
+    const size_t need = fp::kTicketBytes + (size_t)b->B * p->nt * 16 + kAlign;
+    if (need > ctx->parts.cap) {
+        HIP_TRY(hipStreamSynchronize(stream));  // the buffer is reallocated: drain its users
+        FP_TRY(ctx->parts.reserve(need));
+        // ticket counters start at zero; every launch leaves them at zero
+        HIP_TRY(hipMemsetAsync(ctx->parts.base, 0, fp::kTicketBytes, stream));
+    }
     *nsplit = p->nt;
     *parts = ctx->parts.base;
     return FP_OK;

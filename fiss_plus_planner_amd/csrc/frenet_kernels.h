@@ -50,7 +50,9 @@ hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream);
 // of the per-ego fp32 pose-obstacle pair table (0: no table, pairs are read from the scene table).
 hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb);
 
-// part_scratch: device buffer of B * nsplit * 16 bytes (partial argmins) or nullptr; nsplit > 1 = latency mode.
+// part_scratch: device buffer of kTicketBytes (ticket counters, int per ego, ZERO before the first launch; the kernel leaves
+// them zero) + B * nsplit * 16 bytes (partial argmins), or nullptr; nsplit > 1 = latency mode (B <= kTicketBytes / 4).
+constexpr size_t kTicketBytes = 64 * 1024;
 // *winner_done (optional): the kernel also wrote ka.r.best_traj / best_flags (asked for, and not in latency mode).
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done = nullptr);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);

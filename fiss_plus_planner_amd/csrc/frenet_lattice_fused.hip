@@ -137,8 +137,8 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
 }
 
 // nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
-// writes its partial argmin to part_best[ego * nsplit + part]; merge_best_kernel combines them.
-__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best)
+// writes its partial argmin to part_best[ego * nsplit + part]; the last one to arrive (ticket counter) merges them.
+__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best, int* part_count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const fp_params& p = ka.p;
@@ -184,9 +184,12 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     Best* s_best = (Best*)(smem + L.best);
 
     if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch (block-uniform exit)
-        if (tid == 0) {
-            if (nsplit == 1) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
-            else part_best[blockIdx.x] = Best{0.0, -1};
+        if (part == 0) {
+            if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
+            if (ka.r.best_traj) {  // NaN series, flag word 0 (returns before it touches the spline or the scratch)
+                const double nan = __builtin_nan("");
+                winner_series(ka, b, b, false, nan, nan, nan, tid, SplineLds{nullptr, nullptr, 0, 0}, nullptr);
+            }
         }
         return;
     }
@@ -701,26 +704,47 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     mine = wave_best(mine);
     if (lane == 0) s_best[wave] = mine;
     __syncthreads();
-    if (tid == 0) {
+    if (nsplit > 1) {
+        // Latency mode: this workgroup holds the argmin of its slices.  The LAST workgroup of the ego to arrive (ticket counter,
+        // release / acquire fences at device scope) merges the partial argmins in part order - the result does not depend on
+        // the arrival order - and carries on as the ego's only workgroup: results, epilogue.  No merge launch.
+        if (tid == 0) {
+            Best r = s_best[0];
+            for (int w = 1; w < kWaves; ++w) r = best_merge(r, s_best[w]);
+            part_best[blockIdx.x] = r;
+            __threadfence();
+            const int ticket = atomicAdd(&part_count[b], 1);
+            s_cnt[3] = ticket;
+        }
+        __syncthreads();
+        if (s_cnt[3] != nsplit - 1) return;
+        if (tid == 0) {
+            __threadfence();
+            part_count[b] = 0;  // ready for the next launch
+            const volatile Best* pb = part_best + (size_t)b * nsplit;
+            Best r{pb[0].cost, pb[0].idx};
+            for (int w = 1; w < nsplit; ++w) r = best_merge(r, Best{pb[w].cost, pb[w].idx});
+            s_best[0] = r;
+        }
+        __syncthreads();
+    } else if (tid == 0) {
         Best r = s_best[0];
         for (int w = 1; w < kWaves; ++w) r = best_merge(r, s_best[w]);
-        if (nsplit > 1) {
-            part_best[blockIdx.x] = r;
-        } else {
-            ka.r.best_idx[b] = r.idx;
-            ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
-            if (ka.r.stats) {
-                int32_t* st = ka.r.stats + (size_t)b * 4;
-                st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
-            }
-            s_best[0] = r;
+        s_best[0] = r;
+    }
+    if (tid == 0) {
+        const Best r = s_best[0];
+        ka.r.best_idx[b] = r.idx;
+        ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
+        if (ka.r.stats) {
+            int32_t* st = ka.r.stats + (size_t)b * 4;
+            st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
         }
     }
     // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
     // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
-    // 16 KB of stores per ego hide behind the other workgroups' arithmetic.  (Latency mode: merge_best_kernel picks the winner,
-    // the standalone winner_traj_kernel follows.)
-    if (nsplit > 1 || !ka.r.best_traj) return;
+    // 16 KB of stores per ego hide behind the other workgroups' arithmetic.
+    if (!ka.r.best_traj) return;
     __syncthreads();
     const int win = s_best[0].idx;
     double d_end = __builtin_nan(""), v_end = d_end, T_end = d_end;
@@ -731,21 +755,6 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     }
     __syncthreads();  // everything behind the spline tables is dead now: the epilogue's scratch lives there
     winner_series(ka, b, b, win >= 0, d_end, v_end, T_end, tid, sp, (double*)(smem + L.dim));
-}
-
-__global__ void merge_best_kernel(KernelArgs ka, int nsplit, const Best* part_best)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= ka.b.B) return;
-    Best r = part_best[(size_t)b * nsplit];
-    for (int k = 1; k < nsplit; ++k) r = best_merge(r, part_best[(size_t)b * nsplit + k]);
-    ka.r.best_idx[b] = r.idx;
-    ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
-    if (ka.r.stats) {
-        const int C = ka.p.nd * ka.p.nv * ka.p.nt;
-        int32_t* st = ka.r.stats + (size_t)b * 4;
-        st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
-    }
 }
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the
@@ -773,9 +782,11 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     if (e != hipSuccess) return e;
     if (!part_scratch || nsplit < 1) nsplit = 1;
     if (nsplit > p.nt) nsplit = p.nt;
-    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, (Best*)part_scratch);
-    if (winner_done) *winner_done = nsplit == 1 && ka.r.best_traj != nullptr;
-    if (nsplit > 1) hipLaunchKernelGGL(merge_best_kernel, dim3((b.B + 63) / 64), dim3(64), 0, stream, ka, nsplit, (const Best*)part_scratch);
+    // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
+    int* part_count = (int*)part_scratch;
+    Best* part_best = part_scratch ? (Best*)((char*)part_scratch + kTicketBytes) : nullptr;
+    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count);
+    if (winner_done) *winner_done = ka.r.best_traj != nullptr;
     return hipGetLastError();
 }
 

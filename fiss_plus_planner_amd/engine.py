@@ -40,12 +40,24 @@ _BATCH_PTRS = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "fr
                "obs_pose", "obs_dims", "final_time_step")
 
 
+def _ptr(a: np.ndarray) -> int:
+    """Address of a contiguous array's data (several times cheaper than a.ctypes.data, which builds a helper object)."""
+    return a.__array_interface__["data"][0]
+
+
 def _host_batch(batch: ProblemBatch) -> _abi.FpBatch:
+    """FpBatch over the batch's own numpy arrays.  A planner re-plans with the same (in-place updated) arrays every cycle, so
+    the struct is cached on the batch and rebuilt only when one of the arrays was replaced."""
+    arrays = [getattr(batch, name) for name in _BATCH_PTRS]
+    key = tuple(map(id, arrays))
+    cached = batch.__dict__.get("_fb_cache")
+    if cached is not None and cached[0] == key:
+        return _abi.FpBatch.from_buffer_copy(cached[1])  # a copy: callers may edit their struct
     fb = _abi.FpBatch()
     fb.B, fb.F, fb.NX, fb.S, fb.T_obs, fb.n_obs = batch.B, batch.F, batch.NX, batch.S, batch.T_obs, batch.n_obs
-    for name in _BATCH_PTRS:
-        a = getattr(batch, name)
-        setattr(fb, name, a.ctypes.data if a.size else None)
+    for name, a in zip(_BATCH_PTRS, arrays):
+        setattr(fb, name, _ptr(a) if a.size else None)
+    batch.__dict__["_fb_cache"] = (key, _abi.FpBatch.from_buffer_copy(fb), arrays)  # the arrays are kept alive with the pointers
     return fb
 
 
@@ -103,13 +115,13 @@ class FrenetEngine:
         out = SimpleNamespace(best_idx=np.empty(B, dtype=np.int32), best_cost=np.empty(B), stats=np.empty((B, 4), dtype=np.int32),
                               cost=np.empty((B, Cn)) if tables else None, flags=np.empty((B, Cn), dtype=np.uint32) if tables else None)
         res = _abi.FpResult()
-        res.best_idx, res.best_cost, res.stats = out.best_idx.ctypes.data, out.best_cost.ctypes.data, out.stats.ctypes.data
-        res.cost_tbl = out.cost.ctypes.data if tables else None
-        res.flag_tbl = out.flags.ctypes.data if tables else None
+        res.best_idx, res.best_cost, res.stats = _ptr(out.best_idx), _ptr(out.best_cost), _ptr(out.stats)
+        res.cost_tbl = _ptr(out.cost) if tables else None
+        res.flag_tbl = _ptr(out.flags) if tables else None
         out.best_flags = np.empty(B, dtype=np.uint32) if winner else None
         out.best_traj = np.empty((B, 16, TRAJ_STRIDE)) if winner else None
-        res.best_flags = out.best_flags.ctypes.data if winner else None
-        res.best_traj = out.best_traj.ctypes.data if winner else None
+        res.best_flags = _ptr(out.best_flags) if winner else None
+        res.best_traj = _ptr(out.best_traj) if winner else None
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
