@@ -569,7 +569,7 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit), "lattice kernel");
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
     if (R > 0) LAUNCH_TRY(fp::launch_fiss_refine(fa, stream, ctx->refine_table_kb), "refinement kernel");
-    if (fa.io.best_traj) {
+    if (fa.io.best_traj && R <= 0) {  // with refinement rounds the refinement kernel writes the series itself
         fp::KernelArgs kw = fa.ka;
         kw.r.best_flags = fa.io.best_flags;
         kw.r.best_traj = fa.io.best_traj;

@@ -16,6 +16,7 @@
 //           fiss_plus_planner.py:30-59, :80-148.
 #include "frenet_device.h"
 #include "frenet_kernels.h"
+#include "frenet_winner.h"
 
 namespace fp {
 
@@ -613,7 +614,16 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
     constexpr int kThreads = kWave * kRefineWaves;
     const int32_t* ijk = fa.io.best_ijk + (size_t)b * 3;
     const int R = fa.opts.max_refine_iters;
-    if (ijk[0] < 0 || R <= 0) return;  // nothing found by the coarse search: plan() returns None
+    if (ijk[0] < 0 || R <= 0) {  // nothing found by the coarse search: plan() returns None
+        if (fa.io.best_traj) {   // NaN series, flag word 0
+            KernelArgs kw = ka;
+            kw.r.best_traj = fa.io.best_traj;
+            kw.r.best_flags = fa.io.best_flags;
+            const double none = __builtin_nan("");
+            winner_series(kw, b, b, false, none, none, none, tid, SplineLds{nullptr, nullptr, 0, 0}, nullptr);
+        }
+        return;
+    }
     const int f = bt.frame_of[b];
     const int nx = bt.nx[f];
     const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 2 * kQueue;
@@ -705,6 +715,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
         lo[m] = fa.io.samp_min[(size_t)b * 3 + m];
         hi[m] = fa.io.samp_max[(size_t)b * 3 + m];
     }
+    const double coarse_x[3] = {x[0], x[1], x[2]};
     const double coarse_cost = analytic_cost(p, eg, target_speed, x, L.S);
 
     double my_x[3] = {nan, nan, nan}, my_cost = nan;  // lane c = refinement trajectory c (generation order)
@@ -794,24 +805,38 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
         }
         if (done) break;
     }
-    if (wave != 0) return;
-    if (fa.io.trace && lane < R * 7) {
-        double* tr = fa.io.trace + ((size_t)b * R * 7 + lane) * 4;
-        const bool have = lane < ncand;
-        tr[0] = have ? my_x[0] : nan; tr[1] = have ? my_x[1] : nan; tr[2] = have ? my_x[2] : nan; tr[3] = have ? my_cost : nan;
+    if (wave == 0) {
+        if (fa.io.trace && lane < R * 7) {
+            double* tr = fa.io.trace + ((size_t)b * R * 7 + lane) * 4;
+            const bool have = lane < ncand;
+            tr[0] = have ? my_x[0] : nan; tr[1] = have ? my_x[1] : nan; tr[2] = have ? my_x[2] : nan; tr[3] = have ? my_cost : nan;
+        }
+        if (lane == 0) {
+            int32_t* s4 = fa.io.stats + (size_t)b * 4;
+            s4[1] += ncand;
+            s4[2] += validated;
+            s4[3] += checks;
+            fa.io.best_cost[b] = coarse_cost;  // same evaluator as the refined costs
+        }
+        if (winner >= 0 && lane == winner) {
+            fa.io.refined[b] = 1;
+            fa.io.best_cost[b] = my_cost;
+            double* es = fa.io.end_state + (size_t)b * 3;
+            es[0] = my_x[0]; es[1] = my_x[1]; es[2] = my_x[2];
+        }
     }
-    if (lane == 0) {
-        int32_t* s4 = fa.io.stats + (size_t)b * 4;
-        s4[1] += ncand;
-        s4[2] += validated;
-        s4[3] += checks;
-        fa.io.best_cost[b] = coarse_cost;  // same evaluator as the refined costs
-    }
-    if (winner >= 0 && lane == winner) {
-        fa.io.refined[b] = 1;
-        fa.io.best_cost[b] = my_cost;
-        double* es = fa.io.end_state + (size_t)b * 3;
-        es[0] = my_x[0]; es[1] = my_x[1]; es[2] = my_x[2];
+    // winner epilogue (what plan() returns) on request: the series of the refined trajectory, or of the coarse winner when no
+    // refined one survived.  Every wavefront holds the same candidate list, so each reads the end state from its own registers;
+    // the power-sum table is dead by now and lends its LDS to the epilogue.
+    if (fa.io.best_traj) {
+        double fx[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) fx[m] = winner >= 0 ? __shfl(my_x[m], winner, kWave) : coarse_x[m];
+        KernelArgs kw = ka;
+        kw.r.best_traj = fa.io.best_traj;
+        kw.r.best_flags = fa.io.best_flags;
+        __syncthreads();
+        winner_series(kw, b, b, true, fx[0], fx[1], fx[2], tid, SplineLds{L.knots, L.coef, nx, nx}, L.S);
     }
 }
 
