@@ -674,10 +674,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 
     // ---------------------------------------------------------------- per-candidate assembly + argmin
     Best mine{0.0, -1};
-    // [section ASM]
     const float inv_nv_a = 1.0f / (float)nv, inv_nt_a = 1.0f / (float)nt;
+    // [section ASM]
     for (int c = tid; c < C; c += kThreads) {
-        // c = mul24(mul24(id, nt) + it, nv) + iv
+        // c = (id * nt + it) * nv + iv
         const int q1 = div_small(c, inv_nv_a), iv = c - mul24(q1, nv);
         const int id = div_small(q1, inv_nt_a), it = q1 - mul24(id, nt);
         if (it < it_lo || it >= it_hi) continue;  // another workgroup's slice (latency mode)
