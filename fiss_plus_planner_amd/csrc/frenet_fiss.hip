@@ -634,46 +634,28 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
     L.knots = L.S + refine_spline_off();
     L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * kQueue;
     L.coef = L.knots + nx;
+    // Order of the prologue: (1) the power-sum table, by all four wavefronts; (2) wavefront 0 runs the refinement rounds (they
+    // only need the table and the ego state) WHILE wavefronts 1..3 stage the spline and the pair table; (3) the candidate list
+    // goes through LDS to every wavefront.  The rounds are ~half of the kernel's instructions: running them once instead of
+    // four times is what matters (the kernel is instruction-issue bound), hiding them behind the staging is a bonus.
+    const double* gk = bt.knots + (size_t)f * bt.NX;
+    const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
+    L.pt = nullptr;
+    L.ox = gc[0];                       // x, y of the first knot
+    L.oy = gc[(size_t)4 * bt.NX];
+    const int sc0 = bt.scene_of[b];
+    L.scene = sc0;
+    L.t_now = bt.t_now[b];
+    L.horizon_cap = sc0 >= 0 ? bt.final_time_step[sc0] - L.t_now : 0;
+    int pt_rows = 0;
+    if (sc0 >= 0 && bt.n_obs > 0 && pt_rows_max > 0) {
+        int h = L.horizon_cap;
+        if (h > FP_MAX_POINTS) h = FP_MAX_POINTS;
+        if (h > bt.T_obs - L.t_now) h = bt.T_obs - L.t_now;
+        pt_rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;  // <= pt_rows_max by construction
+        L.pt = (float4*)(L.S + refine_pt_off(bt.NX));
+    }
     {
-        const double* gk = bt.knots + (size_t)f * bt.NX;
-        const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
-        for (int i = tid; i < nx; i += kThreads) L.knots[i] = gk[i];
-        for (int i = tid; i < 8 * nx; i += kThreads) {
-            const int r = i / nx, c = i - r * nx;
-            L.coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
-        }
-        // fp32 broad-phase table of every (checked row, obstacle) pair the collision horizon can touch, once per ego: the
-        // validation loop may visit the same pair for up to 21 trajectories
-        L.pt = nullptr;
-        L.ox = gc[0];                       // x, y of the first knot
-        L.oy = gc[(size_t)4 * bt.NX];
-        const int sc0 = bt.scene_of[b];
-        L.scene = sc0;
-        L.t_now = bt.t_now[b];
-        L.horizon_cap = sc0 >= 0 ? bt.final_time_step[sc0] - L.t_now : 0;
-        if (sc0 >= 0 && bt.n_obs > 0 && pt_rows_max > 0) {
-            const int t0 = L.t_now;
-            int h = L.horizon_cap;
-            if (h > FP_MAX_POINTS) h = FP_MAX_POINTS;
-            if (h > bt.T_obs - t0) h = bt.T_obs - t0;
-            const int rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;  // <= pt_rows_max by construction
-            L.pt = (float4*)(L.S + refine_pt_off(bt.NX));
-            const double* scene = bt.obs_pose + (size_t)sc0 * bt.T_obs * bt.n_obs * 4;
-            const double* gd = bt.obs_dims + (size_t)sc0 * bt.n_obs * 2;
-            const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
-            const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
-            for (int e = tid; e < rows * bt.n_obs; e += kThreads) {
-                const int r = e / bt.n_obs, j = e - r * bt.n_obs;
-                const double4 ps = *(const double4*)(scene + ((size_t)(r * p.check_stride + t0) * bt.n_obs + j) * 4);
-                const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
-                const double rx = ps.x - L.ox, ry = ps.y - L.oy;
-                // padding: 1 cm + 2e-6 of the coordinate magnitude dwarfs the fp32 rounding of rx, ry, the pose and the sum
-                const double R = r_ego + sqrt(fma(hl, hl, hw * hw)) + 1e-2 + 2e-6 * (fabs(rx) + fabs(ry));
-                float R2 = (float)(R * R * (1.0 + 1e-5));
-                if (ps.w == 0.0 || !(R2 >= 0.0f)) R2 = -1.0f;  // absent at this step (or NaN size): never passes
-                L.pt[e] = make_float4((float)rx, (float)ry, R2, __int_as_float((r * p.check_stride) | (j << 8)));
-            }
-        }
         // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane, the 128 steps split into one chunk per wavefront
         constexpr int kChunk = FP_MAX_POINTS / kRefineWaves;
         if (lane < 11) {
@@ -716,50 +698,88 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
         hi[m] = fa.io.samp_max[(size_t)b * 3 + m];
     }
     const double coarse_x[3] = {x[0], x[1], x[2]};
-    const double coarse_cost = analytic_cost(p, eg, target_speed, x, L.S);
-
-    double my_x[3] = {nan, nan, nan}, my_cost = nan;  // lane c = refinement trajectory c (generation order)
-    int ncand = 0;
-    for (int r = 0; r < R; ++r) {
-        const int dim = lane >> 1;
-        double xp[3] = {x[0], x[1], x[2]};
-        if (lane < 6) xp[dim] += (lane & 1) ? res[dim] : -res[dim];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) xp[m] = fmin(fmax(xp[m], lo[m]), hi[m]);  // np.clip
-        const bool bad = lane < 6 && (!(xp[0] == xp[0]) || !(xp[1] == xp[1]) || !(xp[2] == xp[2]));
-        if (__ballot(bad)) break;
-        const double cp = analytic_cost(p, eg, target_speed, xp, L.S);  // lanes >= 6 price x itself (unused)
-        for (int k = 0; k < 6; ++k) {  // hand probe k to lane ncand + k
-            const double c = __shfl(cp, k, kWave), a0 = __shfl(xp[0], k, kWave), a1 = __shfl(xp[1], k, kWave), a2 = __shfl(xp[2], k, kWave);
-            if (lane == ncand + k) { my_cost = c; my_x[0] = a0; my_x[1] = a1; my_x[2] = a2; }
+    double* cand = (double*)(smem + verdict_off + 32);  // [64][4] + {ncand, coarse cost}: the queues' bytes, free until validation
+    if (wave > 0) {
+        const int stid = tid - kWave;
+        constexpr int kStagers = kThreads - kWave;
+        for (int i = stid; i < nx; i += kStagers) L.knots[i] = gk[i];
+        for (int i = stid; i < 8 * nx; i += kStagers) {
+            const int r = i / nx, c = i - r * nx;
+            L.coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
         }
-        ncand += 6;
-        double g[3], nrm2 = 0.0;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const double Jl = __shfl(cp, 2 * m, kWave), Jr = __shfl(cp, 2 * m + 1, kWave);
-            const double xl = __shfl(xp[m], 2 * m, kWave), xr = __shfl(xp[m], 2 * m + 1, kWave);
-            g[m] = (Jr - Jl) / (xr - xl);
-            nrm2 += g[m] * g[m];
+        // fp32 broad-phase table of every (checked row, obstacle) pair the collision horizon can touch, once per ego: the
+        // validation loop may visit the same pair for up to 21 trajectories
+        if (L.pt) {
+            const int t0 = L.t_now;
+            const double* scene = bt.obs_pose + (size_t)sc0 * bt.T_obs * bt.n_obs * 4;
+            const double* gd = bt.obs_dims + (size_t)sc0 * bt.n_obs * 2;
+            const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
+            const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
+            for (int e = stid; e < pt_rows * bt.n_obs; e += kStagers) {
+                const int r = e / bt.n_obs, j = e - r * bt.n_obs;
+                const double4 ps = *(const double4*)(scene + ((size_t)(r * p.check_stride + t0) * bt.n_obs + j) * 4);
+                const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
+                const double rx = ps.x - L.ox, ry = ps.y - L.oy;
+                // padding: 1 cm + 2e-6 of the coordinate magnitude dwarfs the fp32 rounding of rx, ry, the pose and the sum
+                const double R = r_ego + sqrt(fma(hl, hl, hw * hw)) + 1e-2 + 2e-6 * (fabs(rx) + fabs(ry));
+                float R2 = (float)(R * R * (1.0 + 1e-5));
+                if (ps.w == 0.0 || !(R2 >= 0.0f)) R2 = -1.0f;  // absent at this step (or NaN size): never passes
+                L.pt[e] = make_float4((float)rx, (float)ry, R2, __int_as_float((r * p.check_stride) | (j << 8)));
+            }
         }
-        const double nrm = sqrt(nrm2);
-        double xn[3];
-        bool nan_step = false;
+    } else {
+        const double coarse_cost0 = analytic_cost(p, eg, target_speed, x, L.S);
+        double my_x[3] = {nan, nan, nan}, my_cost = nan;  // lane c = refinement trajectory c (generation order)
+        int ncand = 0;
+        for (int r = 0; r < R; ++r) {
+            const int dim = lane >> 1;
+            double xp[3] = {x[0], x[1], x[2]};
+            if (lane < 6) xp[dim] += (lane & 1) ? res[dim] : -res[dim];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            res[m] *= fa.opts.decaying_factor;  // decays in place, like the reference's aliasing of sampling_res (:282)
-            xn[m] = x[m] - res[m] * g[m] / nrm;
-            xn[m] = fmin(fmax(xn[m], lo[m]), hi[m]);
-            nan_step |= !(xn[m] == xn[m]);
+            for (int m = 0; m < 3; ++m) xp[m] = fmin(fmax(xp[m], lo[m]), hi[m]);  // np.clip
+            const bool bad = lane < 6 && (!(xp[0] == xp[0]) || !(xp[1] == xp[1]) || !(xp[2] == xp[2]));
+            if (__ballot(bad)) break;
+            const double cp = analytic_cost(p, eg, target_speed, xp, L.S);  // lanes >= 6 price x itself (unused)
+            for (int k = 0; k < 6; ++k) {  // hand probe k to lane ncand + k
+                const double c = __shfl(cp, k, kWave), a0 = __shfl(xp[0], k, kWave), a1 = __shfl(xp[1], k, kWave), a2 = __shfl(xp[2], k, kWave);
+                if (lane == ncand + k) { my_cost = c; my_x[0] = a0; my_x[1] = a1; my_x[2] = a2; }
+            }
+            ncand += 6;
+            double g[3], nrm2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const double Jl = __shfl(cp, 2 * m, kWave), Jr = __shfl(cp, 2 * m + 1, kWave);
+                const double xl = __shfl(xp[m], 2 * m, kWave), xr = __shfl(xp[m], 2 * m + 1, kWave);
+                g[m] = (Jr - Jl) / (xr - xl);
+                nrm2 += g[m] * g[m];
+            }
+            const double nrm = sqrt(nrm2);
+            double xn[3];
+            bool nan_step = false;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                res[m] *= fa.opts.decaying_factor;  // decays in place, like the reference's aliasing of sampling_res (:282)
+                xn[m] = x[m] - res[m] * g[m] / nrm;
+                xn[m] = fmin(fmax(xn[m], lo[m]), hi[m]);
+                nan_step |= !(xn[m] == xn[m]);
+            }
+            if (nan_step) break;  // zero gradient: the reference raises inside np.arange(nan); refinement stops here
+            const double cn = analytic_cost(p, eg, target_speed, xn, L.S);
+            if (lane == ncand) { my_cost = cn; my_x[0] = xn[0]; my_x[1] = xn[1]; my_x[2] = xn[2]; }
+            ncand += 1;
+            x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
         }
-        if (nan_step) break;  // zero gradient: the reference raises inside np.arange(nan); refinement stops here
-        const double cn = analytic_cost(p, eg, target_speed, xn, L.S);
-        if (lane == ncand) { my_cost = cn; my_x[0] = xn[0]; my_x[1] = xn[1]; my_x[2] = xn[2]; }
-        ncand += 1;
-        x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
+        cand[lane * 4] = my_x[0]; cand[lane * 4 + 1] = my_x[1]; cand[lane * 4 + 2] = my_x[2]; cand[lane * 4 + 3] = my_cost;
+        if (lane == 0) { cand[4 * kWave] = (double)ncand; cand[4 * kWave + 1] = coarse_cost0; }
     }
-    // refined_trajs.get() in cost order (ties: generation order), :301-323.  Every wavefront holds the same candidate list (the
-    // rounds above are replicated, bit-identical); the next kRefineWaves trajectories in pop order are checked SPECULATIVELY side
+    __syncthreads();
+    double my_x[3] = {cand[lane * 4], cand[lane * 4 + 1], cand[lane * 4 + 2]};  // lane c = refinement trajectory c (generation order)
+    const double my_cost = cand[lane * 4 + 3];
+    const int ncand = (int)cand[4 * kWave];
+    const double coarse_cost = cand[4 * kWave + 1];
+    __syncthreads();  // the queues take their bytes back
+    // refined_trajs.get() in cost order (ties: generation order), :301-323.  Every wavefront holds the same candidate list;
+    // the next kRefineWaves trajectories in pop order are checked SPECULATIVELY side
     // by side, one whole wavefront each, and the verdicts are then consumed in pop order exactly like the sequential loop -
     // validated / checks count only what the reference would have popped before its first collision-free trajectory.
     uint32_t* verdict = (uint32_t*)(smem + verdict_off);  // [2][kRefineWaves], double-buffered across groups
