@@ -109,7 +109,7 @@ class FrenetEngine:
 
         Returns best_idx [B] (flat (i_d*nt+i_T)*nv+i_v, -1 = none), best_cost [B], stats [B,4] and, with
         tables=True, cost [B,C] and flags [B,C]; with winner=True also best_flags [B] and best_traj [B,16,128]
-        (the argmin's full series, computed by the epilogue kernel of the same call).
+        (the argmin's full series, written by the lattice kernel itself).
         """
         B, Cn = batch.B, batch.C
         out = SimpleNamespace(best_idx=np.empty(B, dtype=np.int32), best_cost=np.empty(B), stats=np.empty((B, 4), dtype=np.int32),

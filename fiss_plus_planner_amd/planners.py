@@ -223,7 +223,7 @@ class FrenetOptimalPlanner:
         self.stats = Stats()
         self.settings.highest_speed = max_target_speed
         batch = self._make_batch(frenet_state, obstacles, time_step_now)
-        out = self._dense(batch, winner=True)  # one call: lattice kernel + winner epilogue kernel
+        out = self._dense(batch, winner=True)  # one call, one launch: lattice + argmin + the winner's series
         C = batch.C
         self.stats = Stats(0, C, C, C)
         best = int(out.best_idx[0])

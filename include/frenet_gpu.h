@@ -141,8 +141,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
                   void* stream);
 
 /* Winner epilogue on its own: full series of lattice candidate best_idx[b] for every ego -> best_flags [B],
- * best_traj [B][16][FP_MAX_POINTS].  fp_plan_dense runs it itself when result.best_traj is set; exported separately so a
- * caller can time / schedule the two kernels independently.  Replaces the object hand-back of plan() (:264-270). */
+ * best_traj [B][16][FP_MAX_POINTS].  fp_plan_dense produces the same output inside its own launch when result.best_traj is set
+ * (the workgroup that finds the argmin writes the series); exported separately for callers that pick the trajectory
+ * themselves.  Replaces the object hand-back of plan() (:264-270). */
 int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
                     double* best_traj, int mem, void* stream);
 
