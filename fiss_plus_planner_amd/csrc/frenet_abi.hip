@@ -98,9 +98,13 @@ class HostStage {
   public:
     explicit HostStage(fp_ctx* ctx) : ctx_(ctx) {}
 
-    int reserve(size_t large_bytes)
+    // zero_copy_out (latency regime, a handful of egos): small outputs are written by the kernels straight into the pinned
+    // host block (it is device-visible) - no D2H command at all after the launch, only the stream synchronisation.  Larger
+    // batches keep the outputs in HBM (kernels of the same call read each other's outputs) and fetch them with one copy.
+    int reserve(size_t large_bytes, bool zero_copy_out = false)
     {
         FP_TRY(ctx_->arena.reserve(kSmallRegion + large_bytes + kAlign));
+        zero_copy_out_ = zero_copy_out;
         small_ = 0;
         large_ = kSmallRegion;
         outs_.clear();
@@ -136,7 +140,7 @@ class HostStage {
         const T* c = nullptr;
         FP_TRY(in((const T*)host, count, &c));
         *dev = const_cast<T*>(c);
-        outs_.push_back({host, (char*)*dev, sizeof(T) * count, false});
+        outs_.push_back({host, 0, (char*)*dev, sizeof(T) * count, false});
         return FP_OK;
     }
     int flush_in()  // the output window of the small region starts after the inputs
@@ -152,13 +156,13 @@ class HostStage {
         if (!host || count == 0) return nullptr;
         if (bytes <= kSmallMax && align_up(small_out_hi_) + bytes <= kSmallRegion) {
             small_out_hi_ = align_up(small_out_hi_);
-            T* d = (T*)(ctx_->arena.base + small_out_hi_);
-            outs_.push_back({host, (char*)d, bytes, true});
+            T* d = (T*)((zero_copy_out_ ? ctx_->pinned : ctx_->arena.base) + small_out_hi_);
+            outs_.push_back({host, small_out_hi_, (char*)d, bytes, true});
             small_out_hi_ += bytes;
             return d;
         }
         T* d = temp<T>(count);
-        outs_.push_back({host, (char*)d, bytes, false});
+        outs_.push_back({host, 0, (char*)d, bytes, false});
         return d;
     }
     template <typename T>
@@ -171,25 +175,27 @@ class HostStage {
     }
     int fetch_out()
     {
-        if (small_out_hi_ > small_out_lo_)
+        if (small_out_hi_ > small_out_lo_ && !zero_copy_out_)
             HIP_TRY(hipMemcpyAsync(ctx_->pinned + small_out_lo_, ctx_->arena.base + small_out_lo_, small_out_hi_ - small_out_lo_,
                                    hipMemcpyDeviceToHost, ctx_->stream));
         for (const Out& o : outs_)
             if (!o.via_pinned) HIP_TRY(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx_->stream));
         HIP_TRY(hipStreamSynchronize(ctx_->stream));
         for (const Out& o : outs_)
-            if (o.via_pinned) memcpy(o.host, ctx_->pinned + (o.dev - ctx_->arena.base), o.bytes);
+            if (o.via_pinned) memcpy(o.host, ctx_->pinned + o.small_off, o.bytes);
         return FP_OK;
     }
 
   private:
     struct Out {
         void* host;
+        size_t small_off;  // offset in the small region (via_pinned)
         char* dev;
         size_t bytes;
         bool via_pinned;
     };
     fp_ctx* ctx_;
+    bool zero_copy_out_ = false;
     size_t small_ = 0, large_ = 0, small_out_lo_ = 0, small_out_hi_ = 0;
     std::vector<Out> outs_;
 };
@@ -415,7 +421,8 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<int32_t>(B * 4) + 2 * HostStage::need<double>(B) + HostStage::need<int32_t>(B) +
                       HostStage::need<double>(B * C) + HostStage::need<uint32_t>(B * C) + HostStage::need<uint32_t>(B) +
-                      HostStage::need<double>(traj_doubles)));
+                      HostStage::need<double>(traj_doubles),
+                      /*zero_copy_out=*/B <= 8));
     FP_TRY(stage_batch(hs, params, batch, &ka.b));
     FP_TRY(hs.flush_in());
     ka.r.best_idx = hs.out(result->best_idx, B);
@@ -547,7 +554,8 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         FP_TRY(check_batch_host(params, batch));
         FP_TRY(hs.reserve(batch_need(params, batch) + 4 * HostStage::need<double>(B * 3) + 2 * HostStage::need<int32_t>(B * 3) +
                           HostStage::need<double>(B) + 2 * HostStage::need<int32_t>(B * 4) + HostStage::need<uint32_t>(B) +
-                          HostStage::need<double>(trace_doubles) + HostStage::need<double>(traj_doubles)));
+                          HostStage::need<double>(trace_doubles) + HostStage::need<double>(traj_doubles),
+                          /*zero_copy_out=*/B <= 8));
         FP_TRY(stage_batch(hs, params, batch, &fa.ka.b));
         fa.io = *io;
         FP_TRY(hs.in(io->samp_min, B * 3, &fa.io.samp_min));
