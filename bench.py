@@ -277,6 +277,22 @@ def main():
                 traffic = json.load(open(tpath)).get(f"config{args.config}_B{B}")
             except Exception:
                 traffic = None
+        # VALU issue: the resource that actually binds the lattice kernel.  Wave-level VALU instructions per launch come from the
+        # committed PMC pass (profiles/, SQ_INSTS_VALU - a property of kernel + input, not of the run); the rate uses this run's
+        # kernel time; the peak is one VALU instruction per SIMD every 4 cycles (wave64 on a 16-lane SIMD) at the boost clock.
+        valu_issue = None
+        ppath = os.path.join(ROOT, "profiles", "r01_config3_pmc_summary.json")
+        if not fiss and args.config == 3 and B == 2048 and os.path.exists(ppath):
+            try:
+                pmc = json.load(open(ppath))
+                insts = next(v["SQ_INSTS_VALU"] for k, v in pmc.items() if "lattice_fused" in k)
+                peak = 256 * 4 * 2.4e9 / 4.0
+                valu_issue = {"wave_instructions_per_launch": insts, "rate": insts / (kern_ms * 1e-3), "peak": peak,
+                              "unit": "wave-instructions/s", "frac": insts / (kern_ms * 1e-3) / peak,
+                              "source": "SQ_INSTS_VALU from profiles/r01_config3_pmc_summary.json (rocprofv3 --pmc), this run's kernel time; "
+                                        "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
+            except Exception:
+                valu_issue = None
         line = {
             "metric": "candidate trajectories/sec (gen+cost+collision) per GPU; plan-cycle p50 latency", "value": value, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -290,12 +306,13 @@ def main():
                          "traffic": traffic, "kernel": "lattice_fused_kernel (lattice + argmin + winner series)" if not fiss else "lattice_fused + fiss_search + fiss_refine + winner_traj (whole pipeline)",
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "fused kernel is FP64-VALU bound, not HBM bound; see valu_fp64"},
+                         "note": "the kernel is VALU-issue bound, not HBM bound: see valu_issue (executed instructions) and valu_fp64"},
             "valu_fp64": {"reference_algorithm_rate": ach_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "reference_algorithm_flops_per_launch": flops_launch,
                           "note": "flops the reference's per-candidate algorithm would need (SURVEY 8d accounting) / kernel time; "
                                   "the kernel executes far fewer (profile sharing, broad phase) - executed-instruction "
                                   "counts from rocprofv3 PMC are in DESIGN.md"},
+            "valu_issue": valu_issue,
             "cpu_baseline": cpu_baseline,
             "plan_cycle_latency": plan_cycle,
             "materialize_mode": materialize,
