@@ -56,7 +56,7 @@ def random_batch(seed):
                         check_stride=int(rng.choice([1, 2, 3])))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FP_PROPERTY_SEEDS", "40"))))
 def test_random_settings_vs_oracle(oracle, engine, seed):
     b = random_batch(1000 + seed)
     probs = oracle.problems_from_batch(b)
@@ -89,7 +89,7 @@ def test_random_settings_vs_oracle(oracle, engine, seed):
 
 
 @pytest.mark.parametrize("kind", ["FISS", "FISS+"])
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FP_PROPERTY_SEEDS_SEARCH", "30"))))
 def test_random_settings_search_vs_oracle(oracle, engine, seed, kind):
     """The device-side search walk + refinement on the same randomised settings (lattice axes of at least two samples):
     Stats, selected index / refined end state and history index exactly as the oracle's restatement of the planners."""
