@@ -8,17 +8,21 @@
 //     spline is evaluated nt*nv*N times per ego, not nd*nv*nt*N times (9x fewer at 9x9x7)
 //   * cost_final = (time + lon sums + lat sums) / N recombines per candidate with the reference's grouping
 //
+// Once per ego (phase A0): one lane per lon profile solves the boundary-value problem and tries to PROVE the profile clean from
+// the extrema of its polynomials (speed / acceleration limits, inside the spline's range); only slices with an unproven profile
+// run the reference's point-by-point scan (lane per (profile, point), LDS atomics).  The cost sums of every profile follow in
+// closed form from the per-slice power sums (Faulhaber) - no per-point work.
 // Per time-horizon slice i_T (all candidates that share T):
-//   phase A  one wavefront per profile, one lane per time point: quartic/quintic evaluation, ballot for the
-//            speed/accel masks and for the truncation index M (first point off the spline), DPP tree sums
-//            for the cost terms, spline frames of the points the collision horizon can touch -> LDS
+//   phase A  one lane per (profile, time point) the collision horizon can touch: spline frames and lateral offsets -> LDS, fan
+//            bounds and per-row bounding boxes by LDS atomic max / min
+//   prep     one lane per (pose row, lon profile): the fan's half-width along the reference normal; row boxes -> circles
 //   phase B  three block-wide stages, every lane busy in each: G  (row, obstacle) items against the circle that encloses the
 //            row's reference points of ALL lon profiles; B  (surviving item, lon profile) pairs against a circle fattened by
 //            the largest lateral offset of the slice and a separating axis along the reference normal; N  (hit, lateral
 //            sample) pairs: exact ego centre + heading, exact circle test, 4-axis separating-axis test (closed: touching
 //            collides).  Survivors are appended to block-wide LDS lists with ballot/popcount + one atomic per wavefront.
-// Finally one lane per candidate assembles cost + flag word and a wave/LDS argmin with FOP's
-// "last minimum wins" rule picks the winner.
+// Finally one lane per candidate assembles cost + flag word, a wave/LDS argmin with FOP's "last minimum wins" rule picks the
+// winner, and - when the caller asked for it - the same workgroup writes the winner's series (frenet_winner.h).
 //
 // Semantics restated from the reference (paths relative to its checkout):
 //   lattice + cost      planners/frenet_optimal_planner.py:69-104, planners/common/cost/cost_function.py:41-50
