@@ -208,7 +208,15 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     int* s_nslice = (int*)(smem + L.nslice);
     Best* s_best = (Best*)(smem + L.best);
 
-    if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch (block-uniform exit)
+    // the ego's scalars: independent global reads, all issued before the first one is waited for (a read costs ~1-2 us)
+    const int skip_flag = bt.skip ? bt.skip[b] : 0;
+    const int f = bt.frame_of[b];
+    const int sc = bt.scene_of[b];
+    const int t_now = bt.t_now[b];
+    const double target_speed = bt.target_speed[b];
+    const double* eg = bt.ego + (size_t)b * 6;
+    const double s0 = eg[0], s_d0 = eg[1], s_dd0 = eg[2], d0 = eg[3], d_d0 = eg[4], d_dd0 = eg[5];
+    if (skip_flag) {  // finished ego of a closed-loop batch (block-uniform exit)
         if (part == 0) {
             if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
             if (ka.r.best_traj) {  // NaN series, flag word 0 (returns before it touches the spline or the scratch)
@@ -219,11 +227,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         return;
     }
     // ---------------------------------------------------------------- stage: ego, spline, obstacle rows
-    const double* eg = bt.ego + (size_t)b * 6;
-    const double s0 = eg[0], s_d0 = eg[1], s_dd0 = eg[2], d0 = eg[3], d_d0 = eg[4], d_dd0 = eg[5];
-    const double target_speed = bt.target_speed[b];
-    const int f = bt.frame_of[b];
     const int nx = bt.nx[f];
+    const int fts = sc >= 0 && bt.n_obs > 0 ? bt.final_time_step[sc] : 0;
     {
         const double* gk = bt.knots + (size_t)f * bt.NX;
         const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
@@ -255,13 +260,11 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         s_lut[bkt] = (unsigned short)seg;
     }
 
-    const int sc = bt.scene_of[b];
     const int n_obs = sc >= 0 ? bt.n_obs : 0;
-    const int t_now = bt.t_now[b];
     int horizon_cap = 0;  // final_time_step - time_step_now (:173-174)
     int rows = 0;         // obstacle rows that exist for this ego: poses k = r*stride, k + t_now < T_obs
     if (n_obs > 0) {
-        horizon_cap = bt.final_time_step[sc] - t_now;
+        horizon_cap = fts - t_now;
         int h = horizon_cap < FP_MAX_POINTS ? horizon_cap : FP_MAX_POINTS;
         if (h < 0) h = 0;
         rows = (h + stride - 1) / stride;
