@@ -88,6 +88,7 @@ struct fp_ctx {
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
     int refine_table_kb = 24;      // fp_ctx_set_option("refine_table_kb")
+    int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
 };
 
 namespace {
@@ -280,9 +281,11 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
 {
     *nsplit = 1;
     *parts = nullptr;
-    const bool want = ctx->lattice_split == 2 || (ctx->lattice_split == 0 && (long)b->B * p->nt <= 1024);
+    // auto: split while all B * nt workgroups are resident at once (measured on MI355X: 1.6-2.5x faster up to that point,
+    // slower beyond it - a second round of workgroups costs more than the shorter critical path saves)
+    const bool want = ctx->lattice_split == 2 || (ctx->lattice_split == 0 && (long)b->B * p->nt <= ctx->resident_groups);
     if (!want || p->nt < 2) return FP_OK;
-    // want implies B * nt <= 1024 or an explicit request: the counters get a fixed region in front (kTicketBytes) so that they
+    // want implies a small batch or an explicit request: the counters get a fixed region in front (kTicketBytes) so that they
     // never share bytes with the partial argmins of a call with another B
     if ((size_t)b->B * 4 > fp::kTicketBytes) return FP_OK;  // (an explicitly requested split of a huge batch: not worth it)
     const size_t need = fp::kTicketBytes + (size_t)b->B * p->nt * 16 + kAlign;
@@ -357,6 +360,8 @@ int fp_ctx_create(int device, fp_ctx** out)
         delete ctx;
         return fail(FP_EHIP, "ctx resources: %s", hipGetErrorString(e));
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->resident_groups = 2 * prop.multiProcessorCount;
     *out = ctx;
     return FP_OK;
 }
