@@ -281,10 +281,22 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
 {
     *nsplit = 1;
     *parts = nullptr;
-    // auto: split while all B * nt workgroups are resident at once (measured on MI355X: 1.6-2.5x faster up to that point,
-    // slower beyond it - a second round of workgroups costs more than the shorter critical path saves)
-    const bool want = ctx->lattice_split == 2 || (ctx->lattice_split == 0 && (long)b->B * p->nt <= ctx->resident_groups);
-    if (!want || p->nt < 2) return FP_OK;
+    // auto: as many workgroups per ego as keep ALL workgroups resident at once (measured on MI355X: 1.6-2.5x faster up to that
+    // point, slower beyond it - a second round of workgroups costs more than the shorter critical path saves); at most one
+    // workgroup per slice
+    int parts_per_ego = p->nt;
+    if (ctx->lattice_split == 0) {
+        const long fit = b->B > 0 ? ctx->resident_groups / (long)b->B : 0;
+        parts_per_ego = (int)(fit < p->nt ? fit : p->nt);
+        // fewer workgroups than slices only pays when the slices carry the work (obstacle-time items); with a handful of
+        // obstacles the per-workgroup fixed cost (staging, profile sums, ticket) dominates and one workgroup per ego is faster
+        const long t_rows = (b->T_obs < FP_MAX_POINTS ? b->T_obs : FP_MAX_POINTS) / (p->check_stride > 0 ? p->check_stride : 1);
+        const bool has_obs = b->S > 0 && b->n_obs > 0;
+        if (parts_per_ego < p->nt && (!has_obs || t_rows * b->n_obs < 600)) parts_per_ego = 1;
+    } else if (ctx->lattice_split == 1) {
+        parts_per_ego = 1;
+    }
+    if (parts_per_ego < 2 || p->nt < 2) return FP_OK;
     // want implies a small batch or an explicit request: the counters get a fixed region in front (kTicketBytes) so that they
     // never share bytes with the partial argmins of a call with another B
     if ((size_t)b->B * 4 > fp::kTicketBytes) return FP_OK;  // (an explicitly requested split of a huge batch: not worth it)
@@ -295,7 +307,7 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
         // ticket counters start at zero; every launch leaves them at zero
         HIP_TRY(hipMemsetAsync(ctx->parts.base, 0, fp::kTicketBytes, stream));
     }
-    *nsplit = p->nt;
+    *nsplit = parts_per_ego;
     *parts = ctx->parts.base;
     return FP_OK;
 }

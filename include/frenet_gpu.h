@@ -125,8 +125,10 @@ int fp_ctx_destroy(fp_ctx* ctx);
 /* Diagnostic knobs.  "lattice_kernel": 0 = auto (default), 1 = lane-per-candidate kernel, 2 = fused
  * profile-sharing kernel only (fails with FP_EHIP if the problem does not fit it).  Results are identical
  * (flags / indices exactly, costs to ~1e-13); used by the A/B parity tests and by profiling.
- * "lattice_split": 0 = auto (default: batches with B*nt <= 2 x compute units - all workgroups resident at once - spread the time-horizon slices of every ego over nt
- * workgroups - latency mode), 1 = never, 2 = always.  Identical results either way.
+ * "lattice_split": 0 = auto (default: an ego's time-horizon slices are spread over as many workgroups - at most one per
+ * slice - as keep ALL workgroups of the launch resident at once, 2 per compute unit: latency mode for small batches; fewer
+ * workgroups than slices only when the scene has enough obstacle-time items to make the slices the bulk of the work), 1 = never,
+ * 2 = always one workgroup per slice.  Identical results either way.
  * "refine_table_kb": LDS budget (KiB, default 24, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
  * table; scenes whose table does not fit are checked straight from the scene table.  Identical results either way. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
