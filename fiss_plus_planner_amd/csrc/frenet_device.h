@@ -293,7 +293,6 @@ __device__ __forceinline__ double dpp_f64(double v)
 // v_min / v_max without the canonicalising v_max x, x, x the compiler puts in front of every fmin / fmax operand (IEEE mode);
 // a quiet NaN operand yields the other operand, like fmin / fmax.  Halves the length of the DPP reduction chains.
 __device__ __forceinline__ double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmax_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // after these four steps every lane holds the reduction of its row of 16 lanes
@@ -311,35 +310,6 @@ __device__ __forceinline__ double row16_min(double v)
     v = vmin_f64(v, dpp_f64<0x4E>(v));
     v = vmin_f64(v, dpp_f64<0x141>(v));
     v = vmin_f64(v, dpp_f64<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ double row16_max(double v)
-{
-    v = vmax_f64(v, dpp_f64<0xB1>(v));
-    v = vmax_f64(v, dpp_f64<0x4E>(v));
-    v = vmax_f64(v, dpp_f64<0x141>(v));
-    v = vmax_f64(v, dpp_f64<0x140>(v));
-    return v;
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v)
-{
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_min_f32(float v)
-{
-    v = vmin_f32(v, dpp_f32<0xB1>(v));
-    v = vmin_f32(v, dpp_f32<0x4E>(v));
-    v = vmin_f32(v, dpp_f32<0x141>(v));
-    v = vmin_f32(v, dpp_f32<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ float row16_max_f32(float v)
-{
-    v = vmax_f32(v, dpp_f32<0xB1>(v));
-    v = vmax_f32(v, dpp_f32<0x4E>(v));
-    v = vmax_f32(v, dpp_f32<0x141>(v));
-    v = vmax_f32(v, dpp_f32<0x140>(v));
     return v;
 }
 __device__ __forceinline__ double lane_value(double v, int src_lane)  // src_lane must be wave-uniform

@@ -72,15 +72,6 @@ struct __attribute__((aligned(16))) ObsDim {
     double hl, hw, r, pad;
 };
 
-__device__ __forceinline__ void lds_wave_sync()
-{
-    // LDS operations of one wavefront are issued and served in order; this only stops the compiler
-    // from moving queue reads above queue writes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
     int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, nslice, best, total;
