@@ -606,10 +606,14 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             const double fat = (r_ego + od.r + (double)s_dmax[k]) * (1.0 + 1e-12);
                             const double dx = op.x - fr.px, dy = op.y - fr.py;
                             // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre
-                            // vs the fan half-width + the obstacle's own reach along n_k.  A NaN pose passes both (-> "collision").
-                            const double w = fma(dy, fr.tx, -dx * fr.ty);
-                            const double reach = fma(od.hl, fabs(fma(op.s, fr.tx, -op.c * fr.ty)), od.hw * fabs(fma(op.c, fr.tx, op.s * fr.ty)));
-                            pass = !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach);
+                            // vs the fan half-width + the obstacle's own reach along n_k; (3) separating axis t_k: every ego centre
+                            // of the fan lies ON the normal line, so along t_k the fan reaches no further than the ego box's
+                            // half-diagonal.  A NaN pose passes all three (-> "collision").
+                            const double w = fma(dy, fr.tx, -dx * fr.ty), u = fma(dx, fr.tx, dy * fr.ty);
+                            const double a_n = fabs(fma(op.s, fr.tx, -op.c * fr.ty)), a_t = fabs(fma(op.c, fr.tx, op.s * fr.ty));
+                            const double reach = fma(od.hl, a_n, od.hw * a_t), reach_t = fma(od.hl, a_t, od.hw * a_n);
+                            pass = !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach) &&
+                                   !(fabs(u) > r_ego * (1.0 + 1e-12) + reach_t);
                             code = ((uint32_t)iv << 24) | ((uint32_t)r << 12) | (uint32_t)j;
                         }
                         const unsigned long long m = __ballot(pass);
