@@ -215,6 +215,17 @@ class FrenetEngine:
         res.best_flags, res.best_traj = best_flags or None, best_traj or None
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(params), C.byref(fb), C.byref(res), _abi.FP_MEM_DEVICE, stream or None))
 
+    def winner_trajs(self, batch: ProblemBatch, best_idx: np.ndarray):
+        """The standalone winner epilogue (fp_winner_trajs): series of lattice candidate best_idx[b] for every ego
+        -> best_flags [B], best_traj [B,16,128] (NaN rows and flag 0 where best_idx < 0)."""
+        bi = np.ascontiguousarray(best_idx, dtype=np.int32)
+        out = SimpleNamespace(best_flags=np.empty(batch.B, dtype=np.uint32), best_traj=np.empty((batch.B, 16, TRAJ_STRIDE)))
+        p = make_params(batch)
+        fb = _host_batch(batch)
+        _abi.check(self._lib.fp_winner_trajs(self._ctx, C.byref(p), C.byref(fb), _ptr(bi), _ptr(out.best_flags), _ptr(out.best_traj),
+                                             _abi.FP_MEM_HOST, None))
+        return out
+
     def winner_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_flags: int, best_traj: int, stream: int = 0):
         """Enqueue the winner epilogue alone (device addresses)."""
         _abi.check(self._lib.fp_winner_trajs(self._ctx, C.byref(params), C.byref(fb), best_idx, best_flags, best_traj,
