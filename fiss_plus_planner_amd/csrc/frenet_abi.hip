@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "frenet_kernels.h"
@@ -89,6 +90,18 @@ struct fp_ctx {
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
     int refine_table_kb = 24;      // fp_ctx_set_option("refine_table_kb")
     int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
+    // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
+    // leaves its ego's duration in dur_dev; now and then the host fetches them (async copy + event, never a wait), sorts the egos
+    // longest-first and uploads the order the following launches dispatch in.  A stale or missing order only costs speed.
+    int lattice_order = 1;
+    DeviceBuf order_buf;           // [dur: int x cap][perm: int x cap]
+    int* order_host = nullptr;     // pinned: [dur x cap][perm x cap]
+    int order_cap = 0;             // egos the buffers hold
+    int order_valid_B = 0;         // the uploaded order is a permutation of [0, order_valid_B)
+    int order_dur_B = 0;           // batch size of the durations in flight / on the device
+    int order_since = 0;           // launches since the last fetch was enqueued
+    bool order_pending = false;    // a fetch is in flight (order_event)
+    hipEvent_t order_event = nullptr;
 };
 
 namespace {
@@ -275,6 +288,70 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
     return FP_OK;
 }
 
+// Launch order of a multi-round lattice launch (more egos than resident workgroups, one workgroup per ego).  Called right before
+// the launch: hands out the permutation to dispatch in (nullptr = index order) and the array the workgroups leave their durations
+// in.  Host work happens only when a fetched duration table has arrived (hipEventQuery, no wait): an argsort of B ints.
+constexpr int kOrderRefresh = 8;  // launches between two fetches of the duration table
+int lattice_order_before(fp_ctx* ctx, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur)
+{
+    *perm = nullptr;
+    *dur = nullptr;
+    if (!ctx->lattice_order || nsplit != 1 || b->B <= ctx->resident_groups) return FP_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (b->B > ctx->order_cap) {
+        if (capturing) return FP_OK;  // no (re)allocation inside a capture: index order
+        if (ctx->order_pending) { HIP_TRY(hipEventSynchronize(ctx->order_event)); ctx->order_pending = false; }
+        HIP_TRY(hipStreamSynchronize(stream));
+        const int cap_new = b->B + b->B / 4;
+        FP_TRY(ctx->order_buf.reserve((size_t)cap_new * 2 * sizeof(int)));
+        if (ctx->order_host) (void)hipHostFree(ctx->order_host);
+        ctx->order_host = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&ctx->order_host, (size_t)cap_new * 2 * sizeof(int), hipHostMallocDefault));
+        if (!ctx->order_event) HIP_TRY(hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
+        ctx->order_cap = cap_new;
+        ctx->order_valid_B = ctx->order_dur_B = 0;
+        ctx->order_since = 0;
+    }
+    int* d_dur = (int*)ctx->order_buf.base;
+    int* d_perm = d_dur + ctx->order_cap;
+    if (!capturing && ctx->order_pending && hipEventQuery(ctx->order_event) == hipSuccess) {
+        ctx->order_pending = false;
+        const int n = ctx->order_dur_B;
+        if (n == b->B) {  // longest first; ties in index order (std::stable_sort keeps the result deterministic)
+            const int* h_dur = ctx->order_host;
+            int* h_perm = ctx->order_host + ctx->order_cap;
+            for (int i = 0; i < n; ++i) h_perm[i] = i;
+            std::stable_sort(h_perm, h_perm + n, [h_dur](int x, int y) { return h_dur[x] > h_dur[y]; });
+            HIP_TRY(hipMemcpyAsync(d_perm, h_perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+            ctx->order_valid_B = n;
+        }
+    } else if (ctx->order_pending) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error
+    }
+    if (ctx->order_valid_B == b->B) *perm = d_perm;
+    *dur = d_dur;
+    return FP_OK;
+}
+
+// Right after the launch: every kOrderRefresh launches enqueue the fetch of the durations this launch leaves behind.
+int lattice_order_after(fp_ctx* ctx, const fp_batch* b, const int* dur, hipStream_t stream)
+{
+    if (!dur) return FP_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone || ctx->order_pending) return FP_OK;
+    const bool first = ctx->order_valid_B != b->B;  // no order for this batch size yet: fetch at once
+    if (!first && ++ctx->order_since < kOrderRefresh) return FP_OK;
+    ctx->order_since = 0;
+    HIP_TRY(hipMemcpyAsync(ctx->order_host, dur, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ctx->order_event, stream));
+    ctx->order_dur_B = b->B;
+    ctx->order_pending = true;
+    return FP_OK;
+}
+
 // Latency mode: a small batch cannot fill 256 CUs with one workgroup per ego, so the time-horizon slices of every ego are
 // spread over nt workgroups.  Returns the split factor and makes sure the partial-argmin buffer exists.
 int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, int* nsplit, void** parts)
@@ -386,6 +463,9 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     if (ctx->parts.base) (void)hipFree(ctx->parts.base);
+    if (ctx->order_buf.base) (void)hipFree(ctx->order_buf.base);
+    if (ctx->order_host) (void)hipHostFree(ctx->order_host);
+    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
     return FP_OK;
@@ -397,6 +477,12 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
     if (strcmp(name, "lattice_kernel") == 0) {
         if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_kernel must be 0 (auto), 1 (per-candidate) or 2 (fused)");
         ctx->lattice_kernel = value;
+        return FP_OK;
+    }
+    if (strcmp(name, "lattice_order") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "lattice_order must be 0 or 1");
+        ctx->lattice_order = value;
+        ctx->order_valid_B = 0;
         return FP_OK;
     }
     if (strcmp(name, "refine_table_kb") == 0) {
@@ -429,7 +515,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         int nsplit; void* parts;
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
         bool winner_done = false;
-        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done), "lattice kernel");
+        const int* perm; int* dur;
+        FP_TRY(lattice_order_before(ctx, batch, nsplit, (hipStream_t)stream, &perm, &dur));
+        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
+        FP_TRY(lattice_order_after(ctx, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
     }
@@ -452,7 +541,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     int nsplit; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts));
     bool winner_done = false;
-    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done), "lattice kernel");
+    const int* perm; int* dur;
+    FP_TRY(lattice_order_before(ctx, batch, nsplit, ctx->stream, &perm, &dur));
+    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
+    FP_TRY(lattice_order_after(ctx, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     return hs.fetch_out();
 }
@@ -591,7 +683,10 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     }
     int nsplit; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
-    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit), "lattice kernel");
+    const int* perm; int* dur;
+    FP_TRY(lattice_order_before(ctx, batch, nsplit, stream, &perm, &dur));
+    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur), "lattice kernel");
+    FP_TRY(lattice_order_after(ctx, batch, dur, stream));
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
     if (R > 0) LAUNCH_TRY(fp::launch_fiss_refine(fa, stream, ctx->refine_table_kb), "refinement kernel");
     if (fa.io.best_traj && R <= 0) {  // with refinement rounds the refinement kernel writes the series itself

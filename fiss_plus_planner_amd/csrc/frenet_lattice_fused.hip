@@ -154,12 +154,15 @@ __device__ __forceinline__ void power_sums_closed(int N, double tick, double* ou
 
 // nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
 // writes its partial argmin to part_best[ego * nsplit + part]; the last one to arrive (ticket counter) merges them.
-__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best, int* part_count)
+__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best, int* part_count, const int* perm,
+                                                                   int* dur)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const long long t_begin = dur ? wall_clock64() : 0;
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
-    const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit;
+    // launch order: longest egos first when the host has an order for this batch (perm; nsplit == 1 then)
+    const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x / nsplit, part = perm ? 0 : (int)blockIdx.x - b * nsplit;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const double s0 = eg[0], s_d0 = eg[1], s_dd0 = eg[2], d0 = eg[3], d_d0 = eg[4], d_dd0 = eg[5];
     if (skip_flag) {  // finished ego of a closed-loop batch (block-uniform exit)
         if (part == 0) {
+            if (tid == 0 && dur) dur[b] = 0;
             if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
             if (ka.r.best_traj) {  // NaN series, flag word 0 (returns before it touches the spline or the scratch)
                 const double nan = __builtin_nan("");
@@ -739,6 +743,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
         }
     }
+    if (tid == 0 && dur && nsplit == 1) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
     // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
     // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
     // 16 KB of stores per ego hide behind the other workgroups' arithmetic.
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the
 // lane-per-candidate kernel, which keeps oversized obstacle tables in HBM/L2).
-hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done)
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur)
 {
     if (winner_done) *winner_done = false;
     const fp_params& p = ka.p;
@@ -783,7 +788,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
     int* part_count = (int*)part_scratch;
     Best* part_best = part_scratch ? (Best*)((char*)part_scratch + kTicketBytes) : nullptr;
-    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count);
+    if (nsplit != 1) perm = nullptr;
+    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur);
     if (winner_done) *winner_done = ka.r.best_traj != nullptr;
     return hipGetLastError();
 }
