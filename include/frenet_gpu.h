@@ -18,7 +18,10 @@
  *     addresses on the ctx's GPU; the call only enqueues work on `stream` and
  *     returns; no synchronisation, no allocation).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *   - a ctx is bound to one device; calls on one ctx must not overlap in time.
+ *   - a ctx is bound to one device; calls on one ctx must not overlap in time, and the work they enqueue must not either: use
+ *     one stream per ctx at a time (the ctx keeps scratch buffers - partial results, launch order - that successive calls reuse
+ *     in stream order).  FP_MEM_DEVICE calls may allocate or grow such a scratch buffer on first use (never inside a stream capture
+ *     after a warm-up call of the same size).
  */
 #ifndef FRENET_GPU_H
 #define FRENET_GPU_H
