@@ -16,7 +16,8 @@
  *     stages through device buffers it owns inside the ctx, runs, copies back and
  *     synchronises before returning) or FP_MEM_DEVICE (pointers are device
  *     addresses on the ctx's GPU; the call only enqueues work on `stream` and
- *     returns; no synchronisation, no allocation).
+ *     returns; no synchronisation and no allocation once the ctx's scratch buffers
+ *     have reached the size the batch needs, i.e. after the first call of that size).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - a ctx is bound to one device; calls on one ctx must not overlap in time, and the work they enqueue must not either: use
  *     one stream per ctx at a time (the ctx keeps scratch buffers - partial results, launch order - that successive calls reuse
