@@ -79,6 +79,24 @@ struct DeviceBuf {
 
 }  // namespace
 
+// State of one kernel's feedback-directed launch order (see lattice_order_before).
+struct LaunchOrder {
+    DeviceBuf buf;              // [dur: int x cap][perm: int x cap]
+    int* host = nullptr;        // pinned: [dur x cap][perm x cap]
+    int cap = 0;                // egos the buffers hold
+    int valid_B = 0;            // the uploaded order is a permutation of [0, valid_B)
+    int dur_B = 0;              // batch size of the durations in flight / on the device
+    int since = 0;              // launches since the last fetch was enqueued
+    bool pending = false;       // a fetch is in flight (event)
+    hipEvent_t event = nullptr;
+    void release()
+    {
+        if (buf.base) (void)hipFree(buf.base);
+        if (host) (void)hipHostFree(host);
+        if (event) (void)hipEventDestroy(event);
+    }
+};
+
 struct fp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // used by FP_MEM_HOST calls
@@ -94,14 +112,7 @@ struct fp_ctx {
     // leaves its ego's duration in dur_dev; now and then the host fetches them (async copy + event, never a wait), sorts the egos
     // longest-first and uploads the order the following launches dispatch in.  A stale or missing order only costs speed.
     int lattice_order = 1;
-    DeviceBuf order_buf;           // [dur: int x cap][perm: int x cap]
-    int* order_host = nullptr;     // pinned: [dur x cap][perm x cap]
-    int order_cap = 0;             // egos the buffers hold
-    int order_valid_B = 0;         // the uploaded order is a permutation of [0, order_valid_B)
-    int order_dur_B = 0;           // batch size of the durations in flight / on the device
-    int order_since = 0;           // launches since the last fetch was enqueued
-    bool order_pending = false;    // a fetch is in flight (order_event)
-    hipEvent_t order_event = nullptr;
+    LaunchOrder order_lattice, order_refine;
 };
 
 namespace {
@@ -292,63 +303,63 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
 // the launch: hands out the permutation to dispatch in (nullptr = index order) and the array the workgroups leave their durations
 // in.  Host work happens only when a fetched duration table has arrived (hipEventQuery, no wait): an argsort of B ints.
 constexpr int kOrderRefresh = 8;  // launches between two fetches of the duration table
-int lattice_order_before(fp_ctx* ctx, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur)
+int launch_order_before(fp_ctx* ctx, LaunchOrder& o, int resident, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur)
 {
     *perm = nullptr;
     *dur = nullptr;
-    if (!ctx->lattice_order || nsplit != 1 || b->B <= ctx->resident_groups) return FP_OK;
+    if (!ctx->lattice_order || nsplit != 1 || b->B <= resident) return FP_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     const bool capturing = cap != hipStreamCaptureStatusNone;
-    if (b->B > ctx->order_cap) {
+    if (b->B > o.cap) {
         if (capturing) return FP_OK;  // no (re)allocation inside a capture: index order
-        if (ctx->order_pending) { HIP_TRY(hipEventSynchronize(ctx->order_event)); ctx->order_pending = false; }
+        if (o.pending) { HIP_TRY(hipEventSynchronize(o.event)); o.pending = false; }
         HIP_TRY(hipStreamSynchronize(stream));
         const int cap_new = b->B + b->B / 4;
-        FP_TRY(ctx->order_buf.reserve((size_t)cap_new * 2 * sizeof(int)));
-        if (ctx->order_host) (void)hipHostFree(ctx->order_host);
-        ctx->order_host = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&ctx->order_host, (size_t)cap_new * 2 * sizeof(int), hipHostMallocDefault));
-        if (!ctx->order_event) HIP_TRY(hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
-        ctx->order_cap = cap_new;
-        ctx->order_valid_B = ctx->order_dur_B = 0;
-        ctx->order_since = 0;
+        FP_TRY(o.buf.reserve((size_t)cap_new * 2 * sizeof(int)));
+        if (o.host) (void)hipHostFree(o.host);
+        o.host = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&o.host, (size_t)cap_new * 2 * sizeof(int), hipHostMallocDefault));
+        if (!o.event) HIP_TRY(hipEventCreateWithFlags(&o.event, hipEventDisableTiming));
+        o.cap = cap_new;
+        o.valid_B = o.dur_B = 0;
+        o.since = 0;
     }
-    int* d_dur = (int*)ctx->order_buf.base;
-    int* d_perm = d_dur + ctx->order_cap;
-    if (!capturing && ctx->order_pending && hipEventQuery(ctx->order_event) == hipSuccess) {
-        ctx->order_pending = false;
-        const int n = ctx->order_dur_B;
+    int* d_dur = (int*)o.buf.base;
+    int* d_perm = d_dur + o.cap;
+    if (!capturing && o.pending && hipEventQuery(o.event) == hipSuccess) {
+        o.pending = false;
+        const int n = o.dur_B;
         if (n == b->B) {  // longest first; ties in index order (std::stable_sort keeps the result deterministic)
-            const int* h_dur = ctx->order_host;
-            int* h_perm = ctx->order_host + ctx->order_cap;
+            const int* h_dur = o.host;
+            int* h_perm = o.host + o.cap;
             for (int i = 0; i < n; ++i) h_perm[i] = i;
             std::stable_sort(h_perm, h_perm + n, [h_dur](int x, int y) { return h_dur[x] > h_dur[y]; });
             HIP_TRY(hipMemcpyAsync(d_perm, h_perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
-            ctx->order_valid_B = n;
+            o.valid_B = n;
         }
-    } else if (ctx->order_pending) {
+    } else if (o.pending) {
         (void)hipGetLastError();  // hipErrorNotReady is not an error
     }
-    if (ctx->order_valid_B == b->B) *perm = d_perm;
+    if (o.valid_B == b->B) *perm = d_perm;
     *dur = d_dur;
     return FP_OK;
 }
 
 // Right after the launch: every kOrderRefresh launches enqueue the fetch of the durations this launch leaves behind.
-int lattice_order_after(fp_ctx* ctx, const fp_batch* b, const int* dur, hipStream_t stream)
+int launch_order_after(LaunchOrder& o, const fp_batch* b, const int* dur, hipStream_t stream)
 {
     if (!dur) return FP_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
-    if (cap != hipStreamCaptureStatusNone || ctx->order_pending) return FP_OK;
-    const bool first = ctx->order_valid_B != b->B;  // no order for this batch size yet: fetch at once
-    if (!first && ++ctx->order_since < kOrderRefresh) return FP_OK;
-    ctx->order_since = 0;
-    HIP_TRY(hipMemcpyAsync(ctx->order_host, dur, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(ctx->order_event, stream));
-    ctx->order_dur_B = b->B;
-    ctx->order_pending = true;
+    if (cap != hipStreamCaptureStatusNone || o.pending) return FP_OK;
+    const bool first = o.valid_B != b->B;  // no order for this batch size yet: fetch at once
+    if (!first && ++o.since < kOrderRefresh) return FP_OK;
+    o.since = 0;
+    HIP_TRY(hipMemcpyAsync(o.host, dur, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(o.event, stream));
+    o.dur_B = b->B;
+    o.pending = true;
     return FP_OK;
 }
 
@@ -463,9 +474,8 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     if (ctx->parts.base) (void)hipFree(ctx->parts.base);
-    if (ctx->order_buf.base) (void)hipFree(ctx->order_buf.base);
-    if (ctx->order_host) (void)hipHostFree(ctx->order_host);
-    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
+    ctx->order_lattice.release();
+    ctx->order_refine.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
     return FP_OK;
@@ -482,7 +492,7 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
     if (strcmp(name, "lattice_order") == 0) {
         if (value < 0 || value > 1) return fail(FP_EINVAL, "lattice_order must be 0 or 1");
         ctx->lattice_order = value;
-        ctx->order_valid_B = 0;
+        ctx->order_lattice.valid_B = ctx->order_refine.valid_B = 0;
         return FP_OK;
     }
     if (strcmp(name, "refine_table_kb") == 0) {
@@ -516,9 +526,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
         bool winner_done = false;
         const int* perm; int* dur;
-        FP_TRY(lattice_order_before(ctx, batch, nsplit, (hipStream_t)stream, &perm, &dur));
+        FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
         LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
-        FP_TRY(lattice_order_after(ctx, batch, dur, (hipStream_t)stream));
+        FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
     }
@@ -542,9 +552,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts));
     bool winner_done = false;
     const int* perm; int* dur;
-    FP_TRY(lattice_order_before(ctx, batch, nsplit, ctx->stream, &perm, &dur));
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
-    FP_TRY(lattice_order_after(ctx, batch, dur, ctx->stream));
+    FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     return hs.fetch_out();
 }
@@ -684,11 +694,17 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     int nsplit; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
     const int* perm; int* dur;
-    FP_TRY(lattice_order_before(ctx, batch, nsplit, stream, &perm, &dur));
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
     LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur), "lattice kernel");
-    FP_TRY(lattice_order_after(ctx, batch, dur, stream));
+    FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
-    if (R > 0) LAUNCH_TRY(fp::launch_fiss_refine(fa, stream, ctx->refine_table_kb), "refinement kernel");
+    if (R > 0) {
+        // three refinement workgroups per CU are resident at once (fiss_refine_kernel: 168 VGPRs, ~52 KB LDS)
+        const int* rperm; int* rdur;
+        FP_TRY(launch_order_before(ctx, ctx->order_refine, ctx->resident_groups / 2 * 3, batch, 1, stream, &rperm, &rdur));
+        LAUNCH_TRY(fp::launch_fiss_refine(fa, stream, ctx->refine_table_kb, rperm, rdur), "refinement kernel");
+        FP_TRY(launch_order_after(ctx->order_refine, batch, rdur, stream));
+    }
     if (fa.io.best_traj && R <= 0) {  // with refinement rounds the refinement kernel writes the series itself
         fp::KernelArgs kw = fa.ka;
         kw.r.best_flags = fa.io.best_flags;

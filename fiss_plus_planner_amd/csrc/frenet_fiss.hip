@@ -604,17 +604,20 @@ __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
     return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 2 * kQueue;
 }
 
-__global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(FissArgs fa, int pt_rows_max)
+__global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(FissArgs fa, int pt_rows_max, const int* perm, int* dur)
 {
+    const long long t_begin = dur ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const KernelArgs& ka = fa.ka;
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x;  // launch order: longest egos first when the host has one
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     constexpr int kThreads = kWave * kRefineWaves;
     const int32_t* ijk = fa.io.best_ijk + (size_t)b * 3;
     const int R = fa.opts.max_refine_iters;
     if (ijk[0] < 0 || R <= 0) {  // nothing found by the coarse search: plan() returns None
+        if (tid == 0 && dur) dur[b] = 0;
         if (fa.io.best_traj) {   // NaN series, flag word 0
             KernelArgs kw = ka;
             kw.r.best_traj = fa.io.best_traj;
@@ -845,6 +848,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
             es[0] = my_x[0]; es[1] = my_x[1]; es[2] = my_x[2];
         }
     }
+    if (tid == 0 && dur) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
     // winner epilogue (what plan() returns) on request: the series of the refined trajectory, or of the coarse winner when no
     // refined one survived.  Every wavefront holds the same candidate list, so each reads the end state from its own registers;
     // the power-sum table is dead by now and lends its LDS to the epilogue.
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
     }
 }
 
-hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb)
+hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb, const int* perm, int* dur)
 {
     // pair table of the checked obstacle rows when it fits in a modest LDS budget (keeps >= 3 workgroups per CU)
     int pt_rows = 0;
@@ -875,7 +879,7 @@ hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_
     FP_LDS_SLOTS(configured);
     hipError_t e = ensure_dynamic_lds((const void*)fiss_refine_kernel, bytes, configured);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, pt_rows);
+    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, pt_rows, perm, dur);
     return hipGetLastError();
 }
 

@@ -48,7 +48,8 @@ struct FissArgs {
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream);
 // One workgroup per ego: FISS+ refinement rounds + cost-ordered validation of the refined trajectories.  table_kb = LDS budget
 // of the per-ego fp32 pose-obstacle pair table (0: no table, pairs are read from the scene table).
-hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb);
+// perm / dur: launch order and duration feedback, like launch_lattice_fused.
+hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb, const int* perm = nullptr, int* dur = nullptr);
 
 // part_scratch: device buffer of kTicketBytes (ticket counters, int per ego, ZERO before the first launch; the kernel leaves
 // them zero) + B * nsplit * 16 bytes (partial argmins), or nullptr; nsplit > 1 = latency mode (B <= kTicketBytes / 4).
