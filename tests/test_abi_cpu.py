@@ -63,3 +63,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_host_batch_struct_is_cached_per_batch_and_safe_to_edit():
+    """engine._host_batch: the ctypes view of a batch is rebuilt only when one of its arrays was replaced, and callers get their
+    own copy (editing it must not leak into the next call)."""
+    import numpy as np
+
+    from fiss_plus_planner_amd import synth
+    from fiss_plus_planner_amd.engine import _host_batch
+
+    b = synth.make_batch(2, 3, 3, 2, 4, 20, False, 5)
+    fb1 = _host_batch(b)
+    ego_ptr = fb1.ego
+    assert ego_ptr == b.ego.ctypes.data and fb1.B == 2 and fb1.n_obs == 4
+    fb1.ego = None                      # a caller scribbles on its struct ...
+    fb2 = _host_batch(b)
+    assert fb2.ego == ego_ptr           # ... the next call still sees the real pointer
+    b.ego[0, 0] += 1.0                  # in-place update: same array, same pointer, no rebuild needed
+    assert _host_batch(b).ego == ego_ptr
+    b.ego = np.ascontiguousarray(b.ego.copy())   # replaced array: new pointer
+    fb3 = _host_batch(b)
+    assert fb3.ego == b.ego.ctypes.data and fb3.ego != ego_ptr
