@@ -113,6 +113,7 @@ struct fp_ctx {
     // longest-first and uploads the order the following launches dispatch in.  A stale or missing order only costs speed.
     int lattice_order = 1;
     LaunchOrder order_lattice, order_refine;
+    DeviceBuf pose_buf;            // converted obstacle rows of scenes too big for LDS (lattice_pose_scratch_bytes)
 };
 
 namespace {
@@ -400,6 +401,20 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
     return FP_OK;
 }
 
+// Scenes whose obstacle rows do not fit LDS: the fused kernel keeps the converted rows in this ctx-owned table instead.
+int lattice_pose_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, int nsplit, hipStream_t stream, void** out)
+{
+    *out = nullptr;
+    const size_t need = fp::lattice_pose_scratch_bytes(*p, *b, nsplit);
+    if (need == 0) return FP_OK;
+    if (need > ctx->pose_buf.cap) {
+        HIP_TRY(hipStreamSynchronize(stream));  // the buffer is reallocated: drain its users
+        FP_TRY(ctx->pose_buf.reserve(need));
+    }
+    *out = ctx->pose_buf.base;
+    return FP_OK;
+}
+
 fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
 
 int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem)
@@ -474,6 +489,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     if (ctx->parts.base) (void)hipFree(ctx->parts.base);
+    if (ctx->pose_buf.base) (void)hipFree(ctx->pose_buf.base);
     ctx->order_lattice.release();
     ctx->order_refine.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -526,8 +542,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
         bool winner_done = false;
         const int* perm; int* dur;
+        void* pose_scratch;
+        FP_TRY(lattice_pose_scratch(ctx, params, &ka.b, nsplit, (hipStream_t)stream, &pose_scratch));
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
-        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
+        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
@@ -552,8 +570,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts));
     bool winner_done = false;
     const int* perm; int* dur;
+    void* pose_scratch;
+    FP_TRY(lattice_pose_scratch(ctx, params, &ka.b, nsplit, ctx->stream, &pose_scratch));
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
-    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     return hs.fetch_out();
@@ -694,8 +714,10 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     int nsplit; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
     const int* perm; int* dur;
+    void* pose_scratch;
+    FP_TRY(lattice_pose_scratch(ctx, params, &fa.ka.b, nsplit, stream, &pose_scratch));
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
-    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, pose_scratch), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
     if (R > 0) {

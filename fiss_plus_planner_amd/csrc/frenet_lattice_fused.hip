@@ -79,7 +79,7 @@ struct Layout {
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
 
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt)
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, bool pose_in_lds = true)
 {
     Layout L;
     int o = 0;
@@ -87,7 +87,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.coef = o;     o = align16(o + 64 * nx_max);
     L.lut = o;      o = align16(o + 2 * (2 * nx_max + 1));  // uint16 segment hint per arclength bucket
     L.dim = o;      o = align16(o + 32 * n_obs);
-    L.pose = o;     o = align16(o + 32 * rows * n_obs);
+    L.pose = o;     o = align16(o + (pose_in_lds ? 32 * rows * n_obs : 0));  // big scenes keep the converted rows in HBM / L2 instead
     L.frames = o;   o = align16(o + 32 * nv * hp);
     L.lat = o;      o = align16(o + 8 * nd * hp);
     L.dmax = o;     o = align16(o + 2 * 4 * hp);   // float, rounded up; two buffers (slice parity): LDS atomic max in phase A
@@ -155,7 +155,7 @@ __device__ __forceinline__ void power_sums_closed(int N, double tick, double* ou
 // nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
 // writes its partial argmin to part_best[ego * nsplit + part]; the last one to arrive (ticket counter) merges them.
 __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur)
+                                                                   int* dur, ObsPose* pose_global)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const long long t_begin = dur ? wall_clock64() : 0;
@@ -173,12 +173,14 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const int stride = p.check_stride;
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt);
+    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt, pose_global == nullptr);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
     ObsDim* s_dim = (ObsDim*)(smem + L.dim);
-    ObsPose* s_pose = (ObsPose*)(smem + L.pose);
+    // obstacle rows of this workgroup: LDS, or - for scenes too big for it - this workgroup's slice of a global scratch table
+    // (written during staging, read by the three collision stages through L2)
+    ObsPose* s_pose = pose_global ? pose_global + (size_t)blockIdx.x * rows_max * bt.n_obs : (ObsPose*)(smem + L.pose);
     Frame* s_frames = (Frame*)(smem + L.frames);
     double* s_lat = (double*)(smem + L.lat);
     float* s_dmax2 = (float*)(smem + L.dmax);    // [2][hp_max]
@@ -762,12 +764,15 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the
 // lane-per-candidate kernel, which keeps oversized obstacle tables in HBM/L2).
-hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur)
+// LDS budget of one workgroup (the CU has 160 KB; beyond ~82 KB only one workgroup fits per CU)
+constexpr int kLdsLimit = 150 * 1024;
+// the obstacle rows stay in LDS only while two workgroups per CU still fit (measured: one workgroup per CU with the rows in LDS is
+// slower than two or three with the rows in L2)
+constexpr int kLdsPoseLimit = 81920;
+
+static bool fused_shape(const fp_params& p, const fp_batch& b, int* rows_out, int* hp_out)
 {
-    if (winner_done) *winner_done = false;
-    const fp_params& p = ka.p;
-    const fp_batch& b = ka.b;
-    if (p.nd > kWave || p.nv > 255 || b.n_obs > 4095) return hipErrorInvalidValue;
+    if (p.nd > kWave || p.nv > 255 || b.n_obs > 4095) return false;
     const int stride = p.check_stride;
     int rows = 0, hp = 0;
     if (b.n_obs > 0) {
@@ -776,10 +781,38 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         if (rows_tab < rows) rows = rows_tab;
         hp = rows * stride + 1;
         if (hp > FP_MAX_POINTS) hp = FP_MAX_POINTS;
-        if (rows > 4095 || (long)rows * b.n_obs > 65535) return hipErrorInvalidValue;
+        if (rows > 4095 || (long)rows * b.n_obs > 65535) return false;
     }
-    const Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt);
-    if (L.total > 150 * 1024) return hipErrorInvalidValue;
+    *rows_out = rows;
+    *hp_out = hp;
+    return true;
+}
+
+size_t lattice_pose_scratch_bytes(const fp_params& p, const fp_batch& b, int nsplit)
+{
+    int rows, hp;
+    if (!fused_shape(p, b, &rows, &hp)) return 0;
+    if (make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, true).total <= kLdsPoseLimit) return 0;
+    if (make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, false).total > kLdsLimit) return 0;  // does not fit either way
+    if (nsplit < 1) nsplit = 1;
+    return (size_t)b.B * nsplit * rows * b.n_obs * sizeof(ObsPose);
+}
+
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
+                                void* pose_scratch)
+{
+    if (winner_done) *winner_done = false;
+    const fp_params& p = ka.p;
+    const fp_batch& b = ka.b;
+    int rows = 0, hp = 0;
+    if (!fused_shape(p, b, &rows, &hp)) return hipErrorInvalidValue;
+    Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, true);
+    ObsPose* pose_global = nullptr;
+    if (L.total > kLdsPoseLimit && pose_scratch) {  // keep the obstacle rows in the caller's scratch table
+        const Layout Lg = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, false);
+        if (Lg.total <= kLdsLimit) { L = Lg; pose_global = (ObsPose*)pose_scratch; }
+    }
+    if (L.total > kLdsLimit) return hipErrorInvalidValue;
     FP_LDS_SLOTS(configured);
     hipError_t e = ensure_dynamic_lds((const void*)lattice_fused_kernel, L.total, configured);
     if (e != hipSuccess) return e;
@@ -789,7 +822,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     int* part_count = (int*)part_scratch;
     Best* part_best = part_scratch ? (Best*)((char*)part_scratch + kTicketBytes) : nullptr;
     if (nsplit != 1) perm = nullptr;
-    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur);
+    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur,
+                       pose_global);
     if (winner_done) *winner_done = ka.r.best_traj != nullptr;
     return hipGetLastError();
 }

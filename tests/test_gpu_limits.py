@@ -25,14 +25,33 @@ def _check_vs_oracle(oracle, engine, batch):
     return out
 
 
-def test_obstacle_table_larger_than_lds_falls_back(oracle, engine):
-    batch = synth.make_batch(3, 5, 5, 5, 150, 100, True, 71)  # 50 rows x 150 obstacles x 32 B = 240 KB > LDS
+def test_obstacle_table_larger_than_lds_stays_fused(oracle, engine):
+    """50 rows x 150 obstacles x 32 B = 240 KB of converted obstacle rows do not fit LDS: the fused kernel keeps them in a
+    ctx-owned table in HBM / L2 instead (written during staging, read by the collision stages) - same flags / costs / argmin, in
+    every launch shape; the lane-per-candidate kernel agrees."""
+    batch = synth.make_batch(3, 5, 5, 5, 150, 100, True, 71)
+    for kernel, split in ((2, 1), (2, 2), (1, 1), (0, 0)):
+        engine.set_option("lattice_kernel", kernel)
+        engine.set_option("lattice_split", split)
+        try:
+            out = _check_vs_oracle(oracle, engine, batch)
+        finally:
+            engine.set_option("lattice_kernel", 0)
+            engine.set_option("lattice_split", 0)
+        assert ((out.flags & 4) != 0).any()
+
+
+def test_obstacle_count_beyond_the_fused_kernel_falls_back(oracle, engine):
+    """More than 65535 (row, obstacle) items (the fused kernel's item index is 16 bits): it refuses, auto mode uses the
+    lane-per-candidate kernel (rows read through L2)."""
+    batch = synth.make_batch(2, 3, 3, 2, 1400, 100, True, 77)  # 50 rows x 1400 obstacles = 70000 items
     engine.set_option("lattice_kernel", 2)
-    with pytest.raises(_abi.FrenetGpuError):  # the fused kernel alone refuses it ...
-        engine.plan_dense(batch)
-    engine.set_option("lattice_kernel", 0)    # ... auto mode uses the lane-per-candidate kernel (rows read through L2)
-    out = _check_vs_oracle(oracle, engine, batch)
-    assert ((out.flags & 4) != 0).any()
+    try:
+        with pytest.raises(_abi.FrenetGpuError):
+            engine.plan_dense(batch)
+    finally:
+        engine.set_option("lattice_kernel", 0)
+    _check_vs_oracle(oracle, engine, batch)
 
 
 def test_more_lateral_samples_than_lanes_falls_back(oracle, engine):
