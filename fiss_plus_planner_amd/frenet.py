@@ -93,6 +93,10 @@ class FrenetState:
         return state
 
 
+_TRAJ_DEFAULTS = dict(lane_id=-1, lane_type=None, is_generated=False, is_searched=False, constraint_passed=False,
+                      collision_passed=False, end_state=None, cost_fix=0.0, cost_dyn=0.0, cost_heu=0.0, cost_est=0.0, cost_final=0.0)
+
+
 class FrenetTrajectory:
     """Result object of ``plan()``; filled from a [16, stride] device dump."""
 
@@ -117,14 +121,17 @@ class FrenetTrajectory:
     def from_dump(cls, dump: np.ndarray, N: int, M: int, cost_final: float, end_state: "FrenetState | None" = None,
                   idx=None) -> "FrenetTrajectory":
         """dump: [16, stride]; N = len(t); M = len(x) (points that stayed on the spline)."""
-        tr = cls()
+        tr = cls.__new__(cls)
+        tr.__dict__.update(_TRAJ_DEFAULTS)
+        tr.idx = np.array([-1, -1, -1])
+        d = np.array(dump[:, :N])  # one copy; the sixteen series are views of it
         for k, name in enumerate(ARRAY_NAMES[:9]):
-            setattr(tr, name, np.array(dump[k, :N]))
-        lens = {"x": M, "y": M, "yaw": M if M >= 2 else 0, "ds": max(M - 1, 0) if M >= 2 else 0,
-                "c": max(M - 1, 0) if M >= 2 else 0, "c_d": max(M - 2, 0) if M >= 2 else 0,
-                "c_dd": max(M - 3, 0) if M >= 2 else 0}
+            tr.__dict__[name] = d[k]
+        m1 = max(M - 1, 0) if M >= 2 else 0
+        lens = (M, M, M if M >= 2 else 0, m1, m1, max(M - 2, 0) if M >= 2 else 0, max(M - 3, 0) if M >= 2 else 0)
         for k, name in enumerate(ARRAY_NAMES[9:], start=9):
-            setattr(tr, name, np.array(dump[k, : lens[name]]))
+            tr.__dict__[name] = d[k, : lens[k - 9]]
+        tr.lane_type = LaneType.UNDEFINED
         tr.cost_final = float(cost_final)
         tr.is_generated = True
         tr.end_state = end_state

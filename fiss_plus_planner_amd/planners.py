@@ -228,8 +228,8 @@ class FrenetOptimalPlanner:
         self.stats = Stats(0, C, C, C)
         best = int(out.best_idx[0])
         if best >= 0:
-            _, N, M = unpack_flags(out.best_flags[:1])
-            self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], int(N[0]), int(M[0]), float(out.best_cost[0]))
+            fl = int(out.best_flags[0])  # N and M ride in the flag word (FP_FLAG_N_SHIFT / FP_FLAG_M_SHIFT)
+            self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], (fl >> 8) & 0xFFF, fl >> 20, float(out.best_cost[0]))
             self.best_traj.lattice_index = best
         return self.best_traj
 
