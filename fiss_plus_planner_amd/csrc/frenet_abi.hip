@@ -163,10 +163,20 @@ class HostStage {
     template <typename T>
     int in_mut(T* host, size_t count, T** dev)  // in/out array: staged in, copied straight back by fetch_out
     {
+        const size_t bytes = sizeof(T) * count;
+        if (zero_copy_out_ && count > 0 && bytes <= kSmallMax && align_up(small_) + bytes <= kSmallRegion) {
+            // latency regime: the kernels read and update the array in the pinned host block itself - no copy either way
+            small_ = align_up(small_);
+            memcpy(ctx_->pinned + small_, host, bytes);
+            *dev = (T*)(ctx_->pinned + small_);
+            outs_.push_back({host, small_, (char*)*dev, bytes, true});
+            small_ += bytes;
+            return FP_OK;
+        }
         const T* c = nullptr;
         FP_TRY(in((const T*)host, count, &c));
         *dev = const_cast<T*>(c);
-        outs_.push_back({host, 0, (char*)*dev, sizeof(T) * count, false});
+        outs_.push_back({host, 0, (char*)*dev, bytes, false});
         return FP_OK;
     }
     int flush_in()  // the output window of the small region starts after the inputs
