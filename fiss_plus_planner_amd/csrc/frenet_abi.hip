@@ -387,11 +387,8 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
     if (ctx->lattice_split == 0) {
         const long fit = b->B > 0 ? ctx->resident_groups / (long)b->B : 0;
         parts_per_ego = (int)(fit < p->nt ? fit : p->nt);
-        // fewer workgroups than slices only pays when the slices carry the work (obstacle-time items); with a handful of
-        // obstacles the per-workgroup fixed cost (staging, profile sums, ticket) dominates and one workgroup per ego is faster
-        const long t_rows = (b->T_obs < FP_MAX_POINTS ? b->T_obs : FP_MAX_POINTS) / (p->check_stride > 0 ? p->check_stride : 1);
-        const bool has_obs = b->S > 0 && b->n_obs > 0;
-        if (parts_per_ego < p->nt && (!has_obs || t_rows * b->n_obs < 600)) parts_per_ego = 1;
+        // without obstacles the slices carry no work: one workgroup per ego
+        if (parts_per_ego < p->nt && !(b->S > 0 && b->n_obs > 0)) parts_per_ego = 1;
     } else if (ctx->lattice_split == 1) {
         parts_per_ego = 1;
     }

@@ -709,25 +709,31 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     if (lane == 0) s_best[wave] = mine;
     __syncthreads();
     if (nsplit > 1) {
-        // Latency mode: this workgroup holds the argmin of its slices.  The LAST workgroup of the ego to arrive (ticket counter,
-        // release / acquire fences at device scope) merges the partial argmins in part order - the result does not depend on
+        // Latency mode: this workgroup holds the argmin of its slices.  The LAST workgroup of the ego to arrive (ticket counter;
+        // the partial argmins travel as device-coherent atomic stores / loads) merges the partial argmins in part order - the result does not depend on
         // the arrival order - and carries on as the ego's only workgroup: results, epilogue.  No merge launch.
         if (tid == 0) {
             Best r = s_best[0];
             for (int w = 1; w < kWaves; ++w) r = best_merge(r, s_best[w]);
-            part_best[blockIdx.x] = r;
-            __threadfence();
-            const int ticket = atomicAdd(&part_count[b], 1);
+            // device-coherent (agent scope) stores, acknowledged before the ticket is taken: no whole-L2 write-back fence
+            Best* mine = part_best + blockIdx.x;
+            __hip_atomic_store(&mine->cost, r.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mine->idx, r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            const int ticket = __hip_atomic_fetch_add(&part_count[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_cnt[3] = ticket;
         }
         __syncthreads();
         if (s_cnt[3] != nsplit - 1) return;
         if (tid == 0) {
-            __threadfence();
             part_count[b] = 0;  // ready for the next launch
-            const volatile Best* pb = part_best + (size_t)b * nsplit;
-            Best r{pb[0].cost, pb[0].idx};
-            for (int w = 1; w < nsplit; ++w) r = best_merge(r, Best{pb[w].cost, pb[w].idx});
+            Best* pb = part_best + (size_t)b * nsplit;
+            auto part = [&](int w) {
+                return Best{__hip_atomic_load(&pb[w].cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                            __hip_atomic_load(&pb[w].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+            };
+            Best r = part(0);
+            for (int w = 1; w < nsplit; ++w) r = best_merge(r, part(w));
             s_best[0] = r;
         }
         __syncthreads();

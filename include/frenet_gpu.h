@@ -130,8 +130,7 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * profile-sharing kernel only (fails with FP_EHIP if the problem does not fit it).  Results are identical
  * (flags / indices exactly, costs to ~1e-13); used by the A/B parity tests and by profiling.
  * "lattice_split": 0 = auto (default: an ego's time-horizon slices are spread over as many workgroups - at most one per
- * slice - as keep ALL workgroups of the launch resident at once, 2 per compute unit: latency mode for small batches; fewer
- * workgroups than slices only when the scene has enough obstacle-time items to make the slices the bulk of the work), 1 = never,
+ * slice - as keep ALL workgroups of the launch resident at once, 2 per compute unit: latency mode for small batches), 1 = never,
  * 2 = always one workgroup per slice.  Identical results either way.
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
