@@ -106,7 +106,7 @@ struct fp_ctx {
     DeviceBuf parts;               // latency-mode lattice launch: [ticket counters, fixed-size region][partial argmins]
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
-    int refine_table_kb = 24;      // fp_ctx_set_option("refine_table_kb")
+    int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
     // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
     // leaves its ego's duration in dur_dev; now and then the host fetches them (async copy + event, never a wait), sorts the egos

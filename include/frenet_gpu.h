@@ -134,7 +134,7 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * 2 = always one workgroup per slice.  Identical results either way.
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
- * "refine_table_kb": LDS budget (KiB, default 24, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
+ * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
  * table; scenes whose table does not fit are checked straight from the scene table.  Identical results either way. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
 

@@ -119,7 +119,7 @@ def test_refinement_collision_paths_match_oracle(oracle, engine, table_kb, shift
     try:
         out = engine.plan_fiss(b, "FISS+", trace=True)
     finally:
-        engine.set_option("refine_table_kb", 24)
+        engine.set_option("refine_table_kb", 96)
     n_refined = 0
     for e, p in enumerate(oracle.problems_from_batch(b)):
         r = p.fissplus_plan(None)

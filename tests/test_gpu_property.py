@@ -111,7 +111,7 @@ def test_random_settings_search_vs_oracle(oracle, engine, seed, kind):
         try:
             out = engine.plan_fiss(b, kind, prev_best_idx=prev, trace=True)
         finally:
-            engine.set_option("refine_table_kb", 24)
+            engine.set_option("refine_table_kb", 96)
         for e, p in enumerate(oracle.problems_from_batch(b)):
             pv = None if prev[e, 0] < 0 else prev[e]
             r = p.fiss_plan(pv) if kind == "FISS" else p.fissplus_plan(pv)
