@@ -107,11 +107,13 @@ struct fp_ctx {
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
+    int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
     int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
     // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
     // leaves its ego's duration in dur_dev; now and then the host fetches them (async copy + event, never a wait), sorts the egos
     // longest-first and uploads the order the following launches dispatch in.  A stale or missing order only costs speed.
     int lattice_order = 1;
+    int lattice_launches = 0, lattice_ordered_launches = 0;  // fp_ctx_get_option counters
     LaunchOrder order_lattice, order_refine;
     DeviceBuf pose_buf;            // converted obstacle rows of scenes too big for LDS (lattice_pose_scratch_bytes)
 };
@@ -318,6 +320,7 @@ int launch_order_before(fp_ctx* ctx, LaunchOrder& o, int resident, const fp_batc
 {
     *perm = nullptr;
     *dur = nullptr;
+    if (&o == &ctx->order_lattice) ++ctx->lattice_launches;
     if (!ctx->lattice_order || nsplit != 1 || b->B <= resident) return FP_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
@@ -354,6 +357,7 @@ int launch_order_before(fp_ctx* ctx, LaunchOrder& o, int resident, const fp_batc
     }
     if (o.valid_B == b->B) *perm = d_perm;
     *dur = d_dur;
+    if (&o == &ctx->order_lattice && *perm) ++ctx->lattice_ordered_launches;
     return FP_OK;
 }
 
@@ -523,11 +527,28 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->refine_table_kb = value;
         return FP_OK;
     }
+    if (strcmp(name, "fiss_stages") == 0) {
+        if (value < 1 || value > 3) return fail(FP_EINVAL, "fiss_stages must be 1 (lattice only), 2 (+ search) or 3 (all)");
+        ctx->fiss_stages = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_split") == 0) {
         if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_split must be 0 (auto), 1 (never) or 2 (always)");
         ctx->lattice_split = value;
         return FP_OK;
     }
+    return fail(FP_EINVAL, "unknown option '%s'", name);
+}
+
+int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
+{
+    if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
+    const struct { const char* n; int v; } tab[] = {
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_order", ctx->lattice_order},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"lattice_launches", ctx->lattice_launches},
+        {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
+    for (const auto& t : tab)
+        if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
     return fail(FP_EINVAL, "unknown option '%s'", name);
 }
 
@@ -726,8 +747,9 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
     LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, pose_scratch), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
+    if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
-    if (R > 0) {
+    if (R > 0 && ctx->fiss_stages >= 3) {
         // three refinement workgroups per CU are resident at once (fiss_refine_kernel: 168 VGPRs, ~52 KB LDS)
         const int* rperm; int* rdur;
         FP_TRY(launch_order_before(ctx, ctx->order_refine, ctx->resident_groups / 2 * 3, batch, 1, stream, &rperm, &rdur));

@@ -264,18 +264,29 @@ __device__ __forceinline__ bool obb_overlap(const Obb& a, const Obb& b)
     return true;
 }
 
-// heading unit vector of the step (dx,dy): cos/sin(atan2(dy,dx)); atan2(0,0) = 0 -> (1,0)
+// heading unit vector of the step (dx,dy): cos/sin(atan2(dy,dx)); atan2(0,0) = 0 -> (1,0).
+// An axis-parallel step gives exactly (+-1, 0) / (0, +-1), as cos / sin of atan2's exact 0, pi, +-pi/2 do after shapely's snap
+// (see sincos_snapped): boxes that touch exactly are then decided by exact arithmetic, like in the reference.
 __device__ __forceinline__ void step_heading(double dx, double dy, double& c, double& s)
 {
     const double h2 = fma(dx, dx, dy * dy);
     if (h2 > 0.0) {
         const double inv = rsqrt_nr(h2);
-        c = dx * inv;
-        s = dy * inv;
+        c = dy == 0.0 ? (dx > 0.0 ? 1.0 : -1.0) : dx * inv;
+        s = dx == 0.0 ? (dy > 0.0 ? 1.0 : -1.0) : dy * inv;
     } else {
         c = 1.0;
         s = 0.0;
     }
+}
+
+// cos / sin of an obstacle's orientation as shapely.affinity.rotate computes them (construct_polygon,
+// frenet_optimal_planner.py:162-166): |cos| or |sin| below 2.5e-16 is snapped to 0, so that yaw = k pi/2 rotates exactly.
+__device__ __forceinline__ void sincos_snapped(double yaw, double& s, double& c)
+{
+    sincos(yaw, &s, &c);
+    if (fabs(c) < 2.5e-16) c = 0.0;
+    if (fabs(s) < 2.5e-16) s = 0.0;
 }
 
 // ---------------------------------------------------------------------------

@@ -515,7 +515,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
         step_heading(pb.x - pa.x, pb.y - pa.y, ego.c, ego.s);
         ego.x = pc.x; ego.y = pc.y; ego.hl = veh_hl; ego.hw = veh_hw;
         double oc, os;
-        sincos(ps.z, &os, &oc);
+        sincos_snapped(ps.z, os, oc);
         return obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
     };
     if (L.pt) {

@@ -108,7 +108,7 @@ __device__ void stage_ego(const KernelArgs& ka, int b, double* lds, EgoCtx& e, i
                     if (ps[3] != 0.0) {
                         x = ps[0];
                         y = ps[1];
-                        sincos(ps[2], &s, &c);
+                        sincos_snapped(ps[2], s, c);
                     }
                 }
                 tab[4 * i] = x; tab[4 * i + 1] = y; tab[4 * i + 2] = c; tab[4 * i + 3] = s;
@@ -150,7 +150,7 @@ __device__ __forceinline__ bool pose_collides(const KernelArgs& ka, const EgoCtx
             const double dx = ox - x, dy = oy - y;
             if (!(fma(dx, dx, dy * dy) <= R * R)) continue;
             double oc, os;
-            sincos(row[4 * j + 2], &os, &oc);
+            sincos_snapped(row[4 * j + 2], os, oc);
             Obb ob{ox, oy, oc, os, e.obs_dim[4 * j], e.obs_dim[4 * j + 1]};
             if (obb_overlap(ego, ob)) return true;
         }

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     if (ps[u].w != 0.0) {
                         o.x = ps[u].x;
                         o.y = ps[u].y;
-                        sincos(ps[u].z, &o.s, &o.c);
+                        sincos_snapped(ps[u].z, o.s, o.c);
                     }
                     s_pose[i] = o;
                 }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
     }
     __syncthreads();
-    if (tid < n_it) power_sums_closed(s_nslice[it_lo + tid], tick, s_pows + (it_lo + tid) * 11);
+    for (int i = tid; i < n_it; i += kThreads) power_sums_closed(s_nslice[it_lo + i], tick, s_pows + (it_lo + i) * 11);
     // [section MASKS]
     const uint32_t scan_mask = (uint32_t)s_cnt[2];
     for (int it = it_lo; it < it_hi; ++it) {
@@ -699,9 +699,14 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         if (n_obs > 0 && M == 1 && horizon_cap >= 1) hit = true;  // traj.yaw is empty -> IndexError -> collision (:178-182)
         if (hit) flags |= FP_FLAG_COLLISION;
         if (M < N) flags |= FP_FLAG_TRUNCATED;
-        const double cost = combine_cost(p, N, ls, ds);  // cost_function.py:41-50, same grouping as the reference
+        double cost = combine_cost(p, N, ls, ds);  // cost_function.py:41-50, same grouping as the reference
+        uint32_t word = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+        if (N <= 0 || N > FP_MAX_POINTS) {  // a time sample the ABI's limits exclude (unvalidated in FP_MEM_DEVICE mode): no trajectory,
+            cost = __builtin_nan("");        // exactly what the lane-per-candidate kernel reports (traj_eval)
+            word = flags = FP_FLAG_INFEASIBLE;
+        }
         if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = cost;
-        if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+        if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = word;
         if (!(flags & FP_FLAG_INFEASIBLE) && cost == cost) mine = best_merge(mine, Best{cost, c});
     }
     // [/section ASM]
@@ -716,17 +721,30 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             Best r = s_best[0];
             for (int w = 1; w < kWaves; ++w) r = best_merge(r, s_best[w]);
             // device-coherent (agent scope) stores, acknowledged before the ticket is taken: no whole-L2 write-back fence
+            // Ordering: relaxed agent-scope atomics go to the device-coherent L2 in program order per wavefront; s_waitcnt(0) holds
+            // the ticket back until both stores are acknowledged by L2, and the merging workgroup reads the partials with
+            // agent-scope atomic loads (served by L2, never by a stale L1 / scalar cache line).  That is a hardware argument
+            // (gfx950: one coherent L2 per agent for atomics with agent scope), not a C++ memory-model one - a release / acquire
+            // pair would be the portable spelling, but on this chip it writes back the whole L2 per workgroup (measured: 15-35 %
+            // of the launch).  The signal fences pin the COMPILER to the same order (no motion of the stores, the wait, the ticket
+            // or the loads across each other).  A kernel that faults leaves the ticket counters non-zero, but a GPU fault ends
+            // the process on this stack, and with it the ctx that owns the counters.
             Best* mine = part_best + blockIdx.x;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __hip_atomic_store(&mine->cost, r.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&mine->idx, r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __builtin_amdgcn_s_waitcnt(0);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             const int ticket = __hip_atomic_fetch_add(&part_count[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             s_cnt[3] = ticket;
         }
         __syncthreads();
         if (s_cnt[3] != nsplit - 1) return;
         if (tid == 0) {
             part_count[b] = 0;  // ready for the next launch
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the loads below stay behind the ticket
             Best* pb = part_best + (size_t)b * nsplit;
             auto part = [&](int w) {
                 return Best{__hip_atomic_load(&pb[w].cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),

@@ -91,6 +91,11 @@ class FrenetEngine:
         """Diagnostic knobs of the ctx, e.g. set_option("lattice_kernel", 1) pins the lane-per-candidate kernel."""
         _abi.check(self._lib.fp_ctx_set_option(self._ctx, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        _abi.check(self._lib.fp_ctx_get_option(self._ctx, name.encode(), C.byref(v)))
+        return v.value
+
     def __del__(self):
         try:
             self.close()

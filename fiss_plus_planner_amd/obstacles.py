@@ -12,6 +12,7 @@ bound, :173-176), so T_obs = final_time_step rows are enough.
 """
 from __future__ import annotations
 
+import warnings
 from dataclasses import dataclass
 
 import numpy as np
@@ -29,14 +30,40 @@ class ObstacleTable:
         assert self.pose.ndim == 3 and self.pose.shape[2] == 4 and self.dims.shape == (self.pose.shape[1], 2)
 
 
-def _rect_dims(shape) -> tuple[float, float]:
-    """length, width of a commonroad-like Rectangle (``.length``/``.width``) or of a polygon-like object
-    exposing ``.bounds`` = (minx, miny, maxx, maxy) in the obstacle's own frame."""
+def _shape_vertices(poly):
+    """Exterior ring of a polygon-like object as an [n, 2] array (closing point dropped), or None when it exposes none."""
+    for get in (lambda p: p.exterior.coords, lambda p: p.pts, lambda p: p.vertices):
+        try:
+            v = np.asarray(get(poly), dtype=float).reshape(-1, 2)
+        except Exception:
+            continue
+        if len(v) >= 2 and np.array_equal(v[0], v[-1]):
+            v = v[:-1]
+        return v
+    return None
+
+
+def _rect_dims(shape) -> tuple[float, float, float, float]:
+    """(length, width, cx, cy) of an obstacle shape in its own frame.
+
+    A commonroad-like Rectangle exposes ``.length`` / ``.width`` (centred, cx = cy = 0).  Anything else is read through its
+    polygon (``.shapely_object`` or the object itself): an axis-aligned rectangle is taken exactly - including one that is not
+    centred on the origin: the reference rotates the translated polygon about the centre of ITS bounding box
+    (affinity.rotate(origin='center'), frenet_optimal_planner.py:162-166), i.e. it behaves like a centred rectangle displaced by
+    the unrotated offset (cx, cy).  Any other shape is replaced by its bounding box with a warning: the kernels test rectangles
+    only, and the box over-approximates the shape (never misses a collision the reference reports at yaw = 0, but is not the same
+    test)."""
     if hasattr(shape, "length") and hasattr(shape, "width"):
-        return float(shape.length), float(shape.width)
+        return float(shape.length), float(shape.width), 0.0, 0.0
     poly = getattr(shape, "shapely_object", shape)
     minx, miny, maxx, maxy = poly.bounds
-    return float(maxx - minx), float(maxy - miny)
+    v = _shape_vertices(poly)
+    is_rect = v is not None and len(v) == 4 and all((p[0] in (minx, maxx)) and (p[1] in (miny, maxy)) for p in v) and \
+        len({(float(p[0]), float(p[1])) for p in v}) == 4
+    if not is_rect:
+        warnings.warn("obstacle shape is not an axis-aligned rectangle in its own frame: the collision kernels use its bounding box "
+                      f"({maxx - minx:.3f} x {maxy - miny:.3f} m), which over-approximates the reference's polygon test", RuntimeWarning, stacklevel=3)
+    return float(maxx - minx), float(maxy - miny), float(0.5 * (minx + maxx)), float(0.5 * (miny + maxy))
 
 
 def flatten_obstacles(obstacles) -> ObstacleTable:
@@ -46,10 +73,18 @@ def flatten_obstacles(obstacles) -> ObstacleTable:
     pose = np.zeros((T, n, 4))
     dims = np.zeros((n, 2))
     for j, ob in enumerate(obstacles):
-        dims[j] = _rect_dims(ob.obstacle_shape)
+        l, w, cx, cy = _rect_dims(ob.obstacle_shape)
+        dims[j] = (l, w)
         for t in range(T):
             st = ob.state_at_time(t)
             if st is None:
                 continue
-            pose[t, j] = (st.position[0], st.position[1], st.orientation, 1.0)
+            pose[t, j] = (st.position[0] + cx, st.position[1] + cy, st.orientation, 1.0)
     return ObstacleTable(pose, dims, fts)
+
+
+def obstacles_fingerprint(obstacles) -> tuple:
+    """Cheap identity of an obstacle list for the planners' table cache: the objects themselves (ids of the elements, in order)
+    plus the horizon.  A caller that rebuilds the list from NEW obstacle objects every cycle gets a fresh table; mutating an
+    obstacle object in place is not detected (pass an ObstacleTable to control the table yourself)."""
+    return (tuple(id(o) for o in obstacles), int(obstacles[0].prediction.final_time_step))

@@ -18,7 +18,7 @@ from . import search
 from .batch import FISS_KINDS, ProblemBatch
 from .engine import TRAJ_STRIDE, FrenetEngine, unpack_flags
 from .frenet import FrenetState, FrenetTrajectory
-from .obstacles import ObstacleTable, flatten_obstacles
+from .obstacles import ObstacleTable, flatten_obstacles, obstacles_fingerprint
 from .spline import CubicSpline2D
 from .vehicle import Vehicle
 
@@ -115,7 +115,7 @@ class FrenetOptimalPlanner:
         assert frame_on in ("device", "host")
         self.frame_on = frame_on  # where generate_frenet_frame() solves the spline system (fp_frames_build or numpy)
         self._engine = engine if engine is not None else _engine_for(device)
-        self._obs_cache = (None, None)
+        self._obs_cache = (None, None, None)
         self.last_tables = None  # (cost [C], flags [C]) of the last dense pass, flat FOP order
 
     # ------------------------------------------------------------------ frame
@@ -137,9 +137,11 @@ class FrenetOptimalPlanner:
             return obstacles
         if obstacles is None or len(obstacles) == 0:
             return None  # has_collision: empty list -> no collision (:170-171)
-        key = (id(obstacles), len(obstacles))
+        # The flattened table is reused only while the list holds the SAME obstacle objects (element identities + horizon); the
+        # cache keeps them alive, so a recycled address cannot alias a different obstacle.
+        key = obstacles_fingerprint(obstacles)
         if self._obs_cache[0] != key:
-            self._obs_cache = (key, flatten_obstacles(obstacles))
+            self._obs_cache = (key, flatten_obstacles(obstacles), list(obstacles))
         return self._obs_cache[1]
 
     def _sampling_width(self) -> float:

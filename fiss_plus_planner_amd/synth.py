@@ -50,12 +50,15 @@ def sample_frames(knots, coef, s):
 
 def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving: bool, seed: int,
                kind: str = "FOP", vehicle: Vehicle | None = None, max_target_speed: float = 13.5,
-               ego_offset: int = 0) -> ProblemBatch:
+               ego_offset: int = 0, layout: str = "lanes") -> ProblemBatch:
     """B egos, each with its own 81-knot centerline and its own n_obs-rectangle scene.
 
     ego_offset lets a rank generate only its shard [ego_offset, ego_offset+B) of a larger batch:
     every ego draws from its own child stream SeedSequence(seed).spawn-like key (seed, index).
+    layout: "lanes" (module docstring; the bench default) or "survey8d" = SURVEY.md section 8d verbatim: every obstacle
+    at s_o = s + U(8, 120), d_o ~ U(-4, 4), speed U(0, 12) when moving.
     """
+    assert layout in ("lanes", "survey8d")
     veh = vehicle or Vehicle()
     st = default_settings(nd, nv, nt)
     NX = 81
@@ -78,6 +81,12 @@ def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving
         if n_obs > 0:
             dims[b, :, 0] = rng.uniform(3.5, 7.5, n_obs)
             dims[b, :, 1] = rng.uniform(1.6, 2.3, n_obs)
+            if layout == "survey8d":
+                so[b] = ego[b, 0] + rng.uniform(8, 120, n_obs)
+                do[b] = rng.uniform(-4, 4, n_obs)
+                if moving:
+                    vo[b] = rng.uniform(0, 12, n_obs)
+                continue
             n_lane = max(1, int(round(0.15 * n_obs)))
             side = rng.uniform(2.9, 7.5, n_obs) * np.where(rng.uniform(size=n_obs) < 0.5, -1.0, 1.0)
             lane = rng.uniform(-1.0, 1.0, n_obs)
@@ -114,17 +123,17 @@ def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving
         frame_of=np.arange(B), scene_of=scene_of, t_now=np.zeros(B), nx=np.full(B, NX), knots=knots, coef=coef,
         obs_pose=pose, obs_dims=dims, final_time_step=fts, veh_l=veh.l, veh_w=veh.w, max_speed=veh.max_speed,
         max_accel=veh.max_accel, tick_t=st.tick_t, check_stride=2, samp_min=samp_min, samp_max=samp_max, samp_res=samp_res,
-        meta=dict(seed=seed, kind=kind, moving=moving, ego_offset=ego_offset))
+        meta=dict(seed=seed, kind=kind, moving=moving, ego_offset=ego_offset, layout=layout))
 
 
-def make_config(config: int, B: int | None = None, ego_offset: int = 0, kind: str | None = None) -> ProblemBatch:
+def make_config(config: int, B: int | None = None, ego_offset: int = 0, kind: str | None = None, layout: str = "lanes") -> ProblemBatch:
     """BASELINE.json configs[config-1] (2..5)."""
     if config == 2:
-        return make_batch(B or 256, 5, 5, 5, 10, 100, False, CONFIG_SEEDS[2], kind or "FOP", ego_offset=ego_offset)
+        return make_batch(B or 256, 5, 5, 5, 10, 100, False, CONFIG_SEEDS[2], kind or "FOP", ego_offset=ego_offset, layout=layout)
     if config == 3:
-        return make_batch(B or 2048, 9, 9, 7, 50, 50, True, CONFIG_SEEDS[3], kind or "FOP", ego_offset=ego_offset)
+        return make_batch(B or 2048, 9, 9, 7, 50, 50, True, CONFIG_SEEDS[3], kind or "FOP", ego_offset=ego_offset, layout=layout)
     if config == 4:
-        return make_batch(B or 2048, 9, 9, 7, 50, 50, True, CONFIG_SEEDS[4], kind or "FISS+", ego_offset=ego_offset)
+        return make_batch(B or 2048, 9, 9, 7, 50, 50, True, CONFIG_SEEDS[4], kind or "FISS+", ego_offset=ego_offset, layout=layout)
     if config == 5:
-        return make_batch(B or 16384, 9, 9, 7, 50, 50, True, CONFIG_SEEDS[5], kind or "FOP", ego_offset=ego_offset)
+        return make_batch(B or 16384, 9, 9, 7, 50, 50, True, CONFIG_SEEDS[5], kind or "FOP", ego_offset=ego_offset, layout=layout)
     raise ValueError(f"unknown config {config}")

@@ -18,6 +18,9 @@
  *     addresses on the ctx's GPU; the call only enqueues work on `stream` and
  *     returns; no synchronisation and no allocation once the ctx's scratch buffers
  *     have reached the size the batch needs, i.e. after the first call of that size).
+ *     FP_MEM_DEVICE calls cannot look at the arrays: frame_of / scene_of / nx / t_now / best_idx are NOT range-checked (an
+ *     out-of-range index is a GPU memory fault, not FP_EINVAL), and a time sample that needs more than FP_MAX_POINTS points
+ *     yields NaN cost + FP_FLAG_INFEASIBLE for its candidates instead of FP_ELIMIT.  Validate on the host, or use FP_MEM_HOST.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - a ctx is bound to one device; calls on one ctx must not overlap in time, and the work they enqueue must not either: use
  *     one stream per ctx at a time (the ctx keeps scratch buffers - partial results, launch order - that successive calls reuse
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 6
+#define FP_ABI_VERSION 7
 
 /* error codes */
 #define FP_OK 0
@@ -135,8 +138,13 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
  * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
- * table; scenes whose table does not fit are checked straight from the scene table.  Identical results either way. */
+ * table; scenes whose table does not fit are checked straight from the scene table.  Identical results either way.
+ * "fiss_stages": timing diagnostic of fp_plan_fiss, 3 (default) = the whole pipeline, 2 = stop after the search walk (no
+ * refinement), 1 = stop after the dense lattice pass; with 1 or 2 the outputs of the skipped stages are NOT produced. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
+/* Reads an option back, or one of the read-only counters "lattice_launches" (dense lattice launches of this ctx so far) and
+ * "lattice_ordered_launches" (those dispatched in a feedback order) - bench.py reports when the order took effect. */
+int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value);
 
 /* Dense lattice pass = FrenetOptimalPlanner.plan() for B egos at once:
  *   calc_frenet_paths (:69-104) + CostFunction.cost_total (cost_function.py:41-50)

@@ -324,6 +324,14 @@ static uint32_t traj_constraints(const orc_problem* p, const traj_t* t)
         if (t->a[ORC_S_D][i] > p->max_speed) { f |= ORC_FLAG_SPEED; break; }
     for (int i = 0; i < t->N; ++i)
         if (fabs(t->a[ORC_S_DD][i]) > p->max_accel) { f |= ORC_FLAG_ACCEL; break; }
+    if (p->curvature_mask && t->M >= 2) { /* :145-150 (commented out in the reference); c / c_d / c_dd are [] when M < 2 */
+        for (int i = 0; i < t->M - 1; ++i)
+            if (fabs(t->a[ORC_C][i]) > p->max_curvature) { f |= ORC_FLAG_CURVATURE; break; }
+        for (int i = 0; i < t->M - 2; ++i)
+            if (fabs(t->a[ORC_C_D][i]) > p->max_kappa_d) { f |= ORC_FLAG_KAPPA_D; break; }
+        for (int i = 0; i < t->M - 3; ++i)
+            if (fabs(t->a[ORC_C_DD][i]) > p->max_kappa_dd) { f |= ORC_FLAG_KAPPA_DD; break; }
+    }
     return f;
 }
 
@@ -381,6 +389,14 @@ static int quads_intersect(double A[4][2], double B[4][2])
         }
     }
     return 1;
+}
+
+int orc_boxes_intersect(double l1, double w1, double x1, double y1, double yaw1, double l2, double w2, double x2, double y2,
+                        double yaw2)
+{
+    double A[4][2], B[4][2];
+    if (make_box(l1, w1, x1, y1, yaw1, A) || make_box(l2, w2, x2, y2, yaw2, B)) return -1;
+    return quads_intersect(A, B);
 }
 
 /* has_collision, frenet_optimal_planner.py:168-195 */
@@ -676,7 +692,7 @@ static int fiss_validate(fiss_t* f, int q, uint32_t* flags_out)
     double c;
     int rc = orc_eval_traj(f->p, f->p->d_samples[i], f->p->v_samples[j], f->p->t_samples[k], 0, NULL, 0, NULL, NULL, &c, &fl);
     if (rc) return rc;
-    if (fl & (ORC_FLAG_SPEED | ORC_FLAG_ACCEL)) { *flags_out = fl; return 0; }
+    if (fl & ORC_FLAG_CONSTRAINTS) { *flags_out = fl; return 0; }
     rc = orc_eval_traj(f->p, f->p->d_samples[i], f->p->v_samples[j], f->p->t_samples[k], 1, NULL, 0, NULL, NULL, &c, &fl);
     if (rc) return rc;
     f->stats[3] += 1;
@@ -884,7 +900,7 @@ int orc_fissplus_plan(const orc_problem* p, double w_heuristic, int32_t max_refi
             uint32_t fl;
             double c;
             orc_eval_traj(p, rt[b].x[0], rt[b].x[1], rt[b].x[2], 0, NULL, 0, NULL, NULL, &c, &fl);
-            if (fl & (ORC_FLAG_SPEED | ORC_FLAG_ACCEL)) continue;
+            if (fl & ORC_FLAG_CONSTRAINTS) continue;
             orc_eval_traj(p, rt[b].x[0], rt[b].x[1], rt[b].x[2], 1, NULL, 0, NULL, NULL, &c, &fl);
             stats[3] += 1;
             if (!(fl & ORC_FLAG_COLLISION)) {

@@ -19,7 +19,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfrenet_oracle.so")
 
 FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED = 1, 2, 4, 8
-FLAG_INFEASIBLE = 7
+FLAG_CURVATURE, FLAG_KAPPA_D, FLAG_KAPPA_DD = 16, 32, 64
+FLAG_CONSTRAINTS = 1 | 2 | 16 | 32 | 64
+FLAG_INFEASIBLE = FLAG_CONSTRAINTS | 4
 ARRAY_NAMES = ["t", "s", "s_d", "s_dd", "s_ddd", "d", "d_d", "d_dd", "d_ddd", "x", "y", "yaw", "ds", "c", "c_d", "c_dd"]
 
 _dp = C.POINTER(C.c_double)
@@ -38,6 +40,7 @@ class OrcProblem(C.Structure):
         ("nx", C.c_int32), ("knots", _dp), ("coef_x", _dp), ("coef_y", _dp),
         ("n_obs", C.c_int32), ("T_obs", C.c_int32), ("obs_pose", _dp), ("obs_dims", _dp),
         ("final_time_step", C.c_int32), ("t_now", C.c_int32), ("check_stride", C.c_int32),
+        ("curvature_mask", C.c_int32), ("max_curvature", C.c_double), ("max_kappa_d", C.c_double), ("max_kappa_dd", C.c_double),
     ]
 
 
@@ -76,6 +79,8 @@ def lib():
         L.orc_fiss_cost_est.argtypes = [PP, C.c_double, _ip, _dp]
         L.orc_from_state.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp]
         L.orc_fop_plan_batch.argtypes = [PP, C.c_int32, C.c_int32, _ip, _dp]
+        L.orc_boxes_intersect.argtypes = [C.c_double] * 10
+        L.orc_boxes_intersect.restype = C.c_int
         _lib = L
     return _lib
 
@@ -133,6 +138,12 @@ def spline2d_eval(knots, cx, cy, s):
     return None if rc else out
 
 
+def boxes_intersect(box_a, box_b):
+    """The collision primitive: boxes are (length, width, x, y, yaw).  True / False, or None when a polygon cannot be built."""
+    rc = lib().orc_boxes_intersect(*[float(v) for v in box_a], *[float(v) for v in box_b])
+    return None if rc < 0 else bool(rc)
+
+
 def from_state(x, y, yaw, v, polyline):
     pl = _f64(polyline)
     st = _f64([x, y, yaw, v])
@@ -149,7 +160,7 @@ class Problem:
 
     def __init__(self, *, d_samples, v_samples, t_samples, tick_t, target_speed, veh_l, veh_w, max_speed, max_accel,
                  ego, knots, coef_x, coef_y, obs_pose=None, obs_dims=None, final_time_step=0, t_now=0, check_stride=2,
-                 samp_min=None, samp_max=None, samp_res=None):
+                 samp_min=None, samp_max=None, samp_res=None, curvature_limits=None):
         self._keep = k = SimpleNamespace()
         k.d = _f64(d_samples); k.v = _f64(v_samples); k.t = _f64(t_samples)
         k.knots = _f64(knots); k.cx = _f64(coef_x); k.cy = _f64(coef_y)
@@ -176,6 +187,9 @@ class Problem:
         P.T_obs, P.n_obs = (k.pose.shape[0], k.pose.shape[1]) if k.pose.size else (0, 0)
         P.obs_pose = _p(k.pose); P.obs_dims = _p(k.dims)
         P.final_time_step = int(final_time_step); P.t_now = int(t_now); P.check_stride = int(check_stride)
+        if curvature_limits is not None:  # (max_curvature, max_kappa_d, max_kappa_dd): turns the optional checks on
+            P.curvature_mask = 1
+            P.max_curvature, P.max_kappa_d, P.max_kappa_dd = (float(v) for v in curvature_limits)
         self.c = P
 
     @property
@@ -266,7 +280,8 @@ def problems_from_batch(batch, egos=None, d_samples=None):
             check_stride=batch.check_stride,
             samp_min=batch.samp_min[b] if getattr(batch, "samp_min", None) is not None else None,
             samp_max=batch.samp_max[b] if getattr(batch, "samp_max", None) is not None else None,
-            samp_res=batch.samp_res[b] if getattr(batch, "samp_res", None) is not None else None))
+            samp_res=batch.samp_res[b] if getattr(batch, "samp_res", None) is not None else None,
+            curvature_limits=getattr(batch, "curvature_limits", None)))
     return out
 
 

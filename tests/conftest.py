@@ -48,3 +48,40 @@ def engine():
     eng = FrenetEngine(0)  # raises when there is no GPU / no built library: no silent fallback
     yield eng
     eng.close()
+
+
+def series_tol(w: np.ndarray, dt: float = 0.1, pos_err: float = 4e-13) -> np.ndarray:
+    """Per-element tolerance for comparing a [16, n] trajectory dump (NaN padded) with a reference dump `w`.
+
+    Rows 0-10 (t, s.., d.., x, y): 1e-8 absolute.  Rows 11-15 (yaw, ds, c, c_d, c_dd) are finite differences of x / y
+    (frenet_optimal_planner.py:121-134), so two correct implementations whose positions differ by `pos_err` (a few ulp of a
+    500 m coordinate) differ by that error propagated through the difference chain: 2 pos_err / ds in yaw, then a division by ds
+    for c and by dt for each further derivative.  Candidates that come to a stop have ds ~ 1e-4 m at the end, which makes their
+    last curvature samples noise in ANY implementation (the reference's included); the bound follows the noise instead of hiding it
+    behind one loose number."""
+    tol = np.full(w.shape, 1e-8)
+    ds = w[12]
+    n = w.shape[1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_yaw = np.where(ds > 0, 2 * pos_err / ds, np.inf)
+        m_last = int(np.sum(~np.isnan(w[11])))  # yaw has M entries, the last one repeats the one before
+        if m_last >= 2:
+            t_yaw[m_last - 1] = t_yaw[m_last - 2]
+        nxt = lambda a: np.append(a[1:], np.inf)
+        t_c = (t_yaw + nxt(t_yaw)) / ds + np.abs(w[13]) * 2 * pos_err / ds
+        t_cd = (t_c + nxt(t_c)) / dt
+        t_cdd = (t_cd + nxt(t_cd)) / dt
+    for row, t in ((11, t_yaw), (12, np.full(n, 2 * pos_err)), (13, t_c), (14, t_cd), (15, t_cdd)):
+        tol[row] = np.maximum(1e-9, np.nan_to_num(t, nan=np.inf, posinf=np.inf)) * 4 + 1e-9
+    return tol
+
+
+def assert_series_close(got: np.ndarray, want: np.ndarray, dt: float = 0.1, what: str = ""):
+    """NaN pattern identical and every finite element within series_tol of the reference dump."""
+    assert got.shape == want.shape, what
+    assert np.array_equal(np.isnan(got), np.isnan(want)), what
+    m = ~np.isnan(want)
+    tol = series_tol(want, dt)
+    bad = m & ~(np.abs(np.where(m, got - want, 0.0)) <= tol)
+    assert not bad.any(), f"{what}: rows {sorted(set(np.nonzero(bad)[0].tolist()))} first {np.argwhere(bad)[:4].tolist()} " \
+                          f"err {np.abs(got - want)[bad][:4]} tol {tol[bad][:4]}"

@@ -1,0 +1,95 @@
+"""GPU: the N-rank bench path and BASELINE configs[4] (16384 egos, sharded).
+
+* `python bench.py --gpus 2` spawns two ranks by itself (torch.distributed.run); on the 1-GPU test box both ranks share
+  device 0 and rendezvous over gloo (BENCH_ALL_ON_DEVICE0 / BENCH_DIST_BACKEND hooks) - everything else is the code the
+  8-GPU run executes: per-rank shard generation, barrier, max-over-ranks, one JSON line with n_gpus = 2.
+* the full 16384-ego config-5 batch on ONE GPU: every shard a rank would plan equals the same rows of the full-batch
+  result (that is the whole multi-GPU contract: no collective, concatenation), invariants of the tables hold for every
+  ego, and an oracle sample spread over all eight shards agrees exactly.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from fiss_plus_planner_amd import synth
+
+pytestmark = pytest.mark.gpu
+COST_TOL = 1e-6
+
+
+def _run_bench(extra, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    line = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--egos", "512"],
+                      {"BENCH_DIST_BACKEND": "gloo", "BENCH_ALL_ON_DEVICE0": "1"})
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2
+    assert line["scaling"] == "weak" and line["unit"] == "candidates/s"
+    assert "configs[4]" in line["config"]["workload"]
+    # whole-job aggregate: both ranks' candidates over the max-over-ranks time
+    assert abs(line["value"] - 2 * 512 * 567 * 6 / (line["ms_per_step"] * 6e-3)) / line["value"] < 1e-9
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["kernel_ms"] > 0
+    assert line["cpu_baseline"] is None  # rank 0 at N = 1 only
+
+
+def test_bench_rejects_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def test_bench_single_gpu_line_has_every_configuration():
+    line = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-seconds", "2", "--no-latency"])
+    assert line["n_gpus"] == 1 and "configs[2]" in line["config"]["workload"]
+    for key in ("config2", "config4", "lattice_order_off", "rotating_batches", "survey8d_layout"):
+        assert line[key]["value"] > 0 and 0 < line[key]["roofline"]["frac"] < 1, key
+    assert set(line["config4"]["stage_ms"]) == {"lattice_fused_kernel (dense tables)", "fiss_search_kernel",
+                                                "fiss_refine_kernel (3 rounds + validation + winner series)"}
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline_1thread"]["cores"] == 1
+
+
+def test_config5_full_batch_equals_its_eight_shards(oracle, engine):
+    """BASELINE configs[4] at full size on one GPU."""
+    B, W = 16384, 8
+    full = synth.make_config(5, B=B)
+    out = engine.plan_dense(full, tables=True)
+    # (1) the multi-GPU contract: rank r generates + plans only its shard; concatenation == full batch
+    for r in (0, 3, 7):
+        part = synth.make_config(5, B=B // W, ego_offset=r * (B // W))
+        po = engine.plan_dense(part, tables=False)
+        sl = slice(r * (B // W), (r + 1) * (B // W))
+        np.testing.assert_array_equal(po.best_idx, out.best_idx[sl])
+        np.testing.assert_array_equal(po.best_cost, out.best_cost[sl])
+    # (2) invariants for every ego: the winner is feasible and no feasible candidate is cheaper; N/M words are consistent
+    ok = out.best_idx >= 0
+    assert 0.5 < ok.mean() < 1.0
+    feas = (out.flags & 7) == 0
+    masked = np.where(feas, out.cost, np.inf)
+    assert np.array_equal(masked.min(axis=1)[ok], out.best_cost[ok])
+    assert np.array_equal(feas.any(axis=1), ok)
+    # FOP keeps the LAST minimal index (frenet_optimal_planner.py:266)
+    last_min = out.cost.shape[1] - 1 - np.argmin(masked[:, ::-1], axis=1)
+    np.testing.assert_array_equal(out.best_idx[ok], last_min[ok])
+    N, M = (out.flags >> 8) & 0xFFF, out.flags >> 20
+    assert (M <= N).all() and (N >= 80).all() and (N <= 100).all()
+    assert np.array_equal(((out.flags & 8) != 0), M < N)
+    np.testing.assert_array_equal(out.stats, np.tile([0, full.C, full.C, full.C], (B, 1)))
+    # (3) oracle sample: 24 egos of every shard
+    egos = np.concatenate([np.arange(24) * 85 + r * (B // W) for r in range(W)])
+    threads = len(os.sched_getaffinity(0))
+    idx, cost = oracle.fop_plan_batch(oracle.problems_from_batch(full, egos), threads=threads)
+    np.testing.assert_array_equal(out.best_idx[egos], idx)
+    good = idx >= 0
+    np.testing.assert_allclose(out.best_cost[egos][good], cost[good], rtol=0, atol=COST_TOL)

@@ -152,3 +152,43 @@ def test_flensburg_closed_loop(engine, kind, search_on):
         if kind in ("FISS", "FISS+"):  # FOP/FOP+ trajectories carry no end_state in the reference
             np.testing.assert_allclose(r.end, w[16:19], rtol=0, atol=1e-7)
     np.testing.assert_allclose(states, g[f"{kind}_states"], rtol=0, atol=1e-6)
+
+
+def test_fresh_obstacle_lists_are_never_served_from_a_stale_table(engine):
+    """plan() is called cycle after cycle with a NEW list of NEW obstacle objects of the same length (a perception stack that
+    rebuilds its tracks): the flattened table must follow the objects, never the recycled address or length of the list.
+    A blocked lane must be reported blocked even when the previous cycle's (equal-length) list left it free, and vice versa."""
+    import gc
+    import sys
+
+    sys.path.insert(0, GOLDEN)
+    from refshim import StubObstacle
+
+    from fiss_plus_planner_amd import planners as P
+    from fiss_plus_planner_amd.frenet import FrenetState
+    from fiss_plus_planner_amd.vehicle import Vehicle
+
+    pl = P.FrenetOptimalPlanner(P.FrenetOptimalPlannerSettings(5, 5, 5), Vehicle(), None, engine=engine)
+    pl.generate_frenet_frame(np.column_stack([np.linspace(0, 300, 61), np.zeros(61)]))
+    fs = FrenetState(t=0.0, s=10.0, s_d=8.0, s_dd=0.0, d=0.1, d_d=0.0, d_dd=0.0)
+
+    def wall(x):  # a 40 m wide wall across the road at arclength x, for 60 time steps
+        return [StubObstacle(2.0, 40.0, np.tile([x, 0.0, 0.0], (60, 1)), 59) for _ in range(3)]
+
+    verdicts = []
+    for cycle in range(12):
+        blocked = cycle % 2 == 0
+        obstacles = wall(25.0 if blocked else 5000.0)
+        pl.best_traj = None
+        best = pl.plan(fs, 10.0, obstacles, 0)
+        verdicts.append(best is None)
+        coll = (pl.last_tables[1] & 4) != 0
+        assert coll.all() if blocked else not coll.any(), cycle
+        del obstacles, best
+        gc.collect()  # lets CPython hand the freed list's address to the next one
+    assert verdicts == [c % 2 == 0 for c in range(12)]
+    # the same objects in a new list: one flattening serves both
+    obstacles = wall(25.0)
+    t1 = pl._obstacle_table(obstacles)
+    assert pl._obstacle_table(list(obstacles)) is t1
+    assert pl._obstacle_table(wall(25.0)) is not t1

@@ -5,6 +5,7 @@ egos sharing frames and scenes."""
 import numpy as np
 import pytest
 
+from conftest import assert_series_close
 from fiss_plus_planner_amd import synth
 from fiss_plus_planner_amd.batch import ProblemBatch
 from fiss_plus_planner_amd.spline import build_frames
@@ -86,6 +87,7 @@ def test_random_settings_vs_oracle(oracle, engine, seed):
             assert np.array_equal(np.isnan(a), np.isnan(w))
             m = ~np.isnan(w)
             np.testing.assert_allclose(a[:11][m[:11]], w[:11][m[:11]], rtol=0, atol=1e-8)
+            assert_series_close(a, w, b.tick_t, f"seed {seed} ego {e} traj {k}")  # all 16 rows, rows 11-15 with derived bounds
 
 
 @pytest.mark.parametrize("kind", ["FISS", "FISS+"])
