@@ -290,6 +290,74 @@ __device__ __forceinline__ void sincos_snapped(double yaw, double& s, double& c)
 }
 
 // ---------------------------------------------------------------------------
+// Optional curvature checks (frenet_optimal_planner.py:145-150, commented out in the reference; fp_params.curvature_mask).
+// The checked series are finite-difference chains over the Cartesian points (:121-134):
+//     yaw_k = atan2(y_{k+1} - y_k, x_{k+1} - x_k), k < M-1;  yaw_{M-1} = yaw_{M-2};   ds_k = hypot(...)
+//     c_k = (yaw_{k+1} - yaw_k) / ds_k (M-1 values),  c_d = diff(c) / dt (M-2),  c_dd = diff(c_d) / dt (M-3)
+// CurvTrack consumes the segments (yaw_k, ds_k) in order and keeps only the previous element of each chain.
+// `abs(nan) > limit` is False in the reference (a 0/0 of a standing segment never violates); inf does.
+// ---------------------------------------------------------------------------
+struct CurvTrack {
+    double yaw_prev, ds_prev, c_prev, cd_prev, inv_dt;
+    double max_c, max_cd, max_cdd;
+    uint32_t flags;
+    int have;  // bit 0: a segment, bit 1: a c value, bit 2: a c_d value
+
+    __device__ __forceinline__ void init(const fp_params& p)
+    {
+        max_c = p.max_curvature; max_cd = p.max_kappa_d; max_cdd = p.max_kappa_dd;
+        yaw_prev = ds_prev = c_prev = cd_prev = 0.0;
+        flags = 0; have = 0;
+    }
+    __device__ __forceinline__ void push_cd(double cd, double dt)
+    {
+        if (fabs(cd) > max_cd) flags |= FP_FLAG_KAPPA_D;
+        if ((have & 4) && fabs((cd - cd_prev) / dt) > max_cdd) flags |= FP_FLAG_KAPPA_DD;
+        cd_prev = cd; have |= 4;
+    }
+    __device__ __forceinline__ void push_c(double c, double dt)
+    {
+        if (fabs(c) > max_c) flags |= FP_FLAG_CURVATURE;
+        if (have & 2) push_cd((c - c_prev) / dt, dt);
+        c_prev = c; have |= 2;
+    }
+    __device__ __forceinline__ void push_segment(double yaw, double ds, double dt)
+    {
+        if (have & 1) push_c((yaw - yaw_prev) / ds_prev, dt);
+        yaw_prev = yaw; ds_prev = ds; have |= 1;
+    }
+    // yaw[M-1] repeats yaw[M-2] (:129): the last curvature sample is 0 / ds_{M-2}
+    __device__ __forceinline__ void finish(double dt)
+    {
+        if (have & 1) push_c((yaw_prev - yaw_prev) / ds_prev, dt);
+    }
+};
+
+// FP_FLAG_CURVATURE / KAPPA_D / KAPPA_DD of ONE trajectory, sequentially over its points (one lane per trajectory).  Positions come
+// from the same spline_frame / frenet_to_cartesian arithmetic as every series dump of this library.
+__device__ __forceinline__ uint32_t curvature_flags(const fp_params& p, const SplineLds& sp, const Quartic& lon, const Quintic& lat, int N)
+{
+    CurvTrack ct;
+    ct.init(p);
+    int seg = -1;
+    double xp = 0.0, yp = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double t = (double)i * p.tick_t;
+        const double s = fma(fma(fma(fma(lon.a4, t, lon.a3), t, lon.a2), t, lon.a1), t, lon.a0);
+        seg = spline_segment(sp, s, seg);
+        if (seg < 0) break;  // truncation (:112-113)
+        const double d = fma(fma(fma(fma(fma(lat.a5, t, lat.a4), t, lat.a3), t, lat.a2), t, lat.a1), t, lat.a0);
+        double px, py, tx, ty, x, y;
+        spline_frame(sp, seg, s - sp.knots[seg], px, py, tx, ty);
+        frenet_to_cartesian(px, py, tx, ty, d, x, y);
+        if (i >= 1) ct.push_segment(atan2(y - yp, x - xp), hypot(x - xp, y - yp), p.tick_t);
+        xp = x; yp = y;
+    }
+    ct.finish(p.tick_t);
+    return ct.flags;
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (64-lane wavefronts)
 // ---------------------------------------------------------------------------
 // DPP lane exchange inside a row of 16 lanes (no LDS round trip, unlike __shfl_xor -> ds_bpermute):

@@ -31,6 +31,9 @@ struct KernelArgs {
     fp_params p;
     fp_batch b;
     fp_result r;
+    // [B][C] FP_FLAG_CURVATURE / KAPPA_D / KAPPA_DD of every lattice candidate (flat FOP order), written by
+    // launch_curvature_flags ahead of the fused lattice kernel when p.curvature_mask is set; nullptr otherwise
+    const uint8_t* curv_tbl = nullptr;
 };
 
 // Production dense-lattice kernel (profile sharing + compacted collision).  Returns hipErrorInvalidValue when the
@@ -62,6 +65,8 @@ size_t lattice_pose_scratch_bytes(const fp_params& p, const fp_batch& b, int nsp
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done = nullptr,
                                 const int* perm = nullptr, int* dur = nullptr, void* pose_scratch = nullptr);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
+// Curvature flags of every lattice candidate -> out [B][C] (one workgroup per ego, one lane per candidate, spline in LDS).
+hipError_t launch_curvature_flags(const KernelArgs& ka, uint8_t* out, hipStream_t stream);
 // Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done = nullptr,
                           const int* perm = nullptr, int* dur = nullptr, void* pose_scratch = nullptr);

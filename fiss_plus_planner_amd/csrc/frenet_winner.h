@@ -28,15 +28,18 @@ __device__ __forceinline__ void winner_series(const KernelArgs& ka, int b, int s
     int* sM = (int*)(scd + FP_MAX_POINTS + 1);
     const bool worker = i < FP_MAX_POINTS;
     const double nan = __builtin_nan("");
-    double* out = ka.r.best_traj + (size_t)slot * FP_ARR_COUNT * FP_MAX_POINTS;
+    // output layout (fp_result.traj_stride / traj_sparse): [16][stride] per slot; sparse = only existing elements are written
+    const int stride = ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS;
+    const bool sparse = ka.r.traj_sparse != 0;
+    double* out = ka.r.best_traj + (size_t)slot * FP_ARR_COUNT * stride;
     const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
     double row[FP_ARR_COUNT];
 #pragma unroll
     for (int r = 0; r < FP_ARR_COUNT; ++r) row[r] = nan;
     if (!valid || N <= 0 || N > FP_MAX_POINTS || !(d_end == d_end) || !(v_end == v_end)) {  // workgroup-uniform
-        if (worker) {
+        if (worker && i < stride && !sparse) {
 #pragma unroll
-            for (int r = 0; r < FP_ARR_COUNT; ++r) out[r * FP_MAX_POINTS + i] = nan;
+            for (int r = 0; r < FP_ARR_COUNT; ++r) out[r * stride + i] = nan;
         }
         if (i == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
         return;
@@ -90,9 +93,19 @@ __device__ __forceinline__ void winner_series(const KernelArgs& ka, int b, int s
         if (i < M) row[FP_ARR_YAW] = yaw;
         row[FP_ARR_DS] = ds; row[FP_ARR_C] = c; row[FP_ARR_C_D] = c_d; row[FP_ARR_C_DD] = c_dd;
     }
-    if (worker) {
+    if (worker && i < stride) {
+        if (!sparse) {
 #pragma unroll
-        for (int r = 0; r < FP_ARR_COUNT; ++r) __builtin_nontemporal_store(row[r], &out[r * FP_MAX_POINTS + i]);  // write-once stream
+            for (int r = 0; r < FP_ARR_COUNT; ++r) __builtin_nontemporal_store(row[r], &out[r * stride + i]);  // write-once stream
+        } else {
+            // row lengths: N (t, s.., d..), M (x, y, yaw), M-1 (ds, c), M-2 (c_d), M-3 (c_dd); M < 2 leaves only x / y of length M
+            const int Mx = M, My = M >= 2 ? M : 0;
+#pragma unroll
+            for (int r = 0; r < FP_ARR_COUNT; ++r) {
+                const int len = r < FP_ARR_X ? N : (r <= FP_ARR_Y ? Mx : (r == FP_ARR_YAW ? My : (r <= FP_ARR_C ? My - 1 : (r == FP_ARR_C_D ? My - 2 : My - 3))));
+                if (i < len) __builtin_nontemporal_store(row[r], &out[r * stride + i]);
+            }
+        }
     }
     if (i == 0 && ka.r.best_flags) {
         uint32_t fl = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);

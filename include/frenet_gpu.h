@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 7
+#define FP_ABI_VERSION 8
 
 /* error codes */
 #define FP_OK 0
@@ -60,7 +60,13 @@ extern "C" {
 #define FP_FLAG_ACCEL 2u      /* any(|s_dd| > max_accel)    frenet_optimal_planner.py:155 */
 #define FP_FLAG_COLLISION 4u  /* has_collision()            frenet_optimal_planner.py:168-195 */
 #define FP_FLAG_TRUNCATED 8u  /* M < N: left the spline     frenet_optimal_planner.py:112-113 */
-#define FP_FLAG_INFEASIBLE 7u
+/* the three checks check_constraints carries commented out (frenet_optimal_planner.py:145-150); set only when
+ * fp_params.curvature_mask != 0 */
+#define FP_FLAG_CURVATURE 16u /* any(|c| > max_curvature)    :145-146 */
+#define FP_FLAG_KAPPA_D 32u   /* any(|c_d| > max_kappa_d)    :147-148 */
+#define FP_FLAG_KAPPA_DD 64u  /* any(|c_dd| > max_kappa_dd)  :149-150 */
+#define FP_FLAG_CONSTRAINTS (FP_FLAG_SPEED | FP_FLAG_ACCEL | FP_FLAG_CURVATURE | FP_FLAG_KAPPA_D | FP_FLAG_KAPPA_DD) /* check_constraints */
+#define FP_FLAG_INFEASIBLE (FP_FLAG_CONSTRAINTS | FP_FLAG_COLLISION)
 #define FP_FLAG_N_SHIFT 8     /* bits 8..19  N = len(t) */
 #define FP_FLAG_M_SHIFT 20    /* bits 20..31 M = len(x) */
 
@@ -83,6 +89,13 @@ typedef struct {
     double w_speed, w_accel, w_jerk, w_offset; /* w_V=1, w_A=0.1, w_J=0.1, w_LC=10 */
     double veh_l, veh_w;    /* ego footprint */
     double max_speed, max_accel;
+    /* Optional curvature checks: the reference has them in check_constraints but commented out (:145-150), so 0 = off is the
+     * reference's behaviour.  != 0: a candidate whose Cartesian series has any |c| > max_curvature, |c_d| > max_kappa_d or
+     * |c_dd| > max_kappa_dd (c = diff(yaw)/ds, c_d = diff(c)/tick_t, c_dd = diff(c_d)/tick_t, :131-134) fails the constraints
+     * like a speed / acceleration violation does.  Limits: Vehicle.max_curvature / max_kappa_d / max_kappa_dd (vehicle.py:44-46). */
+    int32_t curvature_mask;
+    int32_t reserved0;
+    double max_curvature, max_kappa_d, max_kappa_dd;
 } fp_params;
 
 /* A batch of B independent ego planning problems (layout: DESIGN.md "problem batch"). */
@@ -115,8 +128,14 @@ typedef struct {
     uint32_t* flag_tbl;  /* [B][C]  FP_FLAG_* | N << 8 | M << 20 */
     int32_t* stats;      /* [B][4]  num_iter, generated, validated, collision_checks                    :254-256 */
     uint32_t* best_flags; /* [B]    flag word (N, M) of the argmin, 0 when best_idx = -1 */
-    double* best_traj;   /* [B][16][FP_MAX_POINTS]  winner epilogue: the argmin's full FrenetTrajectory series (NaN padded;
+    double* best_traj;   /* [B][16][traj_stride]  winner epilogue: the argmin's full FrenetTrajectory series (NaN padded;
                             all NaN when best_idx = -1) = what plan() returns                           :264-270 */
+    int32_t traj_stride; /* columns per series row; 0 = FP_MAX_POINTS.  Must be >= the largest N = ceil(T / tick_t) of the batch
+                            (e.g. 100 for T <= 10 s at 0.1 s): a smaller stride is FP_EINVAL (host) / truncates the rows (device) */
+    int32_t traj_sparse; /* 0: every element of the [16][traj_stride] block is written (NaN where a row has no element).
+                            1: only the elements that exist are written - row r gets its len(r) leading elements (N for the Frenet
+                            rows, M / M-1 / M-2 / M-3 for x y yaw / ds c / c_d / c_dd), the rest of the block and the blocks of egos
+                            without a winner (best_flags = 0) are left untouched: the bytes written are the algorithmic bytes */
 } fp_result;
 
 int fp_abi_version(void);
@@ -156,28 +175,28 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
                   void* stream);
 
 /* Winner epilogue on its own: full series of lattice candidate best_idx[b] for every ego -> best_flags [B],
- * best_traj [B][16][FP_MAX_POINTS].  fp_plan_dense produces the same output inside its own launch when result.best_traj is set
+ * best_traj [B][16][traj_stride] (traj_stride / traj_sparse as in fp_result).  fp_plan_dense produces the same output inside its own launch when result.best_traj is set
  * (the workgroup that finds the argmin writes the series); exported separately for callers that pick the trajectory
  * themselves.  Replaces the object hand-back of plan() (:264-270). */
 int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
-                    double* best_traj, int mem, void* stream);
+                    double* best_traj, int32_t traj_stride, int32_t traj_sparse, int mem, void* stream);
 
 /* Materialise the whole lattice: the full series of EVERY candidate of every ego, in FOP order
- *   traj [B][C][16][FP_MAX_POINTS] (NaN padded), flags [B][C] (N << 8 | M << 20 | FP_FLAG_TRUNCATED; the feasibility bits
+ *   traj [B][C][16][traj_stride] (traj_stride / traj_sparse as in fp_result), flags [B][C] (N << 8 | M << 20 | FP_FLAG_TRUNCATED; the feasibility bits
  *   come from fp_plan_dense's flag_tbl).
  * = what calc_frenet_paths + calc_global_paths leave in `all_trajs` for the visualisation (frenet_optimal_planner.py:102,
- * planners/benchmark/planning.py:336-357).  This is the one mode of the path that is HBM bound: 16 KiB written per candidate. */
-int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, uint32_t* flags, double* traj, int mem,
-                       void* stream);
+ * planners/benchmark/planning.py:336-357).  This is the one mode of the path that is HBM bound: 128 B per trajectory point. */
+int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, uint32_t* flags, double* traj, int32_t traj_stride,
+                       int32_t traj_sparse, int mem, void* stream);
 
 /* Explicit end states: K trajectories per ego with end state (d_end, v_end, T_end)
  *   = generate_trajectory_by_end_state (fiss_plus_planner.py:172-205) / generate_trajectory
  *   (fiss_planner.py:101-138) + calc_global_paths + check_constraints + has_collision.
- * end_states [B][K][3]; cost [B][K]; flags [B][K]; traj NULL or [B][K][16][stride] (NaN padded),
+ * end_states [B][K][3]; cost [B][K]; flags [B][K]; traj NULL or [B][K][16][traj_stride] (traj_stride / traj_sparse as in fp_result),
  * the full FrenetTrajectory series of every requested trajectory (winner epilogue,
  * FISS+ refinement, all_trajs visualisation payload). */
 int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states,
-                  double* cost, uint32_t* flags, double* traj, int32_t stride, int mem, void* stream);
+                  double* cost, uint32_t* flags, double* traj, int32_t traj_stride, int32_t traj_sparse, int mem, void* stream);
 
 /* ---- FISS / FISS+ for a whole batch, entirely on the device --------------------------------------------------
  * fp_plan_fiss = FissPlanner.plan (fiss_planner.py:190-270) or FissPlusPlanner.plan (fiss_plus_planner.py:61-170)
@@ -211,7 +230,9 @@ typedef struct {
     int32_t* stats;            /* [B][4] num_iter, generated, validated, collision_checks (incl. refinement) */
     double* trace;             /* NULL or [B][max_refine_iters*7][4] = d, v, T, cost of every refinement trajectory */
     uint32_t* best_flags;      /* NULL or [B] flag word (N, M) of the returned trajectory */
-    double* best_traj;         /* NULL or [B][16][FP_MAX_POINTS] its full series (requires best_flags) */
+    double* best_traj;         /* NULL or [B][16][traj_stride] its full series (requires best_flags) */
+    int32_t traj_stride;       /* as in fp_result (0 = FP_MAX_POINTS) */
+    int32_t traj_sparse;       /* as in fp_result */
 } fp_fiss_io;
 
 /* In FP_MEM_DEVICE mode the ctx grows an internal scratch arena (dense tables, B*C*12 bytes) on first use. */
