@@ -11,11 +11,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 7
+FP_ABI_VERSION = 8
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
-FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED, FLAG_INFEASIBLE = 1, 2, 4, 8, 7
+FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED = 1, 2, 4, 8
+FLAG_CURVATURE, FLAG_KAPPA_D, FLAG_KAPPA_DD = 16, 32, 64   # optional checks (fp_params.curvature_mask)
+FLAG_CONSTRAINTS = FLAG_SPEED | FLAG_ACCEL | FLAG_CURVATURE | FLAG_KAPPA_D | FLAG_KAPPA_DD
+FLAG_INFEASIBLE = FLAG_CONSTRAINTS | FLAG_COLLISION
 FLAG_N_SHIFT, FLAG_M_SHIFT = 8, 20
 
 _dp = C.POINTER(C.c_double)
@@ -31,7 +34,9 @@ class FpParams(C.Structure):
     _fields_ = [("nd", C.c_int32), ("nv", C.c_int32), ("nt", C.c_int32), ("check_stride", C.c_int32),
                 ("tick_t", C.c_double), ("cost_horizon", C.c_double),
                 ("w_speed", C.c_double), ("w_accel", C.c_double), ("w_jerk", C.c_double), ("w_offset", C.c_double),
-                ("veh_l", C.c_double), ("veh_w", C.c_double), ("max_speed", C.c_double), ("max_accel", C.c_double)]
+                ("veh_l", C.c_double), ("veh_w", C.c_double), ("max_speed", C.c_double), ("max_accel", C.c_double),
+                ("curvature_mask", C.c_int32), ("reserved0", C.c_int32),
+                ("max_curvature", C.c_double), ("max_kappa_d", C.c_double), ("max_kappa_dd", C.c_double)]
 
 
 class FpBatch(C.Structure):
@@ -44,7 +49,8 @@ class FpBatch(C.Structure):
 
 class FpResult(C.Structure):
     _fields_ = [("best_idx", C.c_void_p), ("best_cost", C.c_void_p), ("cost_tbl", C.c_void_p), ("flag_tbl", C.c_void_p),
-                ("stats", C.c_void_p), ("best_flags", C.c_void_p), ("best_traj", C.c_void_p)]
+                ("stats", C.c_void_p), ("best_flags", C.c_void_p), ("best_traj", C.c_void_p),
+                ("traj_stride", C.c_int32), ("traj_sparse", C.c_int32)]
 
 
 class FpFissOpts(C.Structure):
@@ -53,7 +59,8 @@ class FpFissOpts(C.Structure):
 
 class FpFissIo(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("samp_min", "samp_max", "samp_res", "prev_best_idx", "best_ijk", "best_cost", "end_state",
-                                          "refined", "stats", "trace", "best_flags", "best_traj")]
+                                          "refined", "stats", "trace", "best_flags", "best_traj")] + \
+               [("traj_stride", C.c_int32), ("traj_sparse", C.c_int32)]
 
 
 class FpLoopIo(C.Structure):
@@ -98,14 +105,15 @@ def load() -> C.CDLL:
     L.fp_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.fp_ctx_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
     L.fp_plan_dense.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpResult), C.c_int, C.c_void_p]
-    L.fp_winner_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.fp_winner_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_int, C.c_void_p]
     L.fp_eval_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p, C.c_int32, C.c_int, C.c_void_p]
+                                C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
     L.fp_plan_fiss.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpFissOpts), C.POINTER(FpFissIo), C.c_int, C.c_void_p]
     L.fp_advance.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.POINTER(FpLoopIo), C.c_int, C.c_void_p]
     L.fp_frames_build.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fp_from_state.argtypes = [C.c_void_p, C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    L.fp_materialize_all.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.fp_materialize_all.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
     if L.fp_abi_version() != FP_ABI_VERSION:
         raise ImportError(f"libfrenetgpu ABI {L.fp_abi_version()} != binding {FP_ABI_VERSION}: rebuild")
     _lib = L

@@ -73,6 +73,9 @@ class ProblemBatch:
     samp_min: np.ndarray | None = None  # [B, 3] (d, v, t) FISS/FISS+ sampling box
     samp_max: np.ndarray | None = None
     samp_res: np.ndarray | None = None
+    # (max_curvature, max_kappa_d, max_kappa_dd): turns on the curvature checks the reference carries commented out
+    # (frenet_optimal_planner.py:145-150); None = off = the reference's behaviour
+    curvature_limits: tuple | None = None
     meta: dict = field(default_factory=dict)
 
     def __post_init__(self):
@@ -127,7 +130,8 @@ class ProblemBatch:
             max_speed=self.max_speed, max_accel=self.max_accel, tick_t=self.tick_t, check_stride=self.check_stride,
             samp_min=None if self.samp_min is None else self.samp_min[sel],
             samp_max=None if self.samp_max is None else self.samp_max[sel],
-            samp_res=None if self.samp_res is None else self.samp_res[sel], meta=dict(self.meta, rank=rank, world=world))
+            samp_res=None if self.samp_res is None else self.samp_res[sel], curvature_limits=self.curvature_limits,
+            meta=dict(self.meta, rank=rank, world=world))
 
     def digest(self) -> str:
         """SHA-256 over every array: lets the GPU box prove it regenerated the same inputs."""

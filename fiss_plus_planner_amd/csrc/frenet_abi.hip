@@ -9,6 +9,7 @@
 // one transfer per array.  Arrays above kSmallMax bytes are copied directly (no extra host pass over big batches).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -116,6 +117,7 @@ struct fp_ctx {
     int lattice_launches = 0, lattice_ordered_launches = 0;  // fp_ctx_get_option counters
     LaunchOrder order_lattice, order_refine;
     DeviceBuf pose_buf;            // converted obstacle rows of scenes too big for LDS (lattice_pose_scratch_bytes)
+    DeviceBuf curv_buf;            // [B][C] curvature flag bytes of the lattice (fp_params.curvature_mask), written ahead of the fused kernel
 };
 
 namespace {
@@ -245,6 +247,23 @@ int check_params(const fp_params* p)
     if ((long)p->nd * p->nv * p->nt > FP_MAX_CAND) return fail(FP_ELIMIT, "nd*nv*nt = %ld exceeds FP_MAX_CAND", (long)p->nd * p->nv * p->nt);
     if (p->check_stride < 1) return fail(FP_EINVAL, "check_stride must be >= 1");
     if (!(p->tick_t > 0)) return fail(FP_EINVAL, "tick_t must be > 0");
+    if (p->curvature_mask && (!(p->max_curvature >= 0) || !(p->max_kappa_d >= 0) || !(p->max_kappa_dd >= 0)))
+        return fail(FP_EINVAL, "curvature_mask is set but max_curvature / max_kappa_d / max_kappa_dd are not all >= 0");
+    return FP_OK;
+}
+
+// Series layout of a call: columns per row (0 = FP_MAX_POINTS).  Host calls can check it against the batch's time samples.
+int traj_stride_of(int32_t requested, int* stride)
+{
+    if (requested < 0) return fail(FP_EINVAL, "traj_stride must be >= 0");
+    *stride = requested > 0 ? requested : FP_MAX_POINTS;
+    return FP_OK;
+}
+int check_stride_host(const fp_params* p, const fp_batch* b, int stride)
+{
+    for (int k = 0; k < p->nt; ++k)
+        if (ceil(b->t_samples[k] / p->tick_t) > stride)
+            return fail(FP_EINVAL, "traj_stride=%d is smaller than the %g points of t_samples[%d]=%g", stride, ceil(b->t_samples[k] / p->tick_t), k, b->t_samples[k]);
     return FP_OK;
 }
 
@@ -426,7 +445,21 @@ int lattice_pose_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, int
     return FP_OK;
 }
 
-fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
+// Optional curvature checks: the fused lattice kernel reads them from a [B][C] byte table that launch_lattice fills first.
+int lattice_curv_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, const uint8_t** out)
+{
+    *out = nullptr;
+    if (!p->curvature_mask) return FP_OK;
+    const size_t need = (size_t)b->B * p->nd * p->nv * p->nt + kAlign;
+    if (need > ctx->curv_buf.cap) {
+        HIP_TRY(hipStreamSynchronize(stream));  // the buffer is reallocated: drain its users
+        FP_TRY(ctx->curv_buf.reserve(need));
+    }
+    *out = (const uint8_t*)ctx->curv_buf.base;
+    return FP_OK;
+}
+
+fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
 
 int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem)
 {
@@ -501,6 +534,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     if (ctx->parts.base) (void)hipFree(ctx->parts.base);
     if (ctx->pose_buf.base) (void)hipFree(ctx->pose_buf.base);
+    if (ctx->curv_buf.base) (void)hipFree(ctx->curv_buf.base);
     ctx->order_lattice.release();
     ctx->order_refine.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -560,12 +594,15 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t C = (size_t)params->nd * params->nv * params->nt, B = (size_t)batch->B;
+    int stride;
+    FP_TRY(traj_stride_of(result->traj_stride, &stride));
     fp::KernelArgs ka;
     ka.p = *params;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
+        FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
         int nsplit; void* parts;
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
         bool winner_done = false;
@@ -579,7 +616,8 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         return FP_OK;
     }
     FP_TRY(check_batch_host(params, batch));
-    const size_t traj_doubles = result->best_traj ? B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS : 0;
+    if (result->best_traj) FP_TRY(check_stride_host(params, batch, stride));
+    const size_t traj_doubles = result->best_traj ? B * FP_ARR_COUNT * (size_t)stride : 0;
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<int32_t>(B * 4) + 2 * HostStage::need<double>(B) + HostStage::need<int32_t>(B) +
                       HostStage::need<double>(B * C) + HostStage::need<uint32_t>(B * C) + HostStage::need<uint32_t>(B) +
@@ -594,6 +632,11 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     ka.r.flag_tbl = hs.out(result->flag_tbl, B * C);
     ka.r.best_flags = hs.out(result->best_flags, B);
     ka.r.best_traj = hs.out(result->best_traj, traj_doubles);
+    ka.r.traj_stride = result->traj_stride;
+    ka.r.traj_sparse = result->traj_sparse;
+    // sparse rows are only partly written by the kernels: the host block comes back with the caller's own bytes elsewhere
+    if (result->traj_sparse && ka.r.best_traj) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, result->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FP_TRY(lattice_curv_scratch(ctx, params, batch, ctx->stream, &ka.curv_tbl));
     int nsplit; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts));
     bool winner_done = false;
@@ -608,16 +651,20 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
 }
 
 int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
-                    double* best_traj, int mem, void* stream)
+                    double* best_traj, int32_t traj_stride, int32_t traj_sparse, int mem, void* stream)
 {
     FP_TRY(common_checks(ctx, params, batch, mem));
     if (!best_idx || !best_flags || !best_traj) return fail(FP_EINVAL, "best_idx/best_flags/best_traj must not be NULL");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t B = (size_t)batch->B, traj_doubles = B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS;
+    int stride;
+    FP_TRY(traj_stride_of(traj_stride, &stride));
+    const size_t B = (size_t)batch->B, traj_doubles = B * FP_ARR_COUNT * (size_t)stride;
     fp::KernelArgs ka;
     ka.p = *params;
     ka.r = no_result();
+    ka.r.traj_stride = traj_stride;
+    ka.r.traj_sparse = traj_sparse;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         ka.r.best_idx = const_cast<int32_t*>(best_idx);
@@ -627,6 +674,7 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
         return FP_OK;
     }
     FP_TRY(check_batch_host(params, batch));
+    FP_TRY(check_stride_host(params, batch, stride));
     const int C = params->nd * params->nv * params->nt;
     for (size_t i = 0; i < B; ++i)
         if (best_idx[i] >= C) return fail(FP_EINVAL, "best_idx[%zu]=%d out of range", i, best_idx[i]);
@@ -639,21 +687,27 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
     ka.r.best_idx = const_cast<int32_t*>(d_idx);
     ka.r.best_flags = hs.out(best_flags, B);
     ka.r.best_traj = hs.out(best_traj, traj_doubles);
+    if (traj_sparse) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     return hs.fetch_out();
 }
 
-int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, uint32_t* flags, double* traj, int mem, void* stream)
+int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, uint32_t* flags, double* traj, int32_t traj_stride,
+                       int32_t traj_sparse, int mem, void* stream)
 {
     FP_TRY(common_checks(ctx, params, batch, mem));
     if (!flags || !traj) return fail(FP_EINVAL, "flags/traj must not be NULL");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t BC = (size_t)batch->B * params->nd * params->nv * params->nt, traj_doubles = BC * FP_ARR_COUNT * (size_t)FP_MAX_POINTS;
+    int stride;
+    FP_TRY(traj_stride_of(traj_stride, &stride));
+    const size_t BC = (size_t)batch->B * params->nd * params->nv * params->nt, traj_doubles = BC * FP_ARR_COUNT * (size_t)stride;
     if (BC > 0x7fffffffu) return fail(FP_ELIMIT, "B*C = %zu exceeds the grid size limit", BC);
     fp::KernelArgs ka;
     ka.p = *params;
     ka.r = no_result();
+    ka.r.traj_stride = traj_stride;
+    ka.r.traj_sparse = traj_sparse;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         ka.r.best_flags = flags;
@@ -662,12 +716,14 @@ int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* bat
         return FP_OK;
     }
     FP_TRY(check_batch_host(params, batch));
+    FP_TRY(check_stride_host(params, batch, stride));
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<uint32_t>(BC) + HostStage::need<double>(traj_doubles)));
     FP_TRY(stage_batch(hs, params, batch, &ka.b));
     FP_TRY(hs.flush_in());
     ka.r.best_flags = hs.out(flags, BC);
     ka.r.best_traj = hs.out(traj, traj_doubles);
+    if (traj_sparse) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     LAUNCH_TRY(fp::launch_materialize_all(ka, ctx->stream), "materialise kernel");
     return hs.fetch_out();
 }
@@ -709,7 +765,9 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     fa.ka.r.best_cost = (double*)sp;
     fa.cost_tbl = fa.ka.r.cost_tbl;
     fa.flag_tbl = fa.ka.r.flag_tbl;
-    const size_t traj_doubles = io->best_traj ? B * FP_ARR_COUNT * (size_t)FP_MAX_POINTS : 0;
+    int stride;
+    FP_TRY(traj_stride_of(io->traj_stride, &stride));
+    const size_t traj_doubles = io->best_traj ? B * FP_ARR_COUNT * (size_t)stride : 0;
     const size_t trace_doubles = (io->trace && R > 0) ? B * (size_t)R * 7 * 4 : 0;
     HostStage hs(ctx);
     if (mem == FP_MEM_DEVICE) {
@@ -719,6 +777,13 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         if (!trace_doubles) fa.io.trace = nullptr;
     } else {
         FP_TRY(check_batch_host(params, batch));
+        if (io->best_traj) {
+            const double t_max = io->samp_max[2];  // refined trajectories reach T = samp_max (per ego; ego 0 stands for the check below)
+            for (size_t i = 0; i < B; ++i)
+                if (ceil(io->samp_max[3 * i + 2] / params->tick_t) > stride) return fail(FP_EINVAL, "traj_stride=%d is smaller than the points of samp_max[%zu].T=%g", stride, i, io->samp_max[3 * i + 2]);
+            (void)t_max;
+            FP_TRY(check_stride_host(params, batch, stride));
+        }
         FP_TRY(hs.reserve(batch_need(params, batch) + 4 * HostStage::need<double>(B * 3) + 2 * HostStage::need<int32_t>(B * 3) +
                           HostStage::need<double>(B) + 2 * HostStage::need<int32_t>(B * 4) + HostStage::need<uint32_t>(B) +
                           HostStage::need<double>(trace_doubles) + HostStage::need<double>(traj_doubles),
@@ -738,7 +803,9 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         fa.io.trace = trace_doubles ? hs.out(io->trace, trace_doubles) : nullptr;
         fa.io.best_flags = hs.out(io->best_flags, B);
         fa.io.best_traj = hs.out(io->best_traj, traj_doubles);
+        if (io->traj_sparse && fa.io.best_traj) HIP_TRY(hipMemcpyAsync(fa.io.best_traj, io->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     }
+    FP_TRY(lattice_curv_scratch(ctx, params, batch, stream, &fa.ka.curv_tbl));
     int nsplit; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
     const int* perm; int* dur;
@@ -760,6 +827,8 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         fp::KernelArgs kw = fa.ka;
         kw.r.best_flags = fa.io.best_flags;
         kw.r.best_traj = fa.io.best_traj;
+        kw.r.traj_stride = fa.io.traj_stride;
+        kw.r.traj_sparse = fa.io.traj_sparse;
         LAUNCH_TRY(fp::launch_winner_traj(kw, fa.io.end_state, stream), "winner epilogue");
     }
     return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;
@@ -866,11 +935,12 @@ int fp_from_state(fp_ctx* ctx, const fp_batch* batch, const double* states, doub
 }
 
 int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states, double* cost,
-                  uint32_t* flags, double* traj, int32_t stride, int mem, void* stream)
+                  uint32_t* flags, double* traj, int32_t traj_stride, int32_t traj_sparse, int mem, void* stream)
 {
     FP_TRY(common_checks(ctx, params, batch, mem));
     if (K < 1 || !end_states) return fail(FP_EINVAL, "K must be >= 1 and end_states non-NULL");
-    if (traj && stride < FP_MAX_POINTS) return fail(FP_EINVAL, "traj stride must be >= FP_MAX_POINTS (%d)", FP_MAX_POINTS);
+    int stride;
+    FP_TRY(traj_stride_of(traj_stride, &stride));
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t BK = (size_t)batch->B * K;
@@ -880,7 +950,7 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
-        LAUNCH_TRY(fp::launch_eval_trajs(ka, K, end_states, cost, flags, traj, stride, (hipStream_t)stream), "eval kernel");
+        LAUNCH_TRY(fp::launch_eval_trajs(ka, K, end_states, cost, flags, traj, stride, traj_sparse, (hipStream_t)stream), "eval kernel");
         return FP_OK;
     }
     FP_TRY(check_batch_host(params, batch));
@@ -888,6 +958,7 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
         const double n = end_states[3 * i + 2] / params->tick_t;
         if (n != n) continue;  // NaN end state = "no trajectory": the kernels emit NaN cost / all-NaN series
         if (!(n > 0) || n > FP_MAX_POINTS) return fail(FP_ELIMIT, "end_states[%zu].T=%g needs 1..FP_MAX_POINTS points", i, end_states[3 * i + 2]);
+        if (traj && ceil(n) > stride) return fail(FP_EINVAL, "traj_stride=%d is smaller than the %g points of end_states[%zu].T=%g", stride, ceil(n), i, end_states[3 * i + 2]);
     }
     const size_t traj_doubles = traj ? BK * FP_ARR_COUNT * (size_t)stride : 0;
     HostStage hs(ctx);
@@ -900,7 +971,8 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
     double* d_cost = cost ? hs.out(cost, BK) : hs.temp<double>(BK);
     uint32_t* d_flags = flags ? hs.out(flags, BK) : hs.temp<uint32_t>(BK);
     double* d_traj = hs.out(traj, traj_doubles);
-    LAUNCH_TRY(fp::launch_eval_trajs(ka, K, d_end, d_cost, d_flags, d_traj, stride, ctx->stream), "eval kernel");
+    if (traj_sparse && d_traj) HIP_TRY(hipMemcpyAsync(d_traj, traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
+    LAUNCH_TRY(fp::launch_eval_trajs(ka, K, d_end, d_cost, d_flags, d_traj, stride, traj_sparse, ctx->stream), "eval kernel");
     return hs.fetch_out();
 }
 

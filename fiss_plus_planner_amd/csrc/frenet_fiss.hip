@@ -154,7 +154,7 @@ struct Walk {
         head = take_b ? ab : ao;
         head_c = take_b ? mb : mo;  // +inf when the queue is empty (head = -1)
         ++num_validated;
-        if (f & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) return 0;
+        if (f & FP_FLAG_CONSTRAINTS) return 0;
         ++num_checks;
         return (f & FP_FLAG_COLLISION) ? 0 : 1;
     }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         int feasible = 0, pass_constraints = 0;
         for (int q = lane; q < C; q += kWave) {
             feasible += (F[q] & FP_FLAG_INFEASIBLE) == 0;
-            pass_constraints += (F[q] & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) == 0;
+            pass_constraints += (F[q] & FP_FLAG_CONSTRAINTS) == 0;
         }
         if (__ballot(feasible != 0) == 0ull) {
 #pragma unroll
@@ -424,6 +424,50 @@ __device__ __forceinline__ double analytic_cost(const fp_params& p, const double
     return combine_cost(p, N, ls, ds);
 }
 
+// Optional curvature checks (frenet_optimal_planner.py:145-150) of ONE trajectory whose M Cartesian points sit in xy[] (LDS), by
+// the whole wavefront: lane l holds elements l and l + 64 of every chain (M <= 128).  Same difference chains as CurvTrack /
+// winner_series: yaw_k = atan2 of segment k (the last point repeats the previous heading, :129), c = diff(yaw) / ds,
+// c_d = diff(c) / dt, c_dd = diff(c_d) / dt; element i + 1 comes from the neighbouring lane.
+__device__ __forceinline__ uint32_t wave_curvature_flags(const fp_params& p, const double2* xy, int M, int lane)
+{
+    if (M < 2) return 0u;
+    double yaw[2], ds[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + h * kWave;
+        const int k = i < M - 1 ? i : M - 2;  // segment whose heading element i carries
+        const double2 a = xy[k], b2 = xy[k + 1];
+        yaw[h] = atan2(b2.y - a.y, b2.x - a.x);
+        ds[h] = hypot(b2.x - a.x, b2.y - a.y);
+    }
+    auto next = [&](const double* v, int h) {  // element (lane + 64 h) + 1 of a chain
+        const double dn = __shfl_down(v[h], 1, kWave);
+        return (h == 0 && lane == kWave - 1) ? lane_value(v[1], 0) : dn;
+    };
+    uint32_t flags = 0;
+    double c[2], cd[2];
+    bool bad_c = false, bad_cd = false, bad_cdd = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        c[h] = (next(yaw, h) - yaw[h]) / ds[h];
+        bad_c |= lane + h * kWave < M - 1 && fabs(c[h]) > p.max_curvature;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        cd[h] = (next(c, h) - c[h]) / p.tick_t;
+        bad_cd |= lane + h * kWave < M - 2 && fabs(cd[h]) > p.max_kappa_d;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double cdd = (next(cd, h) - cd[h]) / p.tick_t;
+        bad_cdd |= lane + h * kWave < M - 3 && fabs(cdd) > p.max_kappa_dd;
+    }
+    if (__ballot(bad_c)) flags |= FP_FLAG_CURVATURE;
+    if (__ballot(bad_cd)) flags |= FP_FLAG_KAPPA_D;
+    if (__ballot(bad_cdd)) flags |= FP_FLAG_KAPPA_DD;
+    return flags;
+}
+
 // constraint + collision flags of ONE trajectory, computed by the whole wavefront (all arguments wave-uniform)
 __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane)
 {
@@ -467,6 +511,12 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const int M = off_lo ? __ffsll((long long)off_lo) - 1 : (off_hi ? kWave + __ffsll((long long)off_hi) - 1 : N);
     if (M < N) flags |= FP_FLAG_TRUNCATED;
     flags |= ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+    if (p.curvature_mask && M >= 2) {  // optional checks (:145-150): they read the points this wavefront just wrote
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        flags |= wave_curvature_flags(p, L.xy, M, lane);
+    }
     // collision (frenet_optimal_planner.py:168-195)
     const int sc = L.scene;
     const int n_obs = sc >= 0 ? bt.n_obs : 0;
@@ -622,6 +672,8 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
             KernelArgs kw = ka;
             kw.r.best_traj = fa.io.best_traj;
             kw.r.best_flags = fa.io.best_flags;
+            kw.r.traj_stride = fa.io.traj_stride;
+            kw.r.traj_sparse = fa.io.traj_sparse;
             const double none = __builtin_nan("");
             winner_series(kw, b, b, false, none, none, none, tid, SplineLds{nullptr, nullptr, 0, 0}, nullptr);
         }
@@ -822,7 +874,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
             if (pop[u] < 0) { done = true; continue; }
             const uint32_t fl = verdict[(grp & 1) * kRefineWaves + u];
             ++validated;
-            if (fl & (FP_FLAG_SPEED | FP_FLAG_ACCEL)) continue;
+            if (fl & FP_FLAG_CONSTRAINTS) continue;
             ++checks;
             if (!(fl & FP_FLAG_COLLISION)) { winner = pop[u]; done = true; }
         }
@@ -859,6 +911,8 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
         KernelArgs kw = ka;
         kw.r.best_traj = fa.io.best_traj;
         kw.r.best_flags = fa.io.best_flags;
+        kw.r.traj_stride = fa.io.traj_stride;
+        kw.r.traj_sparse = fa.io.traj_sparse;
         __syncthreads();
         winner_series(kw, b, b, true, fx[0], fx[1], fx[2], tid, SplineLds{L.knots, L.coef, nx, nx}, L.S);
     }

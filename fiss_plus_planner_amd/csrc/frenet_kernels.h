@@ -78,9 +78,9 @@ hipError_t launch_frames_build(int F, int NX, const int32_t* n, const double* po
 hipError_t launch_from_state(const fp_batch& bt, const double* states, double* ego, hipStream_t stream);
 // Closed-loop bookkeeping between two plan cycles (one lane per ego).
 hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const double* end_state, const fp_loop_io& io, hipStream_t stream);
-// Series of EVERY lattice candidate: ka.r.best_traj [B*C][16][FP_MAX_POINTS], ka.r.best_flags [B*C] (N, M, truncated).
+// Series of EVERY lattice candidate: ka.r.best_traj [B*C][16][traj_stride], ka.r.best_flags [B*C] (N, M, truncated).
 hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream);
 hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
-                             int stride, hipStream_t stream);
+                             int stride, int sparse, hipStream_t stream);
 
 }  // namespace fp

@@ -160,16 +160,16 @@ __device__ __forceinline__ bool pose_collides(const KernelArgs& ka, const EgoCtx
 
 // One trajectory: generation + cost + conversion + flags (+ optional dump).
 // `dump` = nullptr or the [16][stride] block of this trajectory.
-template <bool DUMP>
+template <bool DUMP, bool CURV>
 __device__ TrajOut traj_eval(const KernelArgs& ka, const EgoCtx& e, double d_end, double v_end, double T_end, bool do_collision,
                              double* dump, int stride_d)
 {
     const fp_params& p = ka.p;
     const int N = arange_len(T_end, p.tick_t);
     TrajOut out;
-    if (N <= 0 || N > FP_MAX_POINTS) {
+    if (N <= 0 || N > FP_MAX_POINTS || (DUMP && N > stride_d)) {  // (a dump row holds stride_d points)
         out.cost = __builtin_nan("");
-        out.flags = FP_FLAG_INFEASIBLE;
+        out.flags = FP_FLAG_SPEED | FP_FLAG_ACCEL | FP_FLAG_COLLISION;  // "no trajectory"
         return out;
     }
     const Quintic lat = quintic_bvp(e.d0, e.d_d0, e.d_dd0, d_end, 0.0, 0.0, T_end);
@@ -237,6 +237,7 @@ __device__ TrajOut traj_eval(const KernelArgs& ka, const EgoCtx& e, double d_end
     }
     if (hit) flags |= FP_FLAG_COLLISION;
     if (M < N) flags |= FP_FLAG_TRUNCATED;
+    if (CURV) flags |= curvature_flags(p, e.sp, lon, lat, N);  // optional checks (:145-150), a second pass over the points
     // cost_function.py:41-50, same grouping
     const double cost_time = p.cost_horizon - (double)(N - 1) * p.tick_t;
     const double cost_speed = p.w_speed * sum_v;
@@ -263,7 +264,9 @@ __device__ TrajOut traj_eval(const KernelArgs& ka, const EgoCtx& e, double d_end
 // ---------------------------------------------------------------------------
 // dense lattice, one lane per candidate
 // ---------------------------------------------------------------------------
-__global__ void lattice_percand_kernel(KernelArgs ka, int lds_doubles)
+// (at most 512 threads: 2 wavefronts per SIMD, so the per-point loop may keep up to 256 VGPRs - no scratch)
+template <bool CURV>
+__global__ __launch_bounds__(512) void lattice_percand_kernel(KernelArgs ka, int lds_doubles)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ Best wave_best_slot[16];
@@ -280,7 +283,7 @@ __global__ void lattice_percand_kernel(KernelArgs ka, int lds_doubles)
     Best mine{0.0, -1};
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int iv = c % p.nv, it = (c / p.nv) % p.nt, id = c / (p.nv * p.nt);
-        const TrajOut o = traj_eval<false>(ka, e, ka.b.d_samples[id], vs[iv], ka.b.t_samples[it], true, nullptr, 0);
+        const TrajOut o = traj_eval<false, CURV>(ka, e, ka.b.d_samples[id], vs[iv], ka.b.t_samples[it], true, nullptr, 0);
         if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = o.cost;
         if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = o.flags;
         // `min_cost >= cost` is False for NaN: a NaN cost can never win (:266)
@@ -304,10 +307,64 @@ __global__ void lattice_percand_kernel(KernelArgs ka, int lds_doubles)
 }
 
 // ---------------------------------------------------------------------------
+// optional curvature checks of the whole lattice (fp_params.curvature_mask): one workgroup per ego, one lane per candidate,
+// the ego's spline in LDS.  Runs ahead of the fused lattice kernel, which ORs the bytes into its flag words (the checks need
+// every Cartesian point of every candidate - exactly the per-candidate work the fused kernel is built to avoid - so they live
+// in their own launch instead of in its register budget).
+// ---------------------------------------------------------------------------
+__global__ void curvature_flags_kernel(KernelArgs ka, uint8_t* out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
+    const int b = blockIdx.x;
+    const int C = p.nd * p.nv * p.nt;
+    if (bt.skip && bt.skip[b]) return;
+    const int f = bt.frame_of[b];
+    const int nx = bt.nx[f];
+    const double* gk = bt.knots + (size_t)f * bt.NX;
+    const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
+    double* knots = lds;
+    double* coef = lds + nx;
+    for (int i = threadIdx.x; i < nx; i += blockDim.x) knots[i] = gk[i];
+    for (int i = threadIdx.x; i < 8 * nx; i += blockDim.x) {
+        const int r = i / nx, c = i - r * nx;
+        coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
+    }
+    __syncthreads();
+    const SplineLds sp{knots, coef, nx, nx};
+    const double* eg = bt.ego + (size_t)b * 6;
+    const double* vs = bt.v_samples + (size_t)b * p.nv;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int iv = c % p.nv, it = (c / p.nv) % p.nt, id = c / (p.nv * p.nt);
+        const double T = bt.t_samples[it];
+        const int N = arange_len(T, p.tick_t);
+        uint32_t fl = 0;
+        if (N > 0 && N <= FP_MAX_POINTS) {
+            const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], bt.d_samples[id], 0.0, 0.0, T);
+            const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], vs[iv], 0.0, T);
+            fl = curvature_flags(p, sp, lon, lat, N);
+        }
+        out[(size_t)b * C + c] = (uint8_t)fl;
+    }
+}
+
+hipError_t launch_curvature_flags(const KernelArgs& ka, uint8_t* out, hipStream_t stream)
+{
+    const int C = ka.p.nd * ka.p.nv * ka.p.nt;
+    int threads = ((C + kWave - 1) / kWave) * kWave;
+    if (threads > 512) threads = 512;
+    const int bytes = 9 * ka.b.NX * (int)sizeof(double);
+    hipLaunchKernelGGL(curvature_flags_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // explicit end states, one lane per trajectory
 // ---------------------------------------------------------------------------
-__global__ void eval_trajs_kernel(KernelArgs ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
-                                  int stride, int lds_doubles)
+template <bool CURV>
+__global__ __launch_bounds__(256) void eval_trajs_kernel(KernelArgs ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
+                                  int stride, int sparse, int lds_doubles)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
@@ -318,10 +375,11 @@ __global__ void eval_trajs_kernel(KernelArgs ka, int K, const double* end_states
         TrajOut o;
         if (traj) {
             double* dump = traj + ((size_t)b * K + k) * FP_ARR_COUNT * stride;
-            for (int i = 0; i < FP_ARR_COUNT * stride; ++i) dump[i] = __builtin_nan("");
-            o = traj_eval<true>(ka, e, es[0], es[1], es[2], true, dump, stride);
+            if (!sparse)  // sparse: only the elements that exist are written (fp_result.traj_sparse)
+                for (int i = 0; i < FP_ARR_COUNT * stride; ++i) dump[i] = __builtin_nan("");
+            o = traj_eval<true, CURV>(ka, e, es[0], es[1], es[2], true, dump, stride);
         } else {
-            o = traj_eval<false>(ka, e, es[0], es[1], es[2], true, nullptr, 0);
+            o = traj_eval<false, CURV>(ka, e, es[0], es[1], es[2], true, nullptr, 0);
         }
         if (cost) cost[(size_t)b * K + k] = o.cost;
         if (flags) flags[(size_t)b * K + k] = o.flags;
@@ -388,13 +446,20 @@ hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream)
 {
     const int C = ka.p.nd * ka.p.nv * ka.p.nt;
     int threads = ((C + kWave - 1) / kWave) * kWave;
-    if (threads > 1024) threads = 1024;
+    if (threads > 512) threads = 512;
     int lds_doubles = 0;
     const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
     FP_LDS_SLOTS(configured);
-    hipError_t err = ensure_dynamic_lds((const void*)lattice_percand_kernel, bytes, configured);
-    if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(lattice_percand_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, lds_doubles);
+    FP_LDS_SLOTS(configured_curv);
+    if (ka.p.curvature_mask) {
+        hipError_t err = ensure_dynamic_lds((const void*)lattice_percand_kernel<true>, bytes, configured_curv);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(lattice_percand_kernel<true>, dim3(ka.b.B), dim3(threads), bytes, stream, ka, lds_doubles);
+    } else {
+        hipError_t err = ensure_dynamic_lds((const void*)lattice_percand_kernel<false>, bytes, configured);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(lattice_percand_kernel<false>, dim3(ka.b.B), dim3(threads), bytes, stream, ka, lds_doubles);
+    }
     return hipGetLastError();
 }
 
@@ -498,17 +563,25 @@ hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, v
 }
 
 hipError_t launch_eval_trajs(const KernelArgs& ka, int K, const double* end_states, double* cost, uint32_t* flags, double* traj,
-                             int stride, hipStream_t stream)
+                             int stride, int sparse, hipStream_t stream)
 {
     int threads = ((K + kWave - 1) / kWave) * kWave;
     if (threads > 256) threads = 256;
     int lds_doubles = 0;
     const int bytes = ego_lds_bytes(ka.p, ka.b, 150 * 1024, &lds_doubles);
     FP_LDS_SLOTS(configured);
-    hipError_t err = ensure_dynamic_lds((const void*)eval_trajs_kernel, bytes, configured);
-    if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(eval_trajs_kernel, dim3(ka.b.B), dim3(threads), bytes, stream, ka, K, end_states, cost, flags, traj, stride,
-                       lds_doubles);
+    FP_LDS_SLOTS(configured_curv);
+    if (ka.p.curvature_mask) {
+        hipError_t err = ensure_dynamic_lds((const void*)eval_trajs_kernel<true>, bytes, configured_curv);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(eval_trajs_kernel<true>, dim3(ka.b.B), dim3(threads), bytes, stream, ka, K, end_states, cost, flags, traj, stride,
+                           sparse, lds_doubles);
+    } else {
+        hipError_t err = ensure_dynamic_lds((const void*)eval_trajs_kernel<false>, bytes, configured);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(eval_trajs_kernel<false>, dim3(ka.b.B), dim3(threads), bytes, stream, ka, K, end_states, cost, flags, traj, stride,
+                           sparse, lds_doubles);
+    }
     return hipGetLastError();
 }
 

@@ -699,11 +699,12 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         if (n_obs > 0 && M == 1 && horizon_cap >= 1) hit = true;  // traj.yaw is empty -> IndexError -> collision (:178-182)
         if (hit) flags |= FP_FLAG_COLLISION;
         if (M < N) flags |= FP_FLAG_TRUNCATED;
+        if (ka.curv_tbl) flags |= ka.curv_tbl[(size_t)b * C + c];  // optional curvature checks, computed by curvature_flags_kernel
         double cost = combine_cost(p, N, ls, ds);  // cost_function.py:41-50, same grouping as the reference
         uint32_t word = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
         if (N <= 0 || N > FP_MAX_POINTS) {  // a time sample the ABI's limits exclude (unvalidated in FP_MEM_DEVICE mode): no trajectory,
             cost = __builtin_nan("");        // exactly what the lane-per-candidate kernel reports (traj_eval)
-            word = flags = FP_FLAG_INFEASIBLE;
+            word = flags = FP_FLAG_SPEED | FP_FLAG_ACCEL | FP_FLAG_COLLISION;
         }
         if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = cost;
         if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = word;
@@ -846,6 +847,11 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     int* part_count = (int*)part_scratch;
     Best* part_best = part_scratch ? (Best*)((char*)part_scratch + kTicketBytes) : nullptr;
     if (nsplit != 1) perm = nullptr;
+    if (p.curvature_mask) {  // optional curvature checks: their own launch, ORed into the flag words by the assembly stage
+        if (!ka.curv_tbl) return hipErrorInvalidValue;
+        e = launch_curvature_flags(ka, const_cast<uint8_t*>(ka.curv_tbl), stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur,
                        pose_global);
     if (winner_done) *winner_done = ka.r.best_traj != nullptr;

@@ -33,6 +33,10 @@ def make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
     p.tick_t = float(batch.tick_t)
     p.cost_horizon, p.w_speed, p.w_accel, p.w_jerk, p.w_offset = (COST_WX1[k] for k in ("cost_horizon", "w_speed", "w_accel", "w_jerk", "w_offset"))
     p.veh_l, p.veh_w, p.max_speed, p.max_accel = float(batch.veh_l), float(batch.veh_w), float(batch.max_speed), float(batch.max_accel)
+    lim = getattr(batch, "curvature_limits", None)
+    if lim is not None:  # optional checks of check_constraints (reference :145-150, commented out there)
+        p.curvature_mask = 1
+        p.max_curvature, p.max_kappa_d, p.max_kappa_dd = (float(v) for v in lim)
     return p
 
 
@@ -109,7 +113,7 @@ class FrenetEngine:
         self.close()
 
     # ------------------------------------------------------------------ host arrays
-    def plan_dense(self, batch: ProblemBatch, tables: bool = True, winner: bool = False):
+    def plan_dense(self, batch: ProblemBatch, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """FrenetOptimalPlanner.plan() for every ego of the batch (reference frenet_optimal_planner.py:247-270).
 
         Returns best_idx [B] (flat (i_d*nt+i_T)*nv+i_v, -1 = none), best_cost [B], stats [B,4] and, with
@@ -124,29 +128,32 @@ class FrenetEngine:
         res.cost_tbl = _ptr(out.cost) if tables else None
         res.flag_tbl = _ptr(out.flags) if tables else None
         out.best_flags = np.empty(B, dtype=np.uint32) if winner else None
-        out.best_traj = np.empty((B, 16, TRAJ_STRIDE)) if winner else None
+        # sparse: the kernels write only the elements that exist; everything else keeps this NaN fill
+        out.best_traj = (np.full((B, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, 16, traj_stride))) if winner else None
         res.best_flags = _ptr(out.best_flags) if winner else None
         res.best_traj = _ptr(out.best_traj) if winner else None
+        res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
         return out
 
-    def eval_trajs(self, batch: ProblemBatch, end_states: np.ndarray, dump: bool = False):
+    def eval_trajs(self, batch: ProblemBatch, end_states: np.ndarray, dump: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """Explicit end states [B,K,3] = (d_end, v_end, T_end) -> cost [B,K], flags [B,K] (+ traj [B,K,16,stride])."""
         es = np.ascontiguousarray(end_states, dtype=np.float64)
         B, K = es.shape[0], es.shape[1]
         assert B == batch.B and es.shape[2] == 3
         cost = np.empty((B, K)); flags = np.empty((B, K), dtype=np.uint32)
-        traj = np.empty((B, K, 16, TRAJ_STRIDE)) if dump else None
+        traj = (np.full((B, K, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, K, 16, traj_stride))) if dump else None
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_eval_trajs(self._ctx, C.byref(p), C.byref(fb), K, es.ctypes.data, cost.ctypes.data, flags.ctypes.data,
-                                           traj.ctypes.data if dump else None, TRAJ_STRIDE, _abi.FP_MEM_HOST, None))
+                                           traj.ctypes.data if dump else None, int(traj_stride), int(traj_sparse), _abi.FP_MEM_HOST, None))
         return SimpleNamespace(cost=cost, flags=flags, traj=traj)
 
     def plan_fiss(self, batch: ProblemBatch, kind: str = "FISS+", prev_best_idx: np.ndarray | None = None, w_heuristic: float = 10.0,
-                  max_refine_iters: int = 3, decaying_factor: float = 0.5, winner: bool = False, trace: bool = False):
+                  max_refine_iters: int = 3, decaying_factor: float = 0.5, winner: bool = False, trace: bool = False,
+                  traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """FissPlanner.plan / FissPlusPlanner.plan for every ego of the batch, entirely on the device (fp_plan_fiss):
         dense tables -> per-ego search walk -> (FISS+) refinement -> optional winner series.
 
@@ -161,7 +168,7 @@ class FrenetEngine:
                               refined=np.empty(B, dtype=np.int32), stats=np.empty((B, 4), dtype=np.int32),
                               trace=np.empty((B, max(R, 1) * 7, 4)) if trace and R > 0 else None,
                               best_flags=np.empty(B, dtype=np.uint32) if winner else None,
-                              best_traj=np.empty((B, 16, TRAJ_STRIDE)) if winner else None)
+                              best_traj=(np.full((B, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, 16, traj_stride))) if winner else None)
         opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
         io = _abi.FpFissIo()
         io.samp_min, io.samp_max, io.samp_res = batch.samp_min.ctypes.data, batch.samp_max.ctypes.data, batch.samp_res.ctypes.data
@@ -170,22 +177,27 @@ class FrenetEngine:
         io.trace = out.trace.ctypes.data if out.trace is not None else None
         io.best_flags = out.best_flags.ctypes.data if winner else None
         io.best_traj = out.best_traj.ctypes.data if winner else None
+        io.traj_stride, io.traj_sparse = int(traj_stride), int(traj_sparse)
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(p), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_HOST, None))
         return out
 
-    def materialize_all(self, batch: ProblemBatch):
-        """Full series of every lattice candidate (fp_materialize_all): traj [B,C,16,128], flags [B,C] (N, M, truncated)."""
+    def materialize_all(self, batch: ProblemBatch, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+        """Full series of every lattice candidate (fp_materialize_all): traj [B,C,16,traj_stride], flags [B,C] (N, M, truncated)."""
         B, Cn = batch.B, batch.C
-        traj = np.empty((B, Cn, 16, TRAJ_STRIDE)); flags = np.empty((B, Cn), dtype=np.uint32)
+        traj = np.full((B, Cn, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, Cn, 16, traj_stride))
+        flags = np.empty((B, Cn), dtype=np.uint32)
         p = make_params(batch)
         fb = _host_batch(batch)
-        _abi.check(self._lib.fp_materialize_all(self._ctx, C.byref(p), C.byref(fb), flags.ctypes.data, traj.ctypes.data, _abi.FP_MEM_HOST, None))
+        _abi.check(self._lib.fp_materialize_all(self._ctx, C.byref(p), C.byref(fb), flags.ctypes.data, traj.ctypes.data, int(traj_stride), int(traj_sparse),
+                                                _abi.FP_MEM_HOST, None))
         return SimpleNamespace(traj=traj, flags=flags)
 
-    def materialize_all_device(self, params: _abi.FpParams, fb: _abi.FpBatch, flags: int, traj: int, stream: int = 0):
-        _abi.check(self._lib.fp_materialize_all(self._ctx, C.byref(params), C.byref(fb), flags, traj, _abi.FP_MEM_DEVICE, stream or None))
+    def materialize_all_device(self, params: _abi.FpParams, fb: _abi.FpBatch, flags: int, traj: int, stream: int = 0,
+                               traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+        _abi.check(self._lib.fp_materialize_all(self._ctx, C.byref(params), C.byref(fb), flags, traj, int(traj_stride), int(traj_sparse),
+                                                _abi.FP_MEM_DEVICE, stream or None))
 
     def build_frames(self, points: np.ndarray, n: np.ndarray | None = None):
         """CubicSpline2D construction for F centerlines on the GPU (fp_frames_build): points [F,NX,2] -> knots [F,NX], coef [F,8,NX]."""
@@ -212,38 +224,42 @@ class FrenetEngine:
 
     # ------------------------------------------------------------------ resident device memory
     def plan_dense_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_cost: int, stats: int = 0,
-                          cost_tbl: int = 0, flag_tbl: int = 0, stream: int = 0, best_flags: int = 0, best_traj: int = 0):
+                          cost_tbl: int = 0, flag_tbl: int = 0, stream: int = 0, best_flags: int = 0, best_traj: int = 0,
+                          traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """Enqueue the dense pass on `stream`; every argument is a device address (int)."""
         res = _abi.FpResult()
         res.best_idx, res.best_cost = best_idx, best_cost
         res.stats, res.cost_tbl, res.flag_tbl = stats or None, cost_tbl or None, flag_tbl or None
         res.best_flags, res.best_traj = best_flags or None, best_traj or None
+        res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(params), C.byref(fb), C.byref(res), _abi.FP_MEM_DEVICE, stream or None))
 
-    def winner_trajs(self, batch: ProblemBatch, best_idx: np.ndarray):
+    def winner_trajs(self, batch: ProblemBatch, best_idx: np.ndarray, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """The standalone winner epilogue (fp_winner_trajs): series of lattice candidate best_idx[b] for every ego
         -> best_flags [B], best_traj [B,16,128] (NaN rows and flag 0 where best_idx < 0)."""
         bi = np.ascontiguousarray(best_idx, dtype=np.int32)
-        out = SimpleNamespace(best_flags=np.empty(batch.B, dtype=np.uint32), best_traj=np.empty((batch.B, 16, TRAJ_STRIDE)))
+        out = SimpleNamespace(best_flags=np.empty(batch.B, dtype=np.uint32),
+                              best_traj=np.full((batch.B, 16, traj_stride), np.nan) if traj_sparse else np.empty((batch.B, 16, traj_stride)))
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_winner_trajs(self._ctx, C.byref(p), C.byref(fb), _ptr(bi), _ptr(out.best_flags), _ptr(out.best_traj),
-                                             _abi.FP_MEM_HOST, None))
+                                             int(traj_stride), int(traj_sparse), _abi.FP_MEM_HOST, None))
         return out
 
-    def winner_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_flags: int, best_traj: int, stream: int = 0):
+    def winner_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, best_idx: int, best_flags: int, best_traj: int, stream: int = 0,
+                            traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """Enqueue the winner epilogue alone (device addresses)."""
         _abi.check(self._lib.fp_winner_trajs(self._ctx, C.byref(params), C.byref(fb), best_idx, best_flags, best_traj,
-                                             _abi.FP_MEM_DEVICE, stream or None))
+                                             int(traj_stride), int(traj_sparse), _abi.FP_MEM_DEVICE, stream or None))
 
     def plan_fiss_device(self, params: _abi.FpParams, fb: _abi.FpBatch, opts: _abi.FpFissOpts, io: _abi.FpFissIo, stream: int = 0):
         """Enqueue the whole FISS / FISS+ pipeline (lattice, search, refinement, winner series); device addresses in `io`."""
         _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(params), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_DEVICE, stream or None))
 
     def eval_trajs_device(self, params: _abi.FpParams, fb: _abi.FpBatch, K: int, end_states: int, cost: int, flags: int,
-                          traj: int = 0, stream: int = 0):
+                          traj: int = 0, stream: int = 0, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         _abi.check(self._lib.fp_eval_trajs(self._ctx, C.byref(params), C.byref(fb), K, end_states, cost or None, flags or None,
-                                           traj or None, TRAJ_STRIDE, _abi.FP_MEM_DEVICE, stream or None))
+                                           traj or None, int(traj_stride), int(traj_sparse), _abi.FP_MEM_DEVICE, stream or None))
 
 
 def device_count() -> int:

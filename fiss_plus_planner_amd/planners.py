@@ -65,6 +65,9 @@ class FrenetOptimalPlannerSettings:
         self.num_t = num_t
         self.check_obstacle = True   # present in the reference, never read there either
         self.check_boundary = True
+        # not in the reference's settings: turns on the curvature / curvature-rate checks that its check_constraints carries
+        # commented out (:145-150), with the Vehicle's max_curvature / max_kappa_d / max_kappa_dd (vehicle.py:44-46)
+        self.check_curvature = False
 
 
 class FissPlannerSettings(FrenetOptimalPlannerSettings):
@@ -156,8 +159,9 @@ class FrenetOptimalPlanner:
         st = self.settings
         tab = self._obstacle_table(obstacles)
         sp = self.cubic_spline
+        curv = (self.vehicle.max_curvature, self.vehicle.max_kappa_d, self.vehicle.max_kappa_dd) if getattr(st, "check_curvature", False) else None
         key = (id(sp), id(tab), st.num_width, st.num_speed, st.num_t, st.min_t, st.max_t, st.tick_t, st.max_road_width, st.lowest_speed,
-               self.vehicle.l, self.vehicle.w, self.vehicle.max_speed, self.vehicle.max_accel)
+               self.vehicle.l, self.vehicle.w, self.vehicle.max_speed, self.vehicle.max_accel, curv)
         cache = getattr(self, "_batch_cache", None)
         if cache is None or cache[0] != key:
             sw = self._sampling_width()
@@ -173,7 +177,7 @@ class FrenetOptimalPlanner:
                 obs_pose=pose, obs_dims=dims, final_time_step=fts, veh_l=self.vehicle.l, veh_w=self.vehicle.w,
                 max_speed=self.vehicle.max_speed, max_accel=self.vehicle.max_accel, tick_t=st.tick_t, check_stride=2,
                 samp_min=np.array([[-sw / 2, st.lowest_speed, st.min_t]]), samp_max=np.array([[sw / 2, 0.0, st.max_t]]),
-                samp_res=np.array([[rd, 0.0, rt]]))
+                samp_res=np.array([[rd, 0.0, rt]]), curvature_limits=curv)
             cache = [key, batch, None, sp, tab]  # sp / tab kept alive so their ids cannot be recycled
             self._batch_cache = cache
         batch = cache[1]
@@ -285,12 +289,22 @@ class FissPlanner(FrenetOptimalPlanner):
         batch = self._make_batch(frenet_state, obstacles, time_step_now)
         self.sampling_min, self.sampling_max, self.sampling_res = batch.samp_min[0].copy(), batch.samp_max[0].copy(), batch.samp_res[0].copy()
         self.sizes = np.array([batch.nd, batch.nv, batch.nt])
-        out = self._dense(batch)
+        out = self._engine.plan_dense(batch, tables=True)
+        self.last_tables = (out.cost[0], out.flags[0])
         J, F = search.tables_to_dvt(out.cost[0], out.flags[0], batch.nd, batch.nv, batch.nt)
         E = search.cost_est_table(batch.d_samples, batch.v_samples[0], batch.t_samples, self.sampling_min, self.sampling_max,
                                   self.prev_best_idx, self.settings.w_heuristic)
-        idx, st = self._search(J, F, E)
+        order = []
+        idx, st = self._search(J, F, E, order)
         self.stats = Stats(*st)
+        # all_trajs (visualisation payload): the reference appends the trajectories it GENERATED this cycle, in generation order
+        # (trajs_per_timestep, fiss_planner.py:131,262-265); with materialize_all their full series come from one eval launch
+        if self.materialize_all and order:
+            es = np.array([[batch.d_samples[i], batch.v_samples[0, j], batch.t_samples[k]] for i, j, k in order])
+            trajs, _ = self._materialize(batch, es, [np.array(o) for o in order])
+            self.all_trajs.append(trajs)
+        else:
+            self.all_trajs.append([])
         return batch, idx
 
     def _plan_on_device(self, frenet_state, max_target_speed, obstacles, time_step_now):
@@ -323,7 +337,7 @@ class FissPlanner(FrenetOptimalPlanner):
         return self.best_traj
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
-        if self.search_on == "device":
+        if self.search_on == "device" and not self.materialize_all:  # the generated set is only known to the host walk
             return self._plan_on_device(frenet_state, max_target_speed, obstacles, time_step_now)
         batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
         if idx is None:
@@ -342,7 +356,7 @@ class FissPlusPlanner(FissPlanner):
     _search = staticmethod(search.fissplus_search)
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
-        if self.search_on == "device":
+        if self.search_on == "device" and not self.materialize_all:
             return self._plan_on_device(frenet_state, max_target_speed, obstacles, time_step_now)
         batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
         if idx is None:
@@ -397,9 +411,9 @@ class FissPlusPlanner(FissPlanner):
             if cost > coarse_cost:
                 break
             self.stats.num_trajs_validated += 1
-            if fl & 3:
+            if fl & search.FLAG_CONSTRAINTS:
                 continue
             self.stats.num_collison_checks += 1
-            if not (fl & 4):
+            if not (fl & search.FLAG_COLLISION):
                 return es
         return None

@@ -16,6 +16,8 @@ import heapq
 import numpy as np
 
 FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION = 1, 2, 4
+FLAG_CONSTRAINTS = 1 | 2 | 16 | 32 | 64   # speed, acceleration + the optional curvature checks (include/frenet_gpu.h FP_FLAG_CONSTRAINTS)
+FLAG_INFEASIBLE = FLAG_CONSTRAINTS | FLAG_COLLISION
 
 
 def tables_to_dvt(cost_flat: np.ndarray, flags_flat: np.ndarray, nd: int, nv: int, nt: int):
@@ -50,6 +52,7 @@ class _Walk:
         self.sizes = J.shape
         self.generated = np.zeros(J.shape, dtype=bool)
         self.queue = []  # heap of (cost, raster index)
+        self.order = []  # index triples in generation order = the reference's trajs_per_timestep (fiss_planner.py:131)
         self.num_iter = self.num_generated = self.num_validated = self.num_collision_checks = 0
 
     def raster(self, idx):
@@ -65,6 +68,7 @@ class _Walk:
             return False, self.J[idx]
         self.num_generated += 1
         self.generated[idx] = True
+        self.order.append(idx)
         heapq.heappush(self.queue, (float(self.J[idx]), self.raster(idx)))
         return True, self.J[idx]
 
@@ -87,7 +91,7 @@ class _Walk:
         idx = self.unraster(q)
         self.num_validated += 1
         f = int(self.F[idx])
-        if f & (FLAG_SPEED | FLAG_ACCEL):
+        if f & FLAG_CONSTRAINTS:
             return idx, False
         self.num_collision_checks += 1
         return idx, not (f & FLAG_COLLISION)
@@ -97,9 +101,12 @@ class _Walk:
         return (self.num_iter, self.num_generated, self.num_validated, self.num_collision_checks)
 
 
-def fiss_search(J, F, E):
-    """FissPlanner.plan coarse search (fiss_planner.py:190-270) -> (best idx triple or None, stats)."""
+def fiss_search(J, F, E, generated_order=None):
+    """FissPlanner.plan coarse search (fiss_planner.py:190-270) -> (best idx triple or None, stats).
+    generated_order: optional list that receives the index triples in generation order."""
     w = _Walk(J, F, E)
+    if generated_order is not None:
+        w.order = generated_order
     sizes = w.sizes
     while True:
         w.num_iter += 1
@@ -140,9 +147,12 @@ def fiss_search(J, F, E):
             return cand, w.stats
 
 
-def fissplus_search(J, F, E):
-    """FissPlusPlanner.plan coarse search (fiss_plus_planner.py:80-148) -> (best idx triple or None, stats)."""
+def fissplus_search(J, F, E, generated_order=None):
+    """FissPlusPlanner.plan coarse search (fiss_plus_planner.py:80-148) -> (best idx triple or None, stats).
+    generated_order: optional list that receives the index triples in generation order."""
     w = _Walk(J, F, E)
+    if generated_order is not None:
+        w.order = generated_order
     sizes = w.sizes
     frontier = []
     while True:
@@ -198,7 +208,7 @@ def fopplus_search(cost_flat, flags_flat):
     while heap:
         popped += 1
         it = heapq.heappop(heap)
-        if not (int(flags_flat[it.idx]) & 7):
+        if not (int(flags_flat[it.idx]) & FLAG_INFEASIBLE):
             return it.idx, (popped, len(cost_flat), popped, popped)
     return None, (popped, len(cost_flat), popped, popped)
 

@@ -498,8 +498,168 @@ def g6():
     save("g6_fiss_search.npz", **out)
 
 
+def curvature_checked_classes():
+    """The four reference planner classes with the curvature checks of check_constraints SWITCHED ON.
+
+    The reference carries the three checks commented out (frenet_optimal_planner.py:145-150).  Nothing of its text is kept here:
+    the method's source is read from the imported class at generation time, the comment markers of those six lines are removed,
+    and the result is compiled in the module's own namespace and installed on subclasses."""
+    import inspect
+    import textwrap
+
+    fn = R.FrenetOptimalPlanner.check_constraints
+    lines = textwrap.dedent(inspect.getsource(fn)).splitlines()
+    out, armed, n = [], False, 0
+    for ln in lines:
+        body = ln.lstrip()
+        if body.startswith("# if any([abs(c"):
+            ln = ln.replace("# ", "", 1); armed = True; n += 1
+        elif armed and body.startswith("#     continue"):
+            ln = ln.replace("# ", "", 1); armed = False; n += 1
+        else:
+            armed = False
+        out.append(ln)
+    assert n == 6, f"expected the 6 commented curvature lines, patched {n}"
+    ns = dict(fn.__globals__)
+    exec(compile("\n".join(out), "<check_constraints with curvature checks>", "exec"), ns)
+    patched = ns["check_constraints"]
+    return {k: type(c.__name__ + "Curv", (c,), {"check_constraints": patched})
+            for k, c in (("FOP", R.FrenetOptimalPlanner), ("FOP+", R.FopPlusPlanner), ("FISS", R.FissPlanner), ("FISS+", R.FissPlusPlanner))}
+
+
+def g9():
+    """Optional curvature / curvature-rate checks (north_star "curvature ... feasibility masks"; reference :145-150 un-commented).
+    Per candidate: which of the three checks the patched check_constraints trips (each isolated by lifting the other two limits),
+    and that speed / accel / the three together reproduce the patched method's verdict; plan() of the four patched planners."""
+    classes = curvature_checked_classes()
+    cases = []
+    cases.append(("c2_static10", synth.make_batch(3, 5, 5, 5, 10, 100, False, 9102)))
+    cases.append(("c3_moving50", synth.make_batch(2, 9, 9, 7, 50, 50, True, 9103)))
+    ct = short_frame_batch(synth.make_batch(3, 5, 5, 5, 10, 100, False, 9104), 25)
+    cases.append(("trunc", ct))
+    # a winding road driven fast with tight limits: the checks also bite on ordinary (non-crawling) candidates
+    cw = synth.make_batch(3, 5, 5, 5, 0, 0, False, 9111)
+    x = np.linspace(0.0, 400.0, 81)
+    from fiss_plus_planner_amd.spline import build_frames
+    pts = np.stack([np.stack([x, a * np.sin(x / lam)], axis=1) for a, lam in ((6.0, 14.0), (9.0, 18.0), (4.0, 9.0))])
+    knots, coef = build_frames(pts)
+    cases.append(("winding", with_overrides(cw, knots=knots, coef=coef)))
+    out, names = {}, []
+    for name, b in cases:
+        t0 = time.time()
+        names.append(name)
+        C = b.C
+        veh = vehicle_for(b)
+        limits = (veh.max_curvature, veh.max_kappa_d, veh.max_kappa_dd) if name != "winding" else (0.12, 0.15, 2.0)
+        curv = np.zeros((b.B, C, 3), dtype=bool); passed_all = np.zeros((b.B, C), dtype=bool)
+        speed = np.zeros((b.B, C), dtype=bool); accel = np.zeros((b.B, C), dtype=bool)
+        maxabs = np.full((b.B, C, 3), np.nan)
+        for e in range(b.B):
+            pl = make_planner("FOP", b, e)
+            pl.__class__ = classes["FOP"]
+            pl.vehicle.max_curvature, pl.vehicle.max_kappa_d, pl.vehicle.max_kappa_dd = limits
+            pl.settings.highest_speed = float(b.target_speed[e])
+            fpl = pl.calc_global_paths(pl.calc_frenet_paths(ego_state(b, e)))
+            ok = {id(t) for t in pl.check_constraints(fpl)}
+            passed_all[e] = [id(t) in ok for t in fpl]
+            speed[e] = [any(v > pl.vehicle.max_speed for v in t.s_d) for t in fpl]
+            accel[e] = [any(abs(a) > pl.vehicle.max_accel for a in t.s_dd) for t in fpl]
+            v_max, a_max = pl.vehicle.max_speed, pl.vehicle.max_accel
+            pl.vehicle.max_speed = pl.vehicle.max_accel = np.inf
+            for k in range(3):  # isolate check k: the other two limits lifted
+                lim = [np.inf] * 3
+                lim[k] = limits[k]
+                pl.vehicle.max_curvature, pl.vehicle.max_kappa_d, pl.vehicle.max_kappa_dd = lim
+                ok_k = {id(t) for t in pl.check_constraints(fpl)}
+                curv[e, :, k] = [id(t) not in ok_k for t in fpl]
+            pl.vehicle.max_speed, pl.vehicle.max_accel = v_max, a_max
+            for i, t in enumerate(fpl):
+                for k, arr in enumerate((t.c, t.c_d, t.c_dd)):
+                    a = np.abs(np.asarray(arr, dtype=np.float64))
+                    a = a[~np.isnan(a)]
+                    if a.size:
+                        maxabs[e, i, k] = a.max()
+            assert np.array_equal(passed_all[e], ~(speed[e] | accel[e] | curv[e].any(axis=1))), (name, e)
+        bb = with_overrides(b)
+        out.update(batch_to_dict(bb, f"{name}_in_"))
+        out.update({f"{name}_limits": np.array(limits), f"{name}_curv": curv, f"{name}_speed": speed, f"{name}_accel": accel,
+                    f"{name}_maxabs": maxabs})
+        # plan() of the four patched planners
+        for kind in ("FOP", "FOP+", "FISS", "FISS+"):
+            bk = b
+            if kind in ("FISS", "FISS+"):
+                sw = 3.5 - b.veh_w + 0.3
+                d, rd = np.linspace(-sw / 2, sw / 2, b.nd, retstep=True)
+                smin = b.samp_min.copy(); smax = b.samp_max.copy(); sres = b.samp_res.copy()
+                smin[:, 0] = -sw / 2; smax[:, 0] = sw / 2; sres[:, 0] = rd
+                bk = with_overrides(b, d_samples=d, samp_min=smin, samp_max=smax, samp_res=sres)
+                out[f"{name}_fiss_d_samples"] = d
+                out[f"{name}_fiss_samp"] = np.stack([smin, smax, sres])
+            B = bk.B
+            cost = np.full(B, np.nan); stats = np.zeros((B, 4), dtype=np.int32); found = np.zeros(B, dtype=bool)
+            flat = np.full(B, -1, dtype=np.int32); idx = np.full((B, 3), -1, dtype=np.int32); end = np.full((B, 3), np.nan)
+            for e in range(B):
+                pl = make_planner(kind, bk, e)
+                pl.__class__ = classes[kind]
+                pl.vehicle.max_curvature, pl.vehicle.max_kappa_d, pl.vehicle.max_kappa_dd = limits
+                try:
+                    best = pl.plan(ego_state(bk, e), float(bk.target_speed[e]), obstacles_for(bk, e), int(bk.t_now[e]))
+                except ValueError as ex:
+                    raise AssertionError((name, kind, e, str(ex)[:80]))
+                stats[e] = [pl.stats.num_iter, pl.stats.num_trajs_generated, pl.stats.num_trajs_validated, pl.stats.num_collison_checks]
+                if best is None:
+                    continue
+                found[e] = True; cost[e] = best.cost_final
+                if kind in ("FOP", "FOP+"):
+                    pl2 = make_planner("FOP", bk, e)
+                    pl2.settings.highest_speed = float(bk.target_speed[e])
+                    fpl = pl2.calc_frenet_paths(ego_state(bk, e))
+                    hits = [i for i, fp in enumerate(fpl) if np.array_equal(fp.d, best.d) and np.array_equal(fp.s, best.s)]
+                    assert len(hits) == 1
+                    flat[e] = hits[0]
+                else:
+                    idx[e] = best.idx
+                    end[e] = [best.end_state.d, best.end_state.s_d, best.end_state.t]
+            out.update({f"{name}_{kind}_cost": cost, f"{name}_{kind}_stats": stats, f"{name}_{kind}_found": found, f"{name}_{kind}_flat": flat,
+                        f"{name}_{kind}_idx": idx, f"{name}_{kind}_end": end})
+            print(f"    {name} {kind}: found={found.tolist()} stats={stats.tolist()}")
+        print(f"  g9 {name}: {time.time() - t0:.1f}s  curv={curv.mean(axis=(0, 1)).round(3).tolist()} passed={passed_all.mean():.2f}")
+    out["names"] = np.array(names)
+    save("g9_curvature.npz", **out)
+
+
+def g10():
+    """FISS / FISS+ visualisation payload: the lattice indices the reference GENERATED during plan(), in generation order
+    (trajs_per_timestep -> all_trajs, fiss_planner.py:131,262-265 / fiss_plus_planner.py:166-168)."""
+    out, names = {}, []
+    for name, b in fop_cases():
+        if name in ("mirror", "limits", "c0_noobs"):
+            continue
+        sw = 3.5 - b.veh_w + 0.3
+        d, rd = np.linspace(-sw / 2, sw / 2, b.nd, retstep=True)
+        smin = b.samp_min.copy(); smax = b.samp_max.copy(); sres = b.samp_res.copy()
+        smin[:, 0] = -sw / 2; smax[:, 0] = sw / 2; sres[:, 0] = rd
+        bb = with_overrides(b, d_samples=d, samp_min=smin, samp_max=smax, samp_res=sres)
+        names.append(name)
+        out.update(batch_to_dict(bb, f"{name}_in_"))
+        for kind in ("FISS", "FISS+"):
+            order = np.full((bb.B, bb.C, 3), -1, dtype=np.int32); count = np.zeros(bb.B, dtype=np.int32)
+            cost = np.full((bb.B, bb.C), np.nan)
+            for e in range(bb.B):
+                pl, best, err = run_plan(kind, bb, e)
+                assert not err, err
+                gen = pl.all_trajs[-1]
+                count[e] = len(gen)
+                for k, t in enumerate(gen):
+                    order[e, k] = t.idx; cost[e, k] = t.cost_final
+            out.update({f"{name}_{kind}_order": order, f"{name}_{kind}_count": count, f"{name}_{kind}_cost": cost})
+            print(f"  g10 {name} {kind}: generated {count.tolist()}")
+    out["names"] = np.array(names)
+    save("g10_generated_order.npz", **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5"]
+    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10"]
     for g in todo:
         t0 = time.time()
         print(f"== {g}")

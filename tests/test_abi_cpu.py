@@ -34,11 +34,32 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.fp_abi_version() == _abi.FP_ABI_VERSION
 
 
-def test_struct_layouts_match_header():
-    # 4 int32 + 10 double ; 6 int32 + 14 pointers ; 5 pointers
-    assert C.sizeof(_abi.FpParams) == 4 * 4 + 10 * 8
-    assert C.sizeof(_abi.FpBatch) == 6 * 4 + 15 * 8
-    assert C.sizeof(_abi.FpResult) == 7 * 8
+def test_struct_layouts_match_header(tmp_path):
+    """Every struct of include/frenet_gpu.h against its ctypes mirror: size and the offset of every field, as gcc lays them out
+    (a C program built from the header prints them)."""
+    pairs = {"fp_params": _abi.FpParams, "fp_batch": _abi.FpBatch, "fp_result": _abi.FpResult, "fp_fiss_opts": _abi.FpFissOpts,
+             "fp_fiss_io": _abi.FpFissIo, "fp_loop_io": _abi.FpLoopIo}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "frenet_gpu.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  printf("version %d\\n", FP_ABI_VERSION);', '  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(got["version"]) == _abi.FP_ABI_VERSION
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    # the flag bits too
+    hdr = open(os.path.join(ROOT, "include", "frenet_gpu.h")).read()
+    for name, val in (("SPEED", _abi.FLAG_SPEED), ("ACCEL", _abi.FLAG_ACCEL), ("COLLISION", _abi.FLAG_COLLISION), ("TRUNCATED", _abi.FLAG_TRUNCATED),
+                      ("CURVATURE", _abi.FLAG_CURVATURE), ("KAPPA_D", _abi.FLAG_KAPPA_D), ("KAPPA_DD", _abi.FLAG_KAPPA_DD)):
+        assert int(re.search(rf"#define FP_FLAG_{name} (\d+)u", hdr).group(1)) == val, name
 
 
 def test_no_device_means_loud_failure(lib):

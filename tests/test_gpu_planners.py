@@ -192,3 +192,38 @@ def test_fresh_obstacle_lists_are_never_served_from_a_stale_table(engine):
     t1 = pl._obstacle_table(obstacles)
     assert pl._obstacle_table(list(obstacles)) is t1
     assert pl._obstacle_table(wall(25.0)) is not t1
+
+
+@pytest.mark.parametrize("kind", ["FISS", "FISS+"])
+def test_fiss_all_trajs_is_the_generated_set_in_generation_order(engine, oracle, kind):
+    """all_trajs of the FISS planners (visualisation payload, planning.py:339-355): the reference appends the trajectories it
+    GENERATED during plan(), in generation order (trajs_per_timestep, fiss_planner.py:131,262-265).  G10 holds that order; the
+    series of every listed trajectory are the oracle's."""
+    from conftest import assert_series_close
+
+    g = load_golden("g10_generated_order.npz")
+    for name in [str(n) for n in g["names"]]:
+        b = batch_from_golden(g, f"{name}_in_")
+        for e in range(b.B):
+            pl = _planner(kind, b, engine)
+            pl.materialize_all = True
+            pts, fs, obs = _inputs(b, e)
+            pl.generate_frenet_frame(pts)
+            pl.plan(fs, float(b.target_speed[e]), obs, int(b.t_now[e]))
+            n = int(g[f"{name}_{kind}_count"][e])
+            gen = pl.all_trajs[-1]
+            assert len(gen) == n, (name, e)
+            if kind == "FISS":
+                assert n == pl.stats.num_trajs_generated
+            np.testing.assert_array_equal(np.array([t.idx for t in gen]), g[f"{name}_{kind}_order"][e, :n], err_msg=f"{name} ego {e}")
+            np.testing.assert_allclose([t.cost_final for t in gen], g[f"{name}_{kind}_cost"][e, :n], rtol=0, atol=TOL)
+            p = oracle.problems_from_batch(b, [e])[0]
+            for t in gen[:: max(1, n // 6)]:
+                i, j, k = (int(v) for v in t.idx)
+                w = p.eval_traj(b.d_samples[i], b.v_samples[e, j], b.t_samples[k], dump=True)
+                assert (len(t.t), len(t.x)) == (w.N, w.M)
+                got = np.full((16, 128), np.nan)
+                from fiss_plus_planner_amd.frenet import ARRAY_NAMES
+                for r, nm in enumerate(ARRAY_NAMES):
+                    a = np.asarray(getattr(t, nm)); got[r, :len(a)] = a
+                assert_series_close(got, w.arrays, b.tick_t, f"{name} ego {e} idx {t.idx}")

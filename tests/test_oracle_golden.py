@@ -186,3 +186,62 @@ def test_g6_search(oracle, kind):
             else:
                 np.testing.assert_allclose(r.end_state, g[f"{kind}_end"][e], rtol=0, atol=1e-9)
         np.testing.assert_array_equal(r.prev_best_idx, g[f"{kind}_prev_out"][e])
+
+
+# ------------------------------------------------------------------ G9 optional curvature checks
+def _g9_names():
+    return [str(n) for n in load_golden("g9_curvature.npz")["names"]]
+
+
+def g9_batch(g, name, kind="FOP"):
+    """Problem batch of a G9 case with the curvature checks on (FISS kinds use their own lateral lattice)."""
+    from fiss_plus_planner_amd.batch import ProblemBatch
+
+    b = batch_from_golden(g, f"{name}_in_")
+    b.curvature_limits = tuple(g[f"{name}_limits"])
+    if kind in ("FISS", "FISS+"):
+        smin, smax, sres = g[f"{name}_fiss_samp"]
+        kw = {k: getattr(b, k) for k in ("t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+                                         "obs_pose", "obs_dims", "final_time_step", "veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride")}
+        b = ProblemBatch(d_samples=g[f"{name}_fiss_d_samples"], samp_min=smin, samp_max=smax, samp_res=sres, curvature_limits=b.curvature_limits, **kw)
+    return b
+
+
+@pytest.mark.parametrize("name", _g9_names())
+def test_g9_curvature_masks(oracle, name):
+    """The three checks the reference carries commented out (frenet_optimal_planner.py:145-150), switched on in the generator
+    by un-commenting them in the imported class: per candidate, which check trips - exactly."""
+    g = load_golden("g9_curvature.npz")
+    b = g9_batch(g, name)
+    for e, p in enumerate(oracle.problems_from_batch(b)):
+        _, flags = p.dense_tables()
+        for k, bit in enumerate((oracle.FLAG_CURVATURE, oracle.FLAG_KAPPA_D, oracle.FLAG_KAPPA_DD)):
+            np.testing.assert_array_equal((flags & bit) != 0, g[f"{name}_curv"][e, :, k], err_msg=f"{name} ego {e} check {k}")
+        np.testing.assert_array_equal((flags & 1) != 0, g[f"{name}_speed"][e])
+        np.testing.assert_array_equal((flags & 2) != 0, g[f"{name}_accel"][e])
+    # off by default: no curvature bit is ever set
+    b.curvature_limits = None
+    for p in oracle.problems_from_batch(b):
+        assert not (p.dense_tables()[1] & 0x70).any()
+
+
+@pytest.mark.parametrize("kind", ["FOP", "FOP+", "FISS", "FISS+"])
+@pytest.mark.parametrize("name", _g9_names())
+def test_g9_plans_with_curvature_checks(oracle, name, kind):
+    g = load_golden("g9_curvature.npz")
+    b = g9_batch(g, name, kind)
+    for e, p in enumerate(oracle.problems_from_batch(b)):
+        r = {"FOP": p.fop_plan, "FOP+": p.fopplus_plan, "FISS": p.fiss_plan, "FISS+": p.fissplus_plan}[kind]()
+        key = f"{name}_{kind}"
+        np.testing.assert_array_equal(r.stats, g[f"{key}_stats"][e], err_msg=f"{key} ego {e}")
+        found = bool(g[f"{key}_found"][e])
+        assert (not np.isnan(r.best_cost)) == found, (key, e)
+        if not found:
+            continue
+        assert abs(r.best_cost - g[f"{key}_cost"][e]) < 1e-9
+        if kind in ("FOP", "FOP+"):
+            assert r.best_idx == g[f"{key}_flat"][e]
+        elif kind == "FISS":
+            np.testing.assert_array_equal(r.best_ijk, g[f"{key}_idx"][e])
+        else:
+            np.testing.assert_allclose(r.end_state, g[f"{key}_end"][e], rtol=0, atol=1e-9)
