@@ -392,7 +392,7 @@ def closed_loop(kind, fl, nd=5, nv=5, nt=5, max_cycles=100):
     states = []
     for i in range(min(fl.final_time_step, max_cycles)):
         start_vec = [cur.s, cur.s_d, cur.s_dd, cur.d, cur.d_d, cur.d_dd]
-        best = pl.plan(cur, 13.5, obstacles, i)
+        best = pl.plan(cur, getattr(fl, "max_speed", 13.5), obstacles, i)
         st = pl.stats
         if best is None:
             rows.append(start_vec + [np.nan, 0, 0, -1, -1, -1, st.num_iter, st.num_trajs_generated, st.num_trajs_validated,
@@ -628,6 +628,97 @@ def g9():
     save("g9_curvature.npz", **out)
 
 
+def parse_demo(path):
+    """One of the reference's demo scenario files (data/demo/*.xml) -> the arrays planning.py:36-100 hands to the planner.
+    Written independently of fiss_plus_planner_amd/commonroad_xml.py (which tests compare against this): exhaustive enumeration of
+    the successor-only lanelet paths from every lanelet under the initial position to the goal lanelet; exactly ONE exists in each of
+    the five files, which is what stands in for commonroad-route-planner's choice (not installable here; route parity unpinned)."""
+    root = ET.parse(path).getroot()
+
+    def bound(ll, tag):
+        return np.array([[float(p.find("x").text), float(p.find("y").text)] for p in ll.find(tag).findall("point")])
+
+    lanelets = {int(ll.get("id")): ll for ll in root.findall("lanelet")}
+    succ = {i: [int(x.get("ref")) for x in ll.findall("successor")] for i, ll in lanelets.items()}
+    pp = root.find("planningProblem")
+    init = pp.find("initialState")
+    init_state = np.array([float(init.find("position/point/x").text), float(init.find("position/point/y").text),
+                           float(init.find("orientation/exact").text), float(init.find("velocity/exact").text)])
+    goal = pp.find("goalState")
+    goal_id = int(goal.find("position/lanelet").get("ref"))
+    gv = goal.find("velocity")
+    max_speed = float(gv.find("intervalEnd").text) if gv is not None else 13.5  # planning.py:44-52
+
+    def winding(poly, q):  # non-zero winding number = inside
+        a = poly - q
+        b = np.roll(a, -1, axis=0)
+        ang = np.arctan2(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0], (a * b).sum(axis=1))
+        return abs(ang.sum()) > np.pi
+
+    starts = [i for i, ll in lanelets.items() if winding(np.vstack([bound(ll, "leftBound"), bound(ll, "rightBound")[::-1]]), init_state[:2])]
+    paths = []
+
+    def walk(path):
+        if path[-1] == goal_id:
+            paths.append(list(path)); return
+        for v in succ[path[-1]]:
+            if v in lanelets and v not in path:
+                walk(path + [v])
+
+    for st in starts:
+        walk([st])
+    assert len(paths) == 1, (path, starts, paths)
+    route = paths[0]
+    lanes = route + ([succ[route[-1]][0]] if succ[route[-1]] else [])  # global_planner.py:68-75
+    centers = {i: (bound(lanelets[i], "leftBound") + bound(lanelets[i], "rightBound")) / 2 for i in set(lanes) | {goal_id}}
+    cc = np.concatenate([centers[i] for i in lanes])
+    _, uniq = np.unique(cc, return_index=True, axis=0)
+    cc = cc[np.sort(uniq)]  # global_planner.py:79-82
+    gcv = centers[goal_id]
+    goal_center = gcv[int((gcv.shape[0] - 1) / 2)]  # planning.py:57-58
+    obs, T = [], 0
+    for ob in root.findall("dynamicObstacle"):
+        rect = ob.find("shape/rectangle")
+        states = {}
+        for st in [ob.find("initialState")] + ob.find("trajectory").findall("state"):
+            states[int(st.find("time/exact").text)] = (float(st.find("position/point/x").text), float(st.find("position/point/y").text),
+                                                       float(st.find("orientation/exact").text))
+        obs.append((float(rect.find("length").text), float(rect.find("width").text), states))
+        T = max(T, max(states) + 1)
+    pose = np.zeros((T, len(obs), 4)); dims = np.zeros((len(obs), 2))
+    for j, (l, w, states) in enumerate(obs):
+        dims[j] = [l, w]
+        for t, (x, y, yaw) in states.items():
+            pose[t, j] = [x, y, yaw, 1.0]
+    return SimpleNamespace(route=np.array(route), centerline=cc, pose=pose, dims=dims, final_time_step=max(obs[0][2]), init_state=init_state,
+                           goal_center=goal_center, max_speed=max_speed, benchmark_id=root.get("benchmarkID"))
+
+
+def g11(kinds=("FOP+", "FISS", "FISS+")):
+    """The reference's five demo scenarios (cfgs/demo_config.yaml: INPUT_DIR data/demo/, 5x5x5 samples): inputs as arrays + the closed
+    loop of the reference planners on them (planning.py:101-162), G5-style rows.  FOP itself is pinned on Flensburg-1 by G5 (its
+    exhaustive per-cycle validation takes minutes per scenario on the polygon stand-in)."""
+    import glob
+
+    out, names = {}, []
+    for path in sorted(glob.glob(os.path.join(refshim.REFERENCE_ROOT, "data/demo/*.xml"))):
+        sc = parse_demo(path)
+        name = sc.benchmark_id
+        names.append(name)
+        fts = sc.final_time_step
+        out.update({f"{name}_centerline": sc.centerline, f"{name}_obs_pose": sc.pose[:max(fts, 1)], f"{name}_obs_dims": sc.dims,
+                    f"{name}_final_time_step": np.array(fts), f"{name}_init_state": sc.init_state, f"{name}_goal_center": sc.goal_center,
+                    f"{name}_route": sc.route, f"{name}_max_speed": np.array(sc.max_speed)})
+        for kind in kinds:
+            t0 = time.time()
+            rows, states, ref = closed_loop(kind, sc)
+            out[f"{name}_{kind}_rows"] = rows
+            out[f"{name}_{kind}_states"] = states
+            print(f"  g11 {name} {kind}: {len(rows)} cycles in {time.time() - t0:.1f}s, last cost {rows[-1][6]:.6f}")
+    out["names"] = np.array(names)
+    save("g11_demo_scenarios.npz", **out)
+
+
 def g10():
     """FISS / FISS+ visualisation payload: the lattice indices the reference GENERATED during plan(), in generation order
     (trajs_per_timestep -> all_trajs, fiss_planner.py:131,262-265 / fiss_plus_planner.py:166-168)."""
@@ -659,7 +750,7 @@ def g10():
 
 
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10"]
+    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10", "g11"]
     for g in todo:
         t0 = time.time()
         print(f"== {g}")
