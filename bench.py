@@ -82,13 +82,15 @@ def read_bytes_per_ego(batch) -> float:
     return float(reads)
 
 
-def series_bytes(best_flags: np.ndarray) -> float:
+def series_bytes(best_flags: np.ndarray, lines: bool = False) -> float:
     """Bytes of the winners' series: 9 Frenet rows of N points, x / y / yaw of M, ds / c of M-1, c_d of M-2, c_dd of M-3 - only
-    for egos that HAVE a winner (flag word != 0)."""
+    for egos that HAVE a winner (flag word != 0).  lines=True: every row rounded up to whole 128-byte lines (what the sparse
+    layout of the ABI stores)."""
     fl = best_flags[best_flags != 0].astype(np.int64)
     N, M = (fl >> 8) & 0xFFF, fl >> 20
-    pos = lambda a: np.maximum(a, 0)
-    return float(8 * (9 * N + 3 * M + 2 * pos(M - 1) + pos(M - 2) + pos(M - 3)).sum())
+    ln = (lambda a: (np.maximum(a, 0) + 15) // 16 * 16) if lines else (lambda a: np.maximum(a, 0))
+    M = np.where(M >= 2, M, 0) if lines else M
+    return float(8 * (9 * ln(N) + 3 * ln(M) + 2 * ln(M - 1) + ln(M - 2) + ln(M - 3)).sum())
 
 
 class Workload:
@@ -113,7 +115,7 @@ class Workload:
         self.best_flags = torch.zeros(B, dtype=torch.int32, device=dev)
         # winner epilogue output, stays in HBM.  Compact layout of the ABI (fp_result.traj_stride / traj_sparse): rows of
         # ceil(max T / tick) columns, only the elements that exist are written - the bytes written ARE the algorithmic bytes
-        self.traj_stride = int(np.ceil(batch.t_samples.max() / batch.tick_t))
+        self.traj_stride = (int(np.ceil(batch.t_samples.max() / batch.tick_t)) + 15) // 16 * 16   # whole 128-byte lines per row
         self.best_traj = torch.empty((B, 16, self.traj_stride), dtype=torch.float64, device=dev)
         self.h_packed = torch.empty(12 * B, dtype=torch.uint8).pin_memory()
         self.h_cost = self.h_packed[:8 * B].view(torch.float64)
@@ -350,8 +352,9 @@ def main():
                 b_.record(stream)
             torch.cuda.synchronize(dev)
             m_ms = float(np.median([a.elapsed_time(b_) for a, b_ in mev]))
-            alg = series_bytes(m_flags.cpu().numpy().view(np.uint32)) + 4 * Bm * C
-            written = alg if m_sparse else Bm * C * (16 * m_stride * 8 + 4)
+            fl_m = m_flags.cpu().numpy().view(np.uint32)
+            alg = series_bytes(fl_m) + 4 * Bm * C
+            written = (series_bytes(fl_m, lines=True) + 4 * Bm * C) if m_sparse else Bm * C * (16 * m_stride * 8 + 4)
             materialize[label] = {"kernel_ms": m_ms, "candidates_per_s": Bm * C / (m_ms * 1e-3), "bytes_written_per_launch": written,
                                   "algorithmic_bytes_per_launch": alg, "achieved_GBps": written / (m_ms * 1e-3) / 1e9,
                                   "algorithmic_GBps": alg / (m_ms * 1e-3) / 1e9, "frac": written / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

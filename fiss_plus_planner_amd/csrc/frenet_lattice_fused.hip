@@ -154,6 +154,9 @@ __device__ __forceinline__ void power_sums_closed(int N, double tick, double* ou
 
 // nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
 // writes its partial argmin to part_best[ego * nsplit + part]; the last one to arrive (ticket counter) merges them.
+// POSE_LDS: the converted obstacle rows live in LDS (plain ds_read in the three collision stages); otherwise in the caller's global
+// scratch table (big scenes).  A run-time choice would make every access a flat (generic address space) load.
+template <bool POSE_LDS>
 __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best, int* part_count, const int* perm,
                                                                    int* dur, ObsPose* pose_global)
 {
@@ -173,14 +176,16 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const int stride = p.check_stride;
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt, pose_global == nullptr);
+    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt, POSE_LDS);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
     ObsDim* s_dim = (ObsDim*)(smem + L.dim);
     // obstacle rows of this workgroup: LDS, or - for scenes too big for it - this workgroup's slice of a global scratch table
     // (written during staging, read by the three collision stages through L2)
-    ObsPose* s_pose = pose_global ? pose_global + (size_t)blockIdx.x * rows_max * bt.n_obs : (ObsPose*)(smem + L.pose);
+    ObsPose* s_pose;  // (one provenance per instantiation: the compiler infers the address space from it)
+    if constexpr (POSE_LDS) s_pose = (ObsPose*)(smem + L.pose);
+    else s_pose = pose_global + (size_t)blockIdx.x * rows_max * bt.n_obs;
     Frame* s_frames = (Frame*)(smem + L.frames);
     double* s_lat = (double*)(smem + L.lat);
     float* s_dmax2 = (float*)(smem + L.dmax);    // [2][hp_max]
@@ -424,7 +429,11 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     fill_slice_lat(it_lo);
     __syncthreads();  // the final assembly reads the sums (with no obstacles there is no other barrier in between)
 
+#if defined(FP_ABL_NO_COLL)
+    for (int it = it_lo; false && it < it_hi; ++it) {
+#else
     for (int it = it_lo; n_obs > 0 && hp > 0 && it < it_hi; ++it) {
+#endif
         const double T = s_ts[it];
         const int N = arange_len(T, tick);
         float* s_dmax = s_dmax2 + (it & 1) * hp_max;    // this slice's buffers (zeroed during the previous slice)
@@ -557,7 +566,11 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             // stage works on [base, counter) and every thread tracks the bases itself, so nothing is reset between stages.
             // Capacity: the item list is filled optimistically by the whole table; if the survivors do not fit (rare) the
             // range is redone in chunks of kItemCap items; the pair range of B is cut into passes of kHitCap pairs.
+#if defined(FP_ABL_NO_GBN)   // timing ablations (tools/variants.sh): results are wrong, only the clock is read
+            const int n_items = 0;
+#else
             const int n_items = rows * n_obs;
+#endif
             const float inv_nobs = 1.0f / (float)n_obs, inv_nvf = 1.0f / (float)nv, inv_ndf = 1.0f / (float)nd;
             int chunk = n_items;
             for (int i0 = 0; i0 < n_items;) {
@@ -592,7 +605,11 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     continue;
                 }
                 // ---- B / N passes over the (survivor, lon profile) pairs
+#if defined(FP_ABL_NO_BN)
+                const int n_pairs = 0;
+#else
                 const int n_pairs = n_surv * nv;
+#endif
                 for (int p0 = 0; p0 < n_pairs; p0 += kHitCap) {
                     const int p1 = p0 + kHitCap < n_pairs ? p0 + kHitCap : n_pairs;
                     for (int q0 = p0 + wave * kWave; q0 < p1; q0 += kThreads) {
@@ -636,7 +653,11 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     const int n_hits = hit_end - hit_base;
                     hit_base = hit_end;
                     // ---- N: exact narrow phase
+#if defined(FP_ABL_NO_N)
+                    const int n_exact = 0;
+#else
                     const int n_exact = n_hits * nd;
+#endif
                     for (int x = tid; x < n_exact; x += kThreads) {
                         const int h = div_small(x, inv_ndf), id = x - mul24(h, nd);
                         const uint32_t code = s_hits[h];
@@ -774,6 +795,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
     // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
     // 16 KB of stores per ego hide behind the other workgroups' arithmetic.
+#if defined(FP_ABL_NO_WINNER)
+    return;
+#endif
     if (!ka.r.best_traj) return;
     __syncthreads();
     const int win = s_best[0].idx;
@@ -839,7 +863,9 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     }
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     FP_LDS_SLOTS(configured);
-    hipError_t e = ensure_dynamic_lds((const void*)lattice_fused_kernel, L.total, configured);
+    FP_LDS_SLOTS(configured_g);
+    hipError_t e = pose_global ? ensure_dynamic_lds((const void*)lattice_fused_kernel<false>, L.total, configured_g)
+                               : ensure_dynamic_lds((const void*)lattice_fused_kernel<true>, L.total, configured);
     if (e != hipSuccess) return e;
     if (!part_scratch || nsplit < 1) nsplit = 1;
     if (nsplit > p.nt) nsplit = p.nt;
@@ -852,8 +878,12 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         e = launch_curvature_flags(ka, const_cast<uint8_t*>(ka.curv_tbl), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur,
-                       pose_global);
+    if (pose_global)
+        hipLaunchKernelGGL(lattice_fused_kernel<false>, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm,
+                           dur, pose_global);
+    else
+        hipLaunchKernelGGL(lattice_fused_kernel<true>, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm,
+                           dur, pose_global);
     if (winner_done) *winner_done = ka.r.best_traj != nullptr;
     return hipGetLastError();
 }

@@ -133,9 +133,11 @@ typedef struct {
     int32_t traj_stride; /* columns per series row; 0 = FP_MAX_POINTS.  Must be >= the largest N = ceil(T / tick_t) of the batch
                             (e.g. 100 for T <= 10 s at 0.1 s): a smaller stride is FP_EINVAL (host) / truncates the rows (device) */
     int32_t traj_sparse; /* 0: every element of the [16][traj_stride] block is written (NaN where a row has no element).
-                            1: only the elements that exist are written - row r gets its len(r) leading elements (N for the Frenet
-                            rows, M / M-1 / M-2 / M-3 for x y yaw / ds c / c_d / c_dd), the rest of the block and the blocks of egos
-                            without a winner (best_flags = 0) are left untouched: the bytes written are the algorithmic bytes */
+                            1: only the rows' leading elements are written - row r gets its len(r) elements (N for the Frenet rows,
+                            M / M-1 / M-2 / M-3 for x y yaw / ds c / c_d / c_dd) plus NaN up to the next multiple of 16 columns (so
+                            that, with a stride that is a multiple of 16, only whole 128-byte lines are stored); the rest of the
+                            block and the blocks of egos without a winner (best_flags = 0) are left untouched.  Bytes written =
+                            the algorithmic bytes rounded up to lines: ~6 % more at N ~ 90.  Use traj_stride = 112 for T <= 10 s */
 } fp_result;
 
 int fp_abi_version(void);

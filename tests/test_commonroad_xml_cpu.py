@@ -44,3 +44,25 @@ def test_all_demo_scenarios_load():
         s = np.arange(0, sp.s[-1], 0.5)
         x, y, _, _ = sp.sample(s)
         assert np.hypot(x - sc.init_state[0], y - sc.init_state[1]).min() < 3.0
+
+
+def test_every_demo_scenario_matches_its_fixture():
+    """The product's XML reader against the arrays of tests/golden/g11_demo_scenarios.npz, which the golden generator parsed
+    with its OWN reader (tests/golden/gen_golden.py:parse_demo - exhaustive route enumeration instead of a breadth-first search,
+    winding-number instead of ray-casting point location): route, centerline, obstacle tables, initial state, goal centre, speed."""
+    from fiss_plus_planner_amd.commonroad_xml import load_scenario
+
+    g = load_golden("g11_demo_scenarios.npz")
+    files = sorted(glob.glob(os.path.join(DEMO, "*.xml")))
+    assert [os.path.basename(f)[:-4] for f in files] == [str(n) for n in g["names"]]
+    for f in files:
+        sc = load_scenario(f)
+        n = sc.benchmark_id
+        assert sc.route == g[f"{n}_route"].tolist(), n
+        np.testing.assert_array_equal(sc.centerline, g[f"{n}_centerline"])
+        assert sc.obstacles.final_time_step == int(g[f"{n}_final_time_step"])
+        np.testing.assert_array_equal(sc.obstacles.pose, g[f"{n}_obs_pose"])
+        np.testing.assert_array_equal(sc.obstacles.dims, g[f"{n}_obs_dims"])
+        np.testing.assert_array_equal(sc.init_state, g[f"{n}_init_state"])
+        np.testing.assert_array_equal(sc.goal_center, g[f"{n}_goal_center"])
+        assert sc.max_speed == float(g[f"{n}_max_speed"])
