@@ -277,6 +277,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     B, C = batch.B, batch.C
     eng = FrenetEngine(local_rank)
+    for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(",")):  # diagnostic: "name=value,..." -> fp_ctx_set_option
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     stream = torch.cuda.current_stream(dev)
     main_wl = Workload(torch, eng, batch, dev, stream, fiss=fiss, tables=args.tables)
 

@@ -109,6 +109,7 @@ struct fp_ctx {
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
+    int lattice_winner = 0;        // fp_ctx_set_option("lattice_winner"): 0 auto, 1 inside the lattice kernel, 2 its own launch
     int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
     // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
     // leaves its ego's duration in dur_dev; now and then the host fetches them (async copy + event, never a wait), sorts the egos
@@ -459,6 +460,17 @@ int lattice_curv_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hip
     return FP_OK;
 }
 
+// Where the winner's series is written: by the lattice kernel's own workgroup (no second launch: what a single plan() call wants)
+// or by winner_traj_kernel right behind it.  In a multi-round launch (more egos than resident workgroups) the epilogue - one
+// wavefront's dependent chain of ~4 us - holds the workgroup's slot while the next ego waits for it; as its own launch the same
+// work runs on idle SIMDs next to nothing else.
+bool winner_inside_lattice(const fp_ctx* ctx, const fp_batch* b)
+{
+    if (ctx->lattice_winner == 1) return true;
+    if (ctx->lattice_winner == 2) return false;
+    return b->B <= ctx->resident_groups;
+}
+
 fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
 
 int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem)
@@ -561,6 +573,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->refine_table_kb = value;
         return FP_OK;
     }
+    if (strcmp(name, "lattice_winner") == 0) {
+        if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_winner must be 0 (auto), 1 (inside the lattice kernel) or 2 (own launch)");
+        ctx->lattice_winner = value;
+        return FP_OK;
+    }
     if (strcmp(name, "fiss_stages") == 0) {
         if (value < 1 || value > 3) return fail(FP_EINVAL, "fiss_stages must be 1 (lattice only), 2 (+ search) or 3 (all)");
         ctx->fiss_stages = value;
@@ -579,7 +596,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
         {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_order", ctx->lattice_order},
-        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"lattice_launches", ctx->lattice_launches},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
         if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
@@ -610,7 +627,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         void* pose_scratch;
         FP_TRY(lattice_pose_scratch(ctx, params, &ka.b, nsplit, (hipStream_t)stream, &pose_scratch));
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
-        LAUNCH_TRY(fp::launch_lattice(ka, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
+        fp::KernelArgs kl = ka;
+        if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
+        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
@@ -644,7 +663,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     void* pose_scratch;
     FP_TRY(lattice_pose_scratch(ctx, params, &ka.b, nsplit, ctx->stream, &pose_scratch));
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
-    LAUNCH_TRY(fp::launch_lattice(ka, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
+    fp::KernelArgs kl = ka;
+    if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
+    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     return hs.fetch_out();

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
             kw.r.traj_stride = fa.io.traj_stride;
             kw.r.traj_sparse = fa.io.traj_sparse;
             const double none = __builtin_nan("");
-            winner_series(kw, b, b, false, none, none, none, tid, SplineLds{nullptr, nullptr, 0, 0}, nullptr);
+            if (wave == 0) winner_series_wave(kw, b, b, false, none, none, none, lane, SplineLds{nullptr, nullptr, 0, 0});
         }
         return;
     }
@@ -902,9 +902,9 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
     }
     if (tid == 0 && dur) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
     // winner epilogue (what plan() returns) on request: the series of the refined trajectory, or of the coarse winner when no
-    // refined one survived.  Every wavefront holds the same candidate list, so each reads the end state from its own registers;
-    // the power-sum table is dead by now and lends its LDS to the epilogue.
-    if (fa.io.best_traj) {
+    // refined one survived.  Every wavefront holds the same candidate list; wavefront 0 writes the series (two time points per
+    // lane, no barrier), the others are done.
+    if (fa.io.best_traj && wave == 0) {
         double fx[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) fx[m] = winner >= 0 ? __shfl(my_x[m], winner, kWave) : coarse_x[m];
@@ -913,8 +913,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(Fi
         kw.r.best_flags = fa.io.best_flags;
         kw.r.traj_stride = fa.io.traj_stride;
         kw.r.traj_sparse = fa.io.traj_sparse;
-        __syncthreads();
-        winner_series(kw, b, b, true, fx[0], fx[1], fx[2], tid, SplineLds{L.knots, L.coef, nx, nx}, L.S);
+        winner_series_wave(kw, b, b, true, fx[0], fx[1], fx[2], lane, SplineLds{L.knots, L.coef, nx, nx});
     }
 }
 

@@ -387,16 +387,18 @@ __global__ __launch_bounds__(256) void eval_trajs_kernel(KernelArgs ka, int K, c
 }
 
 // ---------------------------------------------------------------------------
-// winner epilogue: one workgroup per ego, one lane per time point (no LDS staging of tables: a single
-// trajectory touches ~100 spline segments, read straight through L2)
+// winner epilogue: one WAVEFRONT per trajectory (two time points per lane; no LDS staging of tables: a single trajectory touches
+// ~100 spline segments, read straight through L2); kWinnerWaves trajectories per workgroup.
 // ---------------------------------------------------------------------------
-// all_C > 0: materialise EVERY lattice candidate (workgroup = (ego, candidate), output slot = blockIdx.x): the all_trajs payload.
-__global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C)
+// all_C > 0: materialise EVERY lattice candidate (slot = (ego, candidate) in FOP order): the all_trajs payload.
+constexpr int kWinnerWaves = 4;
+__global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C, int n_slots)
 {
-    __shared__ double scratch[kWinnerScratchDoubles];
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
-    const int slot = blockIdx.x, i = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int slot = blockIdx.x * kWinnerWaves + (int)threadIdx.x / kWave;  // wave-uniform
+    if (slot >= n_slots) return;
     const int b = all_C > 0 ? slot / all_C : slot;
     const double nan = __builtin_nan("");
     const int best = all_C > 0 ? slot - b * all_C : (end_states ? 0 : ka.r.best_idx[b]);
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs k
     }
     const int f = bt.frame_of[b];
     const SplineLds sp{bt.knots + (size_t)f * bt.NX, bt.coef + (size_t)f * 8 * bt.NX, bt.nx[f], bt.NX};
-    winner_series(ka, b, slot, best >= 0, d_end, v_end, T, i, sp, scratch);
+    winner_series_wave(ka, b, slot, best >= 0, d_end, v_end, T, lane, sp);
 }
 
 // ---------------------------------------------------------------------------
@@ -417,14 +419,16 @@ __global__ __launch_bounds__(FP_MAX_POINTS) void winner_traj_kernel(KernelArgs k
 // ---------------------------------------------------------------------------
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream)
 {
-    hipLaunchKernelGGL(winner_traj_kernel, dim3(ka.b.B), dim3(FP_MAX_POINTS), 0, stream, ka, end_states, 0);
+    const int n = ka.b.B;
+    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), 0, stream, ka, end_states, 0, n);
     return hipGetLastError();
 }
 
 hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
 {
     const int C = ka.p.nd * ka.p.nv * ka.p.nt;
-    hipLaunchKernelGGL(winner_traj_kernel, dim3((unsigned)ka.b.B * (unsigned)C), dim3(FP_MAX_POINTS), 0, stream, ka, nullptr, C);
+    const unsigned n = (unsigned)ka.b.B * (unsigned)C;
+    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), 0, stream, ka, nullptr, C, (int)n);
     return hipGetLastError();
 }
 

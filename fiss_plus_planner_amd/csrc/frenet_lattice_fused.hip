@@ -109,7 +109,6 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.cnt = o;      o = align16(o + 16);  // list counters (monotone) + scan mask
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * kWaves);
-    if (o < L.dim + 8 * kWinnerScratchDoubles) o = align16(L.dim + 8 * kWinnerScratchDoubles);  // the winner epilogue reuses [dim, ...)
     L.total = o;
     return L;
 }
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
             if (ka.r.best_traj) {  // NaN series, flag word 0 (returns before it touches the spline or the scratch)
                 const double nan = __builtin_nan("");
-                winner_series(ka, b, b, false, nan, nan, nan, tid, SplineLds{nullptr, nullptr, 0, 0}, nullptr);
+                if (wave == 0) winner_series_wave(ka, b, b, false, nan, nan, nan, lane, SplineLds{nullptr, nullptr, 0, 0});
             }
         }
         return;
@@ -794,12 +793,14 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     if (tid == 0 && dur && nsplit == 1) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
     // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
     // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
-    // 16 KB of stores per ego hide behind the other workgroups' arithmetic.
+    // stores hide behind the other workgroups' arithmetic.  ONE wavefront does it (two time points per lane, neighbours by lane
+    // shuffles: no barrier, no scratch); the other seven are done and leave - their issue slots go to the CU's other workgroup.
 #if defined(FP_ABL_NO_WINNER)
     return;
 #endif
     if (!ka.r.best_traj) return;
     __syncthreads();
+    if (wave != 0) return;
     const int win = s_best[0].idx;
     double d_end = __builtin_nan(""), v_end = d_end, T_end = d_end;
     if (win >= 0) {
@@ -807,8 +808,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const int id = div_small(q1, inv_nt_a), it = q1 - mul24(id, nt);
         d_end = s_ds[id]; v_end = s_vs[iv]; T_end = s_ts[it];
     }
-    __syncthreads();  // everything behind the spline tables is dead now: the epilogue's scratch lives there
-    winner_series(ka, b, b, win >= 0, d_end, v_end, T_end, tid, sp, (double*)(smem + L.dim));
+    winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp);
 }
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the

@@ -160,6 +160,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
  * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
  * table; scenes whose table does not fit are checked straight from the scene table.  Identical results either way.
+ * "lattice_winner": who writes fp_plan_dense's best_traj: 0 = auto (the lattice kernel itself while one round of workgroups
+ * holds the batch, winner_traj_kernel right behind it for bigger batches), 1 = always the lattice kernel, 2 = always its own
+ * launch.  Identical results.
  * "fiss_stages": timing diagnostic of fp_plan_fiss, 3 (default) = the whole pipeline, 2 = stop after the search walk (no
  * refinement), 1 = stop after the dense lattice pass; with 1 or 2 the outputs of the skipped stages are NOT produced. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);

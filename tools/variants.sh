@@ -12,7 +12,7 @@ i=0
 for EXTRA in "$@"; do
   i=$((i+1))
   make -C fiss_plus_planner_amd/csrc -B -s EXTRA="$EXTRA" > $OUT/build_$i.log 2>&1 || { echo "variant $i [$EXTRA]: BUILD FAILED"; tail -5 $OUT/build_$i.log; continue; }
-  python bench.py --steps ${STEPS:-60} --warmup 8 --cpu-seconds ${CPU:-0} --no-latency --no-extras ${BENCH_ARGS:-} > $OUT/bench_$i.json 2> $OUT/bench_$i.err
+  env ${BENCH_ENV:-} python bench.py --steps ${STEPS:-60} --warmup 8 --cpu-seconds ${CPU:-0} --no-latency --no-extras ${BENCH_ARGS:-} > $OUT/bench_$i.json 2> $OUT/bench_$i.err
   python - "$OUT/bench_$i.json" "$EXTRA" <<'PY'
 import json, sys
 try:
