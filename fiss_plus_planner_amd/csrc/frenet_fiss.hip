@@ -3,14 +3,19 @@
 // The reference generates candidates lazily while it moves over the (d, v, t) index grid.  A candidate's cost_final,
 // its constraint / collision outcome and its cost_est are pure functions of its index, so the walk
 // can run over tables the lattice kernel already produced:  J = cost_final,  F = flag word,  E = cost_est.
-// The walk itself is sequential and data dependent; it is kept wave-uniform (every lane follows the same control
-// flow, scalar state lives in uniform registers) and only its search primitives use the 64 lanes:
+// The walk itself is sequential and data dependent - a walk through a blocked scene pops hundreds of candidates one after the
+// other, and the LONGEST walk of the batch is the kernel's duration - so what counts is the length of the dependent chain of one
+// pop.  It is kept wave-uniform (every lane follows the same control flow, scalar state lives in uniform registers), and the
+// two priority queues of the reference cost a handful of scalar instructions per operation:
 //     queue head    = argmin of J over "in queue" entries          (fiss_planner.py:207 / :229, heapq order)
 //     frontier pop  = argmin of J over frontier entries            (fiss_plus_planner.py:113)
+// Both order by (J, raster index), a total order that is fixed before the walk starts.  The prologue sorts the lattice once by
+// that key (bitonic network in LDS, the whole wavefront); afterwards a queue is a BIT SET over ranks - lane L holds ranks
+// 64 L .. 64 L + 63 in one 64-bit register - with insert = set a bit, pop = clear it, argmin = lowest set bit (ballot + two
+// find-first-set).  No key array, no rescans, no reductions.  Exact ties resolve to the LOWEST raster index (documented
+// divergence from the reference's ValueError on tied heap entries); NaN / infinite costs are never popped.
 //     initial guess = argmin of E over not-yet-generated entries, LAST minimum  (fiss_planner.py:140-150)
-// The first two are two-level minima (BlockMin: per-lane cached block minima over an LDS key array, +inf = absent), the last -
-// needed only when the queue runs dry - a strided scan + DPP wave minimum.  A walk through a blocked scene pops hundreds of
-// candidates one after the other, so the cost of one pop (argmin + removal) is what bounds the kernel.
+// is needed only when the queue runs dry: a strided scan + DPP wave minimum.
 //
 // Restated: fiss_planner.py:33-99 (cost_est), :101-138 (generate_trajectory -> table lookup), :140-188, :190-270;
 //           fiss_plus_planner.py:30-59, :80-148.
@@ -22,74 +27,77 @@ namespace fp {
 
 namespace {
 
-constexpr uint8_t kGen = 1, kInQ = 2;
+constexpr uint8_t kGen = 1;
 
-// Two-level minimum over an LDS key array (+inf = absent).  The array is cut into blocks of 64 consecutive raster indices;
-// lane L keeps the minimum of block L and its raster index in registers.  Insert = one compare on the owning lane, removal of a
-// block's cached minimum = one parallel rescan of that block (one LDS read per lane + a DPP wave minimum), argmin = a DPP wave
-// minimum over the cached values - no scan of the whole array anywhere (C <= FP_MAX_CAND = 4096 -> at most 64 blocks).
-// Exact ties resolve to the LOWEST raster index (documented divergence from the reference's ValueError on tied heap entries).
-struct BlockMin {
-    double* key;
-    double bmin;  // lane L: minimum of key[64 L .. 64 L + 63]
-    int barg;     // its raster index, -1 when the block is empty
-    bool few;     // C <= 1024
-
-    __device__ __forceinline__ void reset(double* k, int C) { key = k; bmin = __builtin_inf(); barg = -1; few = C <= 16 * kWave; }
-    // register side of an insert (the key itself is already in LDS); q, c wave-uniform
-    __device__ __forceinline__ void note(int q, double c, int lane)
+// Bit set over ranks 0 .. 4095: lane L owns ranks 64 L .. 64 L + 63.  All arguments wave-uniform.
+struct RankSet {
+    unsigned long long word;
+    __device__ __forceinline__ void clear() { word = 0ull; }
+    __device__ __forceinline__ void set(int r, int lane) { if (lane == (r >> 6)) word |= 1ull << (r & 63); }
+    __device__ __forceinline__ void reset(int r, int lane) { if (lane == (r >> 6)) word &= ~(1ull << (r & 63)); }
+    __device__ __forceinline__ int lowest() const  // -1 when empty
     {
-        if (lane == (q >> 6) && (c < bmin || (c == bmin && q < barg))) { bmin = c; barg = q; }
-    }
-    __device__ __forceinline__ void insert(int q, double c, int lane)
-    {
-        key[q] = c;
-        note(q, c, lane);
-    }
-    __device__ __forceinline__ void remove(int q, int lane, int C)
-    {
-        key[q] = __builtin_inf();
-        const int blk = q >> 6;
-        if (__builtin_amdgcn_readlane(barg, blk) != q) return;  // the block's minimum is untouched
-        const int at = blk * kWave + lane;
-        double v = at < C ? key[at] : __builtin_inf();
-        v = v < __builtin_inf() ? v : __builtin_inf();  // NaN keys are never popped
-        const double m = wave_min_f64(v);
-        const unsigned long long owners = __ballot(v == m && m < __builtin_inf());
-        if (lane == blk) {
-            bmin = m;
-            barg = owners ? blk * kWave + __ffsll((long long)owners) - 1 : -1;
-        }
-    }
-    __device__ __forceinline__ int argmin() const
-    {
-        // at most 16 blocks (C <= 1024): the cached minima sit in the first DPP row
-        const double m = few ? lane_value(row16_min(bmin), 0) : wave_min_f64(bmin);
-        if (!(m < __builtin_inf())) return -1;
-        const unsigned long long owners = __ballot(bmin == m);
-        return __builtin_amdgcn_readlane(barg, __ffsll((long long)owners) - 1);
+        const unsigned long long nz = __ballot(word != 0ull);
+        if (!nz) return -1;
+        const int L = __ffsll((long long)nz) - 1;
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)word, L);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(word >> 32), L);
+        return (L << 6) + (lo ? __ffs((int)lo) - 1 : 32 + __ffs((int)hi) - 1);
     }
 };
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sort (key[i], idx[i]), i < P (a power of two), ascending by key, ties by idx: bitonic network, one wavefront, in LDS.
+// Four compare-exchanges per lane are in flight at a time (their LDS reads are independent).
+__device__ void wave_bitonic_sort(double* key, uint16_t* idx, int P, int lane)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t0 = 0; t0 < (P >> 1); t0 += 4 * kWave) {
+                int a[4], b[4];
+                double ka[4], kb[4];
+                uint16_t ia[4], ib[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * kWave + lane;
+                    a[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // t with a zero inserted at bit log2(j)
+                    b[u] = a[u] | j;
+                    const bool live = t < (P >> 1);
+                    a[u] = live ? a[u] : 0; b[u] = live ? b[u] : 0;  // (idle lanes compare element 0 with itself: no exchange)
+                    ka[u] = key[a[u]]; kb[u] = key[b[u]]; ia[u] = idx[a[u]]; ib[u] = idx[b[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool up = (a[u] & k) == 0;
+                    const bool gt = ka[u] > kb[u] || (ka[u] == kb[u] && ia[u] > ib[u]);
+                    if (gt == up && a[u] != b[u]) {
+                        key[a[u]] = kb[u]; key[b[u]] = ka[u]; idx[a[u]] = ib[u]; idx[b[u]] = ia[u];
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
 
 struct Walk {
     const double* J;
     const uint8_t* F;
     uint8_t* st;
-    BlockMin Q;     // J where "in queue"        -> queue head = argmin   (fiss_planner.py:207 / :229, heapq order)
-    BlockMin Fr;    // J where "on the frontier" -> frontier pop = argmin (fiss_plus_planner.py:113)
+    const uint16_t* rank;  // raster index -> rank in (J, raster index) order
+    const uint16_t* order; // rank -> raster index (the sort's payload)
+    RankSet Q;      // "in queue"        -> queue head = lowest rank   (fiss_planner.py:207 / :229, heapq order)
+    RankSet Fr;     // "on the frontier" -> frontier pop = lowest rank (fiss_plus_planner.py:113)
     double* keyG;   // E where not yet generated, +inf elsewhere -> initial guess = LAST argmin (needed only when the queue runs dry)
     const uint16_t* ijk;  // raster index -> i | j << sh_j | k << sh_k (bit fields sized for nd, nv, nt: at most 15 bits in all)
     int nd, nv, nt, C, lane;
     int num_iter, num_generated, num_validated, num_checks;
-    // the queue head (lexicographic minimum of (J, raster index) over the queue), kept incrementally: inserts compare against
-    // it, the only removal is the pop of the head itself (pop_head recomputes it).  Wave-uniform.
-    int head;
-    double head_c;
-
-    __device__ __forceinline__ void offer_head(int q, double c)
-    {
-        if (c < head_c || (c == head_c && q < head)) { head_c = c; head = q; }
-    }
 
     __device__ __forceinline__ int raster(int i, int j, int k) const { return (i * nv + j) * nt + k; }
 
@@ -99,9 +107,8 @@ struct Walk {
         cost = J[q];
         const uint8_t s = st[q];
         if (s & kGen) return false;
-        st[q] = s | kGen | kInQ;  // candidate_trajs.put((cost_final, idx))
-        Q.insert(q, cost, lane);
-        offer_head(q, cost);
+        st[q] = s | kGen;  // candidate_trajs.put((cost_final, idx))
+        if (cost < __builtin_inf()) Q.set(__builtin_amdgcn_readfirstlane((int)rank[q]), lane);  // NaN / inf: never popped
         keyG[q] = __builtin_inf();
         ++num_generated;
         return true;
@@ -128,41 +135,11 @@ struct Walk {
         }
         return __builtin_amdgcn_readfirstlane(cand);
     }
-
-    // validation of the queue head (fiss_planner.py:229-258): pops it, returns 1 = answer, 0 = rejected, and leaves the NEXT head
-    // in (head, head_c).  The popped cell is its block's cached minimum, so that block is rescanned (one LDS read per lane + a
-    // wave minimum); the minimum over the other blocks' cached values does not depend on that read and overlaps its latency.
-    __device__ __forceinline__ int pop_head()
-    {
-        const int q = head;
-        st[q] &= (uint8_t)~kInQ;
-        Q.key[q] = __builtin_inf();
-        const int blk = q >> 6;
-        const int at = blk * kWave + lane;
-        double v = at < C ? Q.key[at] : __builtin_inf();
-        const uint8_t f = F[q];
-        const double o = lane == blk ? __builtin_inf() : Q.bmin;
-        const double mo = Q.few ? lane_value(row16_min(o), 0) : wave_min_f64(o);
-        int ao = -1;
-        if (mo < __builtin_inf()) ao = __builtin_amdgcn_readlane(Q.barg, __ffsll((long long)__ballot(o == mo)) - 1);
-        v = v < __builtin_inf() ? v : __builtin_inf();  // NaN keys are never popped
-        const double mb = wave_min_f64(v);
-        const unsigned long long owners = __ballot(v == mb && mb < __builtin_inf());
-        const int ab = owners ? blk * kWave + __ffsll((long long)owners) - 1 : -1;
-        if (lane == blk) { Q.bmin = mb; Q.barg = ab; }
-        const bool take_b = ab >= 0 && (ao < 0 || mb < mo || (mb == mo && ab < ao));
-        head = take_b ? ab : ao;
-        head_c = take_b ? mb : mo;  // +inf when the queue is empty (head = -1)
-        ++num_validated;
-        if (f & FP_FLAG_CONSTRAINTS) return 0;
-        ++num_checks;
-        return (f & FP_FLAG_COLLISION) ? 0 : 1;
-    }
 };
 
 }  // namespace
 
-__global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
+__global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const fp_params& p = fa.ka.p;
@@ -182,17 +159,19 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
         }
         return;
     }
+    // LDS: J [C] | sort keys [P] | keyG [C] | order [P] | rank [C] | ijk [C] | F [C] | st [C]     (P = power of two >= C)
     double* J = (double*)smem;
-    double* keyQ = J + C;
-    double* keyF = keyQ + C;
-    double* keyG = keyF + C;
-    uint16_t* ijk = (uint16_t*)(keyG + C);
+    double* skey = J + C;
+    double* keyG = skey + P;
+    uint16_t* order = (uint16_t*)(keyG + C);
+    uint16_t* rank = order + P;
+    uint16_t* ijk = rank + C;
     uint8_t* F = (uint8_t*)(ijk + C);
+    uint8_t* st = F + C;
     // bit fields of the packed index: ceil(log2 nd) + ceil(log2 nv) + ceil(log2 nt) <= log2(FP_MAX_CAND) + 3 = 15
     const int sh_j = nd > 1 ? 32 - __clz(nd - 1) : 0;
     const int sh_k = sh_j + (nv > 1 ? 32 - __clz(nv - 1) : 0);
     const uint32_t mask_i = (1u << sh_j) - 1u, mask_j = (1u << (sh_k - sh_j)) - 1u;
-    uint8_t* st = F + C;
 
     // ---- tables: FOP flat order (i_d, i_T, i_v) -> FISS raster (i_d, i_v, i_t); cost_est (fiss_planner.py:33-99)
     const double* smin = fa.io.samp_min + (size_t)b * 3;
@@ -203,11 +182,23 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
     const double vr = smax[1] - smin[1], tr = smax[2] - smin[2];
     const double max_sqr_dist = (double)(nd * nd + nv * nv + nt * nt);
     const double* vs = bt.v_samples + (size_t)b * nv;
-    for (int q = lane; q < C; q += kWave) {
+    int feasible = 0, pass_constraints = 0;
+    for (int q = lane; q < P; q += kWave) {
+        if (q >= C) {  // padding of the sort: behind every real entry
+            skey[q] = __builtin_inf();
+            order[q] = (uint16_t)q;
+            continue;
+        }
         const int k = q % nt, j = (q / nt) % nv, i = q / (nt * nv);
         const size_t flat = (size_t)b * C + (size_t)(i * nt + k) * nv + j;
-        J[q] = fa.cost_tbl[flat];
-        F[q] = (uint8_t)(fa.flag_tbl[flat] & 0xFFu);
+        const double cost = fa.cost_tbl[flat];
+        const uint8_t f = (uint8_t)(fa.flag_tbl[flat] & 0xFFu);
+        J[q] = cost;
+        skey[q] = cost < __builtin_inf() ? cost : __builtin_inf();  // NaN sorts with the infinities: never popped anyway
+        order[q] = (uint16_t)q;
+        F[q] = f;
+        feasible += (f & FP_FLAG_INFEASIBLE) == 0;
+        pass_constraints += (f & FP_FLAG_CONSTRAINTS) == 0;
         st[q] = 0;
         ijk[q] = (uint16_t)((uint32_t)i | ((uint32_t)j << sh_j) | ((uint32_t)k << sh_k));
         const double d = bt.d_samples[i], v = vs[j], t = bt.t_samples[k];
@@ -220,41 +211,49 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
             const int a = i - p0, bb = j - p1, c = k - p2;
             est += fa.opts.w_heuristic * (double)(a * a + bb * bb + c * c) / max_sqr_dist;
         }
-        keyQ[q] = __builtin_inf();
-        keyF[q] = __builtin_inf();
         keyG[q] = est <= __builtin_inf() ? est : __builtin_inf();  // a NaN estimate can never satisfy `<=`
     }
-    __syncthreads();
 
     // No feasible candidate anywhere in the lattice: the walk would generate and validate every sample, one per outer
     // iteration, and give up (fiss_planner.py:203-206).  Its outcome is closed form: num_iter = C + 1, generated =
     // validated = C, collision checks = samples that pass the constraints.  (Each iteration pops exactly one candidate.)
-    {
-        int feasible = 0, pass_constraints = 0;
-        for (int q = lane; q < C; q += kWave) {
-            feasible += (F[q] & FP_FLAG_INFEASIBLE) == 0;
-            pass_constraints += (F[q] & FP_FLAG_CONSTRAINTS) == 0;
-        }
-        if (__ballot(feasible != 0) == 0ull) {
+    if (__ballot(feasible != 0) == 0ull) {
 #pragma unroll
-            for (int off = kWave / 2; off > 0; off >>= 1) pass_constraints += __shfl_xor(pass_constraints, off, kWave);
-            if (lane == 0) {
-                int32_t* out = fa.io.best_ijk + (size_t)b * 3;
-                out[0] = out[1] = out[2] = -1;
-                fa.io.best_cost[b] = __builtin_nan("");
-                double* es = fa.io.end_state + (size_t)b * 3;
-                es[0] = es[1] = es[2] = __builtin_nan("");
-                fa.io.refined[b] = 0;
-                int32_t* s4 = fa.io.stats + (size_t)b * 4;
-                s4[0] = C + 1; s4[1] = C; s4[2] = C; s4[3] = pass_constraints;
-            }
-            return;
+        for (int off = kWave / 2; off > 0; off >>= 1) pass_constraints += __shfl_xor(pass_constraints, off, kWave);
+        if (lane == 0) {
+            int32_t* out = fa.io.best_ijk + (size_t)b * 3;
+            out[0] = out[1] = out[2] = -1;
+            fa.io.best_cost[b] = __builtin_nan("");
+            double* es = fa.io.end_state + (size_t)b * 3;
+            es[0] = es[1] = es[2] = __builtin_nan("");
+            fa.io.refined[b] = 0;
+            int32_t* s4 = fa.io.stats + (size_t)b * 4;
+            s4[0] = C + 1; s4[1] = C; s4[2] = C; s4[3] = pass_constraints;
         }
+        return;
     }
+    wave_lds_sync();
+    // ---- the total order of the walk's two queues: (J, raster index)
+    wave_bitonic_sort(skey, order, P, lane);
+    // rank -> (raster index | flag byte << 16): one LDS read tells a pop which candidate it is and whether it is feasible.  The
+    // words take over the sort keys' bytes (dead from here on).
+    uint32_t* order32 = (uint32_t*)skey;
+    for (int r0 = 0; r0 < P; r0 += kWave) {
+        const int r = r0 + lane;
+        const int q = r < P ? order[r] : C;
+        uint32_t word = 0xFFFFu;
+        if (q < C) { rank[q] = (uint16_t)r; word = (uint32_t)q | ((uint32_t)F[q] << 16); }
+        wave_lds_sync();  // (the words of this batch overlay keys whose ranks were read above)
+        if (r < P) order32[r] = word;
+    }
+    wave_lds_sync();
 
-    Walk w{J, F, st, {}, {}, keyG, ijk, nd, nv, nt, C, lane, 0, 0, 0, 0, -1, __builtin_inf()};
-    w.Q.reset(keyQ, C);
-    w.Fr.reset(keyF, C);
+    Walk w{J, F, st, rank, order, {}, {}, keyG, ijk, nd, nv, nt, C, lane, 0, 0, 0, 0};
+#if defined(FP_ABL_SEARCH_NOWALK)  // timing ablation: prologue + sort only
+    return;
+#endif
+    w.Q.clear();
+    w.Fr.clear();
     const int sizes[3] = {nd, nv, nt};
     int best = -1;
     const bool plus = fa.opts.kind == FP_FISS_PLUS;
@@ -264,10 +263,15 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
     const int my_size = my_dim == 0 ? nd : (my_dim == 1 ? nv : nt);
     for (;;) {
         ++w.num_iter;
-        int q = w.head;
-        if (q < 0) {
+        const int rh = w.Q.lowest();
+        int q;
+        uint32_t head_word = 0;
+        if (rh < 0) {
             q = w.initial_guess();
             if (q < 0) break;  // every sample searched, nothing feasible (:203-206)
+        } else {
+            head_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)order32[rh]);  // peek the most likely candidate (:207-209)
+            q = (int)(head_word & 0xFFFFu);
         }
         q = __builtin_amdgcn_readfirstlane(q);  // wave-uniform: scalar addressing and branches from here on
         if (!plus) {
@@ -302,10 +306,9 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
             }
         } else {
             // explore_neighbors + frontier (fiss_plus_planner.py:30-59, :106-116).  One LDS round trip per centre: its packed
-            // index, state and cost together with the state and cost of the six axis neighbours (distinct cells, lanes 0..5,
-            // addresses clamped - the range check needs the unpacked index and is applied afterwards).  The centre is generated
-            // first (wave-uniform); the bookkeeping counts are order-independent.
-            int frontier_size = 0;  // wave-uniform number of frontier entries
+            // index, state, cost and rank together with those of the six axis neighbours (distinct cells, lanes 0..5, addresses
+            // clamped - the range check needs the unpacked index and is applied afterwards).  The centre is generated first
+            // (wave-uniform); the bookkeeping counts are order-independent.
             int cq = q;             // raster index of the centre
             for (;;) {
                 int nq = cq + my_stride;
@@ -313,12 +316,13 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
                 const uint32_t pk = ijk[cq];
                 const uint8_t cs = st[cq];
                 const double cost_center = J[cq];
+                const int cr = rank[cq];
                 const uint8_t s = st[nq];
                 const double c = J[nq];
+                const int nr = rank[nq];
                 if (!(cs & kGen)) {  // generate_trajectory of the centre
-                    st[cq] = cs | kGen | kInQ;
-                    w.Q.insert(cq, cost_center, lane);
-                    w.offer_head(cq, cost_center);
+                    st[cq] = cs | kGen;
+                    if (cost_center < __builtin_inf()) w.Q.set(__builtin_amdgcn_readfirstlane(cr), lane);
                     keyG[cq] = __builtin_inf();
                     ++w.num_generated;
                 }
@@ -326,33 +330,38 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa)
                 const bool is_new = lane < 6 && at >= 0 && at < my_size && !(s & kGen);
                 const bool to_frontier = is_new && c <= cost_center;  // frontier_idxs.put((cost, idx))
                 if (is_new) {
-                    st[nq] = s | kGen | kInQ;
-                    keyQ[nq] = c;
+                    st[nq] = s | kGen;
                     keyG[nq] = __builtin_inf();
-                    if (to_frontier) keyF[nq] = c;
                 }
-                unsigned long long fresh = __ballot(is_new);
+                const unsigned long long fresh = __ballot(is_new);
+                unsigned long long queued = __ballot(is_new && c < __builtin_inf());  // NaN / inf: generated, never popped
                 const unsigned long long front = __ballot(to_frontier);
                 w.num_generated += __popcll(fresh);
-                frontier_size += __popcll(front);
-                while (fresh) {  // register side of the (at most six) inserts
-                    const int l = __ffsll((long long)fresh) - 1;
-                    fresh &= fresh - 1;
-                    const int uq = __builtin_amdgcn_readlane(nq, l);
-                    const double uc = lane_value(c, l);
-                    w.Q.note(uq, uc, lane);
-                    w.offer_head(uq, uc);
-                    if ((front >> l) & 1ull) w.Fr.note(uq, uc, lane);
+                while (queued) {  // register side of the (at most six) inserts
+                    const int l = __ffsll((long long)queued) - 1;
+                    queued &= queued - 1;
+                    const int ur = __builtin_amdgcn_readlane(nr, l);
+                    w.Q.set(ur, lane);
+                    if ((front >> l) & 1ull) w.Fr.set(ur, lane);
                 }
-                if (frontier_size == 0) break;
-                cq = w.Fr.argmin();
-                w.Fr.remove(cq, lane, C);
-                --frontier_size;
+                const int rf = w.Fr.lowest();
+                if (rf < 0) break;
+                w.Fr.reset(rf, lane);
+                cq = __builtin_amdgcn_readfirstlane((int)(order32[rf] & 0xFFFFu));
             }
         }
-        if (w.head < 0) break;
-        const int popped = w.head;
-        if (w.pop_head()) { best = popped; break; }
+        // validation of the queue head (fiss_planner.py:229-258)
+        const int rp = w.Q.lowest();
+        if (rp < 0) break;
+        w.Q.reset(rp, lane);
+        // (usually the head the iteration started with: nothing cheaper was generated on the way)
+        const uint32_t pop_word = rp == rh ? head_word : (uint32_t)__builtin_amdgcn_readfirstlane((int)order32[rp]);
+        const int popped = (int)(pop_word & 0xFFFFu);
+        const uint32_t f = pop_word >> 16;
+        ++w.num_validated;
+        if (f & FP_FLAG_CONSTRAINTS) continue;
+        ++w.num_checks;
+        if (!(f & FP_FLAG_COLLISION)) { best = popped; break; }
     }
     if (lane == 0) {
         int32_t* out = fa.io.best_ijk + (size_t)b * 3;
@@ -654,7 +663,10 @@ __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
     return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 2 * kQueue;
 }
 
-__global__ __launch_bounds__(kWave * kRefineWaves, 3) void fiss_refine_kernel(FissArgs fa, int pt_rows_max, const int* perm, int* dur)
+#ifndef FP_REFINE_OCC
+#define FP_REFINE_OCC 3   // workgroups per SIMD the register budget is sized for (tools/trace_c4.sh tries others)
+#endif
+__global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refine_kernel(FissArgs fa, int pt_rows_max, const int* perm, int* dur)
 {
     const long long t_begin = dur ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -939,11 +951,13 @@ hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
 {
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
-    const int bytes = C * (4 * 8 + 2 + 1 + 1) + 16;
+    int P = 2;
+    while (P < C) P <<= 1;  // C <= FP_MAX_CAND = 4096: at most 64 words of rank bits, one per lane
+    const int bytes = C * (8 + 8 + 2 + 2 + 1 + 1) + P * (8 + 2) + 16;
     FP_LDS_SLOTS(configured);
     hipError_t e = ensure_dynamic_lds((const void*)fiss_search_kernel, bytes, configured);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fiss_search_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa);
+    hipLaunchKernelGGL(fiss_search_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa, P);
     return hipGetLastError();
 }
 
