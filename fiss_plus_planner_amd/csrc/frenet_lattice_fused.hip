@@ -106,7 +106,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
     L.queue = o;    L.pows = o;
     o = align16(o + (4 * kHitCap > 88 * nt ? 4 * kHitCap : 88 * nt));
-    L.cnt = o;      o = align16(o + 16);  // list counters (monotone) + scan mask
+    L.cnt = o;      o = align16(o + 32);  // list counters (monotone) + scan mask + ticket + two fp32 bounds
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * kWaves);
     L.total = o;
@@ -161,6 +161,13 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const long long t_begin = dur ? wall_clock64() : 0;
+    // Timing diagnostic (tools/phase_stamps.py, -DFP_PHASE_STAMPS): thread 0 leaves the time since the workgroup started (10 ns
+    // ticks) at the phase boundaries in columns 112.. of the last row of its best_traj block (free with traj_stride = 128, sparse, T <= 11 s).
+#if defined(FP_PHASE_STAMPS)
+#define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && dur) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x) * FP_ARR_COUNT + 15) * ka.r.traj_stride + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
+#else
+#define FP_STAMP(k) do { } while (0)
+#endif
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     // launch order: longest egos first when the host has an order for this batch (perm; nsplit == 1 then)
@@ -228,27 +235,72 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         return;
     }
     // ---------------------------------------------------------------- stage: ego, spline, obstacle rows
+    // Global reads cost 1-2 us each, so everything that depends only on the scalars above is requested at once: the spline's
+    // tables and - held in registers until the spline work is done - the first 4 x 512 obstacle poses.  (The rows the collision
+    // horizon can touch depend on final_time_step, one more dependent read: the rows the TABLE holds from t_now on are fetched
+    // instead; they are the same whenever the prediction covers the table.)
+    const int NX = bt.NX;
+    const int n_obs = sc >= 0 ? bt.n_obs : 0;
+    const float inv_nobs_s = 1.0f / (float)(n_obs > 0 ? n_obs : 1);
+    int rows_stage = 0;  // obstacle rows of the table from t_now on: poses k = r*stride, k + t_now < T_obs
+    if (n_obs > 0) {
+        const int in_table = bt.T_obs - t_now;
+        rows_stage = in_table > 0 ? (in_table + stride - 1) / stride : 0;
+        if (rows_stage > rows_max) rows_stage = rows_max;
+    }
+    const double* gp = bt.obs_pose + (size_t)(sc >= 0 ? sc : 0) * bt.T_obs * bt.n_obs * 4;
+    auto fetch_poses = [&](int i0, double4* ps) {  // four pose reads in flight per lane
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kThreads + tid;
+            ps[u] = make_double4(0.0, 0.0, 0.0, 0.0);
+            if (i < rows_stage * n_obs) {
+                const int r = div_small(i, inv_nobs_s), j = i - mul24(r, n_obs);
+                ps[u] = *(const double4*)(gp + ((size_t)(mul24(r, stride) + t_now) * n_obs + j) * 4);
+            }
+        }
+    };
+    auto store_poses = [&](int i0, const double4* ps) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kThreads + tid;
+            // x = NaN: no state at this step (state_at_time -> None).  The orientation stays an angle (in .c) until the item survives
+            // the group test: ~9 in 10 never need its cosine / sine
+            if (i < rows_stage * n_obs) s_pose[i] = ObsPose{ps[u].w != 0.0 ? ps[u].x : __builtin_nan(""), ps[u].y, ps[u].z, 0.0};
+        }
+    };
+    double4 ps0[4];
+    fetch_poses(0, ps0);
     const int nx = bt.nx[f];
-    const int fts = sc >= 0 && bt.n_obs > 0 ? bt.final_time_step[sc] : 0;
+    const int fts = n_obs > 0 ? bt.final_time_step[sc] : 0;
     {
-        const double* gk = bt.knots + (size_t)f * bt.NX;
-        const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
-        for (int i = tid; i < nx; i += kThreads) s_knots[i] = gk[i];
+        const double* gk = bt.knots + (size_t)f * NX;
+        const double* gc = bt.coef + (size_t)f * 8 * NX;
+        // [0], [1]: list counters; [2]: slices whose lon profiles need the point-by-point scan; [3]: ticket; [5], [6]: fp32 bit patterns
+        // of the spline's speed bound and of the largest lateral offset
+        if (tid < 8) s_cnt[tid] = 0;
+        // all NX columns (the copy does not wait for nx; columns >= nx hold the +inf padding / are never addressed)
+        for (int i = tid; i < NX; i += kThreads) s_knots[i] = gk[i];
         for (int i = tid; i < nt + nv + nd; i += kThreads)
             s_ts[i] = i < nt ? bt.t_samples[i] : (i < nt + nv ? bt.v_samples[(size_t)b * nv + (i - nt)] : bt.d_samples[i - nt - nv]);
-        for (int i = tid; i < 8 * nx; i += kThreads) {
-            const int r = i / nx, c = i - r * nx;
-            s_coef[r * nx + c] = gc[(size_t)r * bt.NX + c];
+        for (int i = tid; i < 8 * NX; i += kThreads) s_coef[i] = gc[i];  // [8][NX], same layout
+        if (n_obs > 0) {
+            const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
+            for (int j = tid; j < n_obs; j += kThreads) {
+                const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
+                s_dim[j] = ObsDim{hl, hw, sqrt(fma(hl, hl, hw * hw)), 0.0};
+            }
         }
     }
-    SplineLds sp{s_knots, s_coef, nx, nx};
+    SplineLds sp{s_knots, s_coef, nx, NX};
+    __syncthreads();
+    FP_STAMP(0);
     // Arclength buckets -> segment hint: lut[b] = bisect_right(knots, k0 + b*width) - 1, 2*nx buckets.  A point then
     // needs one table read plus a short walk instead of a log2(nx) search (knots may be non-uniform: the walk fixes it).
     const int n_buckets = 2 * nx;
-    const double knot0 = gk_first(bt, f), knot_last = gk_last(bt, f, nx);
+    const double knot0 = s_knots[0], knot_last = s_knots[nx - 1];
     const double bucket_w = (knot_last - knot0) / (double)n_buckets;
     const double inv_bucket_w = bucket_w > 0.0 ? 1.0 / bucket_w : 0.0;
-    __syncthreads();
     for (int bkt = tid; bkt <= n_buckets; bkt += kThreads) {
         const double sb = knot0 + (double)bkt * bucket_w;
         int lo = 0, hi = nx;
@@ -260,57 +312,61 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         seg = seg < 0 ? 0 : (seg > nx - 2 ? nx - 2 : seg);
         s_lut[bkt] = (unsigned short)seg;
     }
-
-    const int n_obs = sc >= 0 ? bt.n_obs : 0;
+#if defined(FP_ABL_NO_VMAX)
+    if (false) {
+#else
+    if (n_obs > 0) {
+#endif
+        // upper bound of the spline's parametric speed |P'(s)| (the arclength parameter is the cumulative CHORD length, so it is a
+        // little above 1 in bends): per segment the exact maxima of the two quadratic derivative components (ends + vertex).  The
+        // once-per-ego group test turns an arclength interval into a circle with it.  Wave maximum of fp32 bit patterns, one LDS
+        // atomic per wavefront (a NaN coefficient is the largest pattern: the circle then keeps every obstacle).
+        for (int i0 = wave * kWave; i0 < nx - 1; i0 += kThreads) {
+            const int i = i0 + lane;
+            uint32_t bits = 0u;
+            if (i < nx - 1) {
+                const double h = s_knots[i + 1] - s_knots[i];
+                double m2 = 0.0;
+#pragma unroll
+                for (int ax = 0; ax < 2; ++ax) {
+                    const double b1 = s_coef[(4 * ax + 1) * NX + i], c2 = 2.0 * s_coef[(4 * ax + 2) * NX + i], d3 = 3.0 * s_coef[(4 * ax + 3) * NX + i];
+                    double m = fmax(fabs(b1), fabs(fma(fma(d3, h, c2), h, b1)));  // g(u) = b1 + c2 u + d3 u^2 at u = 0, h
+                    const double uv = -c2 / (2.0 * d3);
+                    if (uv > 0.0 && uv < h) m = fmax(m, fabs(fma(fma(d3, uv, c2), uv, b1)));
+                    if (!(m == m) || !(h == h)) m = __builtin_nan("");
+                    m2 = fma(m, m, m2);
+                }
+                bits = __float_as_uint(float_above(sqrt(m2)) * 1.0000005f);
+            }
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                const uint32_t o2 = (uint32_t)__shfl_xor((int)bits, off, kWave);
+                bits = o2 > bits ? o2 : bits;
+            }
+            if (lane == 0) atomicMax((unsigned int*)&s_cnt[5], bits);
+        }
+    }
     int horizon_cap = 0;  // final_time_step - time_step_now (:173-174)
-    int rows = 0;         // obstacle rows that exist for this ego: poses k = r*stride, k + t_now < T_obs
+    int rows = 0;         // obstacle rows the collision horizon can touch: rows of the table below final_time_step
     if (n_obs > 0) {
         horizon_cap = fts - t_now;
         int h = horizon_cap < FP_MAX_POINTS ? horizon_cap : FP_MAX_POINTS;
         if (h < 0) h = 0;
         rows = (h + stride - 1) / stride;
-        const int in_table = bt.T_obs - t_now;
-        const int rows_tab = in_table > 0 ? (in_table + stride - 1) / stride : 0;
-        if (rows_tab < rows) rows = rows_tab;
-        if (rows > rows_max) rows = rows_max;  // cannot happen: rows_max is the launch-time bound of the same formula
-        const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
-        for (int j = tid; j < n_obs; j += kThreads) {
-            const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
-            s_dim[j] = ObsDim{hl, hw, sqrt(fma(hl, hl, hw * hw)), 0.0};
-        }
+        if (rows_stage < rows) rows = rows_stage;
     // [section STAGE]
-        const double* gp = bt.obs_pose + (size_t)sc * bt.T_obs * n_obs * 4;
-        const float inv_nobs_s = 1.0f / (float)n_obs;
-        for (int i0 = 0; i0 < rows * n_obs; i0 += 4 * kThreads) {  // four pose reads in flight per lane before any sincos
+        store_poses(0, ps0);
+        for (int i0 = 4 * kThreads; i0 < rows_stage * n_obs; i0 += 4 * kThreads) {
             double4 ps[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * kThreads + tid;
-                ps[u] = make_double4(0.0, 0.0, 0.0, 0.0);
-                if (i < rows * n_obs) {
-                    const int r = div_small(i, inv_nobs_s), j = i - mul24(r, n_obs);
-                    ps[u] = *(const double4*)(gp + ((size_t)(mul24(r, stride) + t_now) * n_obs + j) * 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * kThreads + tid;
-                if (i < rows * n_obs) {
-                    ObsPose o{__builtin_nan(""), 0.0, 1.0, 0.0};  // x = NaN: no state at this step (state_at_time -> None)
-                    if (ps[u].w != 0.0) {
-                        o.x = ps[u].x;
-                        o.y = ps[u].y;
-                        sincos_snapped(ps[u].z, o.s, o.c);
-                    }
-                    s_pose[i] = o;
-                }
-            }
+            fetch_poses(i0, ps);
+            store_poses(i0, ps);
         }
     // [/section STAGE]
     }
     for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
-    if (tid < 4) s_cnt[tid] = 0;  // [0], [1]: list counters; [2]: slices whose lon profiles need the point-by-point scan
-    for (int r = tid; r < rows; r += kThreads) s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);  // empty
+    for (int r = tid; r < rows; r += kThreads) {
+        s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);  // empty
+    }
     for (int i = tid; i < 2 * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
     // points whose frame the collision stage can touch: 0 .. hp-1 (pose k needs point k+1 for its heading)
     const int pose_limit = rows * stride < horizon_cap ? rows * stride : horizon_cap;  // poses k < pose_limit (and k < M)
@@ -319,9 +375,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
     const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
     __syncthreads();
+    FP_STAMP(1);
 
     const double* v_samples = s_vs;
-    const double org_x = s_coef[0], org_y = s_coef[4 * nx];  // first knot: origin of the fp32 bounding boxes
+    const double org_x = s_coef[0], org_y = s_coef[4 * NX];  // first knot: fallback centre of an empty row circle
     int item_base = 0, hit_base = 0;  // list counters at the start of the current stage (block-uniform)
 
     // ---------------------------------------------------------------- phase A0 (once): masks / M / cost sums of every profile
@@ -374,8 +431,62 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             if (!proven) atomicOr((unsigned int*)&s_cnt[2], 1u << ((it - it_lo) & 31));
         }
     }
+    // bound of |d(t)| over ALL slices and lateral samples (the once-per-ego group test needs it), by the wavefronts the solves above
+    // leave idle.  In the Hermite form of the quintic with a resting end state,
+    //   d(t) = d_end + (d0 - d_end) h0 + d_d0 T h1 + d_dd0 T^2 h2  (tau = t / T),  h0 = 1 - 10 tau^3 + 15 tau^4 - 6 tau^5 in [0, 1],
+    //   |h1| = |tau - 6 tau^3 + 8 tau^4 - 3 tau^5| <= 16/81,  h2 = tau^2 (1 - tau)^3 / 2 <= 54/3125:
+    //   |d| <= max(|d0|, |d_end|) + 0.1976 |d_d0| T + 0.01729 |d_dd0| T^2.
+    // Wave maximum of the fp32 bit patterns (a NaN is the largest pattern and keeps every obstacle), ONE LDS atomic per wavefront -
+    // same-address LDS atomics of many lanes serialise badly.
+#if defined(FP_ABL_NO_DALL)
+    if (false) {
+#else
+    if (n_obs > 0 && wave >= 1) {
+#endif
+        for (int e0 = (wave - 1) * kWave; e0 < n_it * nd; e0 += (kWaves - 1) * kWave) {
+            const int e = e0 + lane;
+            uint32_t bits = 0u;
+            if (e < n_it * nd) {
+                const double T = s_ts[it_lo + e / nd], de = s_ds[e % nd];
+                double bd = (fabs(d0) > fabs(de) ? fabs(d0) : fabs(de)) + 0.1976 * fabs(d_d0) * T + 0.01729 * fabs(d_dd0) * T * T;
+                if (!(d0 == d0) || !(de == de)) bd = __builtin_nan("");
+                bits = __float_as_uint(float_above(bd) * 1.0000005f);
+            }
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                const uint32_t o2 = (uint32_t)__shfl_xor((int)bits, off, kWave);
+                bits = o2 > bits ? o2 : bits;
+            }
+            if (lane == 0 && bits) atomicMax((unsigned int*)&s_cnt[6], bits);
+        }
+    }
     __syncthreads();
+    FP_STAMP(2);
     for (int i = tid; i < n_it; i += kThreads) power_sums_closed(s_nslice[it_lo + i], tick, s_pows + (it_lo + i) * 11);
+    if (n_obs > 0 && pose_limit > 0) {
+        // ---- arclength range of every checked pose row over the lon profiles of ALL slices of this workgroup: lane = (row, slice),
+        // loop over the end-speed samples, then LDS atomic min / max on order-preserving fp32 bit patterns (relative to the first knot).
+        // (The truncation index M is still being reduced in this phase: poses off the spline count too, the circle clamps the range.)
+        const float inv_rows = 1.0f / (float)(rows > 0 ? rows : 1);
+        for (int e = tid; e < mul24(n_it, rows); e += kThreads) {
+            const int itl = div_small(e, inv_rows), r = e - mul24(itl, rows);
+            const int it = it_lo + itl;
+            const int k = mul24(r, stride);
+            if (k >= pose_limit || k >= s_nslice[it]) continue;
+            const double t = (double)k * tick;
+            double lo = __builtin_inf(), hi = -__builtin_inf();
+            bool bad = false;
+            for (int iv = 0; iv < nv; ++iv) {
+                const double a3 = s_qlon[2 * (mul24(it, nv) + iv)], a4 = s_qlon[2 * (mul24(it, nv) + iv) + 1];
+                const double sv = fma(fma(fma(fma(a4, t, a3), t, s_dd0 * 0.5), t, s_d0), t, s0) - knot0;
+                bad = bad || !(sv == sv);
+                lo = fmin(lo, sv); hi = fmax(hi, sv);
+            }
+            uint32_t* bx = (uint32_t*)&s_box[r];
+            if (bad) { atomicMin(bx + 0, kOrdNegInf); atomicMax(bx + 1, kOrdPosInf); }  // NaN: keep everything
+            else if (lo <= hi) { atomicMin(bx + 0, f32_ordered((float)lo)); atomicMax(bx + 1, f32_ordered((float)hi)); }
+        }
+    }
     // [section MASKS]
     const uint32_t scan_mask = (uint32_t)s_cnt[2];
     for (int it = it_lo; it < it_hi; ++it) {
@@ -397,11 +508,15 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     }
     // [/section MASKS]
     __syncthreads();
-    for (int e = tid; e < n_it * (nv + nd); e += kThreads) {
-        const int it = it_lo + e / (nv + nd), sub = e % (nv + nd);
+    FP_STAMP(3);
+    for (int e0 = wave * kWave; e0 < n_it * (nv + nd); e0 += kThreads) {  // (whole wavefronts: the row maxima below are wave reductions)
+        const int e = e0 + lane;
+        const bool live = e < n_it * (nv + nd);
+        const int it = it_lo + (live ? e / (nv + nd) : 0), sub = live ? e % (nv + nd) : 0;
         const double T = s_ts[it];
         const double* S = s_pows + it * 11;
-        if (sub < nv) {
+        if (!live) {
+        } else if (sub < nv) {
             const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + sub)], s_qlon[2 * (mul24(it, nv) + sub) + 1]};
             double lon[3];
             lon_cost_sums(q, target_speed, S, lon);
@@ -426,184 +541,188 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
     };
     fill_slice_lat(it_lo);
+    // ---- ranges -> circles: every reference point of the row lies within  v_max * (half the range)  of the line's point at
+    // the middle of the range (v_max >= |P'(s)| everywhere); + ego reach + the largest lateral offset.  One test per
+    // (row, obstacle) item then prunes the item for every profile of every slice at once.
+    if (n_obs > 0 && kThreads - 1 - nd - tid >= 0 && kThreads - 1 - nd - tid < rows) {  // (threads next to fill_slice_lat's)
+        const int r = kThreads - 1 - nd - tid;
+        const uint4 bx = s_box[r];
+        const float lo_f = f32_from_ordered(bx.x), hi_f = f32_from_ordered(bx.y);
+        const double v_max = (double)__uint_as_float((uint32_t)s_cnt[5]), d_all = (double)__uint_as_float((uint32_t)s_cnt[6]);
+        // empty row (no valid pose): radius -1 rejects every obstacle; an infinite range or a NaN bound keeps every obstacle
+        double rad = -1.0, cx = org_x, cy = org_y;
+        if (hi_f >= lo_f) {
+            // the ends were rounded to nearest fp32: half an ulp each, covered by slack; points off the spline do not exist
+            const double slack = ((double)fabsf(lo_f) + (double)fabsf(hi_f)) * 1.2e-7 + 1e-6;
+            double s_lo = knot0 + (double)lo_f - slack, s_hi = knot0 + (double)hi_f + slack;
+            s_lo = fmax(s_lo, knot0); s_hi = fmin(s_hi, knot_last);
+            if (!(s_hi >= s_lo)) s_hi = s_lo = fmin(fmax(knot0 + (double)lo_f, knot0), knot_last);  // (a range that only grazes the end)
+            double s_mid = 0.5 * (s_lo + s_hi);
+            if (!(s_mid < knot_last)) s_mid = knot0 + 0.5 * (knot_last - knot0);  // infinite range: any centre will do
+            const int seg = lut_segment(s_knots, s_lut, nx, s_mid, knot0, inv_bucket_w, n_buckets);
+            double tx, ty;
+            spline_frame(sp, seg, s_mid - s_knots[seg], cx, cy, tx, ty);
+            rad = (v_max * (0.5 * (s_hi - s_lo)) * (1.0 + 1e-9) + r_ego + d_all) * (1.0 + 1e-9) + 1e-6;
+            if (!(hi_f <= 3.0e38f) || !(lo_f >= -3.0e38f)) rad = __builtin_inf();
+        }
+        s_grp[r].hl = cx;
+        s_grp[r].hw = cy;
+        s_grp[r].r = rad;
+    }
     __syncthreads();  // the final assembly reads the sums (with no obstacles there is no other barrier in between)
+    FP_STAMP(4);
 
+    // ---------------------------------------------------------------- collision
+    // Once per ego:   G  lane = (row, obstacle) item against the circle that encloses the row's reference points of ALL lon
+    //                    profiles of ALL slices of this workgroup (+ ego reach + the largest lateral offset)     -> s_items
+    // Per slice i_T:  phase A  frames + lateral offsets;  prep  fan half-widths
+    //                 B  lane = (surviving item, lon profile): fattened circle around the reference point + separating axes
+    //                    n_k and t_k of the lateral fan                                                          -> s_hits
+    //                 N  lane = (hit, lateral sample): exact circle + 4-axis separating-axis test                -> s_coll
+    // The time horizon T moves a profile's first seconds only a little (the end speed spreads them by tens of metres), so one
+    // group test per ego keeps about as few items as one per slice did - at a seventh of the work and one barrier less per slice.
+    // Lists are appended with one LDS atomic per wavefront (ballot + popcount); the two counters only ever grow, each stage works
+    // on [base, counter) and every thread tracks the bases itself, so nothing is reset between stages.  Capacity: the item list is
+    // filled optimistically by the whole table; if the survivors do not fit (rare) the table is cut into chunks of kItemCap items
+    // and the slice loop runs once per chunk; the pair range of B is cut into passes of kHitCap pairs.
 #if defined(FP_ABL_NO_COLL)
-    for (int it = it_lo; false && it < it_hi; ++it) {
+    const bool collide = false;
 #else
-    for (int it = it_lo; n_obs > 0 && hp > 0 && it < it_hi; ++it) {
+    const bool collide = n_obs > 0 && hp > 0;
 #endif
-        const double T = s_ts[it];
-        const int N = arange_len(T, tick);
-        float* s_dmax = s_dmax2 + (it & 1) * hp_max;    // this slice's buffers (zeroed during the previous slice)
-        float* s_ddmax = s_ddmax2 + (it & 1) * hp_max;
-        // ------------------------------------------------------------ phase A (per slice): one lane per (profile, point)
-        // reference-line frames of the points the collision horizon can touch (i < hp), lateral offsets, fan bounds
-        const int np = hp < N ? hp : N;
-        const float inv_np = 1.0f / (float)np, inv_stride = 1.0f / (float)stride;
-    // [section FRAMES]
-        for (int e = tid; e < nv * np; e += kThreads) {
-            const int iv = div_small(e, inv_np), i = e - mul24(iv, np);
-            const int M = s_lon_meta[mul24(it, nv) + iv].x;
-            if (i < M) {  // the point is on the spline
-                const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + iv)], s_qlon[2 * (mul24(it, nv) + iv) + 1]};
-                const double t = (double)i * tick;
-                const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
-                const int seg = lut_segment(s_knots, s_lut, nx, s, knot0, inv_bucket_w, n_buckets);
-                Frame fr;
-                spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
-                s_frames[mul24(iv, hp_max) + i] = fr;
-                // bounding box of the row's reference points over the lon profiles (fp32 to nearest, relative to the first knot;
-                // prep widens it): LDS atomic min / max on order-preserving bit patterns
-                const int r = div_small(i, inv_stride);
-                if (mul24(r, stride) == i && r < rows && M >= 2) {
-                    const double rx = fr.px - org_x, ry = fr.py - org_y;
-                    uint32_t* bx = (uint32_t*)&s_box[r];
-                    if (rx == rx && ry == ry) {
-                        const uint32_t ux = f32_ordered((float)rx), uy = f32_ordered((float)ry);
-                        atomicMin(bx + 0, ux); atomicMax(bx + 1, ux);
-                        atomicMin(bx + 2, uy); atomicMax(bx + 3, uy);
-                    } else {  // NaN pose: keep everything
-                        atomicMin(bx + 0, kOrdNegInf); atomicMax(bx + 1, kOrdPosInf);
-                    }
-                }
-            }
-        }
-    // [/section FRAMES]
-    // [section LAT]
-        for (int e = tid; e < nd * np; e += kThreads) {
-            const int id = div_small(e, inv_np), i = e - mul24(id, np);
-            const double* ql = s_qlat + mul24(id, 3);
-            const Quintic q{d0, d_d0, d_dd0 * 0.5, ql[0], ql[1], ql[2]};
-            const double t = (double)i * tick;
-            const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
-            s_lat[mul24(id, hp_max) + i] = d;
-            // fan half-width max|d| and largest lateral step max|d(i+1) - d(i)| over the lateral samples: LDS atomic max on
-            // the bit patterns (non-negative floats order like unsigned integers); float_above: never below the fp64 value
-            atomicMax((unsigned int*)&s_dmax[i], __float_as_uint(float_above(fabs(d))));
-            if (i + 1 < np) {
-                const double tn = (double)(i + 1) * tick;
-                const double dn = fma(fma(fma(fma(fma(q.a5, tn, q.a4), tn, q.a3), tn, q.a2), tn, q.a1), tn, q.a0);
-                atomicMax((unsigned int*)&s_ddmax[i], __float_as_uint(float_above(fabs(dn - d))));
-            }
-        }
-    // [/section LAT]
-        __syncthreads();
-        if (n_obs > 0 && hp > 0) {
-            // ---- prep (one stage): per checked pose (row r, lon profile iv)
-            //  * wfat = lateral half-width of the whole fan along the reference normal n_k:
-            //      every ego centre is P_k + d n_k with |d| <= dmax[k];  the ego box, whose heading deviates from the reference
-            //      tangent by alpha, reaches hw cos(alpha) + hl |sin(alpha)| <= min(r_ego, hw + hl sigma) along n_k, where
-            //      sigma >= |sin(alpha)| for every lateral sample follows from the heading vector
-            //      h = (P_{k+1} - P_k) + d_{k+1} n_{k+1} - d_k n_k:  |h.n_k| <= |dP.n_k| + max|d_{k+1} - d_k| + max|d_{k+1}| |1 - n_{k+1}.n_k|,
-            //      |h| >= |h.t_k| >= |dP.t_k| - max|d_{k+1}| |n_{k+1}.t_k|.   n_k then serves as a (conservative) separating axis.
-            //  * grp = circle around the bounding box of the valid reference points of ALL lon profiles in the row: one test
-            //      per (row, obstacle) item prunes the item for every profile at once.
-            //      The box itself was accumulated by phase A (LDS atomic min / max).
-            {
-                float* z_dmax = s_dmax2 + ((it + 1) & 1) * hp_max;   // zero the other parity for the next slice
-                float* z_ddmax = s_ddmax2 + ((it + 1) & 1) * hp_max;
-                for (int i = tid; i < hp_max; i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
-                fill_slice_lat(it + 1);  // phase A of this slice is done with the table (barrier above)
-                // Both products are conservative bounds, so they are computed in fp32 (coordinates relative to the first knot keep
-                // fp32 at ~1e-4 m over kilometres of road): the ratio is a reciprocal instead of an fp64 division, the radius one
-                // v_sqrt_f32.  One lane per (row, lon profile) pair for wfat; the last `rows` threads turn the boxes phase A
-                // accumulated into circles and empty them for the next slice.
-                const float r_ego_f = float_above(r_ego), hl_f = float_above(veh_hl), hw_f = float_above(veh_hw);
-                const float inv_nv = 1.0f / (float)nv;
-    // [section PREP]
-                for (int e = tid; e < rows * nv; e += kThreads) {
-                    const int r = div_small(e, inv_nv), iv = e - mul24(r, nv);
+    if (collide) {
+#if defined(FP_ABL_NO_GBN)   // timing ablations (tools/variants.sh): results are wrong, only the clock is read
+        const int n_items = 0;
+#else
+        const int n_items = rows * n_obs;
+#endif
+        const float inv_nobs = 1.0f / (float)n_obs, inv_nvf = 1.0f / (float)nv, inv_ndf = 1.0f / (float)nd;
+        int chunk = n_items;
+        for (int i0 = 0; i0 < n_items;) {
+            // ---- G (once per ego and item chunk)
+            const int i1 = i0 + chunk < n_items ? i0 + chunk : n_items;
+            for (int e0 = i0 + wave * kWave; e0 < i1; e0 += kThreads) {
+                const int e = e0 + lane;
+                bool keep = false;
+                if (e < i1) {
+                    const int r = div_small(e, inv_nobs), j = e - mul24(r, n_obs);
                     const int k = mul24(r, stride);
-                    const bool row_ok = k < N && k < hp;
-                    const int M = s_lon_meta[mul24(it, nv) + iv].x;
-                    float wl = r_ego_f;
-                    if (k + 1 < M && k + 1 < hp && k + 1 < N) {
-                        const Frame f0 = s_frames[mul24(iv, hp_max) + k], f1 = s_frames[mul24(iv, hp_max) + k + 1];
-                        const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
-                        const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
-                        const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
-                        const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty);   // n_{k+1} . n_k
-                        const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
-                        const double dm1 = (double)s_dmax[k + 1];
-                        const float num = (float)(fabs(a_n) + (double)s_ddmax[k] + dm1 * fabs(1.0 - nn));
-                        const float den = (float)(fabs(a_t) - dm1 * fabs(nt_));
-                        if (den > 1e-30f) {  // v_rcp_f32: 1 ulp; the factor covers it and the two roundings to nearest
-                            const float sigma = vmin_f32(1.0f, num * __builtin_amdgcn_rcpf(den) * (1.0f + 4e-6f) + 1e-9f);
-                            wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
-                        }
-                    }
-                    s_wfat[mul24(iv, hp_max) + k] = row_ok ? (s_dmax[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
+                    const double2 oxy = *(const double2*)&s_pose[e];
+                    const ObsDim g = s_grp[r];
+                    const double dx = oxy.x - g.hl, dy = oxy.y - g.hw, R = g.r + s_dim[j].r;
+                    keep = k < pose_limit && (oxy.x == oxy.x) && !(g.r < 0.0) && !(fma(dx, dx, dy * dy) > R * R);
                 }
-    // [/section PREP]
-                {
-                    const int r = kThreads - 1 - tid;
-                    if (r < rows) {
-                        const uint4 bx = s_box[r];
-                        s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);
-                        const float minx = f32_from_ordered(bx.x), maxx = f32_from_ordered(bx.y);
-                        const float miny = f32_from_ordered(bx.z), maxy = f32_from_ordered(bx.w);
-                        const float hx = 0.5f * (maxx - minx), hy = 0.5f * (maxy - miny);
-                        // empty row (no valid pose): radius -1 rejects every obstacle; an infinite box keeps every obstacle
-                        double rad = -1.0;
-                        // v_sqrt_f32: 1 ulp; the corners were rounded to nearest: half an ulp of each coordinate, covered by slack
-                        const float slack = (fabsf(maxx) + fabsf(minx) + fabsf(maxy) + fabsf(miny)) * 2.4e-7f + 1e-6f;
-                        if (maxx >= minx) rad = ((double)(__builtin_amdgcn_sqrtf(hx * hx + hy * hy) * (1.0f + 4e-6f) + slack) + r_ego + (double)s_dmax[mul24(r, stride)]) * (1.0 + 1e-9) + 1e-9;
-                        s_grp[r] = ObsDim{org_x + 0.5 * ((double)maxx + (double)minx), org_y + 0.5 * ((double)maxy + (double)miny), rad, 0.0};
-                    }
+                const unsigned long long m = __ballot(keep);
+                if (m) {
+                    const int first = __ffsll((long long)m) - 1;
+                    int base = 0;
+                    if (lane == first) base = atomicAdd(&s_cnt[0], __popcll(m));
+                    const int pos = __builtin_amdgcn_readlane(base, first) - item_base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (keep && pos < kItemCap) s_items[pos] = (unsigned short)e;
                 }
             }
             __syncthreads();
-
-            // -------------------------------------------------------- phase B: collision of this slice
-            // Three block-wide stages, every lane busy in each of them (the survivors of one stage are a few percent of its
-            // input, so per-wavefront queues would run the next stage at a fraction of a wavefront):
-            //   G  lane = (row, obstacle) item: group circle of the row                      -> s_items
-            //   B  lane = (surviving item, lon profile): fattened circle + separating axis n_k -> s_hits
-            //   N  lane = (hit, lateral sample): exact circle + 4-axis separating-axis test    -> s_coll
-            // Lists are appended with one LDS atomic per wavefront (ballot + popcount); the two counters only ever grow, each
-            // stage works on [base, counter) and every thread tracks the bases itself, so nothing is reset between stages.
-            // Capacity: the item list is filled optimistically by the whole table; if the survivors do not fit (rare) the
-            // range is redone in chunks of kItemCap items; the pair range of B is cut into passes of kHitCap pairs.
-#if defined(FP_ABL_NO_GBN)   // timing ablations (tools/variants.sh): results are wrong, only the clock is read
-            const int n_items = 0;
-#else
-            const int n_items = rows * n_obs;
-#endif
-            const float inv_nobs = 1.0f / (float)n_obs, inv_nvf = 1.0f / (float)nv, inv_ndf = 1.0f / (float)nd;
-            int chunk = n_items;
-            for (int i0 = 0; i0 < n_items;) {
-                // ---- G
-                const int i1 = i0 + chunk < n_items ? i0 + chunk : n_items;
-                for (int e0 = i0 + wave * kWave; e0 < i1; e0 += kThreads) {
-                    const int e = e0 + lane;
-                    bool keep = false;
-                    if (e < i1) {
-                        const int r = div_small(e, inv_nobs), j = e - mul24(r, n_obs);
+    FP_STAMP(7);
+            const int item_end = s_cnt[0];
+            const int n_surv = item_end - item_base;
+            item_base = item_end;
+            if (n_surv > kItemCap) {  // block-uniform: does not fit, redo [i0, ...) in chunks whose survivors always fit
+                chunk = kItemCap;
+                continue;
+            }
+            // the survivors' orientations -> (cos, sin), with shapely's snap (frenet_device.h); every item belongs to one chunk
+            for (int si = tid; si < n_surv; si += kThreads) {
+                const int item = s_items[si];
+                double sn, cs;
+                sincos_snapped(s_pose[item].c, sn, cs);
+                s_pose[item].c = cs;
+                s_pose[item].s = sn;
+            }
+            // (the slice loop's first barrier orders these writes before stage B reads them)
+            for (int it = it_lo; it < it_hi; ++it) {
+                const double T = s_ts[it];
+                const int N = arange_len(T, tick);
+                float* s_dmax = s_dmax2 + (it & 1) * hp_max;    // this slice's buffers (zeroed during the previous slice)
+                float* s_ddmax = s_ddmax2 + (it & 1) * hp_max;
+                // ---------------------------------------------------- phase A (per slice): one lane per (profile, point)
+                // reference-line frames of the points the collision horizon can touch (i < hp), lateral offsets, fan bounds
+                const int np = hp < N ? hp : N;
+                const float inv_np = 1.0f / (float)np;
+    // [section FRAMES]
+                for (int e = tid; e < nv * np; e += kThreads) {
+                    const int iv = div_small(e, inv_np), i = e - mul24(iv, np);
+                    const int M = s_lon_meta[mul24(it, nv) + iv].x;
+                    if (i < M) {  // the point is on the spline
+                        const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + iv)], s_qlon[2 * (mul24(it, nv) + iv) + 1]};
+                        const double t = (double)i * tick;
+                        const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
+                        const int seg = lut_segment(s_knots, s_lut, nx, s, knot0, inv_bucket_w, n_buckets);
+                        Frame fr;
+                        spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
+                        s_frames[mul24(iv, hp_max) + i] = fr;
+                    }
+                }
+    // [/section FRAMES]
+    // [section LAT]
+                for (int e = tid; e < nd * np; e += kThreads) {
+                    const int id = div_small(e, inv_np), i = e - mul24(id, np);
+                    const double* ql = s_qlat + mul24(id, 3);
+                    const Quintic q{d0, d_d0, d_dd0 * 0.5, ql[0], ql[1], ql[2]};
+                    const double t = (double)i * tick;
+                    const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
+                    s_lat[mul24(id, hp_max) + i] = d;
+                    // fan half-width max|d| and largest lateral step max|d(i+1) - d(i)| over the lateral samples: LDS atomic max on
+                    // the bit patterns (non-negative floats order like unsigned integers); float_above: never below the fp64 value
+                    atomicMax((unsigned int*)&s_dmax[i], __float_as_uint(float_above(fabs(d))));
+                    if (i + 1 < np) {
+                        const double tn = (double)(i + 1) * tick;
+                        const double dn = fma(fma(fma(fma(fma(q.a5, tn, q.a4), tn, q.a3), tn, q.a2), tn, q.a1), tn, q.a0);
+                        atomicMax((unsigned int*)&s_ddmax[i], __float_as_uint(float_above(fabs(dn - d))));
+                    }
+                }
+            // [/section LAT]
+                __syncthreads();
+                // ---- prep: wfat = lateral half-width of the whole fan along the reference normal n_k, per checked pose (row r, lon
+                // profile iv): every ego centre is P_k + d n_k with |d| <= dmax[k];  the ego box, whose heading deviates from the
+                // reference tangent by alpha, reaches hw cos(alpha) + hl |sin(alpha)| <= min(r_ego, hw + hl sigma) along n_k, where
+                // sigma >= |sin(alpha)| for every lateral sample follows from the heading vector
+                //   h = (P_{k+1} - P_k) + d_{k+1} n_{k+1} - d_k n_k:  |h.n_k| <= |dP.n_k| + max|d_{k+1} - d_k| + max|d_{k+1}| |1 - n_{k+1}.n_k|,
+                //   |h| >= |h.t_k| >= |dP.t_k| - max|d_{k+1}| |n_{k+1}.t_k|.   n_k then serves as a (conservative) separating axis.
+                {
+                    float* z_dmax = s_dmax2 + ((it + 1) & 1) * hp_max;   // zero the other parity for the next slice
+                    float* z_ddmax = s_ddmax2 + ((it + 1) & 1) * hp_max;
+                    for (int i = tid; i < hp_max; i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
+                    fill_slice_lat(it + 1);  // phase A of this slice is done with the table (barrier above)
+                    // A conservative bound, so it is computed in fp32 (the ratio is a reciprocal instead of an fp64 division).
+                    const float r_ego_f = float_above(r_ego), hl_f = float_above(veh_hl), hw_f = float_above(veh_hw);
+                    const float inv_nv = 1.0f / (float)nv;
+    // [section PREP]
+                    for (int e = tid; e < rows * nv; e += kThreads) {
+                        const int r = div_small(e, inv_nv), iv = e - mul24(r, nv);
                         const int k = mul24(r, stride);
-                        const double2 oxy = *(const double2*)&s_pose[e];
-                        const ObsDim g = s_grp[r];
-                        const double dx = oxy.x - g.hl, dy = oxy.y - g.hw, R = g.r + s_dim[j].r;
-                        keep = k < N && k < pose_limit && (oxy.x == oxy.x) && g.r >= 0.0 && !(fma(dx, dx, dy * dy) > R * R);
+                        const bool row_ok = k < N && k < hp;
+                        const int M = s_lon_meta[mul24(it, nv) + iv].x;
+                        float wl = r_ego_f;
+                        if (k + 1 < M && k + 1 < hp && k + 1 < N) {
+                            const Frame f0 = s_frames[mul24(iv, hp_max) + k], f1 = s_frames[mul24(iv, hp_max) + k + 1];
+                            const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
+                            const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
+                            const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
+                            const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty);   // n_{k+1} . n_k
+                            const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
+                            const double dm1 = (double)s_dmax[k + 1];
+                            const float num = (float)(fabs(a_n) + (double)s_ddmax[k] + dm1 * fabs(1.0 - nn));
+                            const float den = (float)(fabs(a_t) - dm1 * fabs(nt_));
+                            if (den > 1e-30f) {  // v_rcp_f32: 1 ulp; the factor covers it and the two roundings to nearest
+                                const float sigma = vmin_f32(1.0f, num * __builtin_amdgcn_rcpf(den) * (1.0f + 4e-6f) + 1e-9f);
+                                wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
+                            }
+                        }
+                        s_wfat[mul24(iv, hp_max) + k] = row_ok ? (s_dmax[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
                     }
-                    const unsigned long long m = __ballot(keep);
-                    if (m) {
-                        const int first = __ffsll((long long)m) - 1;
-                        int base = 0;
-                        if (lane == first) base = atomicAdd(&s_cnt[0], __popcll(m));
-                        const int pos = __builtin_amdgcn_readlane(base, first) - item_base + __popcll(m & ((1ull << lane) - 1ull));
-                        if (keep && pos < kItemCap) s_items[pos] = (unsigned short)e;
-                    }
+        // [/section PREP]
                 }
                 __syncthreads();
-                const int item_end = s_cnt[0];
-                const int n_surv = item_end - item_base;
-                item_base = item_end;
-                if (n_surv > kItemCap) {  // block-uniform: does not fit, redo [i0, ...) in chunks whose survivors always fit
-                    chunk = kItemCap;
-                    continue;
-                }
-                // ---- B / N passes over the (survivor, lon profile) pairs
 #if defined(FP_ABL_NO_BN)
                 const int n_pairs = 0;
 #else
@@ -693,13 +812,18 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     }
                     if (p1 < n_pairs) __syncthreads();  // the next pass overwrites the hit list
                 }
-                i0 = i1;
-                if (i0 < n_items) __syncthreads();  // the next chunk overwrites the item list
+                __syncthreads();  // frames / lat / dmax are rewritten by the next slice
+            }
+            i0 = i1;
+            if (i0 < n_items) {  // another item chunk: its slice loop starts over (rare: crowded scenes)
+                for (int i = tid; i < 2 * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
+                fill_slice_lat(it_lo);
+                __syncthreads();
             }
         }
-        __syncthreads();  // frames / lat / dmax are rewritten by the next slice
     }
 
+    FP_STAMP(8);
     // ---------------------------------------------------------------- per-candidate assembly + argmin
     Best mine{0.0, -1};
     const float inv_nv_a = 1.0f / (float)nv, inv_nt_a = 1.0f / (float)nt;
@@ -734,6 +858,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     mine = wave_best(mine);
     if (lane == 0) s_best[wave] = mine;
     __syncthreads();
+    FP_STAMP(9);
     if (nsplit > 1) {
         // Latency mode: this workgroup holds the argmin of its slices.  The LAST workgroup of the ego to arrive (ticket counter;
         // the partial argmins travel as device-coherent atomic stores / loads) merges the partial argmins in part order - the result does not depend on
@@ -791,6 +916,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
     }
     if (tid == 0 && dur && nsplit == 1) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
+    FP_STAMP(10);
     // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
     // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
     // stores hide behind the other workgroups' arithmetic.  ONE wavefront does it (two time points per lane, neighbours by lane

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Where a workgroup of lattice_fused_kernel spends its time: phase boundaries stamped by thread 0 (build with
+EXTRA=-DFP_PHASE_STAMPS; run on the GPU box).  Prints the median / p90 duration of every phase over the egos of config 3."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from fiss_plus_planner_amd import synth  # noqa: E402
+from fiss_plus_planner_amd.engine import FrenetEngine, device_batch, make_params  # noqa: E402
+
+NAMES = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+         "obs_pose", "obs_dims", "final_time_step")
+PHASES = ["scalars + spline + first obstacle poses", "LUT + speed bound + rest of the obstacle staging", "A0 boundary-value solves + proofs + lateral bound",
+          "power sums + point scans + arclength ranges", "cost sums + row circles", "group test G (+ sincos of survivors)",
+          "slices: frames / lat / prep / B / N", "assembly + argmin", "results"]
+STAMPS = [0, 1, 2, 3, 4, 7, 8, 9, 10]
+
+batch = synth.make_config(3)
+dev = torch.device("cuda", 0)
+eng = FrenetEngine(0)
+eng.set_option("lattice_winner", 1)  # the stamps travel in the winner block the lattice kernel itself writes
+dten = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in NAMES}
+fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in dten.items()})
+params = make_params(batch)
+B = batch.B
+bi = torch.empty(B, dtype=torch.int32, device=dev); bc = torch.empty(B, dtype=torch.float64, device=dev)
+bf = torch.zeros(B, dtype=torch.int32, device=dev); bt = torch.zeros((B, 16, 128), dtype=torch.float64, device=dev)
+st = torch.cuda.current_stream(dev)
+for _ in range(12):
+    eng.plan_dense_device(params, fb, bi.data_ptr(), bc.data_ptr(), stream=st.cuda_stream, best_flags=bf.data_ptr(), best_traj=bt.data_ptr(),
+                          traj_stride=128, traj_sparse=True)
+torch.cuda.synchronize()
+stamps = bt[:, 15, 112:123].cpu().numpy()[:, STAMPS] * 0.01  # us
+d = np.diff(np.concatenate([np.zeros((B, 1)), stamps], axis=1), axis=1)
+print(f"{'phase':48s} {'median us':>10s} {'p90 us':>10s} {'mean us':>10s}")
+for k, name in enumerate(PHASES):
+    print(f"{name:48s} {np.median(d[:, k]):10.2f} {np.percentile(d[:, k], 90):10.2f} {d[:, k].mean():10.2f}")
+print(f"{'workgroup total':48s} {np.median(stamps[:, -1]):10.2f} {np.percentile(stamps[:, -1], 90):10.2f} {stamps[:, -1].mean():10.2f}")
+print(f"sum of workgroup durations / 512 slots = {stamps[:, -1].sum() / 512:.1f} us")
