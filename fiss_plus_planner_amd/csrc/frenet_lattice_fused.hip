@@ -12,17 +12,21 @@
 // the extrema of its polynomials (speed / acceleration limits, inside the spline's range); only slices with an unproven profile
 // run the reference's point-by-point scan (lane per (profile, point), LDS atomics).  The cost sums of every profile follow in
 // closed form from the per-slice power sums (Faulhaber) - no per-point work.
+// Once per ego, collision stage G: for every checked pose row the arclength range of the reference points of ALL lon profiles of
+// ALL slices (a polynomial evaluation each) becomes a circle - centre on the line at the middle of the range, radius = half the
+// range x an upper bound of the spline's parametric speed + ego reach + a closed-form bound of the lateral offsets - and one lane
+// per (row, obstacle) item tests the obstacle against it: ~7 % survive, and only their orientations are turned into (cos, sin).
 // Per time-horizon slice i_T (all candidates that share T):
 //   phase A  one lane per (profile, time point) the collision horizon can touch: spline frames and lateral offsets -> LDS, fan
-//            bounds and per-row bounding boxes by LDS atomic max / min
-//   prep     one lane per (pose row, lon profile): the fan's half-width along the reference normal; row boxes -> circles
-//   phase B  three block-wide stages, every lane busy in each: G  (row, obstacle) items against the circle that encloses the
-//            row's reference points of ALL lon profiles; B  (surviving item, lon profile) pairs against a circle fattened by
-//            the largest lateral offset of the slice and a separating axis along the reference normal; N  (hit, lateral
-//            sample) pairs: exact ego centre + heading, exact circle test, 4-axis separating-axis test (closed: touching
-//            collides).  Survivors are appended to block-wide LDS lists with ballot/popcount + one atomic per wavefront.
+//            bounds by LDS atomic max
+//   prep     one lane per (pose row, lon profile): the fan's half-width along the reference normal
+//   B        one lane per (surviving item, lon profile): circle fattened by the largest lateral offset of the slice, separating
+//            axes along the reference normal and tangent
+//   N        one lane per (hit, lateral sample): exact ego centre + heading, exact circle test, 4-axis separating-axis test
+//            (closed: touching collides).  Survivors of G and B are appended to block-wide LDS lists with ballot / popcount + one
+//            atomic per wavefront.
 // Finally one lane per candidate assembles cost + flag word, a wave/LDS argmin with FOP's "last minimum wins" rule picks the
-// winner, and - when the caller asked for it - the same workgroup writes the winner's series (frenet_winner.h).
+// winner, and - when the caller asked for it - one wavefront of the same workgroup writes the winner's series (frenet_winner.h).
 //
 // Semantics restated from the reference (paths relative to its checkout):
 //   lattice + cost      planners/frenet_optimal_planner.py:69-104, planners/common/cost/cost_function.py:41-50
@@ -682,6 +686,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                 }
             // [/section LAT]
                 __syncthreads();
+                if (it == it_lo + 3) FP_STAMP(11);
                 // ---- prep: wfat = lateral half-width of the whole fan along the reference normal n_k, per checked pose (row r, lon
                 // profile iv): every ego centre is P_k + d n_k with |d| <= dmax[k];  the ego box, whose heading deviates from the
                 // reference tangent by alpha, reaches hw cos(alpha) + hl |sin(alpha)| <= min(r_ego, hw + hl sigma) along n_k, where
@@ -723,6 +728,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         // [/section PREP]
                 }
                 __syncthreads();
+                if (it == it_lo + 3) FP_STAMP(12);
 #if defined(FP_ABL_NO_BN)
                 const int n_pairs = 0;
 #else
@@ -767,6 +773,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                         }
                     }
                     __syncthreads();
+                if (it == it_lo + 3) FP_STAMP(13);
                     const int hit_end = s_cnt[1];
                     const int n_hits = hit_end - hit_base;
                     hit_base = hit_end;
@@ -813,6 +820,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     if (p1 < n_pairs) __syncthreads();  // the next pass overwrites the hit list
                 }
                 __syncthreads();  // frames / lat / dmax are rewritten by the next slice
+                if (it == it_lo + 3) FP_STAMP(14);
             }
             i0 = i1;
             if (i0 < n_items) {  // another item chunk: its slice loop starts over (rare: crowded scenes)

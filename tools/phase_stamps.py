@@ -34,10 +34,15 @@ for _ in range(12):
     eng.plan_dense_device(params, fb, bi.data_ptr(), bc.data_ptr(), stream=st.cuda_stream, best_flags=bf.data_ptr(), best_traj=bt.data_ptr(),
                           traj_stride=128, traj_sparse=True)
 torch.cuda.synchronize()
-stamps = bt[:, 15, 112:123].cpu().numpy()[:, STAMPS] * 0.01  # us
+raw = bt[:, 15, 112:128].cpu().numpy() * 0.01  # us
+stamps = raw[:, STAMPS]
 d = np.diff(np.concatenate([np.zeros((B, 1)), stamps], axis=1), axis=1)
 print(f"{'phase':48s} {'median us':>10s} {'p90 us':>10s} {'mean us':>10s}")
 for k, name in enumerate(PHASES):
     print(f"{name:48s} {np.median(d[:, k]):10.2f} {np.percentile(d[:, k], 90):10.2f} {d[:, k].mean():10.2f}")
 print(f"{'workgroup total':48s} {np.median(stamps[:, -1]):10.2f} {np.percentile(stamps[:, -1], 90):10.2f} {stamps[:, -1].mean():10.2f}")
 print(f"sum of workgroup durations / 512 slots = {stamps[:, -1].sum() / 512:.1f} us")
+# inside the 4th slice of the workgroup: stamps 11..14 after the frames / prep / B / N barriers
+sl = raw[:, 11:15]
+print("one slice (the 4th):  prep {:.2f}  B {:.2f}  N {:.2f} us (medians);  frames + lat = slice total - these".format(
+    np.median(sl[:, 1] - sl[:, 0]), np.median(sl[:, 2] - sl[:, 1]), np.median(sl[:, 3] - sl[:, 2])))
