@@ -54,7 +54,9 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // Sort (key[i], idx[i]), i < P (a power of two), ascending by key, ties by idx: bitonic network, one wavefront, in LDS.
-// Four compare-exchanges per lane are in flight at a time (their LDS reads are independent).
+// Four compare-exchanges per lane are in flight at a time (their LDS reads are independent).  ~85 us for P = 1024 on a lone
+// wavefront (measured; a register-resident network with lane shuffles takes the same: the data movement through the LDS
+// crossbar is the cost either way), against the ~380 us the longest walks of a blocked 567-candidate lattice then take.
 __device__ void wave_bitonic_sort(double* key, uint16_t* idx, int P, int lane)
 {
     for (int k = 2; k <= P; k <<= 1) {
@@ -84,6 +86,53 @@ __device__ void wave_bitonic_sort(double* key, uint16_t* idx, int P, int lane)
             wave_lds_sync();
         }
     }
+}
+
+// The same sort for P = 64 E <= 256 elements with the data in REGISTERS: lane l holds elements l, l + 64, ... (E of them); a
+// compare-exchange at distance j < 64 is a lane shuffle, at distance >= 64 a swap between two registers of the lane.  No LDS
+// round trip per step: the single-ego planners (5 x 5 x 5 lattice, P = 128) pay ~1.5 us for it instead of ~7.
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort_regs(double* skey, uint16_t* order, int lane)
+{
+    double key[E];
+    int idx[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) { key[m] = skey[m * kWave + lane]; idx[m] = order[m * kWave + lane]; }
+#pragma unroll
+    for (int k = 2; k <= E * kWave; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= kWave) {
+                const int dm = j / kWave;
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    if ((m & dm) == 0) {  // pair (m, m + dm), both mine
+                        const int e = m * kWave + lane;
+                        const bool up = (e & k) == 0;
+                        const bool gt = key[m] > key[m + dm] || (key[m] == key[m + dm] && idx[m] > idx[m + dm]);
+                        if (gt == up) {
+                            const double tk = key[m]; key[m] = key[m + dm]; key[m + dm] = tk;
+                            const int ti = idx[m]; idx[m] = idx[m + dm]; idx[m + dm] = ti;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const int e = m * kWave + lane;
+                    const double ok = __shfl_xor(key[m], j, kWave);
+                    const int oi = __shfl_xor(idx[m], j, kWave);
+                    const bool up = (e & k) == 0, lower = (e & j) == 0;
+                    const bool mine_gt = key[m] > ok || (key[m] == ok && idx[m] > oi);
+                    // the lower element of an ascending pair keeps the smaller one
+                    const bool take_other = (lower == up) ? mine_gt : !mine_gt;
+                    if (take_other) { key[m] = ok; idx[m] = oi; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < E; ++m) order[m * kWave + lane] = (uint16_t)idx[m];
 }
 
 struct Walk {
@@ -234,7 +283,13 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
     }
     wave_lds_sync();
     // ---- the total order of the walk's two queues: (J, raster index)
-    wave_bitonic_sort(skey, order, P, lane);
+#if !defined(FP_ABL_SEARCH_NOSORT)  // (timing ablation: without the sort the walk runs in raster order - wrong results)
+    if (P == kWave) wave_bitonic_sort_regs<1>(skey, order, lane);
+    else if (P == 2 * kWave) wave_bitonic_sort_regs<2>(skey, order, lane);
+    else if (P == 4 * kWave) wave_bitonic_sort_regs<4>(skey, order, lane);
+    else wave_bitonic_sort(skey, order, P, lane);
+#endif
+    wave_lds_sync();
     // rank -> (raster index | flag byte << 16): one LDS read tells a pop which candidate it is and whether it is feasible.  The
     // words take over the sort keys' bytes (dead from here on).
     uint32_t* order32 = (uint32_t*)skey;
@@ -951,7 +1006,7 @@ hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
 {
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
-    int P = 2;
+    int P = kWave;  // (at least one element per lane: the register sort of small lattices)
     while (P < C) P <<= 1;  // C <= FP_MAX_CAND = 4096: at most 64 words of rank bits, one per lane
     const int bytes = C * (8 + 8 + 2 + 2 + 1 + 1) + P * (8 + 2) + 16;
     FP_LDS_SLOTS(configured);

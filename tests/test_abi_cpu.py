@@ -106,3 +106,18 @@ def test_host_batch_struct_is_cached_per_batch_and_safe_to_edit():
     b.ego = np.ascontiguousarray(b.ego.copy())   # replaced array: new pointer
     fb3 = _host_batch(b)
     assert fb3.ego == b.ego.ctypes.data and fb3.ego != ego_ptr
+
+
+def test_integration_md_stub_matches_the_binding():
+    """The ctypes stub INTEGRATION.md shows a maintainer of the reference: its struct declarations are executed and compared with
+    the product binding field by field, and its version constant with the header's (round 1 shipped a 5-field FpResult there)."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = txt[txt.index("class FpParams(C.Structure):"):txt.index("_lib.fp_abi_version.restype")]
+    ns = {"C": C}
+    exec(block, ns)
+    assert ns["FP_ABI_VERSION"] == _abi.FP_ABI_VERSION
+    for name in ("FpParams", "FpBatch", "FpResult"):
+        doc, ours = ns[name], getattr(_abi, name)
+        assert [(f[0], C.sizeof(f[1])) for f in doc._fields_] == [(f[0], C.sizeof(f[1])) for f in ours._fields_], name
+        assert C.sizeof(doc) == C.sizeof(ours)
+    assert "best_traj.ctypes.data, 0, 0)" in txt  # the call site passes all nine fields
