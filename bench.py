@@ -449,7 +449,8 @@ def main():
                              "source": "64 lanes x (2 FMA + MUL + ADD + TRANS) wave-level FP64 instructions from the same PMC pass (inactive lanes counted: upper bound)"}
             except Exception:
                 valu_issue = fp64_exec = None
-        kname = "lattice_fused_kernel (lattice + argmin + winner series)" if not fiss else "lattice_fused + fiss_search + fiss_refine (whole pipeline)"
+        kname = ("lattice_fused_kernel (lattice + argmin; 94 % of the time) + winner_traj_kernel (the winners' series): the two launches of one "
+                 "fp_plan_dense call") if not fiss else "lattice_fused + fiss_search + fiss_refine (whole pipeline)"
         line = {
             "metric": "candidate trajectories/sec (gen+cost+collision) per GPU; plan-cycle p50 latency", "value": value, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
