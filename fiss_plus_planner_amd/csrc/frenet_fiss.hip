@@ -143,7 +143,7 @@ struct Walk {
     const uint16_t* order; // rank -> raster index (the sort's payload)
     RankSet Q;      // "in queue"        -> queue head = lowest rank   (fiss_planner.py:207 / :229, heapq order)
     RankSet Fr;     // "on the frontier" -> frontier pop = lowest rank (fiss_plus_planner.py:113)
-    double* keyG;   // E where not yet generated, +inf elsewhere -> initial guess = LAST argmin (needed only when the queue runs dry)
+    const double* keyG;  // E (+inf where it is NaN) -> initial guess = LAST argmin over the not-yet-generated samples (needed only when the queue runs dry)
     const uint16_t* ijk;  // raster index -> i | j << sh_j | k << sh_k (bit fields sized for nd, nv, nt: at most 15 bits in all)
     int nd, nv, nt, C, lane;
     int num_iter, num_generated, num_validated, num_checks;
@@ -158,7 +158,6 @@ struct Walk {
         if (s & kGen) return false;
         st[q] = s | kGen;  // candidate_trajs.put((cost_final, idx))
         if (cost < __builtin_inf()) Q.set(__builtin_amdgcn_readfirstlane((int)rank[q]), lane);  // NaN / inf: never popped
-        keyG[q] = __builtin_inf();
         ++num_generated;
         return true;
     }
@@ -171,7 +170,7 @@ struct Walk {
         int bq = -1;
 #pragma unroll 4
         for (int q = lane; q < C; q += kWave) {
-            const double v = keyG[q];
+            const double v = (st[q] & kGen) ? __builtin_inf() : keyG[q];  // only samples that are not generated yet
             if (v <= best && v < __builtin_inf()) { best = v; bq = q; }
         }
         const double m = wave_min_f64(best);
@@ -248,7 +247,8 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
         F[q] = f;
         feasible += (f & FP_FLAG_INFEASIBLE) == 0;
         pass_constraints += (f & FP_FLAG_CONSTRAINTS) == 0;
-        st[q] = 0;
+        // state byte: bit 0 = generated; bits 2..7 = which of the six axis neighbours (-d, +d, -v, +v, -t, +t) exist
+        st[q] = (uint8_t)(((i > 0) << 2) | ((i < nd - 1) << 3) | ((j > 0) << 4) | ((j < nv - 1) << 5) | ((k > 0) << 6) | ((k < nt - 1) << 7));
         ijk[q] = (uint16_t)((uint32_t)i | ((uint32_t)j << sh_j) | ((uint32_t)k << sh_k));
         const double d = bt.d_samples[i], v = vs[j], t = bt.t_samples[k];
         const double ev = smax[1] - v;
@@ -315,7 +315,6 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
     // lane l < 6 owns the neighbour along axis l / 2 in direction +-1 (FISS+ exploration)
     const int my_dim = lane >> 1, my_step = (lane & 1) ? +1 : -1;
     const int my_stride = my_step * (my_dim == 0 ? nv * nt : (my_dim == 1 ? nt : 1));
-    const int my_size = my_dim == 0 ? nd : (my_dim == 1 ? nv : nt);
     for (;;) {
         ++w.num_iter;
         const int rh = w.Q.lowest();
@@ -365,10 +364,10 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
             // clamped - the range check needs the unpacked index and is applied afterwards).  The centre is generated first
             // (wave-uniform); the bookkeeping counts are order-independent.
             int cq = q;             // raster index of the centre
+            int n_front = 0;        // entries on the frontier (wave-uniform): an empty frontier needs no bit-set search
             for (;;) {
                 int nq = cq + my_stride;
                 nq = nq < 0 ? 0 : (nq > C - 1 ? C - 1 : nq);
-                const uint32_t pk = ijk[cq];
                 const uint8_t cs = st[cq];
                 const double cost_center = J[cq];
                 const int cr = rank[cq];
@@ -378,20 +377,16 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
                 if (!(cs & kGen)) {  // generate_trajectory of the centre
                     st[cq] = cs | kGen;
                     if (cost_center < __builtin_inf()) w.Q.set(__builtin_amdgcn_readfirstlane(cr), lane);
-                    keyG[cq] = __builtin_inf();
                     ++w.num_generated;
                 }
-                const int at = (int)(my_dim == 0 ? (pk & mask_i) : (my_dim == 1 ? ((pk >> sh_j) & mask_j) : (pk >> sh_k))) + my_step;
-                const bool is_new = lane < 6 && at >= 0 && at < my_size && !(s & kGen);
+                const bool is_new = lane < 6 && ((cs >> (2 + lane)) & 1) && !(s & kGen);  // the neighbour exists and is not generated
                 const bool to_frontier = is_new && c <= cost_center;  // frontier_idxs.put((cost, idx))
-                if (is_new) {
-                    st[nq] = s | kGen;
-                    keyG[nq] = __builtin_inf();
-                }
+                if (is_new) st[nq] = s | kGen;
                 const unsigned long long fresh = __ballot(is_new);
                 unsigned long long queued = __ballot(is_new && c < __builtin_inf());  // NaN / inf: generated, never popped
                 const unsigned long long front = __ballot(to_frontier);
                 w.num_generated += __popcll(fresh);
+                n_front += __popcll(front & queued);
                 while (queued) {  // register side of the (at most six) inserts
                     const int l = __ffsll((long long)queued) - 1;
                     queued &= queued - 1;
@@ -399,13 +394,15 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
                     w.Q.set(ur, lane);
                     if ((front >> l) & 1ull) w.Fr.set(ur, lane);
                 }
+                if (n_front == 0) break;
+                --n_front;
                 const int rf = w.Fr.lowest();
-                if (rf < 0) break;
                 w.Fr.reset(rf, lane);
                 cq = __builtin_amdgcn_readfirstlane((int)(order32[rf] & 0xFFFFu));
             }
         }
-        // validation of the queue head (fiss_planner.py:229-258)
+        // validation of the queue head (fiss_planner.py:229-258).  (Reusing the head found at the top of the iteration when nothing
+        // was queued on the way was tried: the extra uniform branch costs more than the ballot + two find-first-set it saves.)
         const int rp = w.Q.lowest();
         if (rp < 0) break;
         w.Q.reset(rp, lane);
