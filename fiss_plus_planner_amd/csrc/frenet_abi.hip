@@ -117,7 +117,6 @@ struct fp_ctx {
     int lattice_order = 1;
     int lattice_launches = 0, lattice_ordered_launches = 0;  // fp_ctx_get_option counters
     LaunchOrder order_lattice, order_refine;
-    DeviceBuf pose_buf;            // converted obstacle rows of scenes too big for LDS (lattice_pose_scratch_bytes)
     DeviceBuf curv_buf;            // [B][C] curvature flag bytes of the lattice (fp_params.curvature_mask), written ahead of the fused kernel
 };
 
@@ -432,20 +431,6 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
     return FP_OK;
 }
 
-// Scenes whose obstacle rows do not fit LDS: the fused kernel keeps the converted rows in this ctx-owned table instead.
-int lattice_pose_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, int nsplit, hipStream_t stream, void** out)
-{
-    *out = nullptr;
-    const size_t need = fp::lattice_pose_scratch_bytes(*p, *b, nsplit);
-    if (need == 0) return FP_OK;
-    if (need > ctx->pose_buf.cap) {
-        HIP_TRY(hipStreamSynchronize(stream));  // the buffer is reallocated: drain its users
-        FP_TRY(ctx->pose_buf.reserve(need));
-    }
-    *out = ctx->pose_buf.base;
-    return FP_OK;
-}
-
 // Optional curvature checks: the fused lattice kernel reads them from a [B][C] byte table that launch_lattice fills first.
 int lattice_curv_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, const uint8_t** out)
 {
@@ -545,7 +530,6 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     if (ctx->parts.base) (void)hipFree(ctx->parts.base);
-    if (ctx->pose_buf.base) (void)hipFree(ctx->pose_buf.base);
     if (ctx->curv_buf.base) (void)hipFree(ctx->curv_buf.base);
     ctx->order_lattice.release();
     ctx->order_refine.release();
@@ -624,12 +608,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
         bool winner_done = false;
         const int* perm; int* dur;
-        void* pose_scratch;
-        FP_TRY(lattice_pose_scratch(ctx, params, &ka.b, nsplit, (hipStream_t)stream, &pose_scratch));
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
         fp::KernelArgs kl = ka;
         if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
-        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
+        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         return FP_OK;
@@ -660,12 +642,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts));
     bool winner_done = false;
     const int* perm; int* dur;
-    void* pose_scratch;
-    FP_TRY(lattice_pose_scratch(ctx, params, &ka.b, nsplit, ctx->stream, &pose_scratch));
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     fp::KernelArgs kl = ka;
     if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
-    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, pose_scratch), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     return hs.fetch_out();
@@ -830,10 +810,8 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     int nsplit; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
     const int* perm; int* dur;
-    void* pose_scratch;
-    FP_TRY(lattice_pose_scratch(ctx, params, &fa.ka.b, nsplit, stream, &pose_scratch));
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
-    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, pose_scratch), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");

@@ -553,11 +553,11 @@ hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const d
 }
 
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done, const int* perm,
-                          int* dur, void* pose_scratch)
+                          int* dur)
 {
     if (winner_done) *winner_done = false;
     if (which == 1) return launch_lattice_percand(ka, stream);
-    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur, pose_scratch);
+    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur);
     if (e == hipErrorInvalidValue && which != 2) {
         (void)hipGetLastError();
         if (winner_done) *winner_done = false;

@@ -64,7 +64,7 @@ __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
 constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass
-constexpr int kItemCap = 1024;   // block-wide list of (row, obstacle) items that pass the group test
+constexpr int kItemCap = 512;    // block-wide list of (row, obstacle) items that pass the group test (+ their poses: 16 KB)
 
 struct __attribute__((aligned(16))) Frame {  // reference-line frame of one lon-profile point
     double px, py, tx, ty;
@@ -83,7 +83,7 @@ struct Layout {
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
 
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, bool pose_in_lds = true)
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt)
 {
     Layout L;
     int o = 0;
@@ -91,7 +91,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.coef = o;     o = align16(o + 64 * nx_max);
     L.lut = o;      o = align16(o + 2 * (2 * nx_max + 1));  // uint16 segment hint per arclength bucket
     L.dim = o;      o = align16(o + 32 * n_obs);
-    L.pose = o;     o = align16(o + (pose_in_lds ? 32 * rows * n_obs : 0));  // big scenes keep the converted rows in HBM / L2 instead
+    L.pose = o;     o = align16(o + 32 * kItemCap);  // poses of the group test's survivors (x, y, cos, sin), in list order
     L.frames = o;   o = align16(o + 32 * nv * hp);
     L.lat = o;      o = align16(o + 8 * nd * hp);
     L.dmax = o;     o = align16(o + 2 * 4 * hp);   // float, rounded up; two buffers (slice parity): LDS atomic max in phase A
@@ -157,11 +157,8 @@ __device__ __forceinline__ void power_sums_closed(int N, double tick, double* ou
 
 // nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
 // writes its partial argmin to part_best[ego * nsplit + part]; the last one to arrive (ticket counter) merges them.
-// POSE_LDS: the converted obstacle rows live in LDS (plain ds_read in the three collision stages); otherwise in the caller's global
-// scratch table (big scenes).  A run-time choice would make every access a flat (generic address space) load.
-template <bool POSE_LDS>
 __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur, ObsPose* pose_global)
+                                                                   int* dur)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const long long t_begin = dur ? wall_clock64() : 0;
@@ -186,16 +183,14 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const int stride = p.check_stride;
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt, POSE_LDS);
+    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
     ObsDim* s_dim = (ObsDim*)(smem + L.dim);
-    // obstacle rows of this workgroup: LDS, or - for scenes too big for it - this workgroup's slice of a global scratch table
-    // (written during staging, read by the three collision stages through L2)
-    ObsPose* s_pose;  // (one provenance per instantiation: the compiler infers the address space from it)
-    if constexpr (POSE_LDS) s_pose = (ObsPose*)(smem + L.pose);
-    else s_pose = pose_global + (size_t)blockIdx.x * rows_max * bt.n_obs;
+    // poses of the (row, obstacle) items that survive the group test, in the order of the item list: the table itself is read from
+    // global memory exactly once (registers -> group test), only the ~7 % the slices can touch are kept
+    ObsPose* s_spose = (ObsPose*)(smem + L.pose);
     Frame* s_frames = (Frame*)(smem + L.frames);
     double* s_lat = (double*)(smem + L.lat);
     float* s_dmax2 = (float*)(smem + L.dmax);    // [2][hp_max]
@@ -239,10 +234,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         return;
     }
     // ---------------------------------------------------------------- stage: ego, spline, obstacle rows
-    // Global reads cost 1-2 us each, so everything that depends only on the scalars above is requested at once: the spline's
-    // tables and - held in registers until the spline work is done - the first 4 x 512 obstacle poses.  (The rows the collision
-    // horizon can touch depend on final_time_step, one more dependent read: the rows the TABLE holds from t_now on are fetched
-    // instead; they are the same whenever the prediction covers the table.)
+    // Global reads cost 1-2 us each, so everything that depends only on the scalars above is requested at once.  The obstacle
+    // table is NOT staged: the group test reads it once, straight from global memory, and keeps the poses of its survivors
+    // (rows_stage = the rows the table holds from t_now on).
     const int NX = bt.NX;
     const int n_obs = sc >= 0 ? bt.n_obs : 0;
     const float inv_nobs_s = 1.0f / (float)(n_obs > 0 ? n_obs : 1);
@@ -253,9 +247,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         if (rows_stage > rows_max) rows_stage = rows_max;
     }
     const double* gp = bt.obs_pose + (size_t)(sc >= 0 ? sc : 0) * bt.T_obs * bt.n_obs * 4;
-    auto fetch_poses = [&](int i0, double4* ps) {  // four pose reads in flight per lane
+    constexpr int kPoseFlight = 2;  // pose reads in flight per lane in the group test
+    auto fetch_poses = [&](int i0, double4* ps) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kPoseFlight; ++u) {
             const int i = i0 + u * kThreads + tid;
             ps[u] = make_double4(0.0, 0.0, 0.0, 0.0);
             if (i < rows_stage * n_obs) {
@@ -264,17 +259,6 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             }
         }
     };
-    auto store_poses = [&](int i0, const double4* ps) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * kThreads + tid;
-            // x = NaN: no state at this step (state_at_time -> None).  The orientation stays an angle (in .c) until the item survives
-            // the group test: ~9 in 10 never need its cosine / sine
-            if (i < rows_stage * n_obs) s_pose[i] = ObsPose{ps[u].w != 0.0 ? ps[u].x : __builtin_nan(""), ps[u].y, ps[u].z, 0.0};
-        }
-    };
-    double4 ps0[4];
-    fetch_poses(0, ps0);
     const int nx = bt.nx[f];
     const int fts = n_obs > 0 ? bt.final_time_step[sc] : 0;
     {
@@ -358,14 +342,6 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         if (h < 0) h = 0;
         rows = (h + stride - 1) / stride;
         if (rows_stage < rows) rows = rows_stage;
-    // [section STAGE]
-        store_poses(0, ps0);
-        for (int i0 = 4 * kThreads; i0 < rows_stage * n_obs; i0 += 4 * kThreads) {
-            double4 ps[4];
-            fetch_poses(i0, ps);
-            store_poses(i0, ps);
-        }
-    // [/section STAGE]
     }
     for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
     for (int r = tid; r < rows; r += kThreads) {
@@ -603,26 +579,35 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         const float inv_nobs = 1.0f / (float)n_obs, inv_nvf = 1.0f / (float)nv, inv_ndf = 1.0f / (float)nd;
         int chunk = n_items;
         for (int i0 = 0; i0 < n_items;) {
-            // ---- G (once per ego and item chunk)
+            // ---- G (once per ego and item chunk): the poses come straight from the scene table (L2 for all but the first ego of a
+            // scene), kPoseFlight reads in flight per lane.  x = NaN / valid = 0: no state at this step (state_at_time -> None).
+            // A survivor's pose goes to the list with its orientation still an angle.
             const int i1 = i0 + chunk < n_items ? i0 + chunk : n_items;
-            for (int e0 = i0 + wave * kWave; e0 < i1; e0 += kThreads) {
-                const int e = e0 + lane;
-                bool keep = false;
-                if (e < i1) {
-                    const int r = div_small(e, inv_nobs), j = e - mul24(r, n_obs);
-                    const int k = mul24(r, stride);
-                    const double2 oxy = *(const double2*)&s_pose[e];
-                    const ObsDim g = s_grp[r];
-                    const double dx = oxy.x - g.hl, dy = oxy.y - g.hw, R = g.r + s_dim[j].r;
-                    keep = k < pose_limit && (oxy.x == oxy.x) && !(g.r < 0.0) && !(fma(dx, dx, dy * dy) > R * R);
-                }
-                const unsigned long long m = __ballot(keep);
-                if (m) {
-                    const int first = __ffsll((long long)m) - 1;
-                    int base = 0;
-                    if (lane == first) base = atomicAdd(&s_cnt[0], __popcll(m));
-                    const int pos = __builtin_amdgcn_readlane(base, first) - item_base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (keep && pos < kItemCap) s_items[pos] = (unsigned short)e;
+            for (int b0 = i0; b0 < i1; b0 += kPoseFlight * kThreads) {
+                double4 ps[kPoseFlight];
+                fetch_poses(b0, ps);
+#pragma unroll
+                for (int u = 0; u < kPoseFlight; ++u) {
+                    const int e = b0 + u * kThreads + tid;
+                    bool keep = false;
+                    if (e < i1) {
+                        const int r = div_small(e, inv_nobs), j = e - mul24(r, n_obs);
+                        const int k = mul24(r, stride);
+                        const ObsDim g = s_grp[r];
+                        const double dx = ps[u].x - g.hl, dy = ps[u].y - g.hw, R = g.r + s_dim[j].r;
+                        keep = k < pose_limit && ps[u].w != 0.0 && (ps[u].x == ps[u].x) && !(g.r < 0.0) && !(fma(dx, dx, dy * dy) > R * R);
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {
+                        const int first = __ffsll((long long)m) - 1;
+                        int base = 0;
+                        if (lane == first) base = atomicAdd(&s_cnt[0], __popcll(m));
+                        const int pos = __builtin_amdgcn_readlane(base, first) - item_base + __popcll(m & ((1ull << lane) - 1ull));
+                        if (keep && pos < kItemCap) {
+                            s_items[pos] = (unsigned short)e;
+                            s_spose[pos] = ObsPose{ps[u].x, ps[u].y, ps[u].z, 0.0};
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -636,11 +621,10 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             }
             // the survivors' orientations -> (cos, sin), with shapely's snap (frenet_device.h); every item belongs to one chunk
             for (int si = tid; si < n_surv; si += kThreads) {
-                const int item = s_items[si];
                 double sn, cs;
-                sincos_snapped(s_pose[item].c, sn, cs);
-                s_pose[item].c = cs;
-                s_pose[item].s = sn;
+                sincos_snapped(s_spose[si].c, sn, cs);
+                s_spose[si].c = cs;
+                s_spose[si].s = sn;
             }
             // (the slice loop's first barrier orders these writes before stage B reads them)
             // No survivor (block-uniform: empty surroundings, obstacles out of reach): nothing can collide, the slices are skipped.
@@ -748,7 +732,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             const int item = s_items[si];
                             const int r = div_small(item, inv_nobs), j = item - mul24(r, n_obs);
                             const int k = mul24(r, stride);
-                            const ObsPose op = s_pose[item];
+                            const ObsPose op = s_spose[si];
                             const ObsDim od = s_dim[j];
                             const Frame fr = s_frames[mul24(iv, hp_max) + k];
                             // Poses beyond a profile's M hold stale frames: they may pass here and are rejected by the narrow
@@ -764,7 +748,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             const double reach = fma(od.hl, a_n, od.hw * a_t), reach_t = fma(od.hl, a_t, od.hw * a_n);
                             pass = !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach) &&
                                    !(fabs(u) > r_ego * (1.0 + 1e-12) + reach_t);
-                            code = ((uint32_t)iv << 24) | ((uint32_t)r << 12) | (uint32_t)j;
+                            code = ((uint32_t)iv << 16) | (uint32_t)si;
                         }
                         const unsigned long long m = __ballot(pass);
                         if (m) {
@@ -789,7 +773,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     for (int x = tid; x < n_exact; x += kThreads) {
                         const int h = div_small(x, inv_ndf), id = x - mul24(h, nd);
                         const uint32_t code = s_hits[h];
-                        const int iv = code >> 24, r = (code >> 12) & 0xFFF, j = code & 0xFFF;
+                        const int iv = code >> 16, si = code & 0xFFFF;
+                        const int item = s_items[si];
+                        const int r = div_small(item, inv_nobs), j = item - mul24(r, n_obs);
                         const int cand = mul24(mul24(id, nt) + it, nv) + iv;
                         const int k = mul24(r, stride);
                         const int M = s_lon_meta[mul24(it, nv) + iv].x;
@@ -807,7 +793,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             ego.y = (ka_ == k) ? ya : yb;
                             ego.hl = veh_hl;
                             ego.hw = veh_hw;
-                            const ObsPose op = s_pose[mul24(r, n_obs) + j];
+                            const ObsPose op = s_spose[si];
                             const ObsDim od = s_dim[j];
                             bool hit;
                             if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
@@ -948,13 +934,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp);
 }
 
-// Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the
-// lane-per-candidate kernel, which keeps oversized obstacle tables in HBM/L2).
+// Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the lane-per-candidate kernel).
 // LDS budget of one workgroup (the CU has 160 KB; beyond ~82 KB only one workgroup fits per CU)
 constexpr int kLdsLimit = 150 * 1024;
-// the obstacle rows stay in LDS only while two workgroups per CU still fit (measured: one workgroup per CU with the rows in LDS is
-// slower than two or three with the rows in L2)
-constexpr int kLdsPoseLimit = 81920;
 
 static bool fused_shape(const fp_params& p, const fp_batch& b, int* rows_out, int* hp_out)
 {
@@ -974,35 +956,17 @@ static bool fused_shape(const fp_params& p, const fp_batch& b, int* rows_out, in
     return true;
 }
 
-size_t lattice_pose_scratch_bytes(const fp_params& p, const fp_batch& b, int nsplit)
-{
-    int rows, hp;
-    if (!fused_shape(p, b, &rows, &hp)) return 0;
-    if (make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, true).total <= kLdsPoseLimit) return 0;
-    if (make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, false).total > kLdsLimit) return 0;  // does not fit either way
-    if (nsplit < 1) nsplit = 1;
-    return (size_t)b.B * nsplit * rows * b.n_obs * sizeof(ObsPose);
-}
-
-hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
-                                void* pose_scratch)
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur)
 {
     if (winner_done) *winner_done = false;
     const fp_params& p = ka.p;
     const fp_batch& b = ka.b;
     int rows = 0, hp = 0;
     if (!fused_shape(p, b, &rows, &hp)) return hipErrorInvalidValue;
-    Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, true);
-    ObsPose* pose_global = nullptr;
-    if (L.total > kLdsPoseLimit && pose_scratch) {  // keep the obstacle rows in the caller's scratch table
-        const Layout Lg = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, false);
-        if (Lg.total <= kLdsLimit) { L = Lg; pose_global = (ObsPose*)pose_scratch; }
-    }
+    const Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     FP_LDS_SLOTS(configured);
-    FP_LDS_SLOTS(configured_g);
-    hipError_t e = pose_global ? ensure_dynamic_lds((const void*)lattice_fused_kernel<false>, L.total, configured_g)
-                               : ensure_dynamic_lds((const void*)lattice_fused_kernel<true>, L.total, configured);
+    hipError_t e = ensure_dynamic_lds((const void*)lattice_fused_kernel, L.total, configured);
     if (e != hipSuccess) return e;
     if (!part_scratch || nsplit < 1) nsplit = 1;
     if (nsplit > p.nt) nsplit = p.nt;
@@ -1015,12 +979,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         e = launch_curvature_flags(ka, const_cast<uint8_t*>(ka.curv_tbl), stream);
         if (e != hipSuccess) return e;
     }
-    if (pose_global)
-        hipLaunchKernelGGL(lattice_fused_kernel<false>, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm,
-                           dur, pose_global);
-    else
-        hipLaunchKernelGGL(lattice_fused_kernel<true>, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm,
-                           dur, pose_global);
+    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur);
     if (winner_done) *winner_done = ka.r.best_traj != nullptr;
     return hipGetLastError();
 }

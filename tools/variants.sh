@@ -11,7 +11,10 @@ export TMPDIR=/tmp
 i=0
 for EXTRA in "$@"; do
   i=$((i+1))
-  make -C fiss_plus_planner_amd/csrc -B -s EXTRA="$EXTRA" > $OUT/build_$i.log 2>&1 || { echo "variant $i [$EXTRA]: BUILD FAILED"; tail -5 $OUT/build_$i.log; continue; }
+  SRCDIR=fiss_plus_planner_amd/csrc; MKX="$EXTRA"
+  # "@base [flags]": build the snapshot of an earlier commit under tools/_tmp/base instead (A/B inside one call)
+  if [ "${EXTRA#@base}" != "$EXTRA" ]; then SRCDIR=tools/_tmp/base/fiss_plus_planner_amd/csrc; MKX="${EXTRA#@base}"; fi
+  make -C $SRCDIR -B -s EXTRA="$MKX" OUT=$R/fiss_plus_planner_amd/libfrenetgpu.so > $OUT/build_$i.log 2>&1 || { echo "variant $i [$EXTRA]: BUILD FAILED"; tail -5 $OUT/build_$i.log; continue; }
   env ${BENCH_ENV:-} python bench.py --steps ${STEPS:-60} --warmup 8 --cpu-seconds ${CPU:-0} --no-latency --no-extras ${BENCH_ARGS:-} > $OUT/bench_$i.json 2> $OUT/bench_$i.err
   python - "$OUT/bench_$i.json" "$EXTRA" <<'PY'
 import json, sys
