@@ -88,6 +88,31 @@ __device__ void wave_bitonic_sort(double* key, uint16_t* idx, int P, int lane)
     }
 }
 
+// Sort (key[i], idx[i]), i < n (any n <= P, P a power of two), ascending by key, ties by idx, by the W wavefronts of a workgroup.
+// Bitonic network in the form whose compare-exchanges ALL put the smaller element at the lower index (a merge starts with the
+// mirrored partner i ^ (k - 1), then half-cleaners i ^ j): elements n .. P-1 are +inf that is never stored - a partner beyond n
+// means no exchange.  Two (P = 1024, 256 threads) compare-exchanges per thread and stage, a barrier per stage: ~20 us where a lone
+// wavefront needs ~100.
+template <int W>
+__device__ void block_bitonic_sort(double* key, uint16_t* idx, int n, int P, int tid)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool mirror = j == (k >> 1);
+            for (int t = tid; t < (P >> 1); t += W * kWave) {
+                const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // t with a zero inserted at bit log2(j)
+                const int b = mirror ? (a ^ (k - 1)) : (a | j);
+                if (b < n) {
+                    const double ka = key[a], kb = key[b];
+                    const uint16_t ia = idx[a], ib = idx[b];
+                    if (ka > kb || (ka == kb && ia > ib)) { key[a] = kb; key[b] = ka; idx[a] = ib; idx[b] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // The same sort for P = 64 E <= 256 elements with the data in REGISTERS: lane l holds elements l, l + 64, ... (E of them); a
 // compare-exchange at distance j < 64 is a lane shuffle, at distance >= 64 a swap between two registers of the lane.  No LDS
 // round trip per step: the single-ego planners (5 x 5 x 5 lattice, P = 128) pay ~1.5 us for it instead of ~7.
@@ -187,15 +212,20 @@ struct Walk {
 
 }  // namespace
 
-__global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
+// W wavefronts build the tables and sort (W = 1: small lattices, the sort runs in registers; W = 4: a barrier-stepped network over
+// the whole workgroup); the walk itself is one wavefront's - the others leave before it starts.
+template <int W>
+__global__ __launch_bounds__(W * kWave) void fiss_search_kernel(FissArgs fa, int P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const fp_params& p = fa.ka.p;
     const fp_batch& bt = fa.ka.b;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1);
     const int nd = p.nd, nv = p.nv, nt = p.nt, C = nd * nv * nt;
+    const int PS = W == 1 ? P : C;  // stored sort entries (the wide sort keeps its padding virtual)
+    auto group_sync = [&]() { if constexpr (W == 1) wave_lds_sync(); else __syncthreads(); };
     if (bt.skip && bt.skip[b]) {  // finished ego of a closed-loop batch
-        if (lane == 0) {
+        if (tid == 0) {
             int32_t* out = fa.io.best_ijk + (size_t)b * 3;
             out[0] = out[1] = out[2] = -1;
             fa.io.best_cost[b] = __builtin_nan("");
@@ -207,15 +237,21 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
         }
         return;
     }
-    // LDS: J [C] | sort keys [P] | keyG [C] | order [P] | rank [C] | ijk [C] | F [C] | st [C]     (P = power of two >= C)
-    double* J = (double*)smem;
+    // LDS: counters [4] | J [C] | sort keys [PS] | keyG [C] | order [PS] | rank [C] | ijk [C] | F [C] | st [C]
+    // (PS = P, a power of two >= C, for the one-wavefront sorts; C for the workgroup sort)
+    int* s_count = (int*)smem;
+    double* J = (double*)(smem + 16);
     double* skey = J + C;
-    double* keyG = skey + P;
+    double* keyG = skey + PS;
     uint16_t* order = (uint16_t*)(keyG + C);
-    uint16_t* rank = order + P;
+    uint16_t* rank = order + PS;
     uint16_t* ijk = rank + C;
     uint8_t* F = (uint8_t*)(ijk + C);
     uint8_t* st = F + C;
+    if (W > 1) {
+        if (tid < 4) s_count[tid] = 0;
+        __syncthreads();
+    }
     // bit fields of the packed index: ceil(log2 nd) + ceil(log2 nv) + ceil(log2 nt) <= log2(FP_MAX_CAND) + 3 = 15
     const int sh_j = nd > 1 ? 32 - __clz(nd - 1) : 0;
     const int sh_k = sh_j + (nv > 1 ? 32 - __clz(nv - 1) : 0);
@@ -231,7 +267,7 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
     const double max_sqr_dist = (double)(nd * nd + nv * nv + nt * nt);
     const double* vs = bt.v_samples + (size_t)b * nv;
     int feasible = 0, pass_constraints = 0;
-    for (int q = lane; q < P; q += kWave) {
+    for (int q = tid; q < PS; q += W * kWave) {
         if (q >= C) {  // padding of the sort: behind every real entry
             skey[q] = __builtin_inf();
             order[q] = (uint16_t)q;
@@ -266,10 +302,19 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
     // No feasible candidate anywhere in the lattice: the walk would generate and validate every sample, one per outer
     // iteration, and give up (fiss_planner.py:203-206).  Its outcome is closed form: num_iter = C + 1, generated =
     // validated = C, collision checks = samples that pass the constraints.  (Each iteration pops exactly one candidate.)
-    if (__ballot(feasible != 0) == 0ull) {
 #pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) pass_constraints += __shfl_xor(pass_constraints, off, kWave);
-        if (lane == 0) {
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        pass_constraints += __shfl_xor(pass_constraints, off, kWave);
+        feasible += __shfl_xor(feasible, off, kWave);
+    }
+    if (W > 1) {  // totals of the workgroup
+        if (lane == 0) { atomicAdd(&s_count[0], feasible); atomicAdd(&s_count[1], pass_constraints); }
+        __syncthreads();
+        feasible = s_count[0];
+        pass_constraints = s_count[1];
+    }
+    if (feasible == 0) {
+        if (tid == 0) {
             int32_t* out = fa.io.best_ijk + (size_t)b * 3;
             out[0] = out[1] = out[2] = -1;
             fa.io.best_cost[b] = __builtin_nan("");
@@ -281,27 +326,32 @@ __global__ __launch_bounds__(kWave) void fiss_search_kernel(FissArgs fa, int P)
         }
         return;
     }
-    wave_lds_sync();
+    group_sync();
     // ---- the total order of the walk's two queues: (J, raster index)
 #if !defined(FP_ABL_SEARCH_NOSORT)  // (timing ablation: without the sort the walk runs in raster order - wrong results)
-    if (P == kWave) wave_bitonic_sort_regs<1>(skey, order, lane);
-    else if (P == 2 * kWave) wave_bitonic_sort_regs<2>(skey, order, lane);
-    else if (P == 4 * kWave) wave_bitonic_sort_regs<4>(skey, order, lane);
-    else wave_bitonic_sort(skey, order, P, lane);
+    if constexpr (W == 1) {
+        if (P == kWave) wave_bitonic_sort_regs<1>(skey, order, lane);
+        else if (P == 2 * kWave) wave_bitonic_sort_regs<2>(skey, order, lane);
+        else if (P == 4 * kWave) wave_bitonic_sort_regs<4>(skey, order, lane);
+        else wave_bitonic_sort(skey, order, P, lane);
+    } else {
+        block_bitonic_sort<W>(skey, order, C, P, tid);
+    }
 #endif
-    wave_lds_sync();
+    group_sync();
     // rank -> (raster index | flag byte << 16): one LDS read tells a pop which candidate it is and whether it is feasible.  The
     // words take over the sort keys' bytes (dead from here on).
     uint32_t* order32 = (uint32_t*)skey;
-    for (int r0 = 0; r0 < P; r0 += kWave) {
-        const int r = r0 + lane;
-        const int q = r < P ? order[r] : C;
+    for (int r0 = 0; r0 < PS; r0 += W * kWave) {
+        const int r = r0 + tid;
+        const int q = r < PS ? order[r] : C;
         uint32_t word = 0xFFFFu;
         if (q < C) { rank[q] = (uint16_t)r; word = (uint32_t)q | ((uint32_t)F[q] << 16); }
-        wave_lds_sync();  // (the words of this batch overlay keys whose ranks were read above)
-        if (r < P) order32[r] = word;
+        group_sync();  // (the words of this batch overlay keys whose ranks were read above)
+        if (r < PS) order32[r] = word;
     }
-    wave_lds_sync();
+    group_sync();
+    if (W > 1 && tid >= kWave) return;  // the walk is one wavefront's
 
     Walk w{J, F, st, rank, order, {}, {}, keyG, ijk, nd, nv, nt, C, lane, 0, 0, 0, 0};
 #if defined(FP_ABL_SEARCH_NOWALK)  // timing ablation: prologue + sort only
@@ -1005,11 +1055,19 @@ hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
     int P = kWave;  // (at least one element per lane: the register sort of small lattices)
     while (P < C) P <<= 1;  // C <= FP_MAX_CAND = 4096: at most 64 words of rank bits, one per lane
-    const int bytes = C * (8 + 8 + 2 + 2 + 1 + 1) + P * (8 + 2) + 16;
     FP_LDS_SLOTS(configured);
-    hipError_t e = ensure_dynamic_lds((const void*)fiss_search_kernel, bytes, configured);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fiss_search_kernel, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa, P);
+    FP_LDS_SLOTS(configured_wide);
+    if (P <= 4 * kWave) {  // the register sorts of one wavefront
+        const int bytes = C * (8 + 8 + 2 + 2 + 1 + 1) + P * (8 + 2) + 32;
+        hipError_t e = ensure_dynamic_lds((const void*)fiss_search_kernel<1>, bytes, configured);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fiss_search_kernel<1>, dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa, P);
+    } else {  // four wavefronts set up and sort (no padding stored: 567 candidates -> 18 KB, eight egos per CU)
+        const int bytes = C * (8 + 8 + 2 + 2 + 1 + 1) + C * (8 + 2) + 32;
+        hipError_t e = ensure_dynamic_lds((const void*)fiss_search_kernel<4>, bytes, configured_wide);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fiss_search_kernel<4>, dim3(fa.ka.b.B), dim3(4 * kWave), bytes, stream, fa, P);
+    }
     return hipGetLastError();
 }
 
