@@ -23,7 +23,7 @@ if has trace; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4 -o c4 -- python $R/bench.py --config 4 --steps 50 --warmup 5 --cpu-seconds 0 --no-latency --no-extras > $OUT/trace_c4.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2 -o c2 -- python $R/bench.py --config 2 --egos 256 --steps 50 --warmup 5 --cpu-seconds 0 --no-latency --no-extras > $OUT/trace_c2.log 2>&1
   cd $R
-  for c in c3 c4 c2; do f=$(ls $OUT/trace_$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/${c}_kernel_stats.csv && head -6 $f; done
+  for c in c3 c4 c2; do f=$(ls $OUT/trace_$c/*kernel_stats.csv $OUT/trace_$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/${c}_kernel_stats.csv && head -6 $f; done
 fi
 if has pmc; then
   bash profiles/collect_pmc.sh $TAG > $OUT/pmc.log 2>&1; tail -40 $OUT/pmc.log

@@ -14,8 +14,8 @@ from fiss_plus_planner_amd.engine import FrenetEngine, device_batch, make_params
 
 NAMES = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
          "obs_pose", "obs_dims", "final_time_step")
-PHASES = ["scalars + spline + first obstacle poses", "LUT + speed bound + rest of the obstacle staging", "A0 boundary-value solves + proofs + lateral bound",
-          "power sums + point scans + arclength ranges", "cost sums + row circles", "group test G (+ sincos of survivors)",
+PHASES = ["scalars + spline tables + obstacle sizes", "LUT + speed bound + lateral extremes", "A0 boundary-value solves + proofs + lateral bound",
+          "power sums + point scans + arclength ranges", "cost sums + row circles", "group test G (scene table read) + sincos",
           "slices: frames / lat / prep / B / N", "assembly + argmin", "results"]
 STAMPS = [0, 1, 2, 3, 4, 7, 8, 9, 10]
 
