@@ -30,6 +30,10 @@ import time
 
 import numpy as np
 
+# The CPU-baseline leg runs the oracle with one OpenMP thread per host core; by default the runtime leaves those threads spinning
+# for a while after the parallel region, next to the thread that launches the workloads measured after it.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "fiss_plus_planner_amd", "csrc")
-FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off".split()
+FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -disable-machine-licm".split()  # as in csrc/Makefile
 rows = []
 for f in sorted(os.listdir(CSRC)):
     if not f.endswith(".hip"):
