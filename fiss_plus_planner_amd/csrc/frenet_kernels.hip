@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void eval_trajs_kernel(KernelArgs ka, int K, c
 // ---------------------------------------------------------------------------
 // all_C > 0: materialise EVERY lattice candidate (slot = (ego, candidate) in FOP order): the all_trajs payload.
 constexpr int kWinnerWaves = 4;
-__global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C, int n_slots)
+__global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C, int n_slots, int spline_in_lds)
 {
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
@@ -410,17 +410,39 @@ __global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(Kerne
         d_end = bt.d_samples[id]; v_end = bt.v_samples[(size_t)b * p.nv + iv]; T = bt.t_samples[it];
     }
     const int f = bt.frame_of[b];
-    const SplineLds sp{bt.knots + (size_t)f * bt.NX, bt.coef + (size_t)f * 8 * bt.NX, bt.nx[f], bt.NX};
+    // The wavefront's own LDS copy of the ego's spline (9 NX doubles, one round of independent global reads): the segment search
+    // and the coefficient reads of the series are then LDS reads - against global memory the bisection alone is ~7 DEPENDENT reads
+    // per point, the longest chain of the kernel.  Wave-private: no barrier (LDS operations of one wavefront execute in order).
+    extern __shared__ __attribute__((aligned(16))) unsigned char wt_smem[];
+    const int NX = bt.NX;
+    double* my = (double*)wt_smem + (size_t)((int)threadIdx.x / kWave) * 9 * NX;
+    const double* gk = bt.knots + (size_t)f * NX;
+    const double* gc = bt.coef + (size_t)f * 8 * NX;
+    if (!spline_in_lds) {  // (a reference line too long for four LDS copies: the tables stay where they are)
+        winner_series_wave(ka, b, slot, best >= 0, d_end, v_end, T, lane, SplineLds{gk, gc, bt.nx[f], NX});
+        return;
+    }
+    if (best >= 0 && T == T) {  // (wave-uniform; an ego without a winner needs no spline)
+        for (int i = lane; i < 9 * NX; i += kWave) my[i] = i < NX ? gk[i] : gc[i - NX];
+    }
+    const SplineLds sp{my, my + NX, bt.nx[f], NX};
     winner_series_wave(ka, b, slot, best >= 0, d_end, v_end, T, lane, sp);
 }
 
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+// LDS of winner_traj_kernel: one spline copy per wavefront while four of them stay under the 64 KB a launch gets without asking
+static int winner_lds_bytes(const KernelArgs& ka)
+{
+    const int bytes = kWinnerWaves * 9 * ka.b.NX * 8;
+    return bytes <= 48 * 1024 ? bytes : 0;
+}
+
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream)
 {
     const int n = ka.b.B;
-    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), 0, stream, ka, end_states, 0, n);
+    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka), stream, ka, end_states, 0, n, winner_lds_bytes(ka) > 0);
     return hipGetLastError();
 }
 
@@ -428,7 +450,7 @@ hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
 {
     const int C = ka.p.nd * ka.p.nv * ka.p.nt;
     const unsigned n = (unsigned)ka.b.B * (unsigned)C;
-    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), 0, stream, ka, nullptr, C, (int)n);
+    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka), stream, ka, nullptr, C, (int)n, winner_lds_bytes(ka) > 0);
     return hipGetLastError();
 }
 
