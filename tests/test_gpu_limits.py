@@ -26,9 +26,9 @@ def _check_vs_oracle(oracle, engine, batch):
 
 
 def test_obstacle_table_larger_than_lds_stays_fused(oracle, engine):
-    """50 rows x 150 obstacles x 32 B = 240 KB of converted obstacle rows do not fit LDS: the fused kernel keeps them in a
-    ctx-owned table in HBM / L2 instead (written during staging, read by the collision stages) - same flags / costs / argmin, in
-    every launch shape; the lane-per-candidate kernel agrees."""
+    """50 rows x 150 obstacles = 7500 (row, obstacle) items, 240 KB of poses: the fused kernel reads the scene table from global
+    memory in its group test and keeps only the survivors' poses in LDS (more survivors than the list holds: the table is cut into
+    chunks) - same flags / costs / argmin in every launch shape; the lane-per-candidate kernel agrees."""
     batch = synth.make_batch(3, 5, 5, 5, 150, 100, True, 71)
     for kernel, split in ((2, 1), (2, 2), (1, 1), (0, 0)):
         engine.set_option("lattice_kernel", kernel)
@@ -148,3 +148,10 @@ def test_long_reference_line(oracle, engine):
         out = _check_vs_oracle(oracle, engine, b)
     engine.set_option("lattice_split", 0)
     assert ((out.flags[2] & 8) != 0).any()
+    # the winner's series: written by the lattice kernel itself (spline in LDS) and by winner_traj_kernel, which leaves a spline of
+    # this size in global memory (four LDS copies would not fit a default launch) - the same arithmetic, bit for bit
+    inline = engine.plan_dense(b, winner=True)
+    own = engine.winner_trajs(b, inline.best_idx)
+    np.testing.assert_array_equal(own.best_flags, inline.best_flags)
+    np.testing.assert_array_equal(np.nan_to_num(own.best_traj, nan=-1.0), np.nan_to_num(inline.best_traj, nan=-1.0))
+    assert (inline.best_idx >= 0).any()
