@@ -410,9 +410,11 @@ __global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(Kerne
         d_end = bt.d_samples[id]; v_end = bt.v_samples[(size_t)b * p.nv + iv]; T = bt.t_samples[it];
     }
     const int f = bt.frame_of[b];
-    // The wavefront's own LDS copy of the ego's spline (9 NX doubles, one round of independent global reads): the segment search
-    // and the coefficient reads of the series are then LDS reads - against global memory the bisection alone is ~7 DEPENDENT reads
-    // per point, the longest chain of the kernel.  Wave-private: no barrier (LDS operations of one wavefront execute in order).
+    // Materialise mode: the wavefront's own LDS copy of the ego's spline (9 NX doubles, one round of independent global reads) - the
+    // segment search and the coefficient reads of the series are then LDS reads; against global memory the bisection alone is ~7
+    // DEPENDENT reads per point.  Wave-private: no barrier (LDS operations of one wavefront execute in order).  The winner epilogue
+    // (one trajectory per ego, every ego another spline) reads the few segments it touches from global memory instead: copying
+    // the whole table doubled its traffic and cost 0.9 us of 10.7.
     extern __shared__ __attribute__((aligned(16))) unsigned char wt_smem[];
     const int NX = bt.NX;
     double* my = (double*)wt_smem + (size_t)((int)threadIdx.x / kWave) * 9 * NX;
@@ -433,16 +435,16 @@ __global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(Kerne
 // launchers
 // ---------------------------------------------------------------------------
 // LDS of winner_traj_kernel: one spline copy per wavefront while four of them stay under the 64 KB a launch gets without asking
-static int winner_lds_bytes(const KernelArgs& ka)
+static int winner_lds_bytes(const KernelArgs& ka, bool all)
 {
     const int bytes = kWinnerWaves * 9 * ka.b.NX * 8;
-    return bytes <= 48 * 1024 ? bytes : 0;
+    return all && bytes <= 48 * 1024 ? bytes : 0;
 }
 
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream)
 {
     const int n = ka.b.B;
-    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka), stream, ka, end_states, 0, n, winner_lds_bytes(ka) > 0);
+    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka, false), stream, ka, end_states, 0, n, 0);
     return hipGetLastError();
 }
 
@@ -450,7 +452,7 @@ hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
 {
     const int C = ka.p.nd * ka.p.nv * ka.p.nt;
     const unsigned n = (unsigned)ka.b.B * (unsigned)C;
-    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka), stream, ka, nullptr, C, (int)n, winner_lds_bytes(ka) > 0);
+    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka, true), stream, ka, nullptr, C, (int)n, winner_lds_bytes(ka, true) > 0);
     return hipGetLastError();
 }
 

@@ -148,10 +148,16 @@ def test_long_reference_line(oracle, engine):
         out = _check_vs_oracle(oracle, engine, b)
     engine.set_option("lattice_split", 0)
     assert ((out.flags[2] & 8) != 0).any()
-    # the winner's series: written by the lattice kernel itself (spline in LDS) and by winner_traj_kernel, which leaves a spline of
-    # this size in global memory (four LDS copies would not fit a default launch) - the same arithmetic, bit for bit
+    # the winner's series: written by the lattice kernel itself (spline in LDS) and by winner_traj_kernel (spline in global
+    # memory) - the same arithmetic, bit for bit; the materialise mode too leaves a spline of this size in global memory (four LDS
+    # copies would not fit a default launch)
     inline = engine.plan_dense(b, winner=True)
     own = engine.winner_trajs(b, inline.best_idx)
     np.testing.assert_array_equal(own.best_flags, inline.best_flags)
     np.testing.assert_array_equal(np.nan_to_num(own.best_traj, nan=-1.0), np.nan_to_num(inline.best_traj, nan=-1.0))
     assert (inline.best_idx >= 0).any()
+    allt = engine.materialize_all(b)
+    for e in range(b.B):
+        if inline.best_idx[e] >= 0:
+            got = allt.traj[e, inline.best_idx[e]]
+            np.testing.assert_array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(inline.best_traj[e], nan=-1.0))
