@@ -53,41 +53,6 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Sort (key[i], idx[i]), i < P (a power of two), ascending by key, ties by idx: bitonic network, one wavefront, in LDS.
-// Four compare-exchanges per lane are in flight at a time (their LDS reads are independent).  ~85 us for P = 1024 on a lone
-// wavefront (measured; a register-resident network with lane shuffles takes the same: the data movement through the LDS
-// crossbar is the cost either way), against the ~380 us the longest walks of a blocked 567-candidate lattice then take.
-__device__ void wave_bitonic_sort(double* key, uint16_t* idx, int P, int lane)
-{
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t0 = 0; t0 < (P >> 1); t0 += 4 * kWave) {
-                int a[4], b[4];
-                double ka[4], kb[4];
-                uint16_t ia[4], ib[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + u * kWave + lane;
-                    a[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // t with a zero inserted at bit log2(j)
-                    b[u] = a[u] | j;
-                    const bool live = t < (P >> 1);
-                    a[u] = live ? a[u] : 0; b[u] = live ? b[u] : 0;  // (idle lanes compare element 0 with itself: no exchange)
-                    ka[u] = key[a[u]]; kb[u] = key[b[u]]; ia[u] = idx[a[u]]; ib[u] = idx[b[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool up = (a[u] & k) == 0;
-                    const bool gt = ka[u] > kb[u] || (ka[u] == kb[u] && ia[u] > ib[u]);
-                    if (gt == up && a[u] != b[u]) {
-                        key[a[u]] = kb[u]; key[b[u]] = ka[u]; idx[a[u]] = ib[u]; idx[b[u]] = ia[u];
-                    }
-                }
-            }
-            wave_lds_sync();
-        }
-    }
-}
-
 // Sort (key[i], idx[i]), i < n (any n <= P, P a power of two), ascending by key, ties by idx, by the W wavefronts of a workgroup.
 // Bitonic network in the form whose compare-exchanges ALL put the smaller element at the lower index (a merge starts with the
 // mirrored partner i ^ (k - 1), then half-cleaners i ^ j): elements n .. P-1 are +inf that is never stored - a partner beyond n
@@ -332,8 +297,7 @@ __global__ __launch_bounds__(W * kWave) void fiss_search_kernel(FissArgs fa, int
     if constexpr (W == 1) {
         if (P == kWave) wave_bitonic_sort_regs<1>(skey, order, lane);
         else if (P == 2 * kWave) wave_bitonic_sort_regs<2>(skey, order, lane);
-        else if (P == 4 * kWave) wave_bitonic_sort_regs<4>(skey, order, lane);
-        else wave_bitonic_sort(skey, order, P, lane);
+        else wave_bitonic_sort_regs<4>(skey, order, lane);  // (the launcher gives lattices above 256 candidates to W = 4)
     } else {
         block_bitonic_sort<W>(skey, order, C, P, tid);
     }
