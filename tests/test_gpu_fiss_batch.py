@@ -76,7 +76,13 @@ def test_batch_pipeline_history_heuristic_g6(engine, kind):
 
 @pytest.mark.parametrize("cfg", [dict(B=24, nd=9, nv=9, nt=7, n_obs=50, T_obs=50, moving=True, seed=51),
                                  dict(B=16, nd=5, nv=5, nt=5, n_obs=10, T_obs=100, moving=False, seed=52),
-                                 dict(B=6, nd=4, nv=3, nt=2, n_obs=0, T_obs=0, moving=False, seed=53)])
+                                 dict(B=6, nd=4, nv=3, nt=2, n_obs=0, T_obs=0, moving=False, seed=53),
+                                 # the search kernel's four-wavefront set-up at sizes that are no multiple of anything: 343 candidates
+                                 # (network of 512, 169 virtual), 260 (just above the one-wavefront register sort) and the ABI's
+                                 # maximum of 4096 = 16^3 (128 KB of LDS per ego)
+                                 dict(B=8, nd=7, nv=7, nt=7, n_obs=20, T_obs=50, moving=True, seed=54),
+                                 dict(B=6, nd=13, nv=5, nt=4, n_obs=12, T_obs=60, moving=True, seed=55),
+                                 dict(B=3, nd=16, nv=16, nt=16, n_obs=6, T_obs=50, moving=False, seed=56)])
 @pytest.mark.parametrize("kind", ["FISS", "FISS+"])
 def test_batch_pipeline_vs_oracle(oracle, engine, cfg, kind):
     b = synth.make_batch(cfg["B"], cfg["nd"], cfg["nv"], cfg["nt"], cfg["n_obs"], cfg["T_obs"], cfg["moving"], cfg["seed"], kind=kind)
