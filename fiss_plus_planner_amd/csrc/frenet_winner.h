@@ -1,4 +1,4 @@
-// frenet_winner.h - the series of ONE trajectory (what plan() returns), written by one wavefront (two time points per lane).
+// frenet_winner.h - the series of ONE trajectory (what plan() returns), written by one wavefront (two adjacent time points per lane).
 // Shared by winner_traj_kernel (standalone epilogue / materialise mode), by lattice_fused_kernel, which appends the epilogue
 // of its own argmin when the caller asked for it (no second launch, no re-staging; the stores hide behind the other workgroups'
 // arithmetic), and by fiss_refine_kernel.
@@ -8,32 +8,44 @@
 
 namespace fp {
 
-// One WAVEFRONT writes the series of one trajectory: lane l owns points l and l + 64 (N <= FP_MAX_POINTS = 128).  No LDS scratch and
-// no workgroup barrier: the neighbour elements the difference chains need (x[i+1], yaw[i+1], c[i+1], c_d[i+1]) come from the next
-// lane.  `valid`, d_end, v_end, T must be wave-uniform.  sp may point at global memory or at an LDS copy of the spline.
+// One WAVEFRONT writes the series of one trajectory: lane l owns points 2l and 2l + 1 (N <= FP_MAX_POINTS = 128), so a row goes out
+// as 16-byte stores, 1 KB per instruction.  No LDS scratch and no workgroup barrier: of the neighbour elements the difference chains
+// need (x[i+1], yaw[i+1], c[i+1], c_d[i+1]) one is the lane's own, the other the next lane's.  `valid`, d_end, v_end, T must be
+// wave-uniform.  sp may point at global memory or at an LDS copy of the spline.
 // Restates calc_global_paths' per-trajectory part (frenet_optimal_planner.py:106-138): yaw / ds / c / c_d / c_dd exactly as the
 // np.arctan2 / hypot / diff chains (:121-134), truncation at the first point off the spline (:112-113).
 // Output layout: fp_result.traj_stride / traj_sparse (include/frenet_gpu.h).
 __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, int slot, bool valid, double d_end, double v_end, double T, int lane,
                                                    const SplineLds& sp)
 {
+    typedef double double2v __attribute__((ext_vector_type(2)));
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const double nan = __builtin_nan("");
     const int stride = ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS;
     const bool sparse = ka.r.traj_sparse != 0;
     double* out = ka.r.best_traj + (size_t)slot * FP_ARR_COUNT * stride;
+    const bool pairs = (stride & 1) == 0 && ((uintptr_t)out & 15) == 0;  // (wave-uniform) every row starts on a 16-byte boundary
     const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
-    // element i of a row that holds `len` elements: the value, NaN padding (whole block, or up to the end of the 128-byte line in
-    // the sparse layout: partial-line stores cost a read-modify-write at the memory side), or nothing
-    auto put = [&](int r, int h, double v, int len) {
-        const int i = lane + h * kWave;
+    // elements 2l, 2l + 1 of a row that holds `len` elements: the value, NaN padding (whole block, or up to the end of the 128-byte
+    // line in the sparse layout: partial-line stores cost a read-modify-write at the memory side), or nothing.  Write-once stream:
+    // non-temporal stores (plain ones are 1.6x slower in the materialise mode).
+    auto put = [&](int r, double v0, double v1, int len) {
+        const int i = 2 * lane;
         const int upto = sparse ? ((len + 15) & ~15) : FP_MAX_POINTS;
-        if (i < stride && i < upto) __builtin_nontemporal_store(i < len ? v : nan, &out[r * stride + i]);  // write-once stream
+        const int lim = stride < upto ? stride : upto;
+        const double a = i < len ? v0 : nan, c = i + 1 < len ? v1 : nan;
+        double* dst = &out[r * stride + i];
+        if (pairs) {  // (lim is even then)
+            if (i < lim) __builtin_nontemporal_store(double2v{a, c}, (double2v*)dst);
+        } else {
+            if (i < lim) __builtin_nontemporal_store(a, dst);
+            if (i + 1 < lim) __builtin_nontemporal_store(c, dst + 1);
+        }
     };
     if (!valid || N <= 0 || N > FP_MAX_POINTS || !(d_end == d_end) || !(v_end == v_end)) {  // wave-uniform
 #pragma unroll
-        for (int r = 0; r < FP_ARR_COUNT; ++r) { put(r, 0, nan, 0); put(r, 1, nan, 0); }
+        for (int r = 0; r < FP_ARR_COUNT; ++r) put(r, nan, nan, 0);
         if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
         return;
     }
@@ -41,39 +53,38 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
     const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], v_end, 0.0, T);
     double x[2] = {nan, nan}, y[2] = {nan, nan};
+    double t[2], s[2], s_d[2], s_dd[2], s_ddd[2], d[2], d_d[2], d_dd[2], d_ddd[2];
     unsigned long long off_mask[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int i = lane + h * kWave;
+        const int i = 2 * lane + h;
         bool off = false;
-        double t = nan, s = nan, s_d = nan, s_dd = nan, s_ddd = nan, d = nan, d_d = nan, d_dd = nan, d_ddd = nan;
+        t[h] = s[h] = s_d[h] = s_dd[h] = s_ddd[h] = d[h] = d_d[h] = d_dd[h] = d_ddd[h] = nan;
         if (i < N) {
-            t = (double)i * p.tick_t;
-            quartic_eval(lon, t, s, s_d, s_dd, s_ddd);
-            quintic_eval(lat, t, d, d_d, d_dd, d_ddd);
-            const int seg = spline_segment(sp, s, -1);
+            t[h] = (double)i * p.tick_t;
+            quartic_eval(lon, t[h], s[h], s_d[h], s_dd[h], s_ddd[h]);
+            quintic_eval(lat, t[h], d[h], d_d[h], d_dd[h], d_ddd[h]);
+            const int seg = spline_segment(sp, s[h], -1);
             off = seg < 0;  // first point off the spline truncates the Cartesian series (:112-113)
             if (!off) {
                 double px, py, tx, ty;
-                spline_frame(sp, seg, s - sp.knots[seg], px, py, tx, ty);
-                frenet_to_cartesian(px, py, tx, ty, d, x[h], y[h]);
+                spline_frame(sp, seg, s[h] - sp.knots[seg], px, py, tx, ty);
+                frenet_to_cartesian(px, py, tx, ty, d[h], x[h], y[h]);
             }
         }
         off_mask[h] = __ballot(off);
-        put(FP_ARR_T, h, t, N);
-        put(FP_ARR_S, h, s, N); put(FP_ARR_S_D, h, s_d, N); put(FP_ARR_S_DD, h, s_dd, N); put(FP_ARR_S_DDD, h, s_ddd, N);
-        put(FP_ARR_D, h, d, N); put(FP_ARR_D_D, h, d_d, N); put(FP_ARR_D_DD, h, d_dd, N); put(FP_ARR_D_DDD, h, d_ddd, N);
     }
-    const int M = off_mask[0] ? __ffsll((long long)off_mask[0]) - 1 : (off_mask[1] ? kWave + __ffsll((long long)off_mask[1]) - 1 : N);
-    // element (lane + 64 h) + 1 / - 1 of a chain held as two values per lane
-    auto next = [&](const double* v, int h) {
-        const double dn = __shfl_down(v[h], 1, kWave);
-        return (h == 0 && lane == kWave - 1) ? lane_value(v[1], 0) : dn;
-    };
-    auto prev = [&](const double* v, int h) {
-        const double up = __shfl_up(v[h], 1, kWave);
-        return (h == 1 && lane == 0) ? lane_value(v[0], kWave - 1) : up;
-    };
+    put(FP_ARR_T, t[0], t[1], N);
+    put(FP_ARR_S, s[0], s[1], N); put(FP_ARR_S_D, s_d[0], s_d[1], N); put(FP_ARR_S_DD, s_dd[0], s_dd[1], N); put(FP_ARR_S_DDD, s_ddd[0], s_ddd[1], N);
+    put(FP_ARR_D, d[0], d[1], N); put(FP_ARR_D_D, d_d[0], d_d[1], N); put(FP_ARR_D_DD, d_dd[0], d_dd[1], N); put(FP_ARR_D_DDD, d_ddd[0], d_ddd[1], N);
+    // first point off the spline (points 2l of the lanes in off_mask[0], points 2l + 1 in off_mask[1])
+    int M = N;
+    if (off_mask[0]) M = 2 * (__ffsll((long long)off_mask[0]) - 1);
+    if (off_mask[1]) { const int m1 = 2 * (__ffsll((long long)off_mask[1]) - 1) + 1; M = m1 < M ? m1 : M; }
+    // element (2 lane + h) + 1 / - 1 of a chain held as two values per lane (the last lane's "next" and the first lane's "previous"
+    // are never used: they would be elements 128 and -1)
+    auto next = [&](const double* v, int h) { return h == 0 ? v[1] : __shfl_down(v[0], 1, kWave); };
+    auto prev = [&](const double* v, int h) { return h == 1 ? v[0] : __shfl_up(v[1], 1, kWave); };
     double yaw[2], ds[2], c[2], cd[2], cdd[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -83,8 +94,8 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
     }
     {   // the last point repeats the previous heading (:129)
         const double p0 = prev(yaw, 0), p1 = prev(yaw, 1);
-        if (lane == M - 1) yaw[0] = p0;
-        if (lane + kWave == M - 1) yaw[1] = p1;
+        if (2 * lane == M - 1) yaw[0] = p0;
+        if (2 * lane + 1 == M - 1) yaw[1] = p1;
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) c[h] = (next(yaw, h) - yaw[h]) / ds[h];
@@ -93,12 +104,9 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
 #pragma unroll
     for (int h = 0; h < 2; ++h) cdd[h] = (next(cd, h) - cd[h]) / p.tick_t;
     const int My = M >= 2 ? M : 0;  // x, y keep their M points; the difference chains need two
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        put(FP_ARR_X, h, x[h], M); put(FP_ARR_Y, h, y[h], M);
-        put(FP_ARR_YAW, h, yaw[h], My); put(FP_ARR_DS, h, ds[h], My - 1); put(FP_ARR_C, h, c[h], My - 1);
-        put(FP_ARR_C_D, h, cd[h], My - 2); put(FP_ARR_C_DD, h, cdd[h], My - 3);
-    }
+    put(FP_ARR_X, x[0], x[1], M); put(FP_ARR_Y, y[0], y[1], M);
+    put(FP_ARR_YAW, yaw[0], yaw[1], My); put(FP_ARR_DS, ds[0], ds[1], My - 1); put(FP_ARR_C, c[0], c[1], My - 1);
+    put(FP_ARR_C_D, cd[0], cd[1], My - 2); put(FP_ARR_C_DD, cdd[0], cdd[1], My - 3);
     if (lane == 0 && ka.r.best_flags) {
         uint32_t fl = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
         if (M < N) fl |= FP_FLAG_TRUNCATED;
