@@ -1016,6 +1016,7 @@ hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_
 
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream)
 {
+    if (fa.opts.kind == FP_FISS_PLUS) return launch_fissplus_search(fa, stream);  // rank-space walk (frenet_fissplus.hip)
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
     int P = kWave;  // (at least one element per lane: the register sort of small lattices)
     while (P < C) P <<= 1;  // C <= FP_MAX_CAND = 4096: at most 64 words of rank bits, one per lane

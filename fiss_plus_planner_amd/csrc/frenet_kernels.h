@@ -49,6 +49,8 @@ struct FissArgs {
 
 // One wavefront per ego: coarse FISS / FISS+ search over the dense tables.
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream);
+// The FISS+ walk in rank space (frenet_fissplus.hip); launch_fiss_search dispatches to it for FP_FISS_PLUS.
+hipError_t launch_fissplus_search(const FissArgs& fa, hipStream_t stream);
 // One workgroup per ego: FISS+ refinement rounds + cost-ordered validation of the refined trajectories.  table_kb = LDS budget
 // of the per-ego fp32 pose-obstacle pair table (0: no table, pairs are read from the scene table).
 // perm / dur: launch order and duration feedback, like launch_lattice_fused.
