@@ -109,6 +109,7 @@ struct fp_ctx {
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
+    int fiss_jump = 1;             // fp_ctx_set_option("fiss_jump"): FISS+ walk skips ahead to the first feasible sample's level
     int lattice_winner = 0;        // fp_ctx_set_option("lattice_winner"): 0 auto, 1 inside the lattice kernel, 2 its own launch
     int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
     // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
@@ -567,6 +568,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->fiss_stages = value;
         return FP_OK;
     }
+    if (strcmp(name, "fiss_jump") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "fiss_jump must be 0 or 1");
+        ctx->fiss_jump = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_split") == 0) {
         if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_split must be 0 (auto), 1 (never) or 2 (always)");
         ctx->lattice_split = value;
@@ -580,7 +586,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
         {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_order", ctx->lattice_order},
-        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
         if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
@@ -814,6 +820,7 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
+    fa.walk_jump = ctx->fiss_jump;
     LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
     if (R > 0 && ctx->fiss_stages >= 3) {
         // three refinement workgroups per CU are resident at once (fiss_refine_kernel: 168 VGPRs, ~52 KB LDS)

@@ -318,12 +318,11 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         }
     }
     group_sync();
-    if (W > 1 && tid >= kWave) return;  // the walk is one wavefront's
 #if defined(FP_ABL_SEARCH_NOWALK)  // timing ablation: prologue + ranking only
     return;
 #endif
 
-    // ---- the walk (fiss_plus_planner.py:80-148)
+    // ---- the walk (fiss_plus_planner.py:80-148): wavefront 0's
     uint32_t G[NW], Q[NW], Fr[NW], fin[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -336,7 +335,10 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
     int num_iter = 0, num_validated = 0, num_checks = 0;
     int best = -1;
     int rs = -1;   // head of the candidate queue (rank), -1: empty
-    for (;;) {
+    int last_pop = -1;
+    bool start_nan = false;  // the last initial guess started on a sample whose cost_final is NaN
+    // one outer iteration of plan() (:80-148) -> 0: go on, 1: found (best), 2: gave up
+    auto iterate = [&]() -> int {
         ++num_iter;
         bool slow = false;
         if (rs < 0) {
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
                 }
             }
             const double m = uniform_f64(wave_min_f64(bv));
-            if (!(m < __builtin_inf())) break;  // every sample searched, nothing feasible (:203-206)
+            if (!(m < __builtin_inf())) return 2;  // every sample searched, nothing feasible (:203-206)
             int cand = (bv == m) ? bqi : -1;
 #pragma unroll
             for (int off = kWave / 2; off > 0; off >>= 1) {
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         }
         rs = __builtin_amdgcn_readfirstlane(rs);
         const uint4 rec = REC[rs];
+        if (slow) start_nan = (((uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) >> 16) & kPayNan) != 0u;
         explore<NW>(rec, lane, G, Q, Fr, fin, ngen);
         if (any_rank<NW>(Fr)) {  // frontier_idxs not empty (:110-113): pop the cheapest, explore it, until the frontier is empty
             slow = true;
@@ -391,38 +394,158 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         uint32_t pw = rec.w;
         if (slow) {
             pr = lowest_rank<NW>(Q);
-            if (pr < 0) break;
+            if (pr < 0) return 2;
             if (pr != rs) pw = REC[pr].w;
         }
         reset_rank<NW>(Q, pr, lane);
+        last_pop = pr;
         const uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)pw) >> 16;
         ++num_validated;
         if (!(bits & kPayCfail)) {
             ++num_checks;
-            if (!(bits & kPayColl)) { best = pr; break; }
+            if (!(bits & kPayColl)) { best = pr; return 1; }
         }
         rs = lowest_rank<NW>(Q);
-    }
+        return 0;
+    };
+    auto finish = [&]() {
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) ngen += __shfl_xor(ngen, off, kWave);
-    if (lane == 0) {
-        if (best >= 0) {
-            const int q = (int)(order[best] >> 3);
-            const int i = q / nvt, rem = q - i * nvt, j = rem / nt, k = rem - j * nt;
-            int32_t* out = fa.io.best_ijk + (size_t)b * 3;
-            int32_t* pv = fa.io.prev_best_idx + (size_t)b * 3;
-            out[0] = i; out[1] = j; out[2] = k;
-            pv[0] = i; pv[1] = j; pv[2] = k;  // prev_best_idx persists across cycles (:140)
-            fa.io.best_cost[b] = fa.cost_tbl[(size_t)b * C + (size_t)(i * nt + k) * nv + j];
-            double* es = fa.io.end_state + (size_t)b * 3;
-            es[0] = bt.d_samples[i]; es[1] = bt.v_samples[(size_t)b * nv + j]; es[2] = bt.t_samples[k];
-            fa.io.refined[b] = 0;
-            int32_t* s4 = fa.io.stats + (size_t)b * 4;
-            s4[0] = num_iter; s4[1] = ngen; s4[2] = num_validated; s4[3] = num_checks;
-        } else {
-            write_none(num_iter, ngen, num_validated, num_checks);
+        for (int off = kWave / 2; off > 0; off >>= 1) ngen += __shfl_xor(ngen, off, kWave);
+        if (lane == 0) {
+            if (best >= 0) {
+                const int q = (int)(order[best] >> 3);
+                const int i = q / nvt, rem = q - i * nvt, j = rem / nt, k = rem - j * nt;
+                int32_t* out = fa.io.best_ijk + (size_t)b * 3;
+                int32_t* pv = fa.io.prev_best_idx + (size_t)b * 3;
+                out[0] = i; out[1] = j; out[2] = k;
+                pv[0] = i; pv[1] = j; pv[2] = k;  // prev_best_idx persists across cycles (:140)
+                fa.io.best_cost[b] = fa.cost_tbl[(size_t)b * C + (size_t)(i * nt + k) * nv + j];
+                double* es = fa.io.end_state + (size_t)b * 3;
+                es[0] = bt.d_samples[i]; es[1] = bt.v_samples[(size_t)b * nv + j]; es[2] = bt.t_samples[k];
+                fa.io.refined[b] = 0;
+                int32_t* s4 = fa.io.stats + (size_t)b * 4;
+                s4[0] = num_iter; s4[1] = ngen; s4[2] = num_validated; s4[3] = num_checks;
+            } else {
+                write_none(num_iter, ngen, num_validated, num_checks);
+            }
+        }
+    };
+
+    // Jump scratch (the histogram's bytes, dead since T5): G / Q words after iteration 1, G / Q words after the jump, levels by rank.
+    uint32_t* jG1 = (uint32_t*)hist;
+    uint32_t* jG2 = jG1 + 64 * NW;
+    uint32_t* jQ2 = jG2 + 64 * NW;
+    uint16_t* lam = (uint16_t*)(jQ2 + 64 * NW);
+    int* s_j = (int*)(smem + 32);  // [0] state after iteration 1 (0 jump, 1 finished, 2 serial only) [1] its pop [2] beta [3..5] counts
+    if (wave == 0) {
+        const int st = iterate();
+        if (st != 0) finish();
+        if (lane == 0) {
+            s_j[0] = st != 0 ? 1 : ((fa.walk_jump && !start_nan) ? 0 : 2);
+            s_j[1] = last_pop;
+            s_j[2] = 0xFFFF;
+            s_j[3] = s_j[4] = s_j[5] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) jG1[lane + 64 * k] = G[k];
+    }
+    group_sync();
+    const int after_first = s_j[0];
+    if (after_first == 1) return;
+    if (after_first == 0) {
+        // ---- THE JUMP.  From the second iteration on the walk is a region growing: the head of the queue is the cheapest
+        // generated sample that was not validated yet, exploring it generates its neighbours, and whatever the descent over the
+        // frontier explores early costs no more than its centre.  So for any cost level: by the first iteration whose queue head
+        // costs at least that level, exactly the samples that are connected to the generated set by samples BELOW the level have
+        // been validated, they are all explored, nothing else is, and the frontier is empty - whatever the order was in which the
+        // walk took them.  With level(v) = the smallest level that connects v (the minimax path cost from the generated set:
+        // lam(v) = max(cost(v), min over neighbours lam(u)), a fixed point every lane relaxes for its own samples) and beta = the
+        // smallest level of a FEASIBLE sample, no feasible sample is validated before the walk's state is
+        //     validated = {first pop} + {lam < beta},  generated = generated + neighbourhood of {lam < beta},
+        //     queue = generated & finite - validated,  num_iter = num_validated = |validated|
+        // and the walk resumes there: typically the feasible sample IS the bottleneck and the next iteration ends the search.
+        // Costs are compared as tie-run ends (the frontier bound of the records), so a level never splits a run of equal costs.
+        // Not taken when the initial guess landed on a NaN cost: its first pop was validated without being explored.
+        for (int r = tid; r < C; r += T) {
+            const uint32_t w3 = REC[r].w;
+            const bool seeded = (jG1[r >> 5] >> (r & 31)) & 1u;
+            lam[r] = (uint16_t)((seeded && r < nfin) ? (w3 & 0xFFFFu) : 0xFFFFu);
+        }
+        group_sync();
+        for (;;) {
+            int changed = 0;
+            for (int r = tid; r < nfin; r += T) {
+                const uint32_t cur = lam[r];
+                const uint4 rec = REC[r];
+                const uint32_t lev = rec.w & 0xFFFFu;
+                if (cur == lev) continue;  // at its floor
+                const uint32_t n[6] = {rec.x & 0xFFFFu, rec.x >> 16, rec.y & 0xFFFFu, rec.y >> 16, rec.z & 0xFFFFu, rec.z >> 16};
+                uint32_t mn = 0xFFFFu;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const uint32_t v = lam[n[e] < (uint32_t)C ? n[e] : r];
+                    mn = v < mn ? v : mn;
+                }
+                const uint32_t v = mn > lev ? mn : lev;
+                if (v < cur) { lam[r] = (uint16_t)v; changed = 1; }
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+        {   // beta: the smallest level of a feasible sample
+            uint32_t mine = 0xFFFFu;
+            for (int r = tid; r < nfin; r += T)
+                if (((REC[r].w >> 16) & (kPayCfail | kPayColl)) == 0u) { const uint32_t v = lam[r]; mine = v < mine ? v : mine; }
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mine, off, kWave); mine = o < mine ? o : mine; }
+            if (lane == 0) atomicMin(&s_j[2], (int)mine);
+        }
+        group_sync();
+        const uint32_t beta = (uint32_t)s_j[2];
+        const int first_pop = s_j[1];
+        int n_pop = 0, n_chk = 0, n_gen = 0;
+        for (int r0 = wave * kWave; r0 < ((C + kWave - 1) & ~(kWave - 1)); r0 += T) {  // whole wavefronts: the words come from ballots
+            const int r = r0 + lane;
+            bool gen = false, pop = false, ok = false;
+            if (r < C) {
+                const uint4 rec = REC[r];
+                const bool in_r = r < nfin && lam[r] < beta;
+                const uint32_t n[6] = {rec.x & 0xFFFFu, rec.x >> 16, rec.y & 0xFFFFu, rec.y >> 16, rec.z & 0xFFFFu, rec.z >> 16};
+                bool near = false;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) near |= n[e] < (uint32_t)nfin && lam[n[e]] < beta;
+                gen = in_r || near || ((jG1[r >> 5] >> (r & 31)) & 1u);
+                pop = in_r || r == first_pop;
+                ok = !((rec.w >> 16) & kPayCfail);
+            }
+            const unsigned long long bg = __ballot(gen), bp = __ballot(pop), bc = __ballot(pop && ok);
+            const unsigned long long bq2 = __ballot(gen && !pop && r < nfin);
+            if (lane == 0) {
+                jG2[r0 >> 5] = (uint32_t)bg; jG2[(r0 >> 5) + 1] = (uint32_t)(bg >> 32);
+                jQ2[r0 >> 5] = (uint32_t)bq2; jQ2[(r0 >> 5) + 1] = (uint32_t)(bq2 >> 32);
+            }
+            n_pop += __popcll(bp); n_chk += __popcll(bc); n_gen += __popcll(bg);
+        }
+        if (lane == 0) { atomicAdd(&s_j[3], n_pop); atomicAdd(&s_j[4], n_chk); atomicAdd(&s_j[5], n_gen); }
+        group_sync();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int widx = lane + 64 * k;
+                const bool have = (widx << 5) < ((C + kWave - 1) & ~(kWave - 1));
+                G[k] = have ? jG2[widx] : 0u;
+                Q[k] = have ? jQ2[widx] : 0u;
+                Fr[k] = 0u;
+            }
+            num_iter = num_validated = s_j[3];
+            num_checks = s_j[4];
+            ngen = lane == 0 ? s_j[5] : 0;
+            rs = lowest_rank<NW>(Q);
         }
     }
+    if (wave != 0) return;
+    int st;
+    do { st = iterate(); } while (st == 0);
+    finish();
 }
 
 namespace {
@@ -430,7 +553,10 @@ int fissplus_lds_bytes(int C, int NB)
 {
     const int C32 = C + (C >> 5) + 1;
     const int C8 = (C + 7) & ~7;
-    return 128 + 8 * ((C32 + 1) & ~1) + 16 * C8 + 3 * 2 * C8 + 4 * 2 * (NB + 2) + 16;
+    const int NW = C <= 2048 ? 1 : 2;
+    const int sort_scratch = 4 * 2 * (NB + 2);                 // histogram + cursors
+    const int jump_scratch = 3 * 4 * 64 * NW + 2 * C8;         // three word arrays + the levels (they reuse the sort's bytes)
+    return 128 + 8 * ((C32 + 1) & ~1) + 16 * C8 + 3 * 2 * C8 + (sort_scratch > jump_scratch ? sort_scratch : jump_scratch) + 16;
 }
 }  // namespace
 

@@ -45,6 +45,7 @@ struct FissArgs {
     fp_fiss_io io;
     const double* cost_tbl;    // [B][C] flat FOP order
     const uint32_t* flag_tbl;  // [B][C]
+    int walk_jump = 1;         // FISS+ walk: skip the iterations below the first feasible sample's minimax level (frenet_fissplus.hip)
 };
 
 // One wavefront per ego: coarse FISS / FISS+ search over the dense tables.

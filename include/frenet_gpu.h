@@ -163,6 +163,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "lattice_winner": who writes fp_plan_dense's best_traj: 0 = auto (the lattice kernel itself while one round of workgroups
  * holds the batch, winner_traj_kernel right behind it for bigger batches), 1 = always the lattice kernel, 2 = always its own
  * launch.  Identical results.
+ * "fiss_jump": 1 (default) = the FISS+ search walk runs its first iteration, then jumps to the state the reference's walk has
+ * when the first feasible sample becomes reachable (minimax cost level, computed in parallel) and resumes there; 0 = every
+ * iteration one after the other.  Identical results and Stats.
  * "fiss_stages": timing diagnostic of fp_plan_fiss, 3 (default) = the whole pipeline, 2 = stop after the search walk (no
  * refinement), 1 = stop after the dense lattice pass; with 1 or 2 the outputs of the skipped stages are NOT produced. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);

@@ -138,3 +138,34 @@ def test_refinement_collision_paths_match_oracle(oracle, engine, table_kb, shift
             n_refined += int(r.refined)
             np.testing.assert_allclose(out.end_state[e], r.end_state, rtol=0, atol=1e-9)
     assert n_refined > 0
+
+
+@pytest.mark.parametrize("cfg", [dict(B=384, nd=9, nv=9, nt=7, n_obs=50, T_obs=50, moving=True, seed=2304, layout="lanes"),
+                                 dict(B=256, nd=9, nv=9, nt=7, n_obs=50, T_obs=50, moving=True, seed=61, layout="survey8d"),
+                                 dict(B=64, nd=5, nv=5, nt=5, n_obs=10, T_obs=100, moving=False, seed=62, layout="lanes"),
+                                 dict(B=24, nd=7, nv=7, nt=7, n_obs=30, T_obs=50, moving=True, seed=63, layout="survey8d"),
+                                 dict(B=4, nd=16, nv=16, nt=16, n_obs=12, T_obs=50, moving=True, seed=64, layout="survey8d")])
+def test_search_jump_changes_nothing_but_speed(engine, cfg):
+    """The FISS+ walk with and without the jump to the first feasible sample's minimax level (frenet_fissplus.hip): the selected
+    index, all four Stats, prev_best_idx and everything downstream are identical - with and without a history term."""
+    b = synth.make_batch(cfg["B"], cfg["nd"], cfg["nv"], cfg["nt"], cfg["n_obs"], cfg["T_obs"], cfg["moving"], cfg["seed"], kind="FISS+",
+                         layout=cfg["layout"])
+    rng = np.random.default_rng(cfg["seed"])
+    prev = np.where(rng.uniform(size=(b.B, 1)) < 0.5, -1, np.column_stack([rng.integers(0, b.nd, b.B), rng.integers(0, b.nv, b.B),
+                                                                          rng.integers(0, b.nt, b.B)])).astype(np.int32)
+    outs = []
+    for jump in (1, 0):
+        engine.set_option("fiss_jump", jump)
+        try:
+            outs.append(engine.plan_fiss(b, "FISS+", prev_best_idx=prev, trace=True))
+        finally:
+            engine.set_option("fiss_jump", 1)
+    a, c = outs
+    np.testing.assert_array_equal(a.stats, c.stats)
+    np.testing.assert_array_equal(a.best_ijk, c.best_ijk)
+    np.testing.assert_array_equal(a.prev_best_idx, c.prev_best_idx)
+    np.testing.assert_array_equal(a.refined, c.refined)
+    np.testing.assert_array_equal(a.best_cost, c.best_cost)
+    np.testing.assert_array_equal(a.end_state, c.end_state)
+    walked = a.stats[:, 0]
+    assert (walked > 50).sum() >= 1 or cfg["B"] < 32  # the batch holds walks the jump shortens
