@@ -14,9 +14,16 @@ One "step" = one full pass of the hot path over the batch: lattice generation + 
 acceleration masks + OBB collision + per-ego argmin + the winner's series, inputs resident in HBM, results (best index /
 cost per ego) copied to pinned host memory.
 
+The synthetic scenes come from SURVEY.md section 8(d)'s generator verbatim (`--layout survey8d`, synth.py), and the timed
+region cycles through `--rotate` (default 4) DISTINCT batches of that generator, so no launch ever sees the batch the
+feedback-directed launch order was learnt on.
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`; at N = 1 the line
-also carries the other single-GPU configurations (`config2`, `config4`), the index-order and rotating-batch variants of
-the headline workload, and the SURVEY 8d obstacle layout.
+also carries the other single-GPU configurations (`config2`, `config4`), the index-order and single-batch variants of the
+headline workload, the builder's `lanes` obstacle layout, the device-resident closed loop (`closed_loop`) and the
+PCIe-inclusive host-buffer entry (`host_buffers`).  EVERY leg that prints a number carries a `parity` object: its outputs
+were compared with the CPU oracle in this run (index / Stats exact, cost <= 1e-6) and a mismatch aborts before anything
+is printed.
 """
 from __future__ import annotations
 
@@ -53,7 +60,8 @@ def parse():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="BASELINE.json configs[N-1]; default: 3 on one GPU, 5 (the sharded 16384-ego batch) on several; "
                          "4 = the FISS+ pipeline (dense tables + search walk + 3 refinement rounds)")
-    ap.add_argument("--layout", default="lanes", choices=["lanes", "survey8d"], help="obstacle layout of the synthetic scenes (synth.py)")
+    ap.add_argument("--layout", default="survey8d", choices=["lanes", "survey8d"], help="obstacle layout of the synthetic scenes (synth.py): SURVEY 8d verbatim, or the builder's lanes layout")
+    ap.add_argument("--rotate", type=int, default=4, help="distinct batches cycled through in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--tables", action="store_true", help="also write the dense cost/flag tables (materialised mode)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-ego plan-cycle latency leg (configs[0]) and the materialise leg")
@@ -213,32 +221,231 @@ def load_profile_json(name):
         return None
 
 
-def cpu_baseline_leg(batch, h_idx, h_cost, seconds, threads, gate):
-    """The oracle (plain-C restatement, OpenMP over egos) on a bounded sample of the same egos.  gate: its indices / costs must
-    equal the GPU's (index exact, cost <= 1e-6) or the bench aborts before printing anything."""
+def materialize_leg(torch, eng, main_wl, dev, stream):
+    from fiss_plus_planner_amd.engine import device_batch
+
+    batch = main_wl.batch
+    B, C = batch.B, batch.C
+    Bm = min(B, 256)
+    fbm = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in main_wl.dten.items()})
+    fbm.B = Bm
+    m_flags = torch.empty(Bm * C, dtype=torch.int32, device=dev)
+    materialize = {"kernel": "winner_traj_kernel (all candidates)", "egos": Bm, "bound": "hbm", "peak_GBps": HBM_PEAK_GBS}
+    # two layouts of the same payload: the compact one (rows of ceil(max T / tick) columns, only existing elements written) and
+    # the round-1 layout (16 x 128 NaN-padded block per candidate).  Every launch writes into a FRESH allocation (the spread over
+    # buffer placements is part of the measurement); median and maximum are both reported.
+    n_launch = 30
+    for label, m_stride, m_sparse in (("compact", main_wl.traj_stride, True), ("padded128", 128, False)):
+        kw = dict(stream=stream.cuda_stream, traj_stride=m_stride, traj_sparse=m_sparse)
+        m_all = []
+        for it in range(n_launch + 2):
+            m_traj = torch.empty((Bm * C, 16, m_stride), dtype=torch.float64, device=dev)
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            eng.materialize_all_device(main_wl.params, fbm, m_flags.data_ptr(), m_traj.data_ptr(), **kw)
+            b_.record(stream)
+            torch.cuda.synchronize(dev)
+            if it >= 2:
+                m_all.append(a.elapsed_time(b_))
+            if it % 3 == 2:
+                keep = m_traj  # noqa: F841  (holding every third buffer moves the following allocations)
+            else:
+                del m_traj
+        m_ms = float(np.median(m_all))
+        fl_m = m_flags.cpu().numpy().view(np.uint32)
+        alg = series_bytes(fl_m) + 4 * Bm * C
+        written = (series_bytes(fl_m, lines=True) + 4 * Bm * C) if m_sparse else Bm * C * (16 * m_stride * 8 + 4)
+        materialize[label] = {"kernel_ms": m_ms, "kernel_ms_min": float(np.min(m_all)), "kernel_ms_max": float(np.max(m_all)),
+                              "spread": float((np.max(m_all) - np.min(m_all)) / m_ms), "launches_timed": len(m_all),
+                              "candidates_per_s": Bm * C / (m_ms * 1e-3), "bytes_written_per_launch": written,
+                              "algorithmic_bytes_per_launch": alg, "achieved_GBps": written / (m_ms * 1e-3) / 1e9,
+                              "algorithmic_GBps": alg / (m_ms * 1e-3) / 1e9, "frac": written / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_over_written": alg / written}
+        keep = None
+    del m_flags
+    return materialize
+
+
+COST_TOL = 1e-6  # BASELINE.json north_star: costs within 1e-6, selected index exact
+
+
+def parity_fail(leg, what):
+    raise SystemExit(f"PARITY FAILURE ({leg}): {what}")
+
+
+def fop_parity(leg, batch, egos, g_idx, g_cost, threads):
+    """FOP outputs of `egos` against the oracle: selected index exact, cost <= 1e-6.  -> the leg's `parity` object."""
+    from oracle import oracle as O
+
+    egos = np.asarray(egos)
+    o_idx, o_cost = O.fop_plan_batch(O.problems_from_batch(batch, egos), threads=threads)
+    if not np.array_equal(g_idx[egos], o_idx):
+        parity_fail(leg, f"selected index differs on egos {egos[np.nonzero(g_idx[egos] != o_idx)[0][:8]].tolist()}")
+    ok = o_idx >= 0
+    err = float(np.abs(g_cost[egos][ok] - o_cost[ok]).max()) if ok.any() else 0.0
+    if not err <= COST_TOL:
+        parity_fail(leg, f"best cost differs by {err:.3e}")
+    return {"checked_egos": int(len(egos)), "index_exact": True, "max_abs_cost_err": err, "cost_tolerance": COST_TOL,
+            "egos_with_a_winner": int(ok.sum()), "oracle": "oracle/libfrenet_oracle.so orc_fop_plan"}
+
+
+def fiss_parity(leg, wl, egos):
+    """FISS+ pipeline outputs (coarse index, refined yes/no, end state, cost, all four Stats) of `egos` against the oracle."""
+    from oracle import oracle as O
+
+    egos = np.asarray(egos)
+    ijk, refined = wl.ijk.cpu().numpy(), wl.best_idx.cpu().numpy()
+    cost, stats, end = wl.best_cost.cpu().numpy(), wl.stats.cpu().numpy(), wl.end_state.cpu().numpy()
+    err = 0.0
+    n_found = n_refined = 0
+    for e, pr in zip(egos, O.problems_from_batch(wl.batch, egos)):
+        r = pr.fissplus_plan(None)
+        found = not np.isnan(r.best_cost)
+        if not np.array_equal(stats[e], r.stats):
+            parity_fail(leg, f"Stats differ on ego {e}: {stats[e].tolist()} vs {r.stats.tolist()}")
+        if (not np.isnan(cost[e])) != found:
+            parity_fail(leg, f"found / not found differs on ego {e}")
+        if not found:
+            continue
+        n_found += 1
+        if bool(refined[e]) != r.refined:
+            parity_fail(leg, f"refined flag differs on ego {e}")
+        n_refined += int(r.refined)
+        if not r.refined and not np.array_equal(ijk[e], r.best_ijk):
+            parity_fail(leg, f"coarse index differs on ego {e}")
+        err = max(err, abs(cost[e] - r.best_cost), float(np.abs(end[e] - r.end_state).max()))
+    if not err <= COST_TOL:
+        parity_fail(leg, f"cost / end state differ by {err:.3e}")
+    return {"checked_egos": int(len(egos)), "index_exact": True, "stats_exact": True, "refined_exact": True, "max_abs_cost_err": err,
+            "cost_tolerance": COST_TOL, "egos_with_a_winner": n_found, "of_them_refined": n_refined,
+            "oracle": "oracle/libfrenet_oracle.so orc_fissplus_plan"}
+
+
+def host_info():
+    """What the CPU baseline ran on: the affinity mask says how many CPUs the process MAY use, the cgroup quota how much CPU
+    time it actually gets."""
+    info = {"affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "os_cpu_count": os.cpu_count()}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_" + os.path.basename(path)] = open(path).read().strip()
+        except OSError:
+            pass
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        info["cpu_model"] = model[0] if model else None
+    except OSError:
+        pass
+    return info
+
+
+def cpu_rate(batch, egos, threads):
+    from oracle import oracle as O
+
+    probs = O.problems_from_batch(batch, egos)
+    t0 = time.perf_counter()
+    o_idx, o_cost = O.fop_plan_batch(probs, threads=threads)
+    dt = time.perf_counter() - t0
+    return len(probs) * batch.C / dt, dt, o_idx, o_cost
+
+
+def cpu_baseline_leg(batch, h_idx, h_cost, seconds, max_threads):
+    """The oracle (plain-C restatement, OpenMP over egos, per-thread scratch) on a bounded sample of the same egos.
+    A short sweep over thread counts first: the reported all-core figure uses the count that was FASTEST, and the sweep is in
+    the line (an affinity mask of 256 CPUs does not mean 256 CPUs' worth of quota).  Its indices / costs gate the GPU's."""
     from oracle import oracle as O
 
     O.build()
     B, C = batch.B, batch.C
-    probe = O.problems_from_batch(batch, range(min(2 * threads, 16, B)))
-    t0 = time.perf_counter()
-    O.fop_plan_batch(probe, threads=threads)
-    per_ego = (time.perf_counter() - t0) / len(probe)
-    n_s = int(max(min(16, B), min(B, seconds / max(per_ego, 1e-6))))
-    probs = O.problems_from_batch(batch, range(n_s))
-    t0 = time.perf_counter()
-    o_idx, o_cost = O.fop_plan_batch(probs, threads=threads)
-    dt = time.perf_counter() - t0
-    if gate:
-        g_idx, g_cost = h_idx[:n_s], h_cost[:n_s]
-        if not np.array_equal(g_idx, o_idx):
-            raise SystemExit(f"PARITY FAILURE: selected index differs on egos {np.nonzero(g_idx != o_idx)[0][:8].tolist()}")
+    cpu_rate(batch, range(min(8, B)), 1)  # page the library in
+    rate1, dt1, _, _ = cpu_rate(batch, range(min(8, B)), 1)
+    sweep = {1: rate1}
+    t = 2
+    cand = []
+    while t < max_threads:
+        cand.append(t)
+        t *= 2
+    cand.append(max_threads)
+    for t in cand:
+        n = min(B, max(2 * t, 16))
+        sweep[t] = cpu_rate(batch, range(n), t)[0]
+    best_t = max(sweep, key=lambda k: sweep[k])
+    out = {}
+    for label, threads, secs in (("cpu_baseline", best_t, seconds), ("cpu_baseline_1thread", 1, min(6.0, seconds))):
+        n_s = int(max(min(16, B), min(B, secs * sweep[threads] / C)))
+        rate, dt, o_idx, o_cost = cpu_rate(batch, range(n_s), threads)
+        if not np.array_equal(h_idx[:n_s], o_idx):
+            parity_fail(label, f"selected index differs on egos {np.nonzero(h_idx[:n_s] != o_idx)[0][:8].tolist()}")
         ok = o_idx >= 0
-        if ok.any() and np.abs(g_cost[ok] - o_cost[ok]).max() > 1e-6:
-            raise SystemExit("PARITY FAILURE: best cost differs by more than 1e-6")
-    return {"value": n_s * C / dt, "unit": "candidates/s", "cores": threads, "kind": "port",
-            "sample": f"first {n_s} egos of the same batch ({n_s * C} candidates), oracle/libfrenet_oracle.so, {threads} OpenMP thread(s) over egos, "
-                      f"{dt:.1f} s" + ("; GPU index/cost parity checked on this sample" if gate else "")}
+        err = float(np.abs(h_cost[:n_s][ok] - o_cost[ok]).max()) if ok.any() else 0.0
+        if not err <= COST_TOL:
+            parity_fail(label, f"best cost differs by {err:.3e}")
+        out[label] = {"value": rate, "unit": "candidates/s", "cores": threads, "kind": "port",
+                      "sample": f"first {n_s} egos of the first timed batch ({n_s * C} candidates), oracle/libfrenet_oracle.so (literal "
+                                f"restatement: pow() per term, point-by-point sums, polygon SAT), {threads} OpenMP thread(s) over egos, {dt:.1f} s; "
+                                f"GPU index / cost parity checked on this sample",
+                      "parity": {"checked_egos": n_s, "index_exact": True, "max_abs_cost_err": err, "cost_tolerance": COST_TOL}}
+    out["cpu_baseline"]["thread_sweep"] = {str(k): v for k, v in sorted(sweep.items())}
+    out["cpu_baseline"]["host"] = host_info()
+    return out
+
+
+def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads):
+    """north_star's workload is "many scenarios x many cycles": B egos stepped `cycles` plan cycles entirely on the device
+    ([plan -> advance] per cycle, planners/benchmark/planning.py:120-162; no host round trip).  Parity: the state the loop left
+    behind is planned once more and compared with the oracle planning the same states."""
+    from fiss_plus_planner_amd import synth
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+    from oracle import oracle as O
+
+    out = {"egos": B, "cycles": cycles, "unit": "ego-plans/s",
+           "workload": f"{B} egos x {cycles} device-resident plan cycles (fp_plan_* + fp_advance per cycle, results stay in HBM), configs[2] scenes"}
+    for planner, cfg in (("FOP", 3), ("FISS+", 4)):
+        batch = synth.make_config(cfg, B=B, layout=layout)
+        goal = np.full((B, 2), 1e9)  # never reached: an ego runs until the map ends or no candidate survives
+        run = ClosedLoopRunner(eng, DeviceBatch(batch, dev.index), goal, planner)
+        run.run(2)
+        # restart from the initial states for the timed loop
+        run.db.t["ego"].copy_(torch.from_numpy(batch.ego)); run.db.t["t_now"].zero_(); run.done.zero_(); run.cycles.zero_()
+        if planner != "FOP":
+            run.prev.fill_(-1)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        res = run.run(cycles - 1)
+        dt = time.perf_counter() - t0
+        plans = int(res.cycles.sum() + (res.done == 2).sum())  # an ego's last plan may have found nothing (FP_DONE_NO_SOLUTION)
+        # parity of the state the loop left behind: one more plan (no advance) of the running egos vs the oracle on those states
+        running = np.nonzero(res.done == 0)[0]
+        egos = running[:: max(1, len(running) // 48)][:48]
+        snap = synth.make_config(cfg, B=B, layout=layout)
+        snap.ego[:] = res.ego
+        snap.t_now[:] = res.t_now
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if planner == "FOP":
+            eng.plan_dense_device(run.db.params, run.db.fb, run.best_idx.data_ptr(), run.best_cost.data_ptr(), run.stats.data_ptr(), stream=stream)
+            torch.cuda.synchronize(dev)
+            par = fop_parity(f"closed_loop {planner}", snap, egos, run.best_idx.cpu().numpy(), run.best_cost.cpu().numpy(), threads) if len(egos) else None
+        else:
+            prev = run.prev.cpu().numpy().copy()
+            eng.plan_fiss_device(run.db.params, run.db.fb, run.fopts, run.fio, stream=stream)
+            torch.cuda.synchronize(dev)
+            cost, stats = run.best_cost.cpu().numpy(), run.stats.cpu().numpy()
+            err = 0.0
+            for e, pr in zip(egos, O.problems_from_batch(snap, egos)):
+                r = pr.fissplus_plan(None if prev[e, 0] < 0 else prev[e])
+                if not np.array_equal(stats[e], r.stats):
+                    parity_fail("closed_loop FISS+", f"Stats differ on ego {e} after {cycles - 1} cycles")
+                if np.isnan(r.best_cost) != np.isnan(cost[e]):
+                    parity_fail("closed_loop FISS+", f"found / not found differs on ego {e}")
+                if not np.isnan(r.best_cost):
+                    err = max(err, abs(cost[e] - r.best_cost))
+            if not err <= COST_TOL:
+                parity_fail("closed_loop FISS+", f"cost differs by {err:.3e}")
+            par = {"checked_egos": int(len(egos)), "stats_exact": True, "max_abs_cost_err": err, "cost_tolerance": COST_TOL,
+                   "oracle": "orc_fissplus_plan on the device loop's states and prev_best_idx"} if len(egos) else None
+        out[planner] = {"value": plans / dt, "ego_plans": plans, "seconds": dt, "us_per_cycle": dt / (cycles - 1) * 1e6,
+                        "egos_still_running": int(len(running)), "candidates_per_s": plans * batch.C / dt, "parity": par}
+        del run
+    return out
 
 
 def main():
@@ -275,16 +482,20 @@ def main():
     from fiss_plus_planner_amd import synth
     from fiss_plus_planner_amd.engine import FrenetEngine
 
-    # ---- this rank's shard, generated directly (every ego has its own RNG stream)
+    # ---- this rank's shards, generated directly (every ego has its own RNG stream): batch k of the rotation holds egos
+    # [(k * world + rank) * B, +B) of the generator's stream - at k = 0 that is rank r's slice of the 16384-ego config-5 batch
     fiss = config == 4
-    batch = synth.make_config(config, B=args.egos, ego_offset=rank * args.egos, layout=args.layout)
+    n_rot = max(1, args.rotate)
     dev = torch.device("cuda", local_rank)
-    B, C = batch.B, batch.C
     eng = FrenetEngine(local_rank)
     for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(",")):  # diagnostic: "name=value,..." -> fp_ctx_set_option
         eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     stream = torch.cuda.current_stream(dev)
-    main_wl = Workload(torch, eng, batch, dev, stream, fiss=fiss, tables=args.tables)
+    wls = [Workload(torch, eng, synth.make_config(config, B=args.egos, ego_offset=(k * world + rank) * args.egos, layout=args.layout), dev, stream,
+                    fiss=fiss, tables=args.tables) for k in range(n_rot)]
+    main_wl = wls[0]
+    batch = main_wl.batch
+    B, C = batch.B, batch.C
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -292,22 +503,31 @@ def main():
             dist.barrier()
 
     # ---- timed region (the contract: W warm-up steps, exactly K timed steps between barrier + synchronize)
-    elapsed, kern_list = timed_run(torch, [main_wl], args.steps, args.warmup, stream, barrier)
+    elapsed, kern_list = timed_run(torch, wls, args.steps, args.warmup, stream, barrier)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean(kern_list))
     solo = rank == 0 and world == 1
+    threads_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    gate_threads = min(threads_all, 64)
 
-    # ---- parity gate + CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same egos.
-    # Runs AFTER the timed region (libgomp workers spin after a parallel region and would steal the launch thread's core);
-    # a parity failure aborts before anything is printed.
-    cpu_baseline = cpu_1t = None
-    if solo and args.cpu_seconds > 0 and not fiss:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        cpu_baseline = cpu_baseline_leg(batch, main_wl.h_idx.numpy(), main_wl.h_cost.numpy(), args.cpu_seconds, cores, gate=True)
-        cpu_1t = cpu_baseline_leg(batch, main_wl.h_idx.numpy(), main_wl.h_cost.numpy(), min(6.0, args.cpu_seconds), 1, gate=True)
+    # ---- parity gates + CPU baseline (rank 0, N=1 only), AFTER the timed region (libgomp workers spin after a parallel region
+    # and would steal the launch thread's core); any mismatch aborts before anything is printed.
+    for w in wls:  # every batch of the rotation leaves the results of its last step behind
+        w.step(); w.fetch()
+    torch.cuda.synchronize(dev)
+    cpu = {}
+    parity_main = None
+    if solo and args.cpu_seconds > 0:
+        if fiss:
+            parity_main = {"batches": [fiss_parity(f"main batch {k}", w, np.arange(0, B, max(1, B // (64 if k == 0 else 16)))) for k, w in enumerate(wls)]}
+        else:
+            cpu = cpu_baseline_leg(batch, main_wl.h_idx.numpy(), main_wl.h_cost.numpy(), args.cpu_seconds, threads_all)
+            parity_main = {"batches": [dict(cpu["cpu_baseline"]["parity"], note="the cpu_baseline sample")] +
+                                      [fop_parity(f"main batch {k}", w.batch, np.arange(0, B, max(1, B // 64)), w.h_idx.numpy(), w.h_cost.numpy(), gate_threads)
+                                       for k, w in enumerate(wls) if k > 0]}
 
     # ---- plan-cycle latency (rank 0, N=1): BASELINE configs[0] - single ego, FOP 5x5x5, DEU_Flensburg-1_1_T-1 closed loop,
     # timed around plan() exactly where the reference times it (planners/benchmark/planning.py:124-128).  Inputs are the
@@ -331,82 +551,63 @@ def main():
             pl = cls(st(5, 5, 5), Vehicle(), None, engine=eng)
             res = run_closed_loop(pl, g["centerline"], g["init_state"], table, g["goal_center"])
             ms = res.plan_seconds * 1e3
-            plan_cycle[kind] = {"p50": float(np.median(ms)), "p90": float(np.percentile(ms, 90)), "cycles": len(ms)}
+            # parity: the per-cycle costs of the reference's own closed loop on this scenario (fixture G5, generated by running the reference)
+            rows = g[f"{kind}_rows"]
+            costs = np.array([c.cost for c in res.cycles])
+            n = min(len(rows), len(costs))
+            err = float(np.abs(costs[:n] - rows[:n, 6]).max()) if n else 0.0
+            if len(costs) != len(rows) or not err <= COST_TOL:
+                parity_fail(f"plan_cycle_latency {kind}", f"{len(costs)} cycles vs {len(rows)}, cost err {err:.3e}")
+            par = {"checked_cycles": n, "max_abs_cost_err": err, "cost_tolerance": COST_TOL,
+                   "reference": "tests/golden/g5_closed_loop.npz: the imported reference's own closed loop on this scenario"}
+            plan_cycle[kind] = {"p50": float(np.median(ms)), "p90": float(np.percentile(ms, 90)), "cycles": len(ms), "parity": par}
 
     # ---- materialise mode (rank 0, N=1): the one HBM-bound mode of the path - every candidate's full series written out
     # (fp_materialize_all = the reference's all_trajs payload).  256 egos of the same batch: 2.4 GB per launch.
     materialize = None
     if solo and not args.no_latency and not fiss:
-        from fiss_plus_planner_amd.engine import device_batch
-
-        Bm = min(B, 256)
-        fbm = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in main_wl.dten.items()})
-        fbm.B = Bm
-        m_flags = torch.empty(Bm * C, dtype=torch.int32, device=dev)
-        materialize = {"kernel": "winner_traj_kernel (all candidates)", "egos": Bm, "bound": "hbm", "peak_GBps": HBM_PEAK_GBS}
-        # two layouts of the same payload: the compact one (rows of ceil(max T / tick) columns, only existing elements written) and
-        # the round-1 layout (16 x 128 NaN-padded block per candidate)
-        for label, m_stride, m_sparse in (("compact", main_wl.traj_stride, True), ("padded128", 128, False)):
-            m_traj = torch.empty((Bm * C, 16, m_stride), dtype=torch.float64, device=dev)
-            kw = dict(stream=stream.cuda_stream, traj_stride=m_stride, traj_sparse=m_sparse)
-            for _ in range(2):
-                eng.materialize_all_device(main_wl.params, fbm, m_flags.data_ptr(), m_traj.data_ptr(), **kw)
-            mev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(11)]
-            for a, b_ in mev:
-                a.record(stream)
-                eng.materialize_all_device(main_wl.params, fbm, m_flags.data_ptr(), m_traj.data_ptr(), **kw)
-                b_.record(stream)
-            torch.cuda.synchronize(dev)
-            m_all = [a.elapsed_time(b_) for a, b_ in mev]
-            m_ms = float(np.median(m_all))
-            fl_m = m_flags.cpu().numpy().view(np.uint32)
-            alg = series_bytes(fl_m) + 4 * Bm * C
-            written = (series_bytes(fl_m, lines=True) + 4 * Bm * C) if m_sparse else Bm * C * (16 * m_stride * 8 + 4)
-            materialize[label] = {"kernel_ms": m_ms, "kernel_ms_min": float(np.min(m_all)), "launches_timed": len(m_all), "candidates_per_s": Bm * C / (m_ms * 1e-3), "bytes_written_per_launch": written,
-                                  "algorithmic_bytes_per_launch": alg, "achieved_GBps": written / (m_ms * 1e-3) / 1e9,
-                                  "algorithmic_GBps": alg / (m_ms * 1e-3) / 1e9, "frac": written / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "algorithmic_over_written": alg / written}
-            del m_traj
-        del m_flags
+        materialize = materialize_leg(torch, eng, main_wl, dev, stream)
 
     # ---- the other single-GPU configurations and variants of the headline workload (rank 0, N=1), each timed like the main run
     extras = {}
     if solo and not args.no_extras and not fiss and config == 3:
         steps_x, warm_x = min(args.steps, 50), min(args.warmup, 5)
 
-        def measure(wls, label_kernel, ev_every=None):
-            el, kl = timed_run(torch, wls, steps_x, warm_x, stream, barrier, ev_every)
+        def measure(ws, label_kernel, ev_every=None):
+            el, kl = timed_run(torch, ws, steps_x, warm_x, stream, barrier, ev_every)
             k_ms = float(np.mean(kl))
-            cand = sum(w.candidates for w in wls) / len(wls)
-            bytes_l = float(np.mean([w.algorithmic_bytes() for w in wls]))
+            cand = sum(w.candidates for w in ws) / len(ws)
+            bytes_l = float(np.mean([w.algorithmic_bytes() for w in ws]))
             return {"value": cand * steps_x / el, "unit": "candidates/s", "ms_per_step": el / steps_x * 1e3, "steps": steps_x, "warmup": warm_x,
                     "roofline": roofline_obj(bytes_l, k_ms, label_kernel)}
 
-        # (a) index order: the same launches without the feedback-directed launch order
-        ordered = eng.get_option("lattice_ordered_launches")
-        launches = eng.get_option("lattice_launches")
+        def gate(leg, w, n):
+            w.step(); w.fetch(); torch.cuda.synchronize(dev)
+            return fop_parity(leg, w.batch, np.arange(0, w.batch.B, max(1, w.batch.B // n)), w.h_idx.numpy(), w.h_cost.numpy(), gate_threads)
+
+        if args.cpu_seconds <= 0:
+            gate = lambda leg, w, n: None  # noqa: E731  (--cpu-seconds 0: profiling runs, no oracle in the process)
+        # (a) one batch replayed (the best case for the feedback-directed launch order) and the same in index order
+        ordered, launches = eng.get_option("lattice_ordered_launches"), eng.get_option("lattice_launches")
+        extras["single_batch_replayed"] = dict(measure([main_wl], "lattice_fused_kernel, one batch replayed: launch order learnt on the batch itself"),
+                                               parity=gate("single_batch_replayed", main_wl, 64))
         eng.set_option("lattice_order", 0)
-        extras["lattice_order_off"] = measure([main_wl], "lattice_fused_kernel, workgroups dispatched in ego index order")
+        extras["lattice_order_off"] = dict(measure(wls, "lattice_fused_kernel, workgroups dispatched in ego index order"),
+                                           parity=gate("lattice_order_off", wls[-1], 64))
         eng.set_option("lattice_order", 1)
         extras["lattice_order_on"] = {"launches_of_the_main_run": launches, "of_them_in_feedback_order": ordered,
-                                      "note": "the main run replays one batch, the best case for the order predictor; lattice_order_off and "
-                                              "rotating_batches are the other two points"}
-        # (b) rotating batches: 4 distinct 2048-ego batches cycled, feedback order on (it is keyed on the batch size only, so every
-        # launch is dispatched in the order of an EARLIER, different batch)
-        rot = [main_wl] + [Workload(torch, eng, synth.make_config(3, B=B, ego_offset=(i + 1) * B, layout=args.layout), dev, stream) for i in range(3)]
-        extras["rotating_batches"] = dict(measure(rot, "lattice_fused_kernel, 4 distinct batches cycled (stale feedback order)"),
-                                          batches=len(rot), egos_per_batch=B)
-        del rot
-        # (c) BASELINE configs[1]: 256 egos x 5x5x5 x 10 static obstacles
-        b2 = synth.make_config(2)
+                                      "note": f"the main run cycles {n_rot} distinct batches, so an order is always one learnt on a DIFFERENT batch"}
+        # (b) BASELINE configs[1]: 256 egos x 5x5x5 x 10 static obstacles; parity on ALL egos
+        b2 = synth.make_config(2, layout=args.layout)
         w2 = Workload(torch, eng, b2, dev, stream)
         extras["config2"] = dict(measure([w2], "lattice_fused_kernel (latency mode: slices of an ego spread over workgroups)"),
-                                 workload=f"BASELINE.json configs[1]: {b2.B} egos x 5x5x5 lattice ({b2.C} cand/ego), {b2.n_obs} static obstacles, T_obs={b2.T_obs}")
+                                 workload=f"BASELINE.json configs[1]: {b2.B} egos x 5x5x5 lattice ({b2.C} cand/ego), {b2.n_obs} static obstacles, T_obs={b2.T_obs}",
+                                 parity=gate("config2", w2, b2.B))
         del w2
-        # (d) BASELINE configs[3]: the FISS+ pipeline on 2048 egos; per-stage times from runs that stop after stage 1 / 2
-        b4 = synth.make_config(4, B=B)
+        # (c) BASELINE configs[3]: the FISS+ pipeline on 2048 egos; per-stage times from runs that stop after stage 1 / 2
+        b4 = synth.make_config(4, B=B, layout=args.layout)
         w4 = Workload(torch, eng, b4, dev, stream, fiss=True)
-        o4 = measure([w4], "lattice_fused + fiss_search + fiss_refine (whole FISS+ pipeline, 3 kernels)")
+        o4 = measure([w4], "lattice_fused + fissplus_search + fiss_refine (whole FISS+ pipeline, 3 kernels)")
         stage_ms = {}
         for st_n in (1, 2):
             eng.set_option("fiss_stages", st_n)
@@ -415,38 +616,53 @@ def main():
         eng.set_option("fiss_stages", 3)
         w4.step(); torch.cuda.synchronize(dev)  # leave complete outputs behind
         k4 = o4["roofline"]["kernel_ms"]
-        o4["stage_ms"] = {"lattice_fused_kernel (dense tables)": stage_ms[1], "fiss_search_kernel": stage_ms[2] - stage_ms[1],
+        o4["stage_ms"] = {"lattice_fused_kernel (dense tables)": stage_ms[1], "fissplus_search_kernel": stage_ms[2] - stage_ms[1],
                           "fiss_refine_kernel (3 rounds + validation + winner series)": k4 - stage_ms[2]}
         o4["workload"] = f"BASELINE.json configs[3]: FISS+ (search walk + 3 refinement rounds) over {b4.B} egos x 9x9x7, 50 dynamic obstacles; counts C + 21 trajectories per ego"
+        if args.cpu_seconds > 0:
+            o4["parity"] = fiss_parity("config4", w4, np.arange(0, B, max(1, B // 128)))
         extras["config4"] = o4
         del w4
-        # (e) SURVEY 8d obstacle layout verbatim (d_o ~ U(-4, 4), s_o = s + U(8, 120), speed U(0, 12))
-        b8 = synth.make_config(3, B=B, layout="survey8d")
+        # (d) the builder's lanes obstacle layout (round 1 / 2 headline): ~15 % of the obstacles in the ego lane, the rest beside it
+        other = "lanes" if args.layout == "survey8d" else "survey8d"
+        b8 = synth.make_config(3, B=B, layout=other)
         w8 = Workload(torch, eng, b8, dev, stream)
         o8 = measure([w8], "lattice_fused_kernel")
-        idx8 = w8.h_idx.numpy()
-        o8["workload"] = "configs[2] sizes with the SURVEY 8d obstacle layout verbatim (every obstacle at d_o ~ U(-4, 4) around the ego lane)"
-        o8["egos_with_a_feasible_candidate"] = float((idx8 >= 0).mean())
-        extras["survey8d_layout"] = o8
+        o8["workload"] = f"configs[2] sizes with the '{other}' obstacle layout (synth.py), one batch replayed"
+        o8["parity"] = gate(f"{other}_layout", w8, 64)
+        o8["egos_with_a_feasible_candidate"] = float((w8.h_idx.numpy() >= 0).mean())
+        extras[f"{other}_layout"] = o8
         del w8
+        # (e) many scenarios x many cycles on the device, and the PCIe-inclusive host-buffer entry
+        if args.cpu_seconds > 0:
+            extras["closed_loop"] = closed_loop_leg(torch, eng, dev, B, args.layout, 50, gate_threads)
+        t_host = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            ho = eng.plan_dense(batch)
+            t_host.append(time.perf_counter() - t0)
+        par_h = fop_parity("host_buffers", batch, np.arange(0, B, max(1, B // 64)), ho.best_idx, ho.best_cost, gate_threads) if args.cpu_seconds > 0 else None
+        extras["host_buffers"] = {"value": B * C / float(np.median(t_host[1:])), "unit": "candidates/s", "ms_per_call": float(np.median(t_host[1:])) * 1e3,
+                                  "what": "fp_plan_dense with FP_MEM_HOST: pageable numpy inputs -> pack -> H2D -> kernels -> D2H (PCIe-inclusive; never the headline value)",
+                                  "parity": par_h}
 
     if rank == 0:
-        value = world * main_wl.candidates * args.steps / elapsed
-        bytes_launch = main_wl.algorithmic_bytes()
+        value = world * np.mean([w.candidates for w in wls]) * args.steps / elapsed
+        bytes_launch = float(np.mean([w.algorithmic_bytes() for w in wls]))
         tr = load_profile_json("traffic.json") or {}
-        traffic = tr.get(f"config{config}_B{B}")
+        traffic = tr.get(f"config{config}_B{B}_{args.layout}", tr.get(f"config{config}_B{B}") if args.layout == "lanes" else None)
         # executed VALU work of the dominant kernel from the committed PMC pass (a property of kernel + input, not of the run);
         # the rates use this run's kernel time
         valu_issue = fp64_exec = None
-        pmc = load_profile_json("r02_config3_pmc_summary.json") or load_profile_json("r01_config3_pmc_summary.json")
-        if pmc and not fiss and config == 3 and B == 2048 and args.layout == "lanes":
+        pmc = load_profile_json(f"r03_config3_{args.layout}_pmc_summary.json")
+        if pmc and not fiss and config == 3 and B == 2048:
             try:
                 k = next(v for kk, v in pmc.items() if "lattice_fused" in kk)
                 insts = k["SQ_INSTS_VALU"]
                 peak = 256 * 4 * 2.4e9 / 4.0
                 valu_issue = {"wave_instructions_per_launch": insts, "rate": insts / (kern_ms * 1e-3), "peak": peak,
                               "unit": "wave-instructions/s", "frac": insts / (kern_ms * 1e-3) / peak,
-                              "source": "SQ_INSTS_VALU from profiles/*_config3_pmc_summary.json (rocprofv3 --pmc), this run's kernel time; "
+                              "source": "SQ_INSTS_VALU from profiles/r03_config3_*_pmc_summary.json (rocprofv3 --pmc), this run's kernel time; "
                                         "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
                 flops = 64.0 * (2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_TRANS_F64"])
                 fp64_exec = {"executed_flops_per_launch": flops, "rate": flops / (kern_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
@@ -454,8 +670,8 @@ def main():
                              "source": "64 lanes x (2 FMA + MUL + ADD + TRANS) wave-level FP64 instructions from the same PMC pass (inactive lanes counted: upper bound)"}
             except Exception:
                 valu_issue = fp64_exec = None
-        kname = ("lattice_fused_kernel (lattice + argmin; 94 % of the time) + winner_traj_kernel (the winners' series): the two launches of one "
-                 "fp_plan_dense call") if not fiss else "lattice_fused + fiss_search + fiss_refine (whole pipeline)"
+        kname = ("lattice_fused_kernel (lattice + argmin; ~94 % of the time) + winner_traj_kernel (the winners' series): the two launches of one "
+                 "fp_plan_dense call") if not fiss else "lattice_fused + fissplus_search + fiss_refine (whole pipeline)"
         line = {
             "metric": "candidate trajectories/sec (gen+cost+collision) per GPU; plan-cycle p50 latency", "value": value, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -463,17 +679,21 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{config - 1}]: {B} egos/GPU x {batch.nd}x{batch.nv}x{batch.nt} lattice "
                                    f"({C} cand/ego), {batch.n_obs} {'dynamic' if batch.meta.get('moving') else 'static'} obstacles, "
                                    f"T_obs={batch.T_obs}, stride-2 OBB checks, " + ("FISS+ search + 3 refinement rounds" if fiss else "FOP argmin")
-                                   + (f"; rank r plans egos [r*{B}, (r+1)*{B}) of the {world * B}-ego batch" if world > 1 else ""),
+                                   + f"; SURVEY 8d generator ('{args.layout}' layout), {n_rot} distinct batches cycled through the timed steps"
+                                   + (f"; rank r plans egos [r*{B}, (r+1)*{B}) of the {world * B}-ego batch (+ {n_rot - 1} further shards of the same stream)" if world > 1 else ""),
                        "egos_per_gpu": B, "candidates_per_ego": C, "tables_written": bool(args.tables), "obstacle_layout": args.layout,
-                       "parallelism": f"ego-shard x{world} (no collectives)", "input_digest": batch.digest()[:16]},
+                       "rotating_batches": n_rot, "parallelism": f"ego-shard x{world} (no collectives)",
+                       "input_digest": batch.digest()[:16], "input_digests": [w.batch.digest()[:16] for w in wls]},
+            "parity": parity_main,
             "roofline": roofline_obj(bytes_launch, kern_ms, kname, traffic,
                                      "the kernel is VALU-issue bound, not HBM bound: see valu_issue / valu_fp64_executed (PMC instruction counts)"),
             "kernel_ms_stats": {"mean": kern_ms, "min": float(np.min(kern_list)), "median": float(np.median(kern_list)), "max": float(np.max(kern_list)),
                                 "launches_timed": len(kern_list)},
+            "egos_with_a_feasible_candidate": float(np.mean([(w.h_idx.numpy() >= 0).mean() for w in wls])) if not fiss else None,
             "valu_issue": valu_issue,
             "valu_fp64_executed": fp64_exec,
-            "cpu_baseline": cpu_baseline,
-            "cpu_baseline_1thread": cpu_1t,
+            "cpu_baseline": cpu.get("cpu_baseline"),
+            "cpu_baseline_1thread": cpu.get("cpu_baseline_1thread"),
             "plan_cycle_latency": plan_cycle,
             "materialize_mode": materialize,
         }

@@ -2,13 +2,13 @@
 
 Deterministic: numpy Generator(PCG64([seed, ego])).  One sinusoidal centerline and one
 obstacle scene per ego.  Obstacles are rectangles that sit on (static) or drive along
-(dynamic) the ego's own road: ~15 % of them in the ego lane ahead of the ego (lead
-vehicles, |d| <= 1 m), the rest in the neighbouring lanes on both sides (2.9 m <= |d| <= 7.5 m)
-from 15 m behind to 120 m ahead.  (SURVEY.md 8d proposed d ~ U(-4, 4) for every obstacle;
-with 50 obstacles that blocks the lane so densely that ~99 % of the fan collides within the
-first poses and most egos have no feasible candidate, which turns the collision stage into an
-early-exit no-op.  This layout keeps the broad phase busy - neighbours graze the corridor -
-and leaves a feasible share of the fan in most scenes.)
+(dynamic) the ego's own road.  Two obstacle layouts:
+  * "survey8d" - SURVEY.md section 8(d) verbatim, the contract workload and make_config's default: every obstacle at
+    s_o = s + U(8, 120), d_o ~ U(-4, 4), speed U(0, 12) when moving.  With 50 obstacles the lane is densely blocked: most
+    of the fan collides and ~58 % of the egos keep no feasible candidate.
+  * "lanes" - the builder's own layout (make_batch's default, used by the unit tests): ~15 % of the obstacles in the ego lane
+    ahead of the ego (lead vehicles, |d| <= 1 m), the rest in the neighbouring lanes on both sides (2.9 m <= |d| <= 7.5 m)
+    from 15 m behind to 120 m ahead; ~75 % of the egos keep a feasible candidate.
 """
 from __future__ import annotations
 
@@ -126,8 +126,8 @@ def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving
         meta=dict(seed=seed, kind=kind, moving=moving, ego_offset=ego_offset, layout=layout))
 
 
-def make_config(config: int, B: int | None = None, ego_offset: int = 0, kind: str | None = None, layout: str = "lanes") -> ProblemBatch:
-    """BASELINE.json configs[config-1] (2..5)."""
+def make_config(config: int, B: int | None = None, ego_offset: int = 0, kind: str | None = None, layout: str = "survey8d") -> ProblemBatch:
+    """BASELINE.json configs[config-1] (2..5) on SURVEY.md section 8(d)'s generator (layout="lanes": the builder's own obstacle layout)."""
     if config == 2:
         return make_batch(B or 256, 5, 5, 5, 10, 100, False, CONFIG_SEEDS[2], kind or "FOP", ego_offset=ego_offset, layout=layout)
     if config == 3:

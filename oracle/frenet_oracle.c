@@ -227,16 +227,27 @@ typedef struct {
     double* block;
 } traj_t;
 
+/* One trajectory is alive per thread at a time (orc_eval_traj), so its 16 arrays live in a per-thread scratch block that only
+   grows: a batch of plans on many threads does not go through the allocator once per candidate. */
+static _Thread_local double* tl_block = NULL;
+static _Thread_local size_t tl_cap = 0;
+
 static int traj_alloc(traj_t* t, int N)
 {
+    const size_t n = (size_t)(N > 0 ? N : 1);
     t->N = N;
     t->M = 0;
-    t->block = (double*)malloc(sizeof(double) * (size_t)ORC_NARR * (size_t)(N > 0 ? N : 1));
-    if (!t->block) return -3;
-    for (int k = 0; k < ORC_NARR; ++k) t->a[k] = t->block + (size_t)k * (size_t)(N > 0 ? N : 1);
+    if (tl_cap < (size_t)ORC_NARR * n) {
+        double* nb = (double*)realloc(tl_block, sizeof(double) * (size_t)ORC_NARR * n);
+        if (!nb) return -3;
+        tl_block = nb;
+        tl_cap = (size_t)ORC_NARR * n;
+    }
+    t->block = tl_block;
+    for (int k = 0; k < ORC_NARR; ++k) t->a[k] = t->block + (size_t)k * n;
     return 0;
 }
-static void traj_free(traj_t* t) { free(t->block); t->block = NULL; }
+static void traj_free(traj_t* t) { t->block = NULL; }
 
 /* len(np.arange(0.0, T, tick)) */
 static int arange_len(double T, double tick)

@@ -16,7 +16,8 @@ from types import SimpleNamespace
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfrenet_oracle.so")
+# FRENET_ORACLE_LIB: load another build of the same source instead (the sanitizer build, tests/test_oracle_sanitize.py)
+_LIB_PATH = os.environ.get("FRENET_ORACLE_LIB") or os.path.join(_HERE, "libfrenet_oracle.so")
 
 FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED = 1, 2, 4, 8
 FLAG_CURVATURE, FLAG_KAPPA_D, FLAG_KAPPA_DD = 16, 32, 64
@@ -47,6 +48,8 @@ class OrcProblem(C.Structure):
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (make -C oracle)."""
     src = os.path.join(_HERE, "frenet_oracle.c")
+    if os.environ.get("FRENET_ORACLE_LIB"):
+        return _LIB_PATH  # somebody else's build
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH

@@ -53,11 +53,23 @@ def test_bench_rejects_a_world_size_that_disagrees_with_gpus():
 def test_bench_single_gpu_line_has_every_configuration():
     line = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-seconds", "2", "--no-latency"])
     assert line["n_gpus"] == 1 and "configs[2]" in line["config"]["workload"]
-    for key in ("config2", "config4", "lattice_order_off", "rotating_batches", "survey8d_layout"):
+    assert line["config"]["obstacle_layout"] == "survey8d" and line["config"]["rotating_batches"] == 4
+    assert len(set(line["config"]["input_digests"])) == 4
+    # every leg that prints a number was compared with the oracle in the same run
+    assert len(line["parity"]["batches"]) == 4 and all(p["index_exact"] for p in line["parity"]["batches"])
+    for key in ("config2", "config4", "lattice_order_off", "single_batch_replayed", "lanes_layout"):
         assert line[key]["value"] > 0 and 0 < line[key]["roofline"]["frac"] < 1, key
-    assert set(line["config4"]["stage_ms"]) == {"lattice_fused_kernel (dense tables)", "fiss_search_kernel",
+        assert line[key]["parity"]["index_exact"] and line[key]["parity"]["max_abs_cost_err"] <= 1e-6, key
+    assert line["config2"]["parity"]["checked_egos"] == 256
+    assert line["config4"]["parity"]["stats_exact"] and line["config4"]["parity"]["checked_egos"] >= 64
+    assert set(line["config4"]["stage_ms"]) == {"lattice_fused_kernel (dense tables)", "fissplus_search_kernel",
                                                 "fiss_refine_kernel (3 rounds + validation + winner series)"}
+    for planner in ("FOP", "FISS+"):
+        cl = line["closed_loop"][planner]
+        assert cl["value"] > 0 and cl["ego_plans"] >= 2048 and cl["parity"]["max_abs_cost_err"] <= 1e-6
+    assert line["host_buffers"]["value"] > 0 and line["host_buffers"]["parity"]["index_exact"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline_1thread"]["cores"] == 1
+    assert line["cpu_baseline"]["cores"] >= 1 and "thread_sweep" in line["cpu_baseline"] and "host" in line["cpu_baseline"]
 
 
 def test_config5_full_batch_equals_its_eight_shards(oracle, engine):
@@ -74,7 +86,7 @@ def test_config5_full_batch_equals_its_eight_shards(oracle, engine):
         np.testing.assert_array_equal(po.best_cost, out.best_cost[sl])
     # (2) invariants for every ego: the winner is feasible and no feasible candidate is cheaper; N/M words are consistent
     ok = out.best_idx >= 0
-    assert 0.5 < ok.mean() < 1.0
+    assert 0.3 < ok.mean() < 1.0
     feas = (out.flags & 7) == 0
     masked = np.where(feas, out.cost, np.inf)
     assert np.array_equal(masked.min(axis=1)[ok], out.best_cost[ok])

@@ -87,10 +87,17 @@ def test_two_rank_gloo_shards_match_single_process(tmp_path, oracle):
 
 def test_generator_is_pinned_by_digest():
     """The synthetic configs are bit-reproducible: SHA-256 over every array of the first 8 egos of BASELINE configs 2-5
-    (the GPU box regenerates them; bench.py prints the digest of what it ran on)."""
-    want = {2: "4ba11b9bb86f1b4a9501f7307a2ad131a74a055cfdf6c376f5c02d985a259e17",
-            3: "1e0a80bd9f1e2360c4e40097ac85ad614f8090686a7620c8edc9450151861c6a",
-            4: "4a7cce28e5bbe33fe1cf30d744f1efd942397e2309b21afea50c4ce5e124aa71",
-            5: "458ad8ea57d41c9e16f06a8bfb473bbf7fbecce0ccac978c93b9fa18ff43ee5f"}
-    for cfg, digest in want.items():
+    (the GPU box regenerates them; bench.py prints the digests of what it ran on).  make_config's default is SURVEY 8d's
+    generator verbatim; the builder's own "lanes" layout is pinned too."""
+    want = {"survey8d": {2: "f400e3e54207883590e0e544293f0de3048547a5642f1af439d1f3b058c5cfc6",
+                         3: "3c3571dfeaf0e44d1bb34f184225aaa4adab455ffbe6af1cf522fc3de8d3ca4b",
+                         4: "77031ac8b78abefce44004ac1d62051763f80cc71f3300936b844ceab0776eb6",
+                         5: "a59811805fae40d3f40918cf3bc3928e35d6c50ab68500697cecb264d28d8d4f"},
+            "lanes": {2: "4ba11b9bb86f1b4a9501f7307a2ad131a74a055cfdf6c376f5c02d985a259e17",
+                      3: "1e0a80bd9f1e2360c4e40097ac85ad614f8090686a7620c8edc9450151861c6a",
+                      4: "4a7cce28e5bbe33fe1cf30d744f1efd942397e2309b21afea50c4ce5e124aa71",
+                      5: "458ad8ea57d41c9e16f06a8bfb473bbf7fbecce0ccac978c93b9fa18ff43ee5f"}}
+    for cfg, digest in want["survey8d"].items():
         assert synth.make_config(cfg, B=8).digest() == digest, cfg
+    for cfg, digest in want["lanes"].items():
+        assert synth.make_config(cfg, B=8, layout="lanes").digest() == digest, cfg
