@@ -785,10 +785,8 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     } else {
         FP_TRY(check_batch_host(params, batch));
         if (io->best_traj) {
-            const double t_max = io->samp_max[2];  // refined trajectories reach T = samp_max (per ego; ego 0 stands for the check below)
-            for (size_t i = 0; i < B; ++i)
+            for (size_t i = 0; i < B; ++i)  // refined trajectories reach T = samp_max of their ego
                 if (ceil(io->samp_max[3 * i + 2] / params->tick_t) > stride) return fail(FP_EINVAL, "traj_stride=%d is smaller than the points of samp_max[%zu].T=%g", stride, i, io->samp_max[3 * i + 2]);
-            (void)t_max;
             FP_TRY(check_stride_host(params, batch, stride));
         }
         FP_TRY(hs.reserve(batch_need(params, batch) + 4 * HostStage::need<double>(B * 3) + 2 * HostStage::need<int32_t>(B * 3) +

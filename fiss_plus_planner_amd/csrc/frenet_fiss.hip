@@ -393,7 +393,7 @@ __global__ __launch_bounds__(W * kWave) void fiss_search_kernel(FissArgs fa, int
                     if (cost_center < __builtin_inf()) w.Q.set(__builtin_amdgcn_readfirstlane(cr), lane);
                     ++w.num_generated;
                 }
-                const bool is_new = lane < 6 && ((cs >> (2 + lane)) & 1) && !(s & kGen);  // the neighbour exists and is not generated
+                const bool is_new = lane < 6 && ((cs >> (2 + (lane < 6 ? lane : 0))) & 1) && !(s & kGen);  // the neighbour exists and is not generated
                 const bool to_frontier = is_new && c <= cost_center;  // frontier_idxs.put((cost, idx))
                 if (is_new) st[nq] = s | kGen;
                 const unsigned long long fresh = __ballot(is_new);

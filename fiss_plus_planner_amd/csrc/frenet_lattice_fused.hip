@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // Timing diagnostic (tools/phase_stamps.py, -DFP_PHASE_STAMPS): thread 0 leaves the time since the workgroup started (10 ns
     // ticks) at the phase boundaries in columns 112.. of the last row of its best_traj block (free with traj_stride = 128, sparse, T <= 11 s).
 #if defined(FP_PHASE_STAMPS)
-#define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && dur) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x) * FP_ARR_COUNT + 15) * ka.r.traj_stride + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
+#define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && dur) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
 #else
 #define FP_STAMP(k) do { } while (0)
 #endif
@@ -617,6 +617,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             item_base = item_end;
             if (n_surv > kItemCap) {  // block-uniform: does not fit, redo [i0, ...) in chunks whose survivors always fit
                 chunk = kItemCap;
+                __syncthreads();  // every thread has read s_cnt[0] before the redone pass adds to it again
                 continue;
             }
             // the survivors' orientations -> (cos, sin), with shapely's snap (frenet_device.h); every item belongs to one chunk

@@ -42,6 +42,10 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
             if (i < lim) __builtin_nontemporal_store(a, dst);
             if (i + 1 < lim) __builtin_nontemporal_store(c, dst + 1);
         }
+        // dense layout with rows wider than the 128 points a lane pair covers: the rest of the row is padding too (every element of
+        // the [16][traj_stride] block is written, as the header promises)
+        if (!sparse && stride > FP_MAX_POINTS)
+            for (int k = FP_MAX_POINTS + lane; k < stride; k += kWave) __builtin_nontemporal_store(nan, &out[r * stride + k]);
     };
     if (!valid || N <= 0 || N > FP_MAX_POINTS || !(d_end == d_end) || !(v_end == v_end)) {  // wave-uniform
 #pragma unroll

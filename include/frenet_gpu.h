@@ -202,7 +202,9 @@ int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* bat
  *   (fiss_planner.py:101-138) + calc_global_paths + check_constraints + has_collision.
  * end_states [B][K][3]; cost [B][K]; flags [B][K]; traj NULL or [B][K][16][traj_stride] (traj_stride / traj_sparse as in fp_result),
  * the full FrenetTrajectory series of every requested trajectory (winner epilogue,
- * FISS+ refinement, all_trajs visualisation payload). */
+ * FISS+ refinement, all_trajs visualisation payload).  One difference to the other entry points: with traj_sparse = 1 this one
+ * writes exactly the elements that exist and NO padding up to the 16-column boundary (one lane walks a trajectory point by point);
+ * a trajectory that needs more points than traj_stride gets NaN cost + FP_FLAG_INFEASIBLE. */
 int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states,
                   double* cost, uint32_t* flags, double* traj, int32_t traj_stride, int32_t traj_sparse, int mem, void* stream);
 
