@@ -60,10 +60,31 @@ constexpr uint32_t kOrdPosInf = 0xFF800000u, kOrdNegInf = 0x007FFFFFu;  // f32_o
 // ~20 of an integer division; the remainder uses the 24-bit multiplier (full rate; v_mul_lo_u32 is quarter rate).
 __device__ __forceinline__ int div_small(int e, float inv_d) { return (int)(((float)e + 0.5f) * inv_d); }
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+// e / D for a divisor known at compile time (the specialised instances of the kernel): one 24-bit multiply and a shift.
+// Exact for 0 <= e <= MAXE: with M = ceil(2^20 / D) the error term e (M D - 2^20) / (D 2^20) stays below 1 / D, and e M < 2^32.
+// D = 0: the divisor is a run-time value, div_small with its reciprocal.
+template <int D, int MAXE>
+__device__ __forceinline__ int div_by(int e, float inv_d)
+{
+    if constexpr (D > 0) {
+        constexpr unsigned long long M = ((1ull << 20) + D - 1) / D;
+        static_assert(M < (1ull << 24) && (unsigned long long)MAXE < (1ull << 24), "24-bit multiplier");
+        static_assert((unsigned long long)MAXE * M < (1ull << 32), "product overflows");
+        static_assert((unsigned long long)MAXE * (M * D - (1ull << 20)) < (1ull << 20), "not exact over the whole range");
+        return (int)(__umul24((unsigned int)e, (unsigned int)M) >> 20);
+    } else {
+        return div_small(e, inv_d);
+    }
+}
 
+#if defined(FP_ABL_NO_SLICE_SYNC)  // timing ablation: the slice loop without its barriers (results are wrong)
+#define SLICE_SYNC() do { } while (0)
+#else
+#define SLICE_SYNC() __syncthreads()
+#endif
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass
+constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass  // block-wide list of live narrow-phase items (pair, lateral sample) of one B pass: 24 KB
 constexpr int kItemCap = 512;    // block-wide list of (row, obstacle) items that pass the group test (+ their poses: 16 KB)
 
 struct __attribute__((aligned(16))) Frame {  // reference-line frame of one lon-profile point
@@ -87,9 +108,6 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
 {
     Layout L;
     int o = 0;
-    L.knots = o;    o = align16(o + 8 * nx_max);
-    L.coef = o;     o = align16(o + 64 * nx_max);
-    L.lut = o;      o = align16(o + 2 * (2 * nx_max + 1));  // uint16 segment hint per arclength bucket
     L.dim = o;      o = align16(o + 32 * n_obs);
     L.pose = o;     o = align16(o + 32 * kItemCap);  // poses of the group test's survivors (x, y, cos, sin), in list order
     L.frames = o;   o = align16(o + 32 * nv * hp);
@@ -113,6 +131,10 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.cnt = o;      o = align16(o + 32);  // list counters (monotone) + scan mask + ticket + two fp32 bounds
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * kWaves);
+    // the spline tables last: theirs is the one size no instance of the kernel knows at compile time, so every other offset folds
+    L.knots = o;    o = align16(o + 8 * nx_max);
+    L.coef = o;     o = align16(o + 64 * nx_max);
+    L.lut = o;      o = align16(o + 2 * (2 * nx_max + 1));  // uint16 segment hint per arclength bucket
     L.total = o;
     return L;
 }
@@ -157,9 +179,19 @@ __device__ __forceinline__ void power_sums_closed(int N, double tick, double* ou
 
 // nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
 // writes its partial argmin to part_best[ego * nsplit + part]; the last one to arrive (ticket counter) merges them.
-__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max, int hp_max, int nsplit, Best* part_best, int* part_count, const int* perm,
+//
+// Template parameters = the problem shape when it is known at compile time (0 = run-time value from the arguments): lattice sizes,
+// collision check stride, obstacles per scene, checked pose rows.  BASELINE.json has two shapes (9 x 9 x 7 with 50 obstacles over
+// 25 rows, 5 x 5 x 5 with 10 obstacles over 50 rows); in their instances every index decode is a constant multiply-shift, the LDS
+// carve-up folds to immediates and the loop bounds are known.  The <0, ...> instance is the same source with everything read from
+// the arguments.
+template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS>
+__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit, Best* part_best, int* part_count, const int* perm,
                                                                    int* dur)
 {
+    constexpr bool kShape = ND > 0;  // (all six are set together)
+    const int rows_max = kShape ? ROWS : rows_max_arg;
+    const int hp_max = kShape ? (ROWS > 0 ? (ROWS * STRIDE + 1 > FP_MAX_POINTS ? FP_MAX_POINTS : ROWS * STRIDE + 1) : 0) : hp_max_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const long long t_begin = dur ? wall_clock64() : 0;
     // Timing diagnostic (tools/phase_stamps.py, -DFP_PHASE_STAMPS): thread 0 leaves the time since the workgroup started (10 ns
@@ -169,6 +201,13 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 #else
 #define FP_STAMP(k) do { } while (0)
 #endif
+#if defined(FP_COUNTERS)  // work statistics (tools/work_counters.py): LDS counters, left in row 14, columns 112.. of the winner block
+    __shared__ int s_dbg[16];
+    if (threadIdx.x < 16) s_dbg[threadIdx.x] = 0;
+#define FP_COUNT(k, v) atomicAdd(&s_dbg[k], (int)(v))
+#else
+#define FP_COUNT(k, v) do { } while (0)
+#endif
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     // launch order: longest egos first when the host has an order for this batch (perm; nsplit == 1 then)
@@ -176,14 +215,15 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
-    const int nd = p.nd, nv = p.nv, nt = p.nt;
+    const int nd = kShape ? ND : p.nd, nv = kShape ? NV : p.nv, nt = kShape ? NT : p.nt;
     const int C = nd * nv * nt;
     const int it_lo = part * nt / nsplit, it_hi = (part + 1) * nt / nsplit;  // this workgroup's slices
     const int n_it = it_hi - it_lo;
-    const int stride = p.check_stride;
+    const int stride = kShape ? STRIDE : p.check_stride;
+    const int n_obs_tab = kShape ? NOBS : bt.n_obs;  // obstacles per scene of the table
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, bt.n_obs, rows_max, hp_max, nd, nv, nt);
+    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
@@ -238,7 +278,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     // table is NOT staged: the group test reads it once, straight from global memory, and keeps the poses of its survivors
     // (rows_stage = the rows the table holds from t_now on).
     const int NX = bt.NX;
-    const int n_obs = sc >= 0 ? bt.n_obs : 0;
+    const int n_obs = sc >= 0 ? n_obs_tab : 0;
     const float inv_nobs_s = 1.0f / (float)(n_obs > 0 ? n_obs : 1);
     int rows_stage = 0;  // obstacle rows of the table from t_now on: poses k = r*stride, k + t_now < T_obs
     if (n_obs > 0) {
@@ -246,7 +286,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         rows_stage = in_table > 0 ? (in_table + stride - 1) / stride : 0;
         if (rows_stage > rows_max) rows_stage = rows_max;
     }
-    const double* gp = bt.obs_pose + (size_t)(sc >= 0 ? sc : 0) * bt.T_obs * bt.n_obs * 4;
+    const double* gp = bt.obs_pose + (size_t)(sc >= 0 ? sc : 0) * bt.T_obs * n_obs_tab * 4;
     constexpr int kPoseFlight = 2;  // pose reads in flight per lane in the group test
     auto fetch_poses = [&](int i0, double4* ps) {
 #pragma unroll
@@ -254,7 +294,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             const int i = i0 + u * kThreads + tid;
             ps[u] = make_double4(0.0, 0.0, 0.0, 0.0);
             if (i < rows_stage * n_obs) {
-                const int r = div_small(i, inv_nobs_s), j = i - mul24(r, n_obs);
+                const int r = div_by<NOBS, ROWS * NOBS>(i, inv_nobs_s), j = i - mul24(r, n_obs);
                 ps[u] = *(const double4*)(gp + ((size_t)(mul24(r, stride) + t_now) * n_obs + j) * 4);
             }
         }
@@ -373,7 +413,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     //     Conditioning is benign on t in [0, 10] (terms ~1e2..1e4 against sums ~1e1..1e3: ~1e-12 absolute), far inside the
     //     1e-6 cost bar, and the expressions are even in the lateral boundary data, so mirrored candidates still tie bit-exactly.
     for (int e = tid; e < n_it * nv; e += kThreads) {
-        const int it = it_lo + e / nv, iv = e % nv;
+        const int eq = div_by<NV, NT * NV>(e, 1.0f / (float)nv);
+        const int it = it_lo + eq, iv = e - mul24(eq, nv);
         const double T = s_ts[it];
         const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
         s_qlon[2 * (mul24(it, nv) + iv)] = q.a3;
@@ -427,7 +468,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             const int e = e0 + lane;
             uint32_t bits = 0u;
             if (e < n_it * nd) {
-                const double T = s_ts[it_lo + e / nd], de = s_ds[e % nd];
+                const int eq = div_by<ND, NT * ND + kWave>(e < n_it * nd ? e : 0, 1.0f / (float)nd);
+                const double T = s_ts[it_lo + eq], de = s_ds[e - mul24(eq, nd)];
                 double bd = (fabs(d0) > fabs(de) ? fabs(d0) : fabs(de)) + 0.1976 * fabs(d_d0) * T + 0.01729 * fabs(d_dd0) * T * T;
                 if (!(d0 == d0) || !(de == de)) bd = __builtin_nan("");
                 bits = __float_as_uint(float_above(bd) * 1.0000005f);
@@ -492,7 +534,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     for (int e0 = wave * kWave; e0 < n_it * (nv + nd); e0 += kThreads) {  // (whole wavefronts: the row maxima below are wave reductions)
         const int e = e0 + lane;
         const bool live = e < n_it * (nv + nd);
-        const int it = it_lo + (live ? e / (nv + nd) : 0), sub = live ? e % (nv + nd) : 0;
+        const int eq = live ? div_by<NV + ND, NT * (NV + ND)>(e, 1.0f / (float)(nv + nd)) : 0;
+        const int it = it_lo + eq, sub = live ? e - mul24(eq, nv + nd) : 0;
         const double T = s_ts[it];
         const double* S = s_pows + it * 11;
         if (!live) {
@@ -591,7 +634,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     const int e = b0 + u * kThreads + tid;
                     bool keep = false;
                     if (e < i1) {
-                        const int r = div_small(e, inv_nobs), j = e - mul24(r, n_obs);
+                        const int r = div_by<NOBS, ROWS * NOBS>(e, inv_nobs), j = e - mul24(r, n_obs);
                         const int k = mul24(r, stride);
                         const ObsDim g = s_grp[r];
                         const double dx = ps[u].x - g.hl, dy = ps[u].y - g.hw, R = g.r + s_dim[j].r;
@@ -615,6 +658,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             const int item_end = s_cnt[0];
             const int n_surv = item_end - item_base;
             item_base = item_end;
+            if (tid == 0) FP_COUNT(0, n_surv);
             if (n_surv > kItemCap) {  // block-uniform: does not fit, redo [i0, ...) in chunks whose survivors always fit
                 chunk = kItemCap;
                 __syncthreads();  // every thread has read s_cnt[0] before the redone pass adds to it again
@@ -673,7 +717,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     }
                 }
             // [/section LAT]
-                __syncthreads();
+                SLICE_SYNC();
                 if (it == it_lo + 3) FP_STAMP(11);
                 // ---- prep: wfat = lateral half-width of the whole fan along the reference normal n_k, per checked pose (row r, lon
                 // profile iv): every ego centre is P_k + d n_k with |d| <= dmax[k];  the ego box, whose heading deviates from the
@@ -691,7 +735,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     const float inv_nv = 1.0f / (float)nv;
     // [section PREP]
                     for (int e = tid; e < rows * nv; e += kThreads) {
-                        const int r = div_small(e, inv_nv), iv = e - mul24(r, nv);
+                        const int r = div_by<NV, ROWS * NV>(e, inv_nv), iv = e - mul24(r, nv);
                         const int k = mul24(r, stride);
                         const bool row_ok = k < N && k < hp;
                         const int M = s_lon_meta[mul24(it, nv) + iv].x;
@@ -715,7 +759,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     }
         // [/section PREP]
                 }
-                __syncthreads();
+                SLICE_SYNC();
                 if (it == it_lo + 3) FP_STAMP(12);
 #if defined(FP_ABL_NO_BN)
                 const int n_pairs = 0;
@@ -729,9 +773,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                         bool pass = false;
                         uint32_t code = 0;
                         if (pr < p1) {
-                            const int si = div_small(pr, inv_nvf), iv = pr - mul24(si, nv);
+                            const int si = div_by<NV, kItemCap * NV>(pr, inv_nvf), iv = pr - mul24(si, nv);
                             const int item = s_items[si];
-                            const int r = div_small(item, inv_nobs), j = item - mul24(r, n_obs);
+                            const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
                             const int k = mul24(r, stride);
                             const ObsPose op = s_spose[si];
                             const ObsDim od = s_dim[j];
@@ -752,6 +796,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             code = ((uint32_t)iv << 16) | (uint32_t)si;
                         }
                         const unsigned long long m = __ballot(pass);
+                        if (lane == 0) { FP_COUNT(1, 1); FP_COUNT(2, __popcll(m)); }
                         if (m) {
                             const int first = __ffsll((long long)m) - 1;
                             int base = 0;
@@ -760,7 +805,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             if (pass) s_hits[pos] = code;  // at most kHitCap pairs per pass: always fits
                         }
                     }
-                    __syncthreads();
+                    SLICE_SYNC();
                 if (it == it_lo + 3) FP_STAMP(13);
                     const int hit_end = s_cnt[1];
                     const int n_hits = hit_end - hit_base;
@@ -772,14 +817,16 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                     const int n_exact = n_hits * nd;
 #endif
                     for (int x = tid; x < n_exact; x += kThreads) {
-                        const int h = div_small(x, inv_ndf), id = x - mul24(h, nd);
+                        const int h = div_by<ND, kHitCap * ND>(x, inv_ndf), id = x - mul24(h, nd);
                         const uint32_t code = s_hits[h];
                         const int iv = code >> 16, si = code & 0xFFFF;
                         const int item = s_items[si];
-                        const int r = div_small(item, inv_nobs), j = item - mul24(r, n_obs);
+                        const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
                         const int cand = mul24(mul24(id, nt) + it, nv) + iv;
                         const int k = mul24(r, stride);
                         const int M = s_lon_meta[mul24(it, nv) + iv].x;
+                        FP_COUNT(3, 1);
+                        if (k < M && M >= 2 && s_coll[cand]) FP_COUNT(4, 1);
                         if (k < M && M >= 2 && !s_coll[cand]) {
                             // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                             const int ka_ = (k + 1 < M) ? k : k - 1;
@@ -804,12 +851,12 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                                 const double dx = op.x - ego.x, dy = op.y - ego.y;
                                 hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
                             }
-                            if (hit) s_coll[cand] = 1;
+                            if (hit) { s_coll[cand] = 1; FP_COUNT(5, 1); FP_COUNT(8 + (k >> 3), 1); }
                         }
                     }
-                    if (p1 < n_pairs) __syncthreads();  // the next pass overwrites the hit list
+                    if (p1 < n_pairs) SLICE_SYNC();  // the next pass overwrites the hit list
                 }
-                __syncthreads();  // frames / lat / dmax are rewritten by the next slice
+                SLICE_SYNC();  // frames / lat / dmax are rewritten by the next slice
                 if (it == it_lo + 3) FP_STAMP(14);
             }
             i0 = i1;
@@ -822,14 +869,18 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     }
 
     FP_STAMP(8);
+#if defined(FP_COUNTERS)
+    __syncthreads();
+    if (tid < 16 && ka.r.best_traj) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 14) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + tid] = (double)s_dbg[tid];
+#endif
     // ---------------------------------------------------------------- per-candidate assembly + argmin
     Best mine{0.0, -1};
     const float inv_nv_a = 1.0f / (float)nv, inv_nt_a = 1.0f / (float)nt;
     // [section ASM]
     for (int c = tid; c < C; c += kThreads) {
         // c = (id * nt + it) * nv + iv
-        const int q1 = div_small(c, inv_nv_a), iv = c - mul24(q1, nv);
-        const int id = div_small(q1, inv_nt_a), it = q1 - mul24(id, nt);
+        const int q1 = div_by<NV, ND * NV * NT>(c, inv_nv_a), iv = c - mul24(q1, nv);
+        const int id = div_by<NT, ND * NT>(q1, inv_nt_a), it = q1 - mul24(id, nt);
         if (it < it_lo || it >= it_hi) continue;  // another workgroup's slice (latency mode)
         const int N = s_nslice[it];
         const double* ls = s_lon_sum + mul24(3, mul24(it, nv) + iv);
@@ -928,8 +979,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const int win = s_best[0].idx;
     double d_end = __builtin_nan(""), v_end = d_end, T_end = d_end;
     if (win >= 0) {
-        const int q1 = div_small(win, inv_nv_a), iv = win - mul24(q1, nv);
-        const int id = div_small(q1, inv_nt_a), it = q1 - mul24(id, nt);
+        const int q1 = div_by<NV, ND * NV * NT>(win, inv_nv_a), iv = win - mul24(q1, nv);
+        const int id = div_by<NT, ND * NT>(q1, inv_nt_a), it = q1 - mul24(id, nt);
         d_end = s_ds[id]; v_end = s_vs[iv]; T_end = s_ts[it];
     }
     winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp);
@@ -966,23 +1017,41 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     if (!fused_shape(p, b, &rows, &hp)) return hipErrorInvalidValue;
     const Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
-    FP_LDS_SLOTS(configured);
-    hipError_t e = ensure_dynamic_lds((const void*)lattice_fused_kernel, L.total, configured);
-    if (e != hipSuccess) return e;
     if (!part_scratch || nsplit < 1) nsplit = 1;
     if (nsplit > p.nt) nsplit = p.nt;
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
     int* part_count = (int*)part_scratch;
     Best* part_best = part_scratch ? (Best*)((char*)part_scratch + kTicketBytes) : nullptr;
     if (nsplit != 1) perm = nullptr;
+    hipError_t e;
     if (p.curvature_mask) {  // optional curvature checks: their own launch, ORed into the flag words by the assembly stage
         if (!ka.curv_tbl) return hipErrorInvalidValue;
         e = launch_curvature_flags(ka, const_cast<uint8_t*>(ka.curv_tbl), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(lattice_fused_kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur);
+    // the instance whose compile-time shape is this problem's (BASELINE.json's two lattice shapes), else the run-time one
+    auto go = [&](auto kernel, int* configured) -> hipError_t {
+        hipError_t err = ensure_dynamic_lds((const void*)kernel, L.total, configured);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur);
+        return hipGetLastError();
+    };
+    FP_LDS_SLOTS(cfg_generic);
+    FP_LDS_SLOTS(cfg_997);
+    FP_LDS_SLOTS(cfg_555);
+    auto is = [&](int nd, int nv, int nt, int stride, int n_obs, int r) {
+        return p.nd == nd && p.nv == nv && p.nt == nt && p.check_stride == stride && b.n_obs == n_obs && rows == r;
+    };
+#if defined(FP_NO_SHAPES)  // (A/B diagnostic: the run-time instance for every shape)
+    e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0>, cfg_generic);
+#else
+    if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25>, cfg_997);
+    else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50>, cfg_555);
+    else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0>, cfg_generic);
+#endif
+    if (e != hipSuccess) return e;
     if (winner_done) *winner_done = ka.r.best_traj != nullptr;
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 }  // namespace fp
