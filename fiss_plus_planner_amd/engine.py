@@ -113,7 +113,18 @@ class FrenetEngine:
         self.close()
 
     # ------------------------------------------------------------------ host arrays
-    def plan_dense(self, batch: ProblemBatch, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+    @staticmethod
+    def dense_outputs(B: int, Cn: int, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+        """Output arrays of plan_dense for B egos (ShardedEngine allocates them once and hands every shard its slice)."""
+        return SimpleNamespace(
+            best_idx=np.empty(B, dtype=np.int32), best_cost=np.empty(B), stats=np.empty((B, 4), dtype=np.int32),
+            cost=np.empty((B, Cn)) if tables else None, flags=np.empty((B, Cn), dtype=np.uint32) if tables else None,
+            best_flags=np.empty(B, dtype=np.uint32) if winner else None,
+            # sparse: the kernels write only the elements that exist; everything else keeps this NaN fill
+            best_traj=(np.full((B, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, 16, traj_stride))) if winner else None)
+
+    def plan_dense(self, batch: ProblemBatch, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False,
+                   out: SimpleNamespace | None = None):
         """FrenetOptimalPlanner.plan() for every ego of the batch (reference frenet_optimal_planner.py:247-270).
 
         Returns best_idx [B] (flat (i_d*nt+i_T)*nv+i_v, -1 = none), best_cost [B], stats [B,4] and, with
@@ -121,15 +132,14 @@ class FrenetEngine:
         (the argmin's full series, written by the lattice kernel itself).
         """
         B, Cn = batch.B, batch.C
-        out = SimpleNamespace(best_idx=np.empty(B, dtype=np.int32), best_cost=np.empty(B), stats=np.empty((B, 4), dtype=np.int32),
-                              cost=np.empty((B, Cn)) if tables else None, flags=np.empty((B, Cn), dtype=np.uint32) if tables else None)
+        if out is None:  # (out: arrays of dense_outputs' shapes, e.g. contiguous slices of a bigger batch's outputs)
+            out = self.dense_outputs(B, Cn, tables, winner, traj_stride, traj_sparse)
+        if B == 0:
+            return out
         res = _abi.FpResult()
         res.best_idx, res.best_cost, res.stats = _ptr(out.best_idx), _ptr(out.best_cost), _ptr(out.stats)
         res.cost_tbl = _ptr(out.cost) if tables else None
         res.flag_tbl = _ptr(out.flags) if tables else None
-        out.best_flags = np.empty(B, dtype=np.uint32) if winner else None
-        # sparse: the kernels write only the elements that exist; everything else keeps this NaN fill
-        out.best_traj = (np.full((B, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, 16, traj_stride))) if winner else None
         res.best_flags = _ptr(out.best_flags) if winner else None
         res.best_traj = _ptr(out.best_traj) if winner else None
         res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
@@ -151,9 +161,18 @@ class FrenetEngine:
                                            traj.ctypes.data if dump else None, int(traj_stride), int(traj_sparse), _abi.FP_MEM_HOST, None))
         return SimpleNamespace(cost=cost, flags=flags, traj=traj)
 
+    @staticmethod
+    def fiss_outputs(B: int, R: int, winner: bool = False, trace: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+        """Output arrays of plan_fiss for B egos with R refinement rounds (prev_best_idx is the in / out history array)."""
+        return SimpleNamespace(prev_best_idx=np.empty((B, 3), dtype=np.int32), best_ijk=np.empty((B, 3), dtype=np.int32), best_cost=np.empty(B),
+                               end_state=np.empty((B, 3)), refined=np.empty(B, dtype=np.int32), stats=np.empty((B, 4), dtype=np.int32),
+                               trace=np.empty((B, max(R, 1) * 7, 4)) if trace and R > 0 else None,
+                               best_flags=np.empty(B, dtype=np.uint32) if winner else None,
+                               best_traj=(np.full((B, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, 16, traj_stride))) if winner else None)
+
     def plan_fiss(self, batch: ProblemBatch, kind: str = "FISS+", prev_best_idx: np.ndarray | None = None, w_heuristic: float = 10.0,
                   max_refine_iters: int = 3, decaying_factor: float = 0.5, winner: bool = False, trace: bool = False,
-                  traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+                  traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False, out: SimpleNamespace | None = None):
         """FissPlanner.plan / FissPlusPlanner.plan for every ego of the batch, entirely on the device (fp_plan_fiss):
         dense tables -> per-ego search walk -> (FISS+) refinement -> optional winner series.
 
@@ -163,12 +182,12 @@ class FrenetEngine:
         B = batch.B
         plus = kind in ("FISS+", _abi.FP_FISS_PLUS)
         R = max_refine_iters if plus else 0
-        prev = np.full((B, 3), -1, dtype=np.int32) if prev_best_idx is None else np.ascontiguousarray(prev_best_idx, dtype=np.int32).copy()
-        out = SimpleNamespace(prev_best_idx=prev, best_ijk=np.empty((B, 3), dtype=np.int32), best_cost=np.empty(B), end_state=np.empty((B, 3)),
-                              refined=np.empty(B, dtype=np.int32), stats=np.empty((B, 4), dtype=np.int32),
-                              trace=np.empty((B, max(R, 1) * 7, 4)) if trace and R > 0 else None,
-                              best_flags=np.empty(B, dtype=np.uint32) if winner else None,
-                              best_traj=(np.full((B, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, 16, traj_stride))) if winner else None)
+        if out is None:
+            out = self.fiss_outputs(B, R, winner, trace, traj_stride, traj_sparse)
+        out.prev_best_idx[...] = -1 if prev_best_idx is None else np.asarray(prev_best_idx, dtype=np.int32)
+        prev = out.prev_best_idx
+        if B == 0:
+            return out
         opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
         io = _abi.FpFissIo()
         io.samp_min, io.samp_max, io.samp_res = batch.samp_min.ctypes.data, batch.samp_max.ctypes.data, batch.samp_res.ctypes.data

@@ -410,6 +410,80 @@ int orc_boxes_intersect(double l1, double w1, double x1, double y1, double yaw1,
     return quads_intersect(A, B);
 }
 
+/* ---- the same predicate, decided EXACTLY on the fp64 vertex coordinates (what a robust geometry kernel such as GEOS decides with
+   its orientation predicates).  Test infrastructure for the collision audit (tests/test_collision_exact.py): the float test above
+   rounds its projections, this one cannot be wrong about the polygons it is handed.
+   Exactness: a vertex coordinate is a double; the difference of two doubles is exact in binary128 as long as their exponents are
+   within 60 of each other (or one is zero) - true for every coordinate a scene produces; the product of two such differences
+   has at most 108 significant bits (exact); the SIGN of the correctly rounded difference of two exact values is exact. */
+static int orient_sign(const double* a, const double* b, const double* c)
+{
+    const __float128 abx = (__float128)b[0] - (__float128)a[0], aby = (__float128)b[1] - (__float128)a[1];
+    const __float128 acx = (__float128)c[0] - (__float128)a[0], acy = (__float128)c[1] - (__float128)a[1];
+    const __float128 l = abx * acy, r = aby * acx;
+    return (l > r) - (l < r);
+}
+
+/* Two closed convex polygons are disjoint iff the line through some edge of one has the whole other polygon strictly on its outer
+   side. */
+static int quads_intersect_exact(double A[4][2], double B[4][2])
+{
+    for (int pass = 0; pass < 2; ++pass) {
+        double(*P)[2] = pass ? B : A;
+        double(*Q)[2] = pass ? A : B;
+        for (int k = 0; k < 4; ++k) {
+            const double* p0 = P[k];
+            const double* p1 = P[(k + 1) & 3];
+            int inside = orient_sign(p0, p1, P[(k + 2) & 3]);
+            if (inside == 0) inside = orient_sign(p0, p1, P[(k + 3) & 3]);
+            if (inside == 0) continue; /* degenerate edge: no half plane */
+            int all_out = 1;
+            for (int v = 0; v < 4 && all_out; ++v) {
+                const int o = orient_sign(p0, p1, Q[v]);
+                if (o == 0 || o == inside) all_out = 0;
+            }
+            if (all_out) return 0;
+        }
+    }
+    return 1;
+}
+
+int orc_boxes_intersect_exact(double l1, double w1, double x1, double y1, double yaw1, double l2, double w2, double x2, double y2,
+                              double yaw2)
+{
+    double A[4][2], B[4][2];
+    if (make_box(l1, w1, x1, y1, yaw1, A) || make_box(l2, w2, x2, y2, yaw2, B)) return -1;
+    return quads_intersect_exact(A, B);
+}
+
+/* n pairs of boxes (l, w, x, y, yaw): out[i] = 1 / 0 / -1 (unbuildable); exact = 0: the float test, 1: the exact one. */
+int orc_boxes_intersect_batch(int32_t n, const double* a, const double* b, int32_t exact, int32_t threads, int8_t* out)
+{
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static, 1024)
+#endif
+    for (int i = 0; i < n; ++i) {
+        double A[4][2], B[4][2];
+        const double* pa = a + (size_t)i * 5;
+        const double* pb = b + (size_t)i * 5;
+        if (make_box(pa[0], pa[1], pa[2], pa[3], pa[4], A) || make_box(pb[0], pb[1], pb[2], pb[3], pb[4], B)) out[i] = -1;
+        else out[i] = (int8_t)(exact ? quads_intersect_exact(A, B) : quads_intersect(A, B));
+    }
+    (void)threads;
+    return 0;
+}
+
+/* the rotated rectangle's four vertices as the reference's construct_polygon produces them (for the audit's second, independent
+   exact implementation in python) */
+int orc_box_vertices(double l, double w, double x, double y, double yaw, double* out8)
+{
+    double A[4][2];
+    if (make_box(l, w, x, y, yaw, A)) return -1;
+    for (int k = 0; k < 4; ++k) { out8[2 * k] = A[k][0]; out8[2 * k + 1] = A[k][1]; }
+    return 0;
+}
+
 /* has_collision, frenet_optimal_planner.py:168-195 */
 static int traj_has_collision(const orc_problem* p, const traj_t* t)
 {

@@ -84,6 +84,10 @@ def lib():
         L.orc_fop_plan_batch.argtypes = [PP, C.c_int32, C.c_int32, _ip, _dp]
         L.orc_boxes_intersect.argtypes = [C.c_double] * 10
         L.orc_boxes_intersect.restype = C.c_int
+        L.orc_boxes_intersect_exact.argtypes = [C.c_double] * 10
+        L.orc_boxes_intersect_exact.restype = C.c_int
+        L.orc_boxes_intersect_batch.argtypes = [C.c_int32, _dp, _dp, C.c_int32, C.c_int32, C.POINTER(C.c_int8)]
+        L.orc_box_vertices.argtypes = [C.c_double] * 5 + [_dp]
         _lib = L
     return _lib
 
@@ -145,6 +149,26 @@ def boxes_intersect(box_a, box_b):
     """The collision primitive: boxes are (length, width, x, y, yaw).  True / False, or None when a polygon cannot be built."""
     rc = lib().orc_boxes_intersect(*[float(v) for v in box_a], *[float(v) for v in box_b])
     return None if rc < 0 else bool(rc)
+
+
+def boxes_intersect_exact(box_a, box_b):
+    """The same polygons decided exactly (binary128 orientation signs on the fp64 vertex coordinates)."""
+    rc = lib().orc_boxes_intersect_exact(*[float(v) for v in box_a], *[float(v) for v in box_b])
+    return None if rc < 0 else bool(rc)
+
+
+def boxes_intersect_batch(a, b, exact=False, threads=1):
+    """a, b: [n, 5] boxes (l, w, x, y, yaw) -> int8 [n]: 1 / 0 / -1 (a polygon could not be built)."""
+    a, b = _f64(a).reshape(-1, 5), _f64(b).reshape(-1, 5)
+    out = np.empty(len(a), dtype=np.int8)
+    lib().orc_boxes_intersect_batch(len(a), _p(a), _p(b), int(exact), int(threads), out.ctypes.data_as(C.POINTER(C.c_int8)))
+    return out
+
+
+def box_vertices(box):
+    out = np.empty(8)
+    rc = lib().orc_box_vertices(*[float(v) for v in box], _p(out))
+    return None if rc else out.reshape(4, 2)
 
 
 def from_state(x, y, yaw, v, polyline):

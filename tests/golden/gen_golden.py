@@ -39,8 +39,11 @@ BATCH_FIELDS = ["d_samples", "t_samples", "v_samples", "target_speed", "ego", "f
 BATCH_SCALARS = ["veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride"]
 
 
+OUT_DIR = os.environ.get("GOLDEN_OUT", HERE)  # GOLDEN_OUT=/tmp/x: regenerate beside the committed fixtures (tools/audit_goldens.sh)
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT_DIR, name)
     np.savez_compressed(path, **arrays)
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
@@ -759,3 +762,10 @@ if __name__ == "__main__":
         else:
             globals()[g]()
         print(f"== {g} done in {time.time() - t0:.1f}s")
+        # collision audit of this generator: Polygon.intersects calls, calls near contact (decided in rational arithmetic), and how
+        # many of those the plain fp64 separating-axis test would have answered differently
+        import json
+        with open(os.path.join(OUT_DIR, f"collision_audit_{g.replace(':', '_').replace(',', '_')}.json"), "w") as fh:
+            json.dump(dict(refshim.AUDIT, generator=g), fh)
+        for k in refshim.AUDIT:
+            refshim.AUDIT[k] = 0

@@ -16,11 +16,13 @@ not installed here and cannot be installed (no network):
 * ``shapely`` (pinned 2.0.0 in environment.yml:184) - ``Polygon``,
   ``affinity.translate``, ``affinity.rotate`` and ``Polygon.intersects`` at
   planners/frenet_optimal_planner.py:162-195 and planners/common/vehicle/vehicle.py:31.
-  -> a small stand-in for exactly those four calls on convex polygons
-  (closed-set separating-axis test).  This is OUR code, not shapely's: collision
-  parity against real GEOS is therefore UNPINNED (stated in DESIGN.md); the
-  stand-in is itself pinned by hand-computed known-answer tests in
-  tests/test_oracle_kats.py.
+  -> a small stand-in for exactly those four calls on convex polygons.  The
+  transform restates shapely 2.0's affinity (rotation about the bounding-box
+  centre, 2.5e-16 snap) in fp64; `intersects` is decided EXACTLY on the
+  resulting fp64 vertex coordinates (rational arithmetic behind a float filter),
+  which is what GEOS's robust predicates do.  This is OUR code, not shapely's;
+  it is pinned by hand-computed known-answer tests (tests/test_oracle_kats.py)
+  and audited against the plain float test (collision_audit.json).
 
 Everything else (polynomials, cubic spline, cost, FrenetState/FrenetTrajectory,
 the four planner classes) is the unmodified reference, imported by path.
@@ -30,11 +32,13 @@ from __future__ import annotations
 import math
 import sys
 import types
+from fractions import Fraction
 from types import SimpleNamespace
 
 import numpy as np
 
 REFERENCE_ROOT = "/root/reference"
+AUDIT = {"calls": 0, "near_contact": 0, "float_differs_from_exact": 0}  # of Polygon.intersects, see there
 
 
 # --------------------------------------------------------------------------
@@ -67,14 +71,64 @@ class Polygon:
         e = np.roll(self.pts, -1, axis=0) - self.pts
         return np.stack([-e[:, 1], e[:, 0]], axis=1)
 
-    def intersects(self, other: "Polygon") -> bool:
-        """Closed-set separating axis test (touching counts as intersecting)."""
+    def intersects_float(self, other: "Polygon") -> bool:
+        """Closed-set separating axis test in fp64 (touching counts as intersecting): rounded projections."""
         for ax in np.concatenate([self._axes(), other._axes()]):
             pa = self.pts @ ax
             pb = other.pts @ ax
             if pa.max() < pb.min() or pb.max() < pa.min():
                 return False
         return True
+
+    def intersects_exact(self, other: "Polygon") -> bool:
+        """The same closed-set predicate decided EXACTLY on the fp64 vertex coordinates (rational arithmetic): what a robust
+        geometry kernel (GEOS: orientation predicates) answers for these polygons.  Two closed convex polygons are disjoint iff
+        the line through some edge of one has the whole other polygon strictly on its outer side."""
+        A = [(Fraction(float(x)), Fraction(float(y))) for x, y in self.pts]
+        B = [(Fraction(float(x)), Fraction(float(y))) for x, y in other.pts]
+
+        def orient(a, b, c):
+            v = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+            return (v > 0) - (v < 0)
+
+        for P, Q in ((A, B), (B, A)):
+            n = len(P)
+            for k in range(n):
+                p0, p1 = P[k], P[(k + 1) % n]
+                inside = 0
+                for m in range(2, n):
+                    inside = orient(p0, p1, P[(k + m) % n])
+                    if inside:
+                        break
+                if inside == 0:
+                    continue
+                if all(orient(p0, p1, q) == -inside for q in Q):
+                    return False
+        return True
+
+    def intersects(self, other: "Polygon") -> bool:
+        """Polygon.intersects as the goldens see it: the EXACT predicate, reached through a float filter - when every axis
+        overlaps, or some axis separates, by a margin far above any rounding (1e-9 relative), the float test's answer is the exact
+        one; everything nearer to contact is decided in rational arithmetic.  AUDIT counts the calls, the near-contact calls and
+        how often the plain float test would have answered differently (tests/golden/collision_audit.json)."""
+        AUDIT["calls"] += 1
+        scale = 1.0 + max(float(np.abs(self.pts).max()), float(np.abs(other.pts).max()))
+        worst = -math.inf  # largest separation over the axes, in units of the tolerance
+        for ax in np.concatenate([self._axes(), other._axes()]):
+            pa = self.pts @ ax
+            pb = other.pts @ ax
+            sep = max(pb.min() - pa.max(), pa.min() - pb.max())
+            tol = 1e-9 * float(np.hypot(ax[0], ax[1])) * scale
+            worst = max(worst, sep / tol if tol > 0 else (math.inf if sep > 0 else -math.inf))
+        if worst > 1.0:
+            return False
+        if worst < -1.0:
+            return True
+        AUDIT["near_contact"] += 1
+        exact = self.intersects_exact(other)
+        if exact != self.intersects_float(other):
+            AUDIT["float_differs_from_exact"] += 1
+        return exact
 
 
 class _Affinity:

@@ -1,0 +1,45 @@
+"""GPU: ShardedEngine with several logical shards on the one device of the test box == the single-engine result, for the dense
+FOP pass, the FISS+ pipeline and the device-resident closed loop (the 8-GPU node runs the same code with one shard per device)."""
+import numpy as np
+import pytest
+
+from fiss_plus_planner_amd import synth
+from fiss_plus_planner_amd.sharded import ShardedEngine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_equals_single_engine(engine, shards):
+    batch = synth.make_config(3, B=301)
+    fb = synth.make_config(4, B=301)
+    rng = np.random.default_rng(3)
+    prev = np.where(rng.uniform(size=(fb.B, 1)) < 0.5, -1, np.column_stack([rng.integers(0, fb.nd, fb.B), rng.integers(0, fb.nv, fb.B),
+                                                                           rng.integers(0, fb.nt, fb.B)])).astype(np.int32)
+    ref = engine.plan_dense(batch, tables=True, winner=True, traj_stride=112, traj_sparse=True)
+    ref_f = engine.plan_fiss(fb, "FISS+", prev_best_idx=prev, winner=True, trace=True)
+    with ShardedEngine(devices=[0], shards_per_device=shards) as eng:
+        assert eng.world == shards
+        out = eng.plan_dense(batch, tables=True, winner=True, traj_stride=112, traj_sparse=True)
+        for k in ("best_idx", "best_cost", "stats", "cost", "flags", "best_flags"):
+            np.testing.assert_array_equal(getattr(out, k), getattr(ref, k), err_msg=k)
+        assert np.array_equal(out.best_traj, ref.best_traj, equal_nan=True)
+        f = eng.plan_fiss(fb, "FISS+", prev_best_idx=prev, winner=True, trace=True)
+        for k in ("best_ijk", "stats", "refined", "prev_best_idx", "best_flags"):
+            np.testing.assert_array_equal(getattr(f, k), getattr(ref_f, k), err_msg=k)
+        for k in ("best_cost", "end_state", "trace", "best_traj"):
+            assert np.array_equal(getattr(f, k), getattr(ref_f, k), equal_nan=True), k
+
+
+def test_sharded_closed_loop_equals_single_runner(engine):
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+
+    batch = synth.make_batch(150, 5, 5, 5, 10, 100, False, 99)
+    goal = np.full((batch.B, 2), 1e9)
+    ref = ClosedLoopRunner(engine, DeviceBatch(batch, 0), goal, "FOP").run(12)
+    with ShardedEngine(devices=[0], shards_per_device=3) as eng:
+        out = eng.closed_loop(synth.make_batch(150, 5, 5, 5, 10, 100, False, 99), goal, "FOP", max_cycles=12)
+    for k in ("done", "cycles", "t_now"):
+        np.testing.assert_array_equal(getattr(out, k), getattr(ref, k), err_msg=k)
+    assert np.array_equal(out.ego, ref.ego) and np.array_equal(out.cart, ref.cart, equal_nan=True)
+    assert out.cycles.sum() > batch.B
