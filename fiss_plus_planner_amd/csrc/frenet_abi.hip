@@ -110,6 +110,9 @@ struct fp_ctx {
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
     int fiss_jump = 1;             // fp_ctx_set_option("fiss_jump"): FISS+ walk skips ahead to the first feasible sample's level
+    int validate = 0;              // fp_ctx_set_option("validate"): FP_MEM_DEVICE calls range-check the batch's index arrays first
+    DeviceBuf validate_buf;        // two ints on the device: first failing check, index
+    int* validate_host = nullptr;  // ... and their pinned mirror
     int lattice_winner = 0;        // fp_ctx_set_option("lattice_winner"): 0 auto, 1 inside the lattice kernel, 2 its own launch
     int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
     // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
@@ -459,12 +462,57 @@ bool winner_inside_lattice(const fp_ctx* ctx, const fp_batch* b)
 
 fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
 
-int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem)
+// The checks of check_batch_host on arrays that live in device memory (fp_ctx_set_option("validate", 1)): one lane per ego / frame /
+// time sample, the first failing check wins.  err[0] = 0: clean.
+__global__ void validate_batch_kernel(fp_params p, fp_batch b, int* err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int code = 0;
+    if (i < b.B) {
+        const int f = b.frame_of[i], sc = b.scene_of[i];
+        if (f < 0 || f >= b.F) code = 1;
+        else if (sc >= b.S) code = 2;
+        else if (b.t_now[i] < 0) code = 3;
+    }
+    if (!code && i < b.F && (b.nx[i] < 2 || b.nx[i] > b.NX)) code = 4;
+    if (!code && i < p.nt) {
+        const double n = b.t_samples[i] / p.tick_t;
+        if (!(n > 0) || n > FP_MAX_POINTS) code = 5;
+    }
+    if (code && atomicCAS(&err[0], 0, code) == 0) err[1] = i;
+}
+
+int device_validate(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    FP_TRY(ctx->validate_buf.reserve(2 * sizeof(int)));
+    if (!ctx->validate_host) HIP_TRY(hipHostMalloc((void**)&ctx->validate_host, 2 * sizeof(int), hipHostMallocDefault));
+    int* d_err = (int*)ctx->validate_buf.base;
+    HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(int), stream));
+    int n = b->B > b->F ? b->B : b->F;
+    if (p->nt > n) n = p->nt;
+    hipLaunchKernelGGL(validate_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *p, *b, d_err);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->validate_host, d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // the price of the option: the call waits for the stream
+    const int code = ctx->validate_host[0], at = ctx->validate_host[1];
+    switch (code) {
+        case 0: return FP_OK;
+        case 1: return fail(FP_EINVAL, "frame_of[%d] out of range (device batch, F=%d)", at, b->F);
+        case 2: return fail(FP_EINVAL, "scene_of[%d] out of range (device batch, S=%d)", at, b->S);
+        case 3: return fail(FP_EINVAL, "t_now[%d] is negative (device batch)", at);
+        case 4: return fail(FP_EINVAL, "nx[%d] out of range (device batch, NX=%d)", at, b->NX);
+        default: return fail(FP_ELIMIT, "t_samples[%d] needs more than FP_MAX_POINTS points (device batch)", at);
+    }
+}
+
+int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem, void* stream = nullptr)
 {
     if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
     FP_TRY(check_params(params));
     FP_TRY(check_batch(batch));
     if (mem != FP_MEM_HOST && mem != FP_MEM_DEVICE) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
+    if (mem == FP_MEM_DEVICE && ctx->validate && batch->B > 0) FP_TRY(device_validate(ctx, params, batch, (hipStream_t)stream));
     return FP_OK;
 }
 
@@ -535,6 +583,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     ctx->order_lattice.release();
     ctx->order_refine.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->validate_host) (void)hipHostFree(ctx->validate_host);
     delete ctx;
     return FP_OK;
 }
@@ -568,6 +617,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->fiss_stages = value;
         return FP_OK;
     }
+    if (strcmp(name, "validate") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "validate must be 0 or 1");
+        ctx->validate = value;
+        return FP_OK;
+    }
     if (strcmp(name, "fiss_jump") == 0) {
         if (value < 0 || value > 1) return fail(FP_EINVAL, "fiss_jump must be 0 or 1");
         ctx->fiss_jump = value;
@@ -586,7 +640,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
         {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_order", ctx->lattice_order},
-        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
         if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
@@ -595,7 +649,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 
 int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
 {
-    FP_TRY(common_checks(ctx, params, batch, mem));
+    FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");
     if (result->best_traj && !result->best_flags) return fail(FP_EINVAL, "result.best_traj requires result.best_flags");
     if (batch->B == 0) return FP_OK;
@@ -660,7 +714,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
 int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
                     double* best_traj, int32_t traj_stride, int32_t traj_sparse, int mem, void* stream)
 {
-    FP_TRY(common_checks(ctx, params, batch, mem));
+    FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if (!best_idx || !best_flags || !best_traj) return fail(FP_EINVAL, "best_idx/best_flags/best_traj must not be NULL");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -702,7 +756,7 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
 int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, uint32_t* flags, double* traj, int32_t traj_stride,
                        int32_t traj_sparse, int mem, void* stream)
 {
-    FP_TRY(common_checks(ctx, params, batch, mem));
+    FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if (!flags || !traj) return fail(FP_EINVAL, "flags/traj must not be NULL");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -738,7 +792,7 @@ int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* bat
 int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, int mem,
                  void* stream_v)
 {
-    FP_TRY(common_checks(ctx, params, batch, mem));
+    FP_TRY(common_checks(ctx, params, batch, mem, stream_v));
     if (!opts || !io) return fail(FP_EINVAL, "opts/io is NULL");
     if (opts->kind != FP_FISS && opts->kind != FP_FISS_PLUS) return fail(FP_EINVAL, "opts.kind must be FP_FISS or FP_FISS_PLUS");
     if (opts->max_refine_iters < 0 || opts->max_refine_iters * 7 > 64) return fail(FP_ELIMIT, "max_refine_iters must be in 0..9");
@@ -841,7 +895,7 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
 int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, const double* end_state,
                const fp_loop_io* io, int mem, void* stream)
 {
-    FP_TRY(common_checks(ctx, params, batch, mem));
+    FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if ((best_idx == nullptr) == (end_state == nullptr)) return fail(FP_EINVAL, "exactly one of best_idx / end_state must be given");
     if (!io || !io->ego || !io->t_now || !io->done || !io->cycles || !io->goal_xy) return fail(FP_EINVAL, "fp_loop_io has a NULL mandatory array");
     if (batch->B == 0) return FP_OK;
@@ -941,7 +995,7 @@ int fp_from_state(fp_ctx* ctx, const fp_batch* batch, const double* states, doub
 int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int32_t K, const double* end_states, double* cost,
                   uint32_t* flags, double* traj, int32_t traj_stride, int32_t traj_sparse, int mem, void* stream)
 {
-    FP_TRY(common_checks(ctx, params, batch, mem));
+    FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if (K < 1 || !end_states) return fail(FP_EINVAL, "K must be >= 1 and end_states non-NULL");
     int stride;
     FP_TRY(traj_stride_of(traj_stride, &stride));

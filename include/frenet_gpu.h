@@ -19,7 +19,7 @@
  *     returns; no synchronisation and no allocation once the ctx's scratch buffers
  *     have reached the size the batch needs, i.e. after the first call of that size).
  *     FP_MEM_DEVICE calls cannot look at the arrays: frame_of / scene_of / nx / t_now / best_idx are NOT range-checked (an
- *     out-of-range index is a GPU memory fault, not FP_EINVAL), and a time sample that needs more than FP_MAX_POINTS points
+ *     out-of-range index is a GPU memory fault, not FP_EINVAL - unless fp_ctx_set_option("validate", 1) is on), and a time sample that needs more than FP_MAX_POINTS points
  *     yields NaN cost + FP_FLAG_INFEASIBLE for its candidates instead of FP_ELIMIT.  Validate on the host, or use FP_MEM_HOST.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - a ctx is bound to one device; calls on one ctx must not overlap in time, and the work they enqueue must not either: use
@@ -163,6 +163,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "lattice_winner": who writes fp_plan_dense's best_traj: 0 = auto (the lattice kernel itself while one round of workgroups
  * holds the batch, winner_traj_kernel right behind it for bigger batches), 1 = always the lattice kernel, 2 = always its own
  * launch.  Identical results.
+ * "validate": 1 = FP_MEM_DEVICE calls first run a one-lane-per-ego range check of frame_of / scene_of / t_now / nx / t_samples on the
+ * device and return FP_EINVAL / FP_ELIMIT (with the offending index in fp_last_error) instead of faulting the GPU; the call then
+ * WAITS for the stream (one small kernel + an 8-byte copy).  0 (default) = no check, nothing waits.
  * "fiss_jump": 1 (default) = the FISS+ search walk runs its first iteration, then jumps to the state the reference's walk has
  * when the first feasible sample becomes reachable (minimax cost level, computed in parallel) and resumes there; 0 = every
  * iteration one after the other.  Identical results and Stats.

@@ -161,3 +161,39 @@ def test_long_reference_line(oracle, engine):
         if inline.best_idx[e] >= 0:
             got = allt.traj[e, inline.best_idx[e]]
             np.testing.assert_array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(inline.best_traj[e], nan=-1.0))
+
+
+def test_validate_option_turns_device_faults_into_errors(engine):
+    """FP_MEM_DEVICE calls trust the index arrays (an out-of-range frame_of is a GPU memory fault).  With
+    fp_ctx_set_option("validate", 1) a range-check kernel runs first and the call returns FP_EINVAL / FP_ELIMIT naming the
+    offending entry; a clean batch plans as usual, and the option costs nothing when it is off."""
+    import re
+
+    import torch
+
+    from fiss_plus_planner_amd._abi import FrenetGpuError
+    from fiss_plus_planner_amd.device_batch import DeviceBatch
+
+    batch = synth.make_batch(16, 5, 5, 5, 4, 20, True, 5)
+    want = engine.plan_dense(batch, tables=False)
+    db = DeviceBatch(batch, 0)
+    bi, bc, st = db.empty(16, torch.int32), db.empty(16, torch.float64), db.empty((16, 4), torch.int32)
+    plan = lambda: engine.plan_dense_device(db.params, db.fb, bi.data_ptr(), bc.data_ptr(), st.data_ptr())
+    engine.set_option("validate", 1)
+    try:
+        plan()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(bi.cpu().numpy(), want.best_idx)
+        for name, at, bad, msg in (("frame_of", 3, 99, "frame_of[3]"), ("frame_of", 0, -1, "frame_of[0]"), ("scene_of", 5, 16, "scene_of[5]"),
+                                   ("t_now", 7, -2, "t_now[7]"), ("nx", 2, 1, "nx[2]"), ("nx", 15, 4096, "nx[15]"), ("t_samples", 4, 50.0, "t_samples[4]")):
+            old = db.t[name][at].item()
+            db.t[name][at] = bad
+            with pytest.raises(FrenetGpuError, match=re.escape(msg)):
+                plan()
+            db.t[name][at] = old
+        plan()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(bi.cpu().numpy(), want.best_idx)
+    finally:
+        engine.set_option("validate", 0)
+    assert engine.get_option("validate") == 0
