@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 8
+FP_ABI_VERSION = 9
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
@@ -49,7 +49,7 @@ class FpBatch(C.Structure):
 
 class FpResult(C.Structure):
     _fields_ = [("best_idx", C.c_void_p), ("best_cost", C.c_void_p), ("cost_tbl", C.c_void_p), ("flag_tbl", C.c_void_p),
-                ("stats", C.c_void_p), ("best_flags", C.c_void_p), ("best_traj", C.c_void_p),
+                ("stats", C.c_void_p), ("best_flags", C.c_void_p), ("best_traj", C.c_void_p), ("fopplus", C.c_void_p),
                 ("traj_stride", C.c_int32), ("traj_sparse", C.c_int32)]
 
 

@@ -111,14 +111,13 @@ class ProblemBatch:
         """N(T) = len(np.arange(0, T, tick_t)) for each T sample."""
         return np.ceil(self.t_samples / self.tick_t).astype(np.int64)
 
-    def shard(self, rank: int, world: int) -> "ProblemBatch":
-        """Contiguous ego range of one rank; frames/scenes referenced by it are re-indexed."""
-        lo, hi = (self.B * rank) // world, (self.B * (rank + 1)) // world
-        sel = slice(lo, hi)
+    def take(self, egos, meta: dict | None = None) -> "ProblemBatch":
+        """The sub-batch of the given egos (index array or slice, in that order); the frames / scenes they reference are re-indexed."""
+        sel = egos if isinstance(egos, slice) else np.asarray(egos, dtype=np.int64)
         fr, fi = np.unique(self.frame_of[sel], return_inverse=True)
         sc_all = self.scene_of[sel]
         sc, si = np.unique(sc_all[sc_all >= 0], return_inverse=True)
-        scene_of = np.full(hi - lo, -1, dtype=np.int32)
+        scene_of = np.full(len(sc_all), -1, dtype=np.int32)
         scene_of[sc_all >= 0] = si
         keep_s = sc if sc.size else np.zeros(0, dtype=np.int64)
         return ProblemBatch(
@@ -131,7 +130,12 @@ class ProblemBatch:
             samp_min=None if self.samp_min is None else self.samp_min[sel],
             samp_max=None if self.samp_max is None else self.samp_max[sel],
             samp_res=None if self.samp_res is None else self.samp_res[sel], curvature_limits=self.curvature_limits,
-            meta=dict(self.meta, rank=rank, world=world))
+            meta=dict(self.meta, **(meta or {})))
+
+    def shard(self, rank: int, world: int) -> "ProblemBatch":
+        """Contiguous ego range of one rank; frames/scenes referenced by it are re-indexed."""
+        lo, hi = (self.B * rank) // world, (self.B * (rank + 1)) // world
+        return self.take(slice(lo, hi), meta=dict(rank=rank, world=world))
 
     def digest(self) -> str:
         """SHA-256 over every array: lets the GPU box prove it regenerated the same inputs."""

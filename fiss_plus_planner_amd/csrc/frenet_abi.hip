@@ -460,7 +460,17 @@ bool winner_inside_lattice(const fp_ctx* ctx, const fp_batch* b)
     return b->B <= ctx->resident_groups;
 }
 
-fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
+fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
+
+// FopPlusPlanner counts pops over the dense tables: when the caller did not ask for them they live in the ctx's scratch buffer.
+int fopplus_tables(fp_ctx* ctx, size_t B, size_t C, fp_result* r)
+{
+    FP_TRY(ctx->scratch.reserve(align_up(sizeof(double) * B * C) + align_up(sizeof(uint32_t) * B * C)));
+    char* sp = (char*)ctx->scratch.base;
+    if (!r->cost_tbl) r->cost_tbl = (double*)sp;
+    if (!r->flag_tbl) r->flag_tbl = (uint32_t*)(sp + align_up(sizeof(double) * B * C));
+    return FP_OK;
+}
 
 // The checks of check_batch_host on arrays that live in device memory (fp_ctx_set_option("validate", 1)): one lane per ego / frame /
 // time sample, the first failing check wins.  err[0] = 0: clean.
@@ -663,6 +673,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
+        if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r));
         FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
         int nsplit; void* parts;
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
@@ -674,6 +685,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
+        if (result->fopplus)
+            LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, result->fopplus, ka.r.stats,
+                                                (hipStream_t)stream), "FOP+ count kernel");
         return FP_OK;
     }
     FP_TRY(check_batch_host(params, batch));
@@ -682,7 +696,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<int32_t>(B * 4) + 2 * HostStage::need<double>(B) + HostStage::need<int32_t>(B) +
                       HostStage::need<double>(B * C) + HostStage::need<uint32_t>(B * C) + HostStage::need<uint32_t>(B) +
-                      HostStage::need<double>(traj_doubles),
+                      HostStage::need<double>(traj_doubles) + HostStage::need<int32_t>(B * 2),
                       /*zero_copy_out=*/B <= 8));
     FP_TRY(stage_batch(hs, params, batch, &ka.b));
     FP_TRY(hs.flush_in());
@@ -695,6 +709,8 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     ka.r.best_traj = hs.out(result->best_traj, traj_doubles);
     ka.r.traj_stride = result->traj_stride;
     ka.r.traj_sparse = result->traj_sparse;
+    int32_t* d_fopplus = hs.out(result->fopplus, B * 2);
+    if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r));
     // sparse rows are only partly written by the kernels: the host block comes back with the caller's own bytes elsewhere
     if (result->traj_sparse && ka.r.best_traj) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, result->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     FP_TRY(lattice_curv_scratch(ctx, params, batch, ctx->stream, &ka.curv_tbl));
@@ -708,6 +724,9 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
+    if (d_fopplus)
+        LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, d_fopplus, ka.r.stats, ctx->stream),
+                   "FOP+ count kernel");
     return hs.fetch_out();
 }
 

@@ -74,6 +74,9 @@ hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, v
 // Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
 // end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);
+// FopPlusPlanner.plan from the dense tables + the FOP argmin (one wavefront per ego): out [B][2] = {popped, tie}, stats [B][4].
+hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint32_t* flag_tbl, const int32_t* best_idx, const double* best_cost,
+                                int32_t* out, int32_t* stats, hipStream_t stream);
 // Frenet frame construction / Cartesian -> Frenet projection (frenet_frame.hip).
 hipError_t launch_frames_build(int F, int NX, const int32_t* n, const double* points, double* knots, double* coef, hipStream_t stream);
 hipError_t launch_from_state(const fp_batch& bt, const double* states, double* ego, hipStream_t stream);

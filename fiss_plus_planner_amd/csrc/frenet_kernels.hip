@@ -576,6 +576,58 @@ hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const d
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// FopPlusPlanner.plan (fop_plus_planner.py:16-41) from the dense tables: every candidate goes on a priority queue ordered by cost_final,
+// candidates are validated in pop order and the first feasible one is the answer - i.e. the cheapest feasible candidate, which
+// the lattice kernel's argmin already found, after as many pops as there are cheaper candidates (+ 1).  Only an exact cost tie at
+// the decision point (or a NaN cost, whose comparisons are all false) leaves the outcome to CPython's heap order: flagged, the
+// caller replays that ego on the host.  One wavefront per ego.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave * 4) void fopplus_count_kernel(int B, int C, const double* cost_tbl, const uint32_t* flag_tbl, const int32_t* best_idx,
+                                                                   const double* best_cost, int32_t* out, int32_t* stats)
+{
+    const int b = blockIdx.x * 4 + (int)threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    if (b >= B) return;
+    const int win = best_idx[b];
+    const double cw = best_cost[b];
+    const double* cost = cost_tbl + (size_t)b * C;
+    const uint32_t* fl = flag_tbl + (size_t)b * C;
+    int cheaper = 0, tied = 0, odd = 0;
+    for (int c = lane; c < C; c += kWave) {
+        const double v = cost[c];
+        odd += !(v == v);
+        if (win >= 0) {
+            cheaper += v < cw;
+            // another candidate at exactly the winner's cost: feasible or not, the heap decides who is popped first
+            tied += v == cw && c != win;
+        } else {
+            odd += (fl[c] & FP_FLAG_INFEASIBLE) == 0;  // (cannot happen: a feasible candidate without an argmin)
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        cheaper += __shfl_xor(cheaper, off, kWave);
+        tied += __shfl_xor(tied, off, kWave);
+        odd += __shfl_xor(odd, off, kWave);
+    }
+    if (lane == 0) {
+        const int popped = win >= 0 ? cheaper + 1 : C;
+        out[2 * b] = popped;
+        out[2 * b + 1] = (tied > 0 || odd > 0) ? 1 : 0;
+        if (stats) {
+            int32_t* st = stats + (size_t)b * 4;
+            st[0] = popped; st[1] = C; st[2] = popped; st[3] = popped;  // fop_plus_planner.py:30-35, generated = the whole lattice (:21-23)
+        }
+    }
+}
+
+hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint32_t* flag_tbl, const int32_t* best_idx, const double* best_cost,
+                                int32_t* out, int32_t* stats, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fopplus_count_kernel, dim3((B + 3) / 4), dim3(kWave * 4), 0, stream, B, C, cost_tbl, flag_tbl, best_idx, best_cost, out, stats);
+    return hipGetLastError();
+}
+
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done, const int* perm,
                           int* dur)
 {

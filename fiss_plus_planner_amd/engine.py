@@ -148,6 +148,43 @@ class FrenetEngine:
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
         return out
 
+    def plan_fopplus(self, batch: ProblemBatch, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+        """FopPlusPlanner.plan() for every ego of the batch (fop_plus_planner.py:16-41) on the device: the cheapest feasible
+        candidate + Stats = how many candidates the cost-ordered lazy validation pops before it.  Egos whose outcome hangs on an
+        exact cost tie (mirror-symmetric start states) are replayed with the reference's heap order over their dense tables
+        (search.fopplus_search); `replayed` lists them.  Same result object as plan_dense plus `fopplus` [B,2]."""
+        from . import search
+
+        B = batch.B
+        out = self.dense_outputs(B, batch.C, False, winner, traj_stride, traj_sparse)
+        out.fopplus = np.zeros((B, 2), dtype=np.int32)
+        out.replayed = np.zeros(0, dtype=np.int64)
+        if B == 0:
+            return out
+        res = _abi.FpResult()
+        res.best_idx, res.best_cost, res.stats, res.fopplus = _ptr(out.best_idx), _ptr(out.best_cost), _ptr(out.stats), _ptr(out.fopplus)
+        res.best_flags = _ptr(out.best_flags) if winner else None
+        res.best_traj = _ptr(out.best_traj) if winner else None
+        res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
+        p = make_params(batch)
+        fb = _host_batch(batch)
+        _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
+        ties = np.nonzero(out.fopplus[:, 1])[0]
+        if len(ties):  # exact ties: CPython's heap order decides, as in the reference
+            sub = batch.take(ties)
+            tab = self.plan_dense(sub, tables=True)
+            for k, e in enumerate(ties):
+                idx, st = search.fopplus_search(tab.cost[k], tab.flags[k])
+                out.best_idx[e] = -1 if idx is None else idx
+                out.best_cost[e] = np.nan if idx is None else tab.cost[k, idx]
+                out.stats[e] = st
+            if winner:
+                w = self.winner_trajs(sub, out.best_idx[ties], traj_stride, traj_sparse)
+                out.best_flags[ties] = w.best_flags
+                out.best_traj[ties] = w.best_traj
+            out.replayed = ties
+        return out
+
     def eval_trajs(self, batch: ProblemBatch, end_states: np.ndarray, dump: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """Explicit end states [B,K,3] = (d_end, v_end, T_end) -> cost [B,K], flags [B,K] (+ traj [B,K,16,stride])."""
         es = np.ascontiguousarray(end_states, dtype=np.float64)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 8
+#define FP_ABI_VERSION 9
 
 /* error codes */
 #define FP_OK 0
@@ -130,6 +130,12 @@ typedef struct {
     uint32_t* best_flags; /* [B]    flag word (N, M) of the argmin, 0 when best_idx = -1 */
     double* best_traj;   /* [B][16][traj_stride]  winner epilogue: the argmin's full FrenetTrajectory series (NaN padded;
                             all NaN when best_idx = -1) = what plan() returns                           :264-270 */
+    int32_t* fopplus;    /* NULL or [B][2]: FopPlusPlanner.plan for every ego (fop_plus_planner.py:16-41: candidates validated lazily in
+                            cost order, the first feasible one wins).  [b][0] = candidates popped up to and including the winner
+                            (all C when nothing is feasible) = num_iter = validated = collision checks, also written to stats;
+                            [b][1] = 1 when an exact cost tie (or a NaN cost) at the decision point leaves the outcome to the
+                            reference's heap order - replay that ego on the host (fiss_plus_planner_amd/search.py:fopplus_search) -
+                            else 0: best_idx / best_cost ARE FopPlusPlanner's answer */
     int32_t traj_stride; /* columns per series row; 0 = FP_MAX_POINTS.  Must be >= the largest N = ceil(T / tick_t) of the batch
                             (e.g. 100 for T <= 10 s at 0.1 s): a smaller stride is FP_EINVAL (host) / truncates the rows (device) */
     int32_t traj_sparse; /* 0: every element of the [16][traj_stride] block is written (NaN where a row has no element).

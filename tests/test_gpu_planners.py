@@ -227,3 +227,46 @@ def test_fiss_all_trajs_is_the_generated_set_in_generation_order(engine, oracle,
                 for r, nm in enumerate(ARRAY_NAMES):
                     a = np.asarray(getattr(t, nm)); got[r, :len(a)] = a
                 assert_series_close(got, w.arrays, b.tick_t, f"{name} ego {e} idx {t.idx}")
+
+
+def test_fopplus_batch_on_the_device(oracle, engine):
+    """FopPlusPlanner.plan for a whole batch without a Python heap per ego (fp_plan_dense with result.fopplus): selected index, cost
+    and Stats = the oracle's lazy validation in cost order; mirror-symmetric egos (exact cost ties at the decision point) are
+    flagged by the kernel and replayed with the reference's heap order - with the winner's series when asked for."""
+    import numpy as np
+
+    from fiss_plus_planner_amd import search, synth
+
+    b = synth.make_batch(96, 4, 5, 5, 10, 100, False, 123)
+    # d = d_d = d_dd = 0 on an EVEN number of lateral samples: the two inner samples mirror each other, tie exactly and are the
+    # cheapest - the decision hangs on the heap order.  No obstacles for those egos, so the tied pair is feasible.
+    b.ego[:6, 3:] = 0.0
+    b.scene_of[:6] = -1
+    out = engine.plan_fopplus(b, winner=True)
+    tab = engine.plan_dense(b, tables=True)
+    assert set(out.replayed.tolist()) <= set(range(6)) and len(out.replayed) >= 3  # (an ego whose tied pair is infeasible needs no replay)
+    n_found = 0
+    for e, pr in enumerate(oracle.problems_from_batch(b)):
+        r = pr.fopplus_plan()
+        if e in out.replayed:  # tie order = CPython's heapq over the tables, like the reference; the oracle's own heap is not CPython's
+            idx, st = search.fopplus_search(tab.cost[e], tab.flags[e])
+            assert out.best_idx[e] == (-1 if idx is None else idx) and tuple(out.stats[e]) == tuple(st)
+            continue
+        assert out.best_idx[e] == r.best_idx, e
+        np.testing.assert_array_equal(out.stats[e], r.stats, err_msg=f"ego {e}")
+        if r.best_idx >= 0:
+            n_found += 1
+            assert abs(out.best_cost[e] - r.best_cost) < 1e-6
+            assert out.best_idx[e] == tab.best_idx[e]  # without ties FOP+ and FOP agree (fop_plus_planner.py:29-39 vs :263-268)
+    assert n_found > 20
+    w = engine.winner_trajs(b, out.best_idx)
+    np.testing.assert_array_equal(out.best_flags, w.best_flags)
+    assert np.array_equal(out.best_traj, w.best_traj, equal_nan=True)
+    # a bigger lattice, dynamic obstacles, nothing symmetric: no replay at all
+    b3 = synth.make_config(3, B=128)
+    o3 = engine.plan_fopplus(b3)
+    assert len(o3.replayed) == 0
+    for e, pr in enumerate(oracle.problems_from_batch(b3, range(0, 128, 4))):
+        r = pr.fopplus_plan()
+        assert o3.best_idx[4 * e] == r.best_idx
+        np.testing.assert_array_equal(o3.stats[4 * e], r.stats)
