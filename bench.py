@@ -393,7 +393,7 @@ def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads):
     """north_star's workload is "many scenarios x many cycles": B egos stepped `cycles` plan cycles entirely on the device
     ([plan -> advance] per cycle, planners/benchmark/planning.py:120-162; no host round trip).  Parity: the state the loop left
     behind is planned once more and compared with the oracle planning the same states."""
-    from fiss_plus_planner_amd import synth
+    from fiss_plus_planner_amd import _abi, synth
     from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
     from oracle import oracle as O
 
@@ -412,7 +412,7 @@ def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads):
         t0 = time.perf_counter()
         res = run.run(cycles - 1)
         dt = time.perf_counter() - t0
-        plans = int(res.cycles.sum() + (res.done == 2).sum())  # an ego's last plan may have found nothing (FP_DONE_NO_SOLUTION)
+        plans = int(res.cycles.sum() + (res.done == _abi.DONE_NO_SOLUTION).sum())  # an ego's last plan may have found nothing
         # parity of the state the loop left behind: one more plan (no advance) of the running egos vs the oracle on those states
         running = np.nonzero(res.done == 0)[0]
         egos = running[:: max(1, len(running) // 48)][:48]
