@@ -193,11 +193,15 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const int rows_max = kShape ? ROWS : rows_max_arg;
     const int hp_max = kShape ? (ROWS > 0 ? (ROWS * STRIDE + 1 > FP_MAX_POINTS ? FP_MAX_POINTS : ROWS * STRIDE + 1) : 0) : hp_max_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#if defined(FP_PHASE_STAMPS)
+    const long long t_begin = wall_clock64();
+#else
     const long long t_begin = dur ? wall_clock64() : 0;
+#endif
     // Timing diagnostic (tools/phase_stamps.py, -DFP_PHASE_STAMPS): thread 0 leaves the time since the workgroup started (10 ns
     // ticks) at the phase boundaries in columns 112.. of the last row of its best_traj block (free with traj_stride = 128, sparse, T <= 11 s).
 #if defined(FP_PHASE_STAMPS)
-#define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && dur) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
+#define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x / nsplit) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
 #else
 #define FP_STAMP(k) do { } while (0)
 #endif

@@ -19,10 +19,13 @@ PHASES = ["scalars + spline tables + obstacle sizes", "LUT + speed bound + later
           "slices: frames / lat / prep / B / N", "assembly + argmin", "results"]
 STAMPS = [0, 1, 2, 3, 4, 7, 8, 9, 10]
 
-batch = synth.make_config(3)
+CONFIG = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+batch = synth.make_config(CONFIG)
 dev = torch.device("cuda", 0)
 eng = FrenetEngine(0)
 eng.set_option("lattice_winner", 1)  # the stamps travel in the winner block the lattice kernel itself writes
+if len(sys.argv) > 2:
+    eng.set_option("lattice_split", int(sys.argv[2]))
 dten = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in NAMES}
 fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in dten.items()})
 params = make_params(batch)
