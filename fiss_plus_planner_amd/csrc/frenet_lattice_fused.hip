@@ -398,7 +398,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     if (hp > hp_max) hp = hp_max;
     const double veh_hl = 0.5 * p.veh_l, veh_hw = 0.5 * p.veh_w;
     const double r_ego = sqrt(fma(veh_hl, veh_hl, veh_hw * veh_hw));
-    __syncthreads();
+    // (no barrier: phase A0 below needs only what the staging barrier made visible - the LUT / speed bound above and the solves below
+    // are independent and share one barrier interval; the solves go to the LAST threads, the LUT to the first)
     FP_STAMP(1);
 
     const double* v_samples = s_vs;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     //     sum_i p(t_i)^2 = sum_k c_k S_k with c = p (*) p (coefficient convolution) - no per-point work and no reductions.
     //     Conditioning is benign on t in [0, 10] (terms ~1e2..1e4 against sums ~1e1..1e3: ~1e-12 absolute), far inside the
     //     1e-6 cost bar, and the expressions are even in the lateral boundary data, so mirrored candidates still tie bit-exactly.
-    for (int e = tid; e < n_it * nv; e += kThreads) {
+    for (int e = kThreads - 1 - tid; e < n_it * nv; e += kThreads) {
         const int eq = div_by<NV, NT * NV>(e, 1.0f / (float)nv);
         const int it = it_lo + eq, iv = e - mul24(eq, nv);
         const double T = s_ts[it];
@@ -486,9 +487,12 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
             if (lane == 0 && bits) atomicMax((unsigned int*)&s_cnt[6], bits);
         }
     }
+    {   // power sums of every slice (they need nothing but the time samples): a few threads of the middle
+        const int i = tid - kThreads / 2;
+        if (i >= 0 && i < n_it) power_sums_closed(arange_len(s_ts[it_lo + i], tick), tick, s_pows + (it_lo + i) * 11);
+    }
     __syncthreads();
     FP_STAMP(2);
-    for (int i = tid; i < n_it; i += kThreads) power_sums_closed(s_nslice[it_lo + i], tick, s_pows + (it_lo + i) * 11);
     if (n_obs > 0 && pose_limit > 0) {
         // ---- arclength range of every checked pose row over the lon profiles of ALL slices of this workgroup: lane = (row, slice),
         // loop over the end-speed samples, then LDS atomic min / max on order-preserving fp32 bit patterns (relative to the first knot).
@@ -533,9 +537,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
     }
     // [/section MASKS]
-    __syncthreads();
-    FP_STAMP(3);
-    for (int e0 = wave * kWave; e0 < n_it * (nv + nd); e0 += kThreads) {  // (whole wavefronts: the row maxima below are wave reductions)
+    for (int e0 = (kWaves - 1 - wave) * kWave; e0 < n_it * (nv + nd); e0 += kThreads) {  // (the last wavefronts: the ranges above keep the first busy)  // (whole wavefronts: the row maxima below are wave reductions)
         const int e = e0 + lane;
         const bool live = e < n_it * (nv + nd);
         const int eq = live ? div_by<NV + ND, NT * (NV + ND)>(e, 1.0f / (float)(nv + nd)) : 0;
@@ -568,6 +570,8 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
         }
     };
     fill_slice_lat(it_lo);
+    __syncthreads();
+    FP_STAMP(3);
     // ---- ranges -> circles: every reference point of the row lies within  v_max * (half the range)  of the line's point at
     // the middle of the range (v_max >= |P'(s)| everywhere); + ego reach + the largest lateral offset.  One test per
     // (row, obstacle) item then prunes the item for every profile of every slice at once.
