@@ -788,8 +788,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             const ObsPose op = s_spose[si];
                             const ObsDim od = s_dim[j];
                             const Frame fr = s_frames[mul24(iv, hp_max) + k];
-                            // Poses beyond a profile's M hold stale frames: they may pass here and are rejected by the narrow
-                            // phase (k < M is tested there).
+                            // Poses beyond a profile's M hold stale frames, and a trajectory of fewer than two points has no heading: no
+                            // pair (the narrow phase relies on it)
+                            const int Mp = s_lon_meta[mul24(it, nv) + iv].x;
                             const double fat = (r_ego + od.r + (double)s_dmax[k]) * (1.0 + 1e-12);
                             const double dx = op.x - fr.px, dy = op.y - fr.py;
                             // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre
@@ -799,9 +800,9 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                             const double w = fma(dy, fr.tx, -dx * fr.ty), u = fma(dx, fr.tx, dy * fr.ty);
                             const double a_n = fabs(fma(op.s, fr.tx, -op.c * fr.ty)), a_t = fabs(fma(op.c, fr.tx, op.s * fr.ty));
                             const double reach = fma(od.hl, a_n, od.hw * a_t), reach_t = fma(od.hl, a_t, od.hw * a_n);
-                            pass = !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach) &&
+                            pass = k < Mp && Mp >= 2 && !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach) &&
                                    !(fabs(u) > r_ego * (1.0 + 1e-12) + reach_t);
-                            code = ((uint32_t)iv << 16) | (uint32_t)si;
+                            code = (uint32_t)iv | ((uint32_t)k << 8) | ((uint32_t)si << 16);  // iv <= 255, k < 128, si < 512
                         }
                         const unsigned long long m = __ballot(pass);
                         if (lane == 0) { FP_COUNT(1, 1); FP_COUNT(2, __popcll(m)); }
@@ -826,16 +827,15 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 #endif
                     for (int x = tid; x < n_exact; x += kThreads) {
                         const int h = div_by<ND, kHitCap * ND>(x, inv_ndf), id = x - mul24(h, nd);
+                        // everything the filter needs rides in the hit word: one LDS read, then the candidate's collision byte
                         const uint32_t code = s_hits[h];
-                        const int iv = code >> 16, si = code & 0xFFFF;
-                        const int item = s_items[si];
-                        const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
+                        const int iv = code & 0xFF, k = (code >> 8) & 0xFF, si = code >> 16;
                         const int cand = mul24(mul24(id, nt) + it, nv) + iv;
-                        const int k = mul24(r, stride);
-                        const int M = s_lon_meta[mul24(it, nv) + iv].x;
                         FP_COUNT(3, 1);
-                        if (k < M && M >= 2 && s_coll[cand]) FP_COUNT(4, 1);
-                        if (k < M && M >= 2 && !s_coll[cand]) {
+                        if (s_coll[cand]) FP_COUNT(4, 1);
+                        if (!s_coll[cand]) {
+                            const int j = (int)s_items[si] - mul24(div_by<STRIDE, FP_MAX_POINTS>(k, 1.0f / (float)stride), n_obs);  // item = row * n_obs + obstacle, k = row * stride
+                            const int M = s_lon_meta[mul24(it, nv) + iv].x;
                             // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                             const int ka_ = (k + 1 < M) ? k : k - 1;
                             const Frame f0 = s_frames[mul24(iv, hp_max) + ka_], f1 = s_frames[mul24(iv, hp_max) + ka_ + 1];
