@@ -85,7 +85,11 @@ __device__ __forceinline__ int div_by(int e, float inv_d)
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
 constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass  // block-wide list of live narrow-phase items (pair, lateral sample) of one B pass: 24 KB
-constexpr int kItemCap = 512;    // block-wide list of (row, obstacle) items that pass the group test (+ their poses: 16 KB)
+// block-wide list of (row, obstacle) items that pass the group test (+ their poses, 32 B each).  Two kernel variants: OCC = 4 waves per
+// SIMD (two workgroups per CU, up to 128 VGPRs, winner epilogue inside) and OCC = 6 (THREE workgroups per CU: 80 VGPRs - a few spill
+// - and at most 53 KB of LDS, so a shorter list; no winner epilogue, the batches it serves get theirs from winner_traj_kernel)
+__host__ __device__ constexpr int item_cap(int occ) { return occ > 4 ? 320 : 512; }
+constexpr int kItemCapMax = 512;
 
 struct __attribute__((aligned(16))) Frame {  // reference-line frame of one lon-profile point
     double px, py, tx, ty;
@@ -104,7 +108,7 @@ struct Layout {
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
 
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt)
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap)
 {
     Layout L;
     int o = 0;
@@ -185,11 +189,12 @@ __device__ __forceinline__ void power_sums_closed(int N, double tick, double* ou
 // 25 rows, 5 x 5 x 5 with 10 obstacles over 50 rows); in their instances every index decode is a constant multiply-shift, the LDS
 // carve-up folds to immediates and the loop bounds are known.  The <0, ...> instance is the same source with everything read from
 // the arguments.
-template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS>
-__global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit, Best* part_best, int* part_count, const int* perm,
+template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC>
+__global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit, Best* part_best, int* part_count, const int* perm,
                                                                    int* dur)
 {
     constexpr bool kShape = ND > 0;  // (all six are set together)
+    constexpr int kItemCap = item_cap(OCC);
     const int rows_max = kShape ? ROWS : rows_max_arg;
     const int hp_max = kShape ? (ROWS > 0 ? (ROWS * STRIDE + 1 > FP_MAX_POINTS ? FP_MAX_POINTS : ROWS * STRIDE + 1) : 0) : hp_max_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
     const int n_obs_tab = kShape ? NOBS : bt.n_obs;  // obstacles per scene of the table
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt);
+    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
@@ -781,7 +786,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
                         bool pass = false;
                         uint32_t code = 0;
                         if (pr < p1) {
-                            const int si = div_by<NV, kItemCap * NV>(pr, inv_nvf), iv = pr - mul24(si, nv);
+                            const int si = div_by<NV, kItemCapMax * NV>(pr, inv_nvf), iv = pr - mul24(si, nv);
                             const int item = s_items[si];
                             const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
                             const int k = mul24(r, stride);
@@ -981,6 +986,7 @@ __global__ __launch_bounds__(kThreads, 4) void lattice_fused_kernel(KernelArgs k
 #if defined(FP_ABL_NO_WINNER)
     return;
 #endif
+    if constexpr (OCC > 4) return;  // (this variant is only launched when the series come from winner_traj_kernel)
     if (!ka.r.best_traj) return;
     __syncthreads();
     if (wave != 0) return;
@@ -1023,9 +1029,16 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     const fp_batch& b = ka.b;
     int rows = 0, hp = 0;
     if (!fused_shape(p, b, &rows, &hp)) return hipErrorInvalidValue;
-    const Layout L = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt);
-    if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (!part_scratch || nsplit < 1) nsplit = 1;
+    // Three workgroups per CU (the OCC = 6 variant) when the launch has more egos than two per CU can hold at once, nobody needs the
+    // series from this kernel and a workgroup's LDS fits a third of the CU's 160 KB; else two per CU (OCC = 4).
+    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6));
+    bool three = nsplit == 1 && !ka.r.best_traj && b.B > 512 && 3 * (L6.total + 256) <= 160 * 1024;
+#if defined(FP_NO_OCC6)  // (A/B diagnostic)
+    three = false;
+#endif
+    const Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4));
+    if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (nsplit > p.nt) nsplit = p.nt;
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
     int* part_count = (int*)part_scratch;
@@ -1047,18 +1060,27 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_generic);
     FP_LDS_SLOTS(cfg_997);
     FP_LDS_SLOTS(cfg_555);
+    FP_LDS_SLOTS(cfg_generic6);
+    FP_LDS_SLOTS(cfg_9976);
+    FP_LDS_SLOTS(cfg_5556);
     auto is = [&](int nd, int nv, int nt, int stride, int n_obs, int r) {
         return p.nd == nd && p.nv == nv && p.nt == nt && p.check_stride == stride && b.n_obs == n_obs && rows == r;
     };
 #if defined(FP_NO_SHAPES)  // (A/B diagnostic: the run-time instance for every shape)
-    e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0>, cfg_generic);
+    e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4>, cfg_generic);
 #else
-    if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25>, cfg_997);
-    else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50>, cfg_555);
-    else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0>, cfg_generic);
+    if (three) {
+        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6>, cfg_9976);
+        else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 6>, cfg_5556);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6>, cfg_generic6);
+    } else {
+        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 4>, cfg_997);
+        else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4>, cfg_555);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4>, cfg_generic);
+    }
 #endif
     if (e != hipSuccess) return e;
-    if (winner_done) *winner_done = ka.r.best_traj != nullptr;
+    if (winner_done) *winner_done = ka.r.best_traj != nullptr && !three;
     return hipSuccess;
 }
 
