@@ -201,9 +201,17 @@ struct SplineLds {
 __device__ __forceinline__ int spline_segment(const SplineLds& sp, double s, int hint)
 {
     const int last = sp.nx - 1;
-    if (!(s >= sp.knots[0]) || !(s < sp.knots[last])) return -1;
-    // s is nearly monotone along a trajectory: try the previous segment and its successor first
+    const double k0 = sp.knots[0], kl = sp.knots[last];
+    if (!(s >= k0) || !(s < kl)) return -1;
+    // s is nearly monotone along a trajectory: try the previous segment and its successor first.  Without a hint: the segment a
+    // uniform knot spacing would give (centerlines are close to it) and its two neighbours - two or three dependent reads instead of
+    // the bisection's log2(nx), which matters when the table sits in global memory (winner_traj_kernel: one trajectory per wavefront)
     int i = hint;
+    if (i < 0) {
+        i = (int)((s - k0) / (kl - k0) * (double)last);
+        i = i < 0 ? 0 : (i > last - 1 ? last - 1 : i);
+        if (i > 0 && s < sp.knots[i]) --i;
+    }
     if (i >= 0 && i < last && sp.knots[i] <= s) {
         if (s < sp.knots[i + 1]) return i;
         if (i + 1 < last && s < sp.knots[i + 2]) return i + 1;
