@@ -347,12 +347,12 @@ def host_info():
     return info
 
 
-def cpu_rate(batch, egos, threads):
+def cpu_rate(batch, egos, threads, fast=False):
     from oracle import oracle as O
 
     probs = O.problems_from_batch(batch, egos)
     t0 = time.perf_counter()
-    o_idx, o_cost = O.fop_plan_batch(probs, threads=threads)
+    o_idx, o_cost = O.fop_plan_batch(probs, threads=threads, fast=fast)
     dt = time.perf_counter() - t0
     return len(probs) * batch.C / dt, dt, o_idx, o_cost
 
@@ -393,6 +393,16 @@ def cpu_baseline_leg(batch, h_idx, h_cost, seconds, max_threads):
                                 f"restatement: pow() per term, point-by-point sums, polygon SAT), {threads} OpenMP thread(s) over egos, {dt:.1f} s; "
                                 f"GPU index / cost parity checked on this sample",
                       "parity": {"checked_egos": n_s, "index_exact": True, "max_abs_cost_err": err, "cost_tolerance": COST_TOL}}
+    # a second, LABELLED baseline: the same restatement built -O3 with `t ** k` as multiplications (oracle/Makefile `fast`)
+    n_f = int(max(min(16, B), min(B, min(6.0, seconds) * 1.5 * sweep[best_t] / C)))
+    cpu_rate(batch, range(min(8, B)), 1, fast=True)
+    rate, dt, o_idx, o_cost = cpu_rate(batch, range(n_f), best_t, fast=True)
+    ok = o_idx >= 0
+    if not np.array_equal(h_idx[:n_f], o_idx) or (ok.any() and not np.abs(h_cost[:n_f][ok] - o_cost[ok]).max() <= COST_TOL):
+        parity_fail("cpu_baseline_optimised", "index / cost differ")
+    out["cpu_baseline_optimised"] = {"value": rate, "unit": "candidates/s", "cores": best_t, "kind": "port",
+                                     "sample": f"first {n_f} egos of the first timed batch, oracle/libfrenet_oracle_fast.so (the same per-candidate restatement, "
+                                               f"-O3, integer powers as multiplications instead of pow()), {best_t} OpenMP threads, {dt:.1f} s; GPU parity checked"}
     out["cpu_baseline"]["thread_sweep"] = {str(k): v for k, v in sorted(sweep.items())}
     out["cpu_baseline"]["host"] = host_info()
     return out
@@ -705,6 +715,7 @@ def main():
             "valu_fp64_executed": fp64_exec,
             "cpu_baseline": cpu.get("cpu_baseline"),
             "cpu_baseline_1thread": cpu.get("cpu_baseline_1thread"),
+            "cpu_baseline_optimised": cpu.get("cpu_baseline_optimised"),
             "plan_cycle_latency": plan_cycle,
             "materialize_mode": materialize,
         }

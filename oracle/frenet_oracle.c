@@ -16,6 +16,22 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+/* -DORC_FAST (libfrenet_oracle_fast.so, `make -C oracle fast`): the same restatement with `t ** k` as multiplications instead of
+   pow() calls - a LABELLED second CPU baseline for bench.py (not bit-identical to the reference any more: ~1e-13 on the costs; the
+   golden-vector suites run on the literal build only). */
+#ifdef ORC_FAST
+static inline double orc_ipow(double x, double k)
+{
+    if (k == 2.0) return x * x;
+    if (k == 3.0) return x * x * x;
+    if (k == 4.0) { const double y = x * x; return y * y; }
+    if (k == 5.0) { const double y = x * x; return y * y * x; }
+    return pow(x, k);
+}
+#define pow orc_ipow
+#endif
+
 #endif
 
 #define ORC_PI 3.141592653589793

@@ -312,11 +312,27 @@ def problems_from_batch(batch, egos=None, d_samples=None):
     return out
 
 
-def fop_plan_batch(problems, threads=1):
+_fast = None
+
+
+def fast_lib():
+    """libfrenet_oracle_fast.so (-DORC_FAST, -O3): the labelled faster CPU baseline of bench.py; only orc_fop_plan_batch is bound."""
+    global _fast
+    if _fast is None:
+        path = os.path.join(_HERE, "libfrenet_oracle_fast.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "fast"])
+        L = C.CDLL(path)
+        L.orc_fop_plan_batch.argtypes = [C.POINTER(OrcProblem), C.c_int32, C.c_int32, _ip, _dp]
+        _fast = L
+    return _fast
+
+
+def fop_plan_batch(problems, threads=1, fast=False):
     B = len(problems)
     arr = (OrcProblem * B)(*[p.c for p in problems])
     bi = np.empty(B, dtype=np.int32); bc = np.empty(B)
-    rc = lib().orc_fop_plan_batch(arr, B, threads, bi.ctypes.data_as(_ip), _p(bc))
+    rc = (fast_lib() if fast else lib()).orc_fop_plan_batch(arr, B, threads, bi.ctypes.data_as(_ip), _p(bc))
     if rc:
         raise ValueError(f"orc_fop_plan_batch rc={rc}")
     return bi, bc

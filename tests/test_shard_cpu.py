@@ -101,3 +101,14 @@ def test_generator_is_pinned_by_digest():
         assert synth.make_config(cfg, B=8).digest() == digest, cfg
     for cfg, digest in want["lanes"].items():
         assert synth.make_config(cfg, B=8, layout="lanes").digest() == digest, cfg
+
+
+def test_fast_oracle_build_agrees_with_the_literal_one(oracle):
+    """bench.py's labelled second CPU baseline (oracle/libfrenet_oracle_fast.so: -O3, integer powers as multiplications) selects the
+    same candidates at the same costs (to 1e-9) as the literal restatement the goldens pin."""
+    b = synth.make_batch(24, 5, 5, 5, 8, 60, True, seed=77)
+    probs = oracle.problems_from_batch(b)
+    i0, c0 = oracle.fop_plan_batch(probs, threads=2)
+    i1, c1 = oracle.fop_plan_batch(probs, threads=2, fast=True)
+    assert np.array_equal(i0, i1) and (i0 >= 0).any()
+    assert np.nanmax(np.abs(c0 - c1)) < 1e-9
