@@ -1033,7 +1033,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     // Three workgroups per CU (the OCC = 6 variant) when the launch has more egos than two per CU can hold at once, nobody needs the
     // series from this kernel and a workgroup's LDS fits a third of the CU's 160 KB; else two per CU (OCC = 4).
     const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6));
-    bool three = nsplit == 1 && !ka.r.best_traj && b.B > 512 && 3 * (L6.total + 256) <= 160 * 1024;
+    bool three = nsplit == 1 && !ka.r.best_traj && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
 #endif
