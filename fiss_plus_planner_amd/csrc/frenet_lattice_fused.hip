@@ -103,7 +103,7 @@ struct __attribute__((aligned(16))) ObsDim {
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, nslice, best, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, nslice, best, konst, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -135,6 +135,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.cnt = o;      o = align16(o + 32);  // list counters (monotone) + scan mask + ticket + two fp32 bounds
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * kWaves);
+    L.konst = o;    o = align16(o + 64);  // per-ego constants the collision stages re-read (instead of registers held through the kernel)
     // the spline tables last: theirs is the one size no instance of the kernel knows at compile time, so every other offset folds
     L.knots = o;    o = align16(o + 8 * nx_max);
     L.coef = o;     o = align16(o + 64 * nx_max);
@@ -262,6 +263,9 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     int* s_cnt = (int*)(smem + L.cnt);
     int* s_nslice = (int*)(smem + L.nslice);
     Best* s_best = (Best*)(smem + L.best);
+    // {first knot, bucket width reciprocal, ego half length, half width, half diagonal}: uniform FP64 values live in VECTOR registers
+    // (the scalar unit has no FP64); kept in registers from the prologue to the last slice they cost the three-workgroup variant spills
+    double* s_k = (double*)(smem + L.konst);
 
     // the ego's scalars: independent global reads, all issued before the first one is waited for (a read costs ~1-2 us)
     const int skip_flag = bt.skip ? bt.skip[b] : 0;
@@ -408,7 +412,6 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     FP_STAMP(1);
 
     const double* v_samples = s_vs;
-    const double org_x = s_coef[0], org_y = s_coef[4 * NX];  // first knot: fallback centre of an empty row circle
     int item_base = 0, hit_base = 0;  // list counters at the start of the current stage (block-uniform)
 
     // ---------------------------------------------------------------- phase A0 (once): masks / M / cost sums of every profile
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
             if (lane == 0 && bits) atomicMax((unsigned int*)&s_cnt[6], bits);
         }
     }
+    if (tid == 0) { s_k[0] = knot0; s_k[1] = inv_bucket_w; s_k[2] = veh_hl; s_k[3] = veh_hw; s_k[4] = r_ego; }
     {   // power sums of every slice (they need nothing but the time samples): a few threads of the middle
         const int i = tid - kThreads / 2;
         if (i >= 0 && i < n_it) power_sums_closed(arange_len(s_ts[it_lo + i], tick), tick, s_pows + (it_lo + i) * 11);
@@ -583,10 +587,11 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     if (n_obs > 0 && kThreads - 1 - nd - tid >= 0 && kThreads - 1 - nd - tid < rows) {  // (threads next to fill_slice_lat's)
         const int r = kThreads - 1 - nd - tid;
         const uint4 bx = s_box[r];
+        const double knot0 = s_knots[0], knot_last = s_knots[nx - 1];  // (fresh reads: the prologue's copies need not live this long)
         const float lo_f = f32_from_ordered(bx.x), hi_f = f32_from_ordered(bx.y);
         const double v_max = (double)__uint_as_float((uint32_t)s_cnt[5]), d_all = (double)__uint_as_float((uint32_t)s_cnt[6]);
         // empty row (no valid pose): radius -1 rejects every obstacle; an infinite range or a NaN bound keeps every obstacle
-        double rad = -1.0, cx = org_x, cy = org_y;
+        double rad = -1.0, cx = s_coef[0], cy = s_coef[4 * NX];  // first knot: fallback centre of an empty row circle
         if (hi_f >= lo_f) {
             // the ends were rounded to nearest fp32: half an ulp each, covered by slack; points off the spline do not exist
             const double slack = ((double)fabsf(lo_f) + (double)fabsf(hi_f)) * 1.2e-7 + 1e-6;
@@ -595,10 +600,10 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
             if (!(s_hi >= s_lo)) s_hi = s_lo = fmin(fmax(knot0 + (double)lo_f, knot0), knot_last);  // (a range that only grazes the end)
             double s_mid = 0.5 * (s_lo + s_hi);
             if (!(s_mid < knot_last)) s_mid = knot0 + 0.5 * (knot_last - knot0);  // infinite range: any centre will do
-            const int seg = lut_segment(s_knots, s_lut, nx, s_mid, knot0, inv_bucket_w, n_buckets);
+            const int seg = lut_segment(s_knots, s_lut, nx, s_mid, s_k[0], s_k[1], n_buckets);
             double tx, ty;
             spline_frame(sp, seg, s_mid - s_knots[seg], cx, cy, tx, ty);
-            rad = (v_max * (0.5 * (s_hi - s_lo)) * (1.0 + 1e-9) + r_ego + d_all) * (1.0 + 1e-9) + 1e-6;
+            rad = (v_max * (0.5 * (s_hi - s_lo)) * (1.0 + 1e-9) + s_k[4] + d_all) * (1.0 + 1e-9) + 1e-6;
             if (!(hi_f <= 3.0e38f) || !(lo_f >= -3.0e38f)) rad = __builtin_inf();
         }
         s_grp[r].hl = cx;
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                         const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + iv)], s_qlon[2 * (mul24(it, nv) + iv) + 1]};
                         const double t = (double)i * tick;
                         const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
-                        const int seg = lut_segment(s_knots, s_lut, nx, s, knot0, inv_bucket_w, n_buckets);
+                        const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
                         Frame fr;
                         spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
                         s_frames[mul24(iv, hp_max) + i] = fr;
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                     for (int i = tid; i < hp_max; i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
                     fill_slice_lat(it + 1);  // phase A of this slice is done with the table (barrier above)
                     // A conservative bound, so it is computed in fp32 (the ratio is a reciprocal instead of an fp64 division).
-                    const float r_ego_f = float_above(r_ego), hl_f = float_above(veh_hl), hw_f = float_above(veh_hw);
+                    const float r_ego_f = float_above(s_k[4]), hl_f = float_above(s_k[2]), hw_f = float_above(s_k[3]);
                     const float inv_nv = 1.0f / (float)nv;
     // [section PREP]
                     for (int e = tid; e < rows * nv; e += kThreads) {
@@ -796,7 +801,8 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                             // Poses beyond a profile's M hold stale frames, and a trajectory of fewer than two points has no heading: no
                             // pair (the narrow phase relies on it)
                             const int Mp = s_lon_meta[mul24(it, nv) + iv].x;
-                            const double fat = (r_ego + od.r + (double)s_dmax[k]) * (1.0 + 1e-12);
+                            const double r_ego_b = s_k[4];
+                            const double fat = (r_ego_b + od.r + (double)s_dmax[k]) * (1.0 + 1e-12);
                             const double dx = op.x - fr.px, dy = op.y - fr.py;
                             // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre
                             // vs the fan half-width + the obstacle's own reach along n_k; (3) separating axis t_k: every ego centre
@@ -806,7 +812,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                             const double a_n = fabs(fma(op.s, fr.tx, -op.c * fr.ty)), a_t = fabs(fma(op.c, fr.tx, op.s * fr.ty));
                             const double reach = fma(od.hl, a_n, od.hw * a_t), reach_t = fma(od.hl, a_t, od.hw * a_n);
                             pass = k < Mp && Mp >= 2 && !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach) &&
-                                   !(fabs(u) > r_ego * (1.0 + 1e-12) + reach_t);
+                                   !(fabs(u) > r_ego_b * (1.0 + 1e-12) + reach_t);
                             code = (uint32_t)iv | ((uint32_t)k << 8) | ((uint32_t)si << 16);  // iv <= 255, k < 128, si < 512
                         }
                         const unsigned long long m = __ballot(pass);
@@ -852,15 +858,15 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                             step_heading(xb - xa, yb - ya, ego.c, ego.s);
                             ego.x = (ka_ == k) ? xa : xb;
                             ego.y = (ka_ == k) ? ya : yb;
-                            ego.hl = veh_hl;
-                            ego.hw = veh_hw;
+                            ego.hl = s_k[2];
+                            ego.hw = s_k[3];
                             const ObsPose op = s_spose[si];
                             const ObsDim od = s_dim[j];
                             bool hit;
                             if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
                                 hit = true;  // polygon construction fails in the reference -> collision (:178-182)
                             } else {
-                                const double R = (r_ego + od.r) * (1.0 + 1e-12);
+                                const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
                                 const double dx = op.x - ego.x, dy = op.y - ego.y;
                                 hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
                             }
