@@ -454,7 +454,7 @@ __global__ __launch_bounds__(W * kWave) void fiss_search_kernel(FissArgs fa, int
 
 // ---------------------------------------------------------------------------
 // FISS+ refinement (fiss_plus_planner.py:207-326), one workgroup of kRefineWaves wavefronts per ego.
-//   * costs in closed form: a table S_k(N) = sum_{i<N} t_i^k for every N <= 128 is built once per workgroup, then the cost of ANY
+//   * costs in closed form: the power sums S_k(N) = sum_{i<N} t_i^k of a horizon come from Faulhaber's polynomials, so the cost of ANY
 //     end state is O(1) (lon_cost_sums / lat_cost_sums): per round lanes 0..5 price the six probes clip(x -/+ res_dim e_dim)
 //     (:213-232), the finite-difference gradient and the decayed step are wave-uniform arithmetic on shuffled lane values
 //     (:262-271), lane 0 prices the trajectory at the new x.  The coarse winner is priced by the same function, so a probe clipped
@@ -493,9 +493,11 @@ __device__ __forceinline__ double analytic_cost(const fp_params& p, const double
     if (N <= 0 || N > FP_MAX_POINTS) return __builtin_nan("");
     const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], x[1], 0.0, T);
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
-    double ls[3], ds[3];
-    lon_cost_sums(lon, target_speed, Stab + N * 11, ls);
-    lat_cost_sums(lat, Stab + N * 11, ds);
+    double S[11], ls[3], ds[3];
+    (void)Stab;
+    power_sums_closed(N, p.tick_t, S);  // S_k(N) = sum_{i<N} t_i^k in closed form (Faulhaber): no table
+    lon_cost_sums(lon, target_speed, S, ls);
+    lat_cost_sums(lat, S, ds);
     return combine_cost(p, N, ls, ds);
 }
 
@@ -719,9 +721,9 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
 constexpr int kRefineWaves = 4;  // trajectories validated speculatively side by side (one wavefront each)
 
 // LDS layout of the refinement kernel, in doubles (every double2 region starts 16-byte aligned):
-//   [0, kRefineS) power-sum table | kRefineWaves x (fp64 poses, fp32 relative poses) | knots + coef (9 NX, padded even)
+//   kRefineWaves x (fp64 poses, fp32 relative poses) | knots + coef (9 NX, padded even)
 //   | pair table (float4 per entry) | verdicts (32 B) | kRefineWaves survivor queues
-constexpr int kRefineS = ((FP_MAX_POINTS + 1) * 11 + 1) & ~1;
+constexpr int kRefineS = 0;  // (round 2 kept a table S[N][k] of power sums here: 11 KB that cost the fourth workgroup per CU)
 __host__ __device__ constexpr int refine_spline_off() { return kRefineS + 3 * FP_MAX_POINTS * kRefineWaves; }
 __host__ __device__ constexpr int refine_pt_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
 __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
@@ -730,7 +732,7 @@ __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
 }
 
 #ifndef FP_REFINE_OCC
-#define FP_REFINE_OCC 3   // workgroups per SIMD the register budget is sized for (tools/trace_c4.sh tries others)
+#define FP_REFINE_OCC 3   // workgroups per CU (= waves per SIMD) the register budget is sized for: 4 fits the LDS (40.7 KB) but spills 61 VGPRs, measured slower
 #endif
 __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refine_kernel(FissArgs fa, int pt_rows_max, const int* perm, int* dur)
 {
@@ -767,9 +769,9 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     L.knots = L.S + refine_spline_off();
     L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * kQueue;
     L.coef = L.knots + nx;
-    // Order of the prologue: (1) the power-sum table, by all four wavefronts; (2) wavefront 0 runs the refinement rounds (they
-    // only need the table and the ego state) WHILE wavefronts 1..3 stage the spline and the pair table; (3) the candidate list
-    // goes through LDS to every wavefront.  The rounds are ~half of the kernel's instructions: running them once instead of
+    // Order of the prologue: wavefront 0 runs the refinement rounds (they only need the ego state: the power sums of a probe's
+    // horizon come in closed form) WHILE wavefronts 1..3 stage the spline and the pair table; then the candidate list goes through
+    // LDS to every wavefront.  The rounds are ~half of the kernel's instructions: running them once instead of
     // four times is what matters (the kernel is instruction-issue bound), hiding them behind the staging is a bonus.
     const double* gk = bt.knots + (size_t)f * bt.NX;
     const double* gc = bt.coef + (size_t)f * 8 * bt.NX;
@@ -788,35 +790,6 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
         pt_rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;  // <= pt_rows_max by construction
         L.pt = (float4*)(L.S + refine_pt_off(bt.NX));
     }
-    {
-        // S[N][k] = sum_{i<N} (i*tick)^k: one running sum per lane, the 128 steps split into one chunk per wavefront
-        constexpr int kChunk = FP_MAX_POINTS / kRefineWaves;
-        if (lane < 11) {
-            double acc = 0.0;
-            if (wave == 0) L.S[lane] = 0.0;
-            for (int i = wave * kChunk; i < (wave + 1) * kChunk; ++i) {
-                const double t = (double)i * p.tick_t;
-                const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;  // t^lane by binary exponentiation (lane <= 10), no inner loop
-                const double tk = ((lane & 1) ? t : 1.0) * ((lane & 2) ? t2 : 1.0) * ((lane & 4) ? t4 : 1.0) * ((lane & 8) ? t8 : 1.0);
-                acc += tk;
-                L.S[(i + 1) * 11 + lane] = acc;
-            }
-        }
-    }
-    __syncthreads();
-    {   // chunk w adds the totals of chunks < w (read before anyone overwrites them: barrier in between)
-        constexpr int kChunk = FP_MAX_POINTS / kRefineWaves;
-        double base = 0.0;
-        if (lane < 11)
-            for (int w = 1; w <= wave; ++w) base += L.S[(w * kChunk) * 11 + lane];
-        __syncthreads();
-        if (wave > 0)
-            for (int e = lane; e < kChunk * 11; e += kWave) {
-                const int k11 = e % 11;
-                L.S[(wave * kChunk + 1) * 11 + e] += __shfl(base, k11, kWave);
-            }
-    }
-    __syncthreads();
     const double nan = __builtin_nan("");
     double eg[6];
 #pragma unroll

@@ -161,27 +161,6 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
     return seg;
 }
 
-// S_k = sum_{i<N} (i*tick)^k = tick^k P_k(N), k = 0..10, with Faulhaber's polynomials P_k(N) = sum_{i<N} i^k
-// = 1/(k+1) sum_j C(k+1, j) B_j N^(k+1-j) (Bernoulli numbers, B_1 = -1/2; coefficients generated with exact rationals and
-// checked against the sums).  One lane per slice, ~90 instructions, instead of a wavefront per slice reducing 11 sums by DPP
-// trees; N <= 128 keeps the Horner evaluation at full double accuracy (leading term dominates: N^(k+1)/(k+1) vs N^k/2).
-__device__ __forceinline__ void power_sums_closed(int N, double tick, double* out)
-{
-    const double x = (double)N;
-    double tk = 1.0;
-    out[0] = (1) * x * tk; tk *= tick;
-    out[1] = (fma(0.5, x, -0.5)) * x * tk; tk *= tick;
-    out[2] = (fma(fma(0.33333333333333331, x, -0.5), x, 0.16666666666666666)) * x * tk; tk *= tick;
-    out[3] = ((fma(fma(0.25, x, -0.5), x, 0.25)) * x) * x * tk; tk *= tick;
-    out[4] = (fma((fma(fma(0.20000000000000001, x, -0.5), x, 0.33333333333333331)) * x, x, -0.033333333333333333)) * x * tk; tk *= tick;
-    out[5] = ((fma((fma(fma(0.16666666666666666, x, -0.5), x, 0.41666666666666669)) * x, x, -0.083333333333333329)) * x) * x * tk; tk *= tick;
-    out[6] = (fma((fma((fma(fma(0.14285714285714285, x, -0.5), x, 0.5)) * x, x, -0.16666666666666666)) * x, x, 0.023809523809523808)) * x * tk; tk *= tick;
-    out[7] = ((fma((fma((fma(fma(0.125, x, -0.5), x, 0.58333333333333337)) * x, x, -0.29166666666666669)) * x, x, 0.083333333333333329)) * x) * x * tk; tk *= tick;
-    out[8] = (fma((fma((fma((fma(fma(0.1111111111111111, x, -0.5), x, 0.66666666666666663)) * x, x, -0.46666666666666667)) * x, x, 0.22222222222222221)) * x, x, -0.033333333333333333)) * x * tk; tk *= tick;
-    out[9] = ((fma((fma((fma((fma(fma(0.10000000000000001, x, -0.5), x, 0.75)) * x, x, -0.69999999999999996)) * x, x, 0.5)) * x, x, -0.14999999999999999)) * x) * x * tk; tk *= tick;
-    out[10] = (fma((fma((fma((fma((fma(fma(0.090909090909090912, x, -0.5), x, 0.83333333333333337)) * x, x, -1)) * x, x, 1)) * x, x, -0.5)) * x, x, 0.07575757575757576)) * x * tk; tk *= tick;
-}
-
 // nsplit > 1 (latency mode for small batches): the time-horizon slices of one ego are spread over nsplit workgroups, each
 // writes its partial argmin to part_best[ego * nsplit + part]; the last one to arrive (ticket counter) merges them.
 //
