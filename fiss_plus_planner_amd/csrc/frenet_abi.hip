@@ -107,6 +107,7 @@ struct fp_ctx {
     DeviceBuf parts;               // latency-mode lattice launch: [ticket counters, fixed-size region][partial argmins]
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
+    int lattice_group = 0;         // fp_ctx_set_option("lattice_group"): 0 auto, 1 never, n >= 2: up to n slices per barrier interval
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
     int fiss_jump = 1;             // fp_ctx_set_option("fiss_jump"): FISS+ walk skips ahead to the first feasible sample's level
@@ -403,10 +404,11 @@ int launch_order_after(LaunchOrder& o, const fp_batch* b, const int* dur, hipStr
 
 // Latency mode: a small batch cannot fill 256 CUs with one workgroup per ego, so the time-horizon slices of every ego are
 // spread over nt workgroups.  Returns the split factor and makes sure the partial-argmin buffer exists.
-int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, int* nsplit, void** parts)
+int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, int* nsplit, void** parts, int* group)
 {
     *nsplit = 1;
     *parts = nullptr;
+    *group = 1;
     // auto: as many workgroups per ego as keep ALL workgroups resident at once (measured on MI355X: 1.6-2.5x faster up to that
     // point, slower beyond it - a second round of workgroups costs more than the shorter critical path saves); at most one
     // workgroup per slice
@@ -417,6 +419,19 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
         // without obstacles the slices carry no work: one workgroup per ego
         if (parts_per_ego < p->nt && !(b->S > 0 && b->n_obs > 0)) parts_per_ego = 1;
     } else if (ctx->lattice_split == 1) {
+        parts_per_ego = 1;
+    }
+    // Grouped slices (launch_lattice_fused, `group`): when the batch leaves room for no more than TWO workgroups per ego but every
+    // ego can have a CU to itself, one 1024-thread workgroup per ego takes all its slices at once - four barrier intervals
+    // instead of 4 nt, one prologue instead of two, no ticket and no merge.  Measured on MI355X (BASELINE configs[1], 5 x 5 x 5,
+    // 10 obstacles): 256 egos 36.3 us against 37.9 split in two; 128 egos (split in four) 34.5 against 31.3 - so only in that
+    // regime.  Needs the whole lattice's per-slice tables in one workgroup's LDS.
+    const bool obstacles = b->S > 0 && b->n_obs > 0;
+    if (ctx->lattice_group >= 2) {
+        *group = ctx->lattice_group;
+    } else if (ctx->lattice_group == 0 && ctx->lattice_split == 0 && obstacles && p->nt > 2 && parts_per_ego == 2 &&
+               (long)b->B * 2 <= ctx->resident_groups && fp::lattice_group_fit(*p, *b) >= p->nt) {
+        *group = p->nt;
         parts_per_ego = 1;
     }
     if (parts_per_ego < 2 || p->nt < 2) return FP_OK;
@@ -637,6 +652,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->fiss_jump = value;
         return FP_OK;
     }
+    if (strcmp(name, "lattice_group") == 0) {
+        if (value < 0) return fail(FP_EINVAL, "lattice_group must be 0 (auto), 1 (never) or the number of slices per group");
+        ctx->lattice_group = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_split") == 0) {
         if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_split must be 0 (auto), 1 (never) or 2 (always)");
         ctx->lattice_split = value;
@@ -649,7 +669,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 {
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
-        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_order", ctx->lattice_order},
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_order", ctx->lattice_order},
         {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
@@ -675,14 +695,14 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.r = *result;
         if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r));
         FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
-        int nsplit; void* parts;
-        FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts));
+        int nsplit, group; void* parts;
+        FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group));
         bool winner_done = false;
         const int* perm; int* dur;
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
         fp::KernelArgs kl = ka;
         if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
-        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
+        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         if (result->fopplus)
@@ -714,14 +734,14 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     // sparse rows are only partly written by the kernels: the host block comes back with the caller's own bytes elsewhere
     if (result->traj_sparse && ka.r.best_traj) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, result->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     FP_TRY(lattice_curv_scratch(ctx, params, batch, ctx->stream, &ka.curv_tbl));
-    int nsplit; void* parts;
-    FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts));
+    int nsplit, group; void* parts;
+    FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts, &group));
     bool winner_done = false;
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     fp::KernelArgs kl = ka;
     if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
-    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     if (d_fopplus)
@@ -884,11 +904,11 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         if (io->traj_sparse && fa.io.best_traj) HIP_TRY(hipMemcpyAsync(fa.io.best_traj, io->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     }
     FP_TRY(lattice_curv_scratch(ctx, params, batch, stream, &fa.ka.curv_tbl));
-    int nsplit; void* parts;
-    FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts));
+    int nsplit, group; void* parts;
+    FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group));
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
-    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     fa.walk_jump = ctx->fiss_jump;

@@ -629,11 +629,11 @@ hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint
 }
 
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done, const int* perm,
-                          int* dur)
+                          int* dur, int group)
 {
     if (winner_done) *winner_done = false;
     if (which == 1) return launch_lattice_percand(ka, stream);
-    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur);
+    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur, group);
     if (e == hipErrorInvalidValue && which != 2) {
         (void)hipGetLastError();
         if (winner_done) *winner_done = false;

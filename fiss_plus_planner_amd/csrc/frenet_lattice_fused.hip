@@ -83,7 +83,9 @@ __device__ __forceinline__ int div_by(int e, float inv_d)
 #define SLICE_SYNC() __syncthreads()
 #endif
 constexpr int kThreads = 512;
-constexpr int kWaves = kThreads / kWave;
+#ifndef FP_GROUP_THREADS
+#define FP_GROUP_THREADS 1024  // threads per workgroup of the grouped instances
+#endif
 constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass  // block-wide list of live narrow-phase items (pair, lateral sample) of one B pass: 24 KB
 // block-wide list of (row, obstacle) items that pass the group test (+ their poses, 32 B each).  Two kernel variants: OCC = 4 waves per
 // SIMD (two workgroups per CU, up to 128 VGPRs, winner epilogue inside) and OCC = 6 (THREE workgroups per CU: 80 VGPRs - a few spill
@@ -108,17 +110,18 @@ struct Layout {
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
 
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap)
+// gs = time-horizon slices the collision stages work on per barrier interval (1: one at a time; the per-slice tables are gs deep)
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs)
 {
     Layout L;
     int o = 0;
     L.dim = o;      o = align16(o + 32 * n_obs);
     L.pose = o;     o = align16(o + 32 * kItemCap);  // poses of the group test's survivors (x, y, cos, sin), in list order
-    L.frames = o;   o = align16(o + 32 * nv * hp);
-    L.lat = o;      o = align16(o + 8 * nd * hp);
-    L.dmax = o;     o = align16(o + 2 * 4 * hp);   // float, rounded up; two buffers (slice parity): LDS atomic max in phase A
-    L.ddmax = o;    o = align16(o + 2 * 4 * hp);
-    L.wfat = o;     o = align16(o + 4 * nv * hp);  // float, rounded up
+    L.frames = o;   o = align16(o + 32 * gs * nv * hp);
+    L.lat = o;      o = align16(o + 8 * gs * nd * hp);
+    L.dmax = o;     o = align16(o + 2 * 4 * gs * hp);   // float, rounded up; two buffers (group parity): LDS atomic max in phase A
+    L.ddmax = o;    o = align16(o + 2 * 4 * gs * hp);
+    L.wfat = o;     o = align16(o + 4 * gs * nv * hp);  // float, rounded up
     L.grp = o;      o = align16(o + 32 * (rows > 0 ? rows : 1));       // per checked pose row: circle enclosing all lon profiles' points
     L.iqueue = o;   o = align16(o + 2 * kItemCap);                           // (row, obstacle) items that pass the group test
     L.samples = o;  o = align16(o + 8 * (nt + nv + nd));  // t / v / d sample grids (read all over the kernel: keep them out of HBM latency)
@@ -126,7 +129,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.lat_sum = o;  o = align16(o + 24 * nd * nt);   // sum_ad, sum_jd, sum_d
     L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
     L.qlon = o;     o = align16(o + 16 * nt * nv);   // a3, a4 of every lon profile (a0..a2 are the ego state)
-    L.qlat = o;     o = align16(o + 24 * nd);        // a3, a4, a5 of the CURRENT slice's lat profiles
+    L.qlat = o;     o = align16(o + 24 * gs * nd);   // a3, a4, a5 of the CURRENT slices' lat profiles
     L.box = o;      o = align16(o + 16 * (rows > 0 ? rows : 1));  // per checked pose row: bounding box of the slice's reference points (ordered-uint fp32)
     L.coll = o;     o = align16(o + nd * nv * nt);
     // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
@@ -134,7 +137,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     o = align16(o + (4 * kHitCap > 88 * nt ? 4 * kHitCap : 88 * nt));
     L.cnt = o;      o = align16(o + 32);  // list counters (monotone) + scan mask + ticket + two fp32 bounds
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
-    L.best = o;     o = align16(o + 16 * kWaves);
+    L.best = o;     o = align16(o + 16 * 16);  // (up to 16 wavefronts)
     L.konst = o;    o = align16(o + 64);  // per-ego constants the collision stages re-read (instead of registers held through the kernel)
     // the spline tables last: theirs is the one size no instance of the kernel knows at compile time, so every other offset folds
     L.knots = o;    o = align16(o + 8 * nx_max);
@@ -169,12 +172,23 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
 // 25 rows, 5 x 5 x 5 with 10 obstacles over 50 rows); in their instances every index decode is a constant multiply-shift, the LDS
 // carve-up folds to immediates and the loop bounds are known.  The <0, ...> instance is the same source with everything read from
 // the arguments.
-template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC>
-__global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur)
+//
+// GS: time-horizon slices per barrier interval of the collision stages.  1 = one slice at a time (the throughput instances: their LDS
+// holds one slice's frames); 0 = gs_arg slices at a time (run-time value): a GROUP of g slices is handled like one slice with g * nv
+// lon profiles and g * nd lat profiles - same four barriers, g times the lanes per pass.  Small lattices with few obstacles are bound
+// by the latency of those barrier intervals (a handful of wavefronts of work each), not by arithmetic: with all nt slices in one group
+// an ego costs 4 intervals instead of 4 nt and needs no split over workgroups (no ticket, no merge).
+// NTH: threads per workgroup, 512 or - the grouped latency instances, one workgroup per CU - 1024 (twice the wavefronts per pass).
+template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH>
+__global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit, Best* part_best, int* part_count, const int* perm,
+                                                                   int* dur, int gs_arg)
 {
     constexpr bool kShape = ND > 0;  // (all six are set together)
+    constexpr bool kGroup = GS != 1;
+    constexpr int kThreads = NTH, kWaves = NTH / kWave;  // (shadow the file-scope defaults)
+    static_assert(GS == 0 || GS == 1, "GS: 1 or 0 (run-time group size)");
     constexpr int kItemCap = item_cap(OCC);
+    const int gs = kGroup ? gs_arg : 1;
     const int rows_max = kShape ? ROWS : rows_max_arg;
     const int hp_max = kShape ? (ROWS > 0 ? (ROWS * STRIDE + 1 > FP_MAX_POINTS ? FP_MAX_POINTS : ROWS * STRIDE + 1) : 0) : hp_max_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     const int n_obs_tab = kShape ? NOBS : bt.n_obs;  // obstacles per scene of the table
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap);
+    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
@@ -222,8 +236,8 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     ObsPose* s_spose = (ObsPose*)(smem + L.pose);
     Frame* s_frames = (Frame*)(smem + L.frames);
     double* s_lat = (double*)(smem + L.lat);
-    float* s_dmax2 = (float*)(smem + L.dmax);    // [2][hp_max]
-    float* s_ddmax2 = (float*)(smem + L.ddmax);  // [2][hp_max]
+    float* s_dmax2 = (float*)(smem + L.dmax);    // [2][gs][hp_max]
+    float* s_ddmax2 = (float*)(smem + L.ddmax);  // [2][gs][hp_max]
     float* s_wfat = (float*)(smem + L.wfat);
     ObsDim* s_grp = (ObsDim*)(smem + L.grp);  // reused as {cx, cy, radius, -}
     unsigned short* s_items = (unsigned short*)(smem + L.iqueue);  // item index mul24(r, n_obs) + j
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     double* s_lat_sum = (double*)(smem + L.lat_sum);
     int2* s_lon_meta = (int2*)(smem + L.lon_meta);
     double* s_qlon = (double*)(smem + L.qlon);  // [nt][nv][2]
-    double* s_qlat = (double*)(smem + L.qlat);  // [nd][3]
+    double* s_qlat = (double*)(smem + L.qlat);  // [gs][nd][3]
     uint4* s_box = (uint4*)(smem + L.box);      // [rows] {min x, max x, min y, max y} relative to the first knot
     unsigned char* s_coll = smem + L.coll;
     uint32_t* s_hits = (uint32_t*)(smem + L.queue);
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     for (int r = tid; r < rows; r += kThreads) {
         s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);  // empty
     }
-    for (int i = tid; i < 2 * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
+    for (int i = tid; i < 2 * gs * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
     // points whose frame the collision stage can touch: 0 .. hp-1 (pose k needs point k+1 for its heading)
     const int pose_limit = rows * stride < horizon_cap ? rows * stride : horizon_cap;  // poses k < pose_limit (and k < M)
     int hp = pose_limit > 0 ? pose_limit + 1 : 0;
@@ -550,20 +564,24 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
     }
     // lat polynomial coefficients of one slice (a boundary-value solve costs two divisions): nd threads per slice instead of once
     // per trajectory point
-    auto fill_slice_lat = [&](int it) {
-        const int id = kThreads - 1 - tid;  // the last threads: they have the least prep work
-        if (id < nd && it < it_hi) {
-            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, s_ts[it]);
-            s_qlat[3 * id] = q.a3; s_qlat[3 * id + 1] = q.a4; s_qlat[3 * id + 2] = q.a5;
+    const float inv_nd_g = 1.0f / (float)nd;
+    auto fill_group_lat = [&](int it0) {  // the group of slices that starts at it0: [slice in group][lateral sample]
+        const int idg = kThreads - 1 - tid;  // the last threads: they have the least prep work
+        if (idg < mul24(gs, nd)) {
+            const int itl = kGroup ? div_small(idg, inv_nd_g) : 0, id = idg - mul24(itl, nd);
+            if (it0 + itl < it_hi) {
+                const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, s_ts[it0 + itl]);
+                s_qlat[3 * idg] = q.a3; s_qlat[3 * idg + 1] = q.a4; s_qlat[3 * idg + 2] = q.a5;
+            }
         }
     };
-    fill_slice_lat(it_lo);
+    fill_group_lat(it_lo);
     __syncthreads();
     FP_STAMP(3);
     // ---- ranges -> circles: every reference point of the row lies within  v_max * (half the range)  of the line's point at
     // the middle of the range (v_max >= |P'(s)| everywhere); + ego reach + the largest lateral offset.  One test per
     // (row, obstacle) item then prunes the item for every profile of every slice at once.
-    if (n_obs > 0 && kThreads - 1 - nd - tid >= 0 && kThreads - 1 - nd - tid < rows) {  // (threads next to fill_slice_lat's)
+    if (n_obs > 0 && kThreads - 1 - nd - tid >= 0 && kThreads - 1 - nd - tid < rows) {  // (threads next to fill_group_lat's first)
         const int r = kThreads - 1 - nd - tid;
         const uint4 bx = s_box[r];
         const double knot0 = s_knots[0], knot_last = s_knots[nx - 1];  // (fresh reads: the prologue's copies need not live this long)
@@ -672,116 +690,136 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
             // No survivor (block-uniform: empty surroundings, obstacles out of reach): nothing can collide, the slices are skipped.
             // (Skipping only the rows without a survivor was tried: a lane that skips its point saves nothing while its wavefront's
             // other lanes work, and the bookkeeping cost 3 % on dense scenes.)
-            for (int it = it_lo; n_surv > 0 && it < it_hi; ++it) {
-                const double T = s_ts[it];
-                const int N = arange_len(T, tick);
-                float* s_dmax = s_dmax2 + (it & 1) * hp_max;    // this slice's buffers (zeroed during the previous slice)
-                float* s_ddmax = s_ddmax2 + (it & 1) * hp_max;
-                // ---------------------------------------------------- phase A (per slice): one lane per (profile, point)
+            int par = 0;  // which of the two fan-bound buffers this group fills (the other one is zeroed meanwhile)
+            for (int it0 = it_lo; n_surv > 0 && it0 < it_hi; it0 += gs) {
+                // ---- a GROUP of g slices (g = 1 in the throughput instances): profile index q = (slice in group) * nv + iv and
+                // idg = (slice in group) * nd + id; the lon tables ([nt][nv]) are contiguous over a group, so q indexes them from it0 * nv
+                const int g = kGroup ? (it_hi - it0 < gs ? it_hi - it0 : gs) : 1;
+                const int nvg = mul24(g, nv), ndg = mul24(g, nd);
+                const int q0 = mul24(it0, nv);
+                float* s_dmax = s_dmax2 + mul24(par, mul24(gs, hp_max));    // [g][hp_max] (zeroed during the previous group)
+                float* s_ddmax = s_ddmax2 + mul24(par, mul24(gs, hp_max));
+                // ---------------------------------------------------- phase A (per group): one lane per (profile, point)
                 // reference-line frames of the points the collision horizon can touch (i < hp), lateral offsets, fan bounds
-                const int np = hp < N ? hp : N;
+                int n_max = s_nslice[it0];  // points per slice, len(np.arange(0, T, tick)); the longest slice of the group sizes the passes
+                if constexpr (kGroup)
+                    for (int j = 1; j < g; ++j) n_max = s_nslice[it0 + j] > n_max ? s_nslice[it0 + j] : n_max;
+                const int np = hp < n_max ? hp : n_max;
                 const float inv_np = 1.0f / (float)np;
     // [section FRAMES]
-                for (int e = tid; e < nv * np; e += kThreads) {
-                    const int iv = div_small(e, inv_np), i = e - mul24(iv, np);
-                    const int M = s_lon_meta[mul24(it, nv) + iv].x;
-                    if (i < M) {  // the point is on the spline
-                        const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + iv)], s_qlon[2 * (mul24(it, nv) + iv) + 1]};
+                for (int e = tid; e < mul24(nvg, np); e += kThreads) {
+                    const int q = div_small(e, inv_np), i = e - mul24(q, np);
+                    const int M = s_lon_meta[q0 + q].x;
+                    if (i < M) {  // the point is on the spline (M <= the slice's N)
+                        const Quartic ql{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (q0 + q)], s_qlon[2 * (q0 + q) + 1]};
                         const double t = (double)i * tick;
-                        const double s = fma(fma(fma(fma(q.a4, t, q.a3), t, q.a2), t, q.a1), t, q.a0);
+                        const double s = fma(fma(fma(fma(ql.a4, t, ql.a3), t, ql.a2), t, ql.a1), t, ql.a0);
                         const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
                         Frame fr;
                         spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
-                        s_frames[mul24(iv, hp_max) + i] = fr;
+                        s_frames[mul24(q, hp_max) + i] = fr;
                     }
                 }
     // [/section FRAMES]
     // [section LAT]
-                for (int e = tid; e < nd * np; e += kThreads) {
-                    const int id = div_small(e, inv_np), i = e - mul24(id, np);
-                    const double* ql = s_qlat + mul24(id, 3);
+                for (int e = tid; e < mul24(ndg, np); e += kThreads) {
+                    const int idg = div_small(e, inv_np), i = e - mul24(idg, np);
+                    const int itl = kGroup ? div_small(idg, inv_nd_g) : 0;
+                    int np_i = np;  // this slice's points inside the horizon
+                    if constexpr (kGroup) {
+                        np_i = s_nslice[it0 + itl];
+                        np_i = hp < np_i ? hp : np_i;
+                        if (i >= np_i) continue;
+                    }
+                    const double* ql = s_qlat + mul24(idg, 3);
                     const Quintic q{d0, d_d0, d_dd0 * 0.5, ql[0], ql[1], ql[2]};
                     const double t = (double)i * tick;
                     const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
-                    s_lat[mul24(id, hp_max) + i] = d;
+                    s_lat[mul24(idg, hp_max) + i] = d;
                     // fan half-width max|d| and largest lateral step max|d(i+1) - d(i)| over the lateral samples: LDS atomic max on
                     // the bit patterns (non-negative floats order like unsigned integers); float_above: never below the fp64 value
-                    atomicMax((unsigned int*)&s_dmax[i], __float_as_uint(float_above(fabs(d))));
-                    if (i + 1 < np) {
+                    atomicMax((unsigned int*)&s_dmax[mul24(itl, hp_max) + i], __float_as_uint(float_above(fabs(d))));
+                    if (i + 1 < np_i) {
                         const double tn = (double)(i + 1) * tick;
                         const double dn = fma(fma(fma(fma(fma(q.a5, tn, q.a4), tn, q.a3), tn, q.a2), tn, q.a1), tn, q.a0);
-                        atomicMax((unsigned int*)&s_ddmax[i], __float_as_uint(float_above(fabs(dn - d))));
+                        atomicMax((unsigned int*)&s_ddmax[mul24(itl, hp_max) + i], __float_as_uint(float_above(fabs(dn - d))));
                     }
                 }
             // [/section LAT]
                 SLICE_SYNC();
-                if (it == it_lo + 3) FP_STAMP(11);
+                if (it0 == it_lo + (kGroup ? 0 : 3)) FP_STAMP(11);
                 // ---- prep: wfat = lateral half-width of the whole fan along the reference normal n_k, per checked pose (row r, lon
-                // profile iv): every ego centre is P_k + d n_k with |d| <= dmax[k];  the ego box, whose heading deviates from the
+                // profile q): every ego centre is P_k + d n_k with |d| <= dmax[k];  the ego box, whose heading deviates from the
                 // reference tangent by alpha, reaches hw cos(alpha) + hl |sin(alpha)| <= min(r_ego, hw + hl sigma) along n_k, where
                 // sigma >= |sin(alpha)| for every lateral sample follows from the heading vector
                 //   h = (P_{k+1} - P_k) + d_{k+1} n_{k+1} - d_k n_k:  |h.n_k| <= |dP.n_k| + max|d_{k+1} - d_k| + max|d_{k+1}| |1 - n_{k+1}.n_k|,
                 //   |h| >= |h.t_k| >= |dP.t_k| - max|d_{k+1}| |n_{k+1}.t_k|.   n_k then serves as a (conservative) separating axis.
                 {
-                    float* z_dmax = s_dmax2 + ((it + 1) & 1) * hp_max;   // zero the other parity for the next slice
-                    float* z_ddmax = s_ddmax2 + ((it + 1) & 1) * hp_max;
-                    for (int i = tid; i < hp_max; i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
-                    fill_slice_lat(it + 1);  // phase A of this slice is done with the table (barrier above)
+                    float* z_dmax = s_dmax2 + mul24(par ^ 1, mul24(gs, hp_max));   // zero the other buffer for the next group
+                    float* z_ddmax = s_ddmax2 + mul24(par ^ 1, mul24(gs, hp_max));
+                    for (int i = tid; i < mul24(gs, hp_max); i += kThreads) { z_dmax[i] = 0.0f; z_ddmax[i] = 0.0f; }
+                    fill_group_lat(it0 + gs);  // phase A of this group is done with the table (barrier above)
                     // A conservative bound, so it is computed in fp32 (the ratio is a reciprocal instead of an fp64 division).
                     const float r_ego_f = float_above(s_k[4]), hl_f = float_above(s_k[2]), hw_f = float_above(s_k[3]);
-                    const float inv_nv = 1.0f / (float)nv;
+                    const float inv_nv = 1.0f / (float)nv, inv_rows_p = 1.0f / (float)(rows > 0 ? rows : 1);
     // [section PREP]
-                    for (int e = tid; e < rows * nv; e += kThreads) {
-                        const int r = div_by<NV, ROWS * NV>(e, inv_nv), iv = e - mul24(r, nv);
+                    for (int e = tid; e < mul24(g, mul24(rows, nv)); e += kThreads) {
+                        // e = ((slice in group) * rows + r) * nv + iv
+                        const int rr = div_by<NV, (NT > 0 ? NT : 1) * ROWS * NV>(e, inv_nv), iv = e - mul24(rr, nv);
+                        const int itl = kGroup ? div_small(rr, inv_rows_p) : 0, r = rr - mul24(itl, rows);
+                        const int q = mul24(itl, nv) + iv;
                         const int k = mul24(r, stride);
-                        const bool row_ok = k < N && k < hp;
-                        const int M = s_lon_meta[mul24(it, nv) + iv].x;
+                        const bool row_ok = k < (kGroup ? s_nslice[it0 + itl] : n_max) && k < hp;
+                        const int M = s_lon_meta[q0 + q].x;  // (M <= N)
+                        const float* dm = s_dmax + mul24(itl, hp_max);
                         float wl = r_ego_f;
-                        if (k + 1 < M && k + 1 < hp && k + 1 < N) {
-                            const Frame f0 = s_frames[mul24(iv, hp_max) + k], f1 = s_frames[mul24(iv, hp_max) + k + 1];
+                        if (k + 1 < M && k + 1 < hp) {
+                            const Frame f0 = s_frames[mul24(q, hp_max) + k], f1 = s_frames[mul24(q, hp_max) + k + 1];
                             const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
                             const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
                             const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
                             const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty);   // n_{k+1} . n_k
                             const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
-                            const double dm1 = (double)s_dmax[k + 1];
-                            const float num = (float)(fabs(a_n) + (double)s_ddmax[k] + dm1 * fabs(1.0 - nn));
+                            const double dm1 = (double)dm[k + 1];
+                            const float num = (float)(fabs(a_n) + (double)s_ddmax[mul24(itl, hp_max) + k] + dm1 * fabs(1.0 - nn));
                             const float den = (float)(fabs(a_t) - dm1 * fabs(nt_));
                             if (den > 1e-30f) {  // v_rcp_f32: 1 ulp; the factor covers it and the two roundings to nearest
                                 const float sigma = vmin_f32(1.0f, num * __builtin_amdgcn_rcpf(den) * (1.0f + 4e-6f) + 1e-9f);
                                 wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
                             }
                         }
-                        s_wfat[mul24(iv, hp_max) + k] = row_ok ? (s_dmax[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
+                        s_wfat[mul24(q, hp_max) + k] = row_ok ? (dm[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
                     }
         // [/section PREP]
                 }
                 SLICE_SYNC();
-                if (it == it_lo + 3) FP_STAMP(12);
+                if (it0 == it_lo + (kGroup ? 0 : 3)) FP_STAMP(12);
+                const float inv_nvg = 1.0f / (float)nvg;
 #if defined(FP_ABL_NO_BN)
                 const int n_pairs = 0;
 #else
-                const int n_pairs = n_surv * nv;
+                const int n_pairs = mul24(n_surv, nvg);
 #endif
                 for (int p0 = 0; p0 < n_pairs; p0 += kHitCap) {
                     const int p1 = p0 + kHitCap < n_pairs ? p0 + kHitCap : n_pairs;
-                    for (int q0 = p0 + wave * kWave; q0 < p1; q0 += kThreads) {
-                        const int pr = q0 + lane;
+                    for (int qq0 = p0 + wave * kWave; qq0 < p1; qq0 += kThreads) {
+                        const int pr = qq0 + lane;
                         bool pass = false;
                         uint32_t code = 0;
                         if (pr < p1) {
-                            const int si = div_by<NV, kItemCapMax * NV>(pr, inv_nvf), iv = pr - mul24(si, nv);
+                            const int si = kGroup ? div_small(pr, inv_nvg) : div_by<NV, kItemCapMax * NV>(pr, inv_nvf), q = pr - mul24(si, nvg);
+                            const int itl = kGroup ? div_small(q, inv_nvf) : 0;
                             const int item = s_items[si];
                             const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
                             const int k = mul24(r, stride);
                             const ObsPose op = s_spose[si];
                             const ObsDim od = s_dim[j];
-                            const Frame fr = s_frames[mul24(iv, hp_max) + k];
+                            const Frame fr = s_frames[mul24(q, hp_max) + k];
                             // Poses beyond a profile's M hold stale frames, and a trajectory of fewer than two points has no heading: no
                             // pair (the narrow phase relies on it)
-                            const int Mp = s_lon_meta[mul24(it, nv) + iv].x;
+                            const int Mp = s_lon_meta[q0 + q].x;
                             const double r_ego_b = s_k[4];
-                            const double fat = (r_ego_b + od.r + (double)s_dmax[k]) * (1.0 + 1e-12);
+                            const double fat = (r_ego_b + od.r + (double)s_dmax[mul24(itl, hp_max) + k]) * (1.0 + 1e-12);
                             const double dx = op.x - fr.px, dy = op.y - fr.py;
                             // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre
                             // vs the fan half-width + the obstacle's own reach along n_k; (3) separating axis t_k: every ego centre
@@ -790,9 +828,9 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                             const double w = fma(dy, fr.tx, -dx * fr.ty), u = fma(dx, fr.tx, dy * fr.ty);
                             const double a_n = fabs(fma(op.s, fr.tx, -op.c * fr.ty)), a_t = fabs(fma(op.c, fr.tx, op.s * fr.ty));
                             const double reach = fma(od.hl, a_n, od.hw * a_t), reach_t = fma(od.hl, a_t, od.hw * a_n);
-                            pass = k < Mp && Mp >= 2 && !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(iv, hp_max) + k] + reach) &&
+                            pass = k < Mp && Mp >= 2 && !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)s_wfat[mul24(q, hp_max) + k] + reach) &&
                                    !(fabs(u) > r_ego_b * (1.0 + 1e-12) + reach_t);
-                            code = (uint32_t)iv | ((uint32_t)k << 8) | ((uint32_t)si << 16);  // iv <= 255, k < 128, si < 512
+                            code = (uint32_t)q | ((uint32_t)k << 8) | ((uint32_t)si << 16);  // q <= 255, k < 128, si < 512
                         }
                         const unsigned long long m = __ballot(pass);
                         if (lane == 0) { FP_COUNT(1, 1); FP_COUNT(2, __popcll(m)); }
@@ -805,7 +843,7 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                         }
                     }
                     SLICE_SYNC();
-                if (it == it_lo + 3) FP_STAMP(13);
+                    if (it0 == it_lo + (kGroup ? 0 : 3)) FP_STAMP(13);
                     const int hit_end = s_cnt[1];
                     const int n_hits = hit_end - hit_base;
                     hit_base = hit_end;
@@ -819,17 +857,19 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                         const int h = div_by<ND, kHitCap * ND>(x, inv_ndf), id = x - mul24(h, nd);
                         // everything the filter needs rides in the hit word: one LDS read, then the candidate's collision byte
                         const uint32_t code = s_hits[h];
-                        const int iv = code & 0xFF, k = (code >> 8) & 0xFF, si = code >> 16;
-                        const int cand = mul24(mul24(id, nt) + it, nv) + iv;
+                        const int q = code & 0xFF, k = (code >> 8) & 0xFF, si = code >> 16;
+                        const int itl = kGroup ? div_small(q, inv_nvf) : 0;
+                        const int cand = mul24(mul24(id, nt), nv) + q0 + q;  // (id * nt + it) * nv + iv with it * nv + iv = q0 + q
                         FP_COUNT(3, 1);
                         if (s_coll[cand]) FP_COUNT(4, 1);
                         if (!s_coll[cand]) {
                             const int j = (int)s_items[si] - mul24(div_by<STRIDE, FP_MAX_POINTS>(k, 1.0f / (float)stride), n_obs);  // item = row * n_obs + obstacle, k = row * stride
-                            const int M = s_lon_meta[mul24(it, nv) + iv].x;
+                            const int M = s_lon_meta[q0 + q].x;
                             // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                             const int ka_ = (k + 1 < M) ? k : k - 1;
-                            const Frame f0 = s_frames[mul24(iv, hp_max) + ka_], f1 = s_frames[mul24(iv, hp_max) + ka_ + 1];
-                            const double da = s_lat[mul24(id, hp_max) + ka_], db = s_lat[mul24(id, hp_max) + ka_ + 1];
+                            const Frame f0 = s_frames[mul24(q, hp_max) + ka_], f1 = s_frames[mul24(q, hp_max) + ka_ + 1];
+                            const double* lt = s_lat + mul24(mul24(itl, nd) + id, hp_max) + ka_;
+                            const double da = lt[0], db = lt[1];
                             double xa, ya, xb, yb;
                             frenet_to_cartesian(f0.px, f0.py, f0.tx, f0.ty, da, xa, ya);
                             frenet_to_cartesian(f1.px, f1.py, f1.tx, f1.ty, db, xb, yb);
@@ -854,13 +894,14 @@ __global__ __launch_bounds__(kThreads, OCC) void lattice_fused_kernel(KernelArgs
                     }
                     if (p1 < n_pairs) SLICE_SYNC();  // the next pass overwrites the hit list
                 }
-                SLICE_SYNC();  // frames / lat / dmax are rewritten by the next slice
-                if (it == it_lo + 3) FP_STAMP(14);
+                SLICE_SYNC();  // frames / lat / dmax are rewritten by the next group
+                if (it0 == it_lo + (kGroup ? 0 : 3)) FP_STAMP(14);
+                par ^= 1;
             }
             i0 = i1;
             if (i0 < n_items) {  // another item chunk: its slice loop starts over (rare: crowded scenes)
-                for (int i = tid; i < 2 * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
-                fill_slice_lat(it_lo);
+                for (int i = tid; i < 2 * mul24(gs, hp_max); i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
+                fill_group_lat(it_lo);
                 __syncthreads();
             }
         }
@@ -1007,7 +1048,22 @@ static bool fused_shape(const fp_params& p, const fp_batch& b, int* rows_out, in
     return true;
 }
 
-hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur)
+// Largest number of time-horizon slices one workgroup can hold at once (the grouped instances, GS = 0): LDS budget and the 8-bit
+// profile index of the hit word.  0 when the problem does not fit the fused kernel at all.
+int lattice_group_fit(const fp_params& p, const fp_batch& b)
+{
+    int rows = 0, hp = 0;
+    if (!fused_shape(p, b, &rows, &hp)) return 0;
+    int gs = 0;
+    for (int g = 1; g <= p.nt; ++g) {
+        if (g * p.nv > 256 || make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), g).total > kLdsLimit) break;
+        gs = g;
+    }
+    return gs;
+}
+
+hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
+                                int group)
 {
     if (winner_done) *winner_done = false;
     const fp_params& p = ka.p;
@@ -1017,12 +1073,18 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     if (!part_scratch || nsplit < 1) nsplit = 1;
     // Three workgroups per CU (the OCC = 6 variant) when the launch has more egos than two per CU can hold at once, nobody needs the
     // series from this kernel and a workgroup's LDS fits a third of the CU's 160 KB; else two per CU (OCC = 4).
-    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6));
-    bool three = nsplit == 1 && !ka.r.best_traj && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
+    // slices per barrier interval (the grouped instances): as asked for, as far as one workgroup's LDS holds them
+    int gs = group < 1 ? 1 : (group > p.nt ? p.nt : group);
+    if (gs > 1) {
+        const int fit = lattice_group_fit(p, b);
+        gs = fit < 1 ? 1 : (gs > fit ? fit : gs);
+    }
+    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1);
+    bool three = gs == 1 && nsplit == 1 && !ka.r.best_traj && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
 #endif
-    const Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4));
+    const Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (nsplit > p.nt) nsplit = p.nt;
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
@@ -1036,10 +1098,10 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         if (e != hipSuccess) return e;
     }
     // the instance whose compile-time shape is this problem's (BASELINE.json's two lattice shapes), else the run-time one
-    auto go = [&](auto kernel, int* configured) -> hipError_t {
+    auto go = [&](auto kernel, int* configured, int threads = kThreads) -> hipError_t {
         hipError_t err = ensure_dynamic_lds((const void*)kernel, L.total, configured);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kernel, dim3(b.B * nsplit), dim3(kThreads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur);
+        hipLaunchKernelGGL(kernel, dim3(b.B * nsplit), dim3(threads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur, gs);
         return hipGetLastError();
     };
     FP_LDS_SLOTS(cfg_generic);
@@ -1048,20 +1110,27 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_generic6);
     FP_LDS_SLOTS(cfg_9976);
     FP_LDS_SLOTS(cfg_5556);
+    FP_LDS_SLOTS(cfg_generic_g);
+    FP_LDS_SLOTS(cfg_997_g);
+    FP_LDS_SLOTS(cfg_555_g);
     auto is = [&](int nd, int nv, int nt, int stride, int n_obs, int r) {
         return p.nd == nd && p.nv == nv && p.nt == nt && p.check_stride == stride && b.n_obs == n_obs && rows == r;
     };
 #if defined(FP_NO_SHAPES)  // (A/B diagnostic: the run-time instance for every shape)
-    e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4>, cfg_generic);
+    e = gs > 1 ? go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS>, cfg_generic_g, FP_GROUP_THREADS) : go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 1, 512>, cfg_generic);
 #else
-    if (three) {
-        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6>, cfg_9976);
-        else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 6>, cfg_5556);
-        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6>, cfg_generic6);
+    if (gs > 1) {
+        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 4, 0, FP_GROUP_THREADS>, cfg_997_g, FP_GROUP_THREADS);
+        else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4, 0, FP_GROUP_THREADS>, cfg_555_g, FP_GROUP_THREADS);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS>, cfg_generic_g, FP_GROUP_THREADS);
+    } else if (three) {
+        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512>, cfg_9976);
+        else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 6, 1, 512>, cfg_5556);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512>, cfg_generic6);
     } else {
-        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 4>, cfg_997);
-        else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4>, cfg_555);
-        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4>, cfg_generic);
+        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 4, 1, 512>, cfg_997);
+        else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4, 1, 512>, cfg_555);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 1, 512>, cfg_generic);
     }
 #endif
     if (e != hipSuccess) return e;

@@ -162,6 +162,10 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "lattice_split": 0 = auto (default: an ego's time-horizon slices are spread over as many workgroups - at most one per
  * slice - as keep ALL workgroups of the launch resident at once, 2 per compute unit: latency mode for small batches), 1 = never,
  * 2 = always one workgroup per slice.  Identical results either way.
+ * "lattice_group": time-horizon slices one workgroup's collision stages take per barrier interval.  0 = auto (default: one at a
+ * time, except for batches of at most one ego per compute unit that "lattice_split" could only cut in two: one 1024-thread
+ * workgroup per ego then takes all nt slices at once, when its LDS holds their tables), 1 = always one at a time, n >= 2 = up to n
+ * at a time (as many as fit).  Identical results.
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
  * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair

@@ -30,14 +30,16 @@ def test_obstacle_table_larger_than_lds_stays_fused(oracle, engine):
     memory in its group test and keeps only the survivors' poses in LDS (more survivors than the list holds: the table is cut into
     chunks) - same flags / costs / argmin in every launch shape; the lane-per-candidate kernel agrees."""
     batch = synth.make_batch(3, 5, 5, 5, 150, 100, True, 71)
-    for kernel, split in ((2, 1), (2, 2), (1, 1), (0, 0)):
+    for kernel, split, group in ((2, 1, 1), (2, 2, 1), (2, 1, 99), (2, 1, 2), (1, 1, 1), (0, 0, 0)):
         engine.set_option("lattice_kernel", kernel)
         engine.set_option("lattice_split", split)
+        engine.set_option("lattice_group", group)
         try:
             out = _check_vs_oracle(oracle, engine, batch)
         finally:
             engine.set_option("lattice_kernel", 0)
             engine.set_option("lattice_split", 0)
+            engine.set_option("lattice_group", 0)
         assert ((out.flags & 4) != 0).any()
 
 

@@ -62,9 +62,10 @@ def test_random_settings_vs_oracle(oracle, engine, seed):
     b = random_batch(1000 + seed)
     probs = oracle.problems_from_batch(b)
     ref = [p.fop_plan() for p in probs]
-    for kernel, split in ((2, 1), (2, 2), (1, 1)):
+    for kernel, split, group in ((2, 1, 1), (2, 2, 1), (2, 1, 3), (2, 1, 99), (1, 1, 1)):
         engine.set_option("lattice_kernel", kernel)
         engine.set_option("lattice_split", split)
+        engine.set_option("lattice_group", group)
         out = engine.plan_dense(b, winner=True)
         for e, r in enumerate(ref):
             np.testing.assert_allclose(out.cost[e], r.cost, rtol=0, atol=1e-6, err_msg=f"seed {seed} kernel {kernel} ego {e}")
@@ -72,6 +73,7 @@ def test_random_settings_vs_oracle(oracle, engine, seed):
             assert out.best_idx[e] == r.best_idx, (seed, kernel, e)
     engine.set_option("lattice_kernel", 0)
     engine.set_option("lattice_split", 0)
+    engine.set_option("lattice_group", 0)
     # explicit end states (continuous): cost, flags and the full series
     rng = np.random.default_rng(seed)
     K = 3

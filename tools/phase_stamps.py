@@ -26,6 +26,8 @@ eng = FrenetEngine(0)
 eng.set_option("lattice_winner", 1)  # the stamps travel in the winner block the lattice kernel itself writes
 if len(sys.argv) > 2:
     eng.set_option("lattice_split", int(sys.argv[2]))
+if len(sys.argv) > 3:
+    eng.set_option("lattice_group", int(sys.argv[3]))
 dten = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in NAMES}
 fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in dten.items()})
 params = make_params(batch)
@@ -49,3 +51,5 @@ print(f"sum of workgroup durations / 512 slots = {stamps[:, -1].sum() / 512:.1f}
 sl = raw[:, 11:15]
 print("one slice (the 4th):  prep {:.2f}  B {:.2f}  N {:.2f} us (medians);  frames + lat = slice total - these".format(
     np.median(sl[:, 1] - sl[:, 0]), np.median(sl[:, 2] - sl[:, 1]), np.median(sl[:, 3] - sl[:, 2])))
+print("absolute stamps of that slice / group (us since the workgroup started): after frames+lat {:.2f}, prep {:.2f}, B {:.2f}, N {:.2f}; G ended at {:.2f}".format(
+    *(np.median(sl[:, i]) for i in range(4)), np.median(raw[:, 7])))

@@ -15,11 +15,16 @@ from fiss_plus_planner_amd.engine import FrenetEngine, device_batch, make_params
 
 NAMES = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
          "obs_pose", "obs_dims", "final_time_step")
-layout = sys.argv[1] if len(sys.argv) > 1 else "survey8d"
-batch = synth.make_config(3, layout=layout)
+# usage: work_counters.py [layout | config number] [lattice_group]
+arg = sys.argv[1] if len(sys.argv) > 1 else "survey8d"
+config, layout = (int(arg), "survey8d") if arg.isdigit() else (3, arg)
+batch = synth.make_config(config, layout=layout)
 dev = torch.device("cuda", 0)
 eng = FrenetEngine(0)
 eng.set_option("lattice_winner", 1)
+eng.set_option("lattice_split", 1)  # (the counters of one workgroup per ego)
+if len(sys.argv) > 2:
+    eng.set_option("lattice_group", int(sys.argv[2]))
 dten = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in NAMES}
 fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in dten.items()})
 params = make_params(batch)
@@ -32,7 +37,7 @@ eng.plan_dense_device(params, fb, bi.data_ptr(), bc.data_ptr(), stream=st.cuda_s
 torch.cuda.synchronize()
 c = bt[:, 14, 112:128].cpu().numpy()
 names = ["G survivors (items)", "B pairs tested", "B pairs passed (hits)", "N items", "N items, candidate already collided", "N new collisions"]
-print(f"layout {layout}: per ego, {B} egos")
+print(f"config {config}, layout {layout}: per ego, {B} egos")
 for k, n in enumerate(names):
     print(f"  {n:40s} mean {c[:, k].mean():9.1f}  median {np.median(c[:, k]):9.1f}  p90 {np.percentile(c[:, k], 90):9.1f}  max {c[:, k].max():9.0f}")
 print("  first-collision marks by pose index (k // 8):", np.round(c[:, 8:16].mean(axis=0), 1).tolist())
