@@ -220,7 +220,9 @@ struct SplineLds {
 };
 
 // returns segment index, or -1 when s is outside [knots[0], knots[nx-1])
-__device__ __forceinline__ int spline_segment(const SplineLds& sp, double s, int hint)
+// guess_scale (optional, with hint < 0): (nx - 1) / (last knot - first knot), computed once by the caller - the guess then costs a
+// multiplication instead of an fp64 division per point (it is only a guess: the knot comparisons below decide).
+__device__ __forceinline__ int spline_segment(const SplineLds& sp, double s, int hint, double guess_scale = 0.0)
 {
     const int last = sp.nx - 1;
     const double k0 = sp.knots[0], kl = sp.knots[last];
@@ -230,7 +232,7 @@ __device__ __forceinline__ int spline_segment(const SplineLds& sp, double s, int
     // the bisection's log2(nx), which matters when the table sits in global memory (winner_traj_kernel: one trajectory per wavefront)
     int i = hint;
     if (i < 0) {
-        i = (int)((s - k0) / (kl - k0) * (double)last);
+        i = guess_scale > 0.0 ? (int)((s - k0) * guess_scale) : (int)((s - k0) / (kl - k0) * (double)last);
         i = i < 0 ? 0 : (i > last - 1 ? last - 1 : i);
         if (i > 0 && s < sp.knots[i]) --i;
     }

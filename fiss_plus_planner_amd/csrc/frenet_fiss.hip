@@ -546,8 +546,11 @@ __device__ __forceinline__ uint32_t wave_curvature_flags(const fp_params& p, con
 }
 
 // constraint + collision flags of ONE trajectory, computed by the whole wavefront (all arguments wave-uniform)
-__device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane)
+__device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane, double* stamp = nullptr,
+                                long long t_begin = 0)
 {
+#define FP_WSTAMP(k) do { if (stamp && lane == 0) stamp[k] = (double)(wall_clock64() - t_begin); } while (0)
+
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const double T = x[2];
@@ -556,6 +559,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
     SplineLds sp{L.knots, L.coef, nx, nx};
     const double knot0 = L.knots[0], knot_last = L.knots[nx - 1];
+    const double seg_scale = (double)(nx - 1) / (knot_last - knot0);  // (NaN / inf / <= 0: spline_segment divides per point instead)
     unsigned long long off_lo = 0, off_hi = 0;
     bool bad_speed = false, bad_accel = false;
 #pragma unroll
@@ -571,7 +575,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
             off = !(s >= knot0) || !(s < knot_last);
             if (!off) {
                 const double d = fma(fma(fma(fma(fma(lat.a5, t, lat.a4), t, lat.a3), t, lat.a2), t, lat.a1), t, lat.a0);
-                const int seg = spline_segment(sp, s, -1);
+                const int seg = spline_segment(sp, s, -1, seg_scale < 1e300 ? seg_scale : 0.0);
                 double px, py, tx, ty, cx, cy;
                 spline_frame(sp, seg, s - L.knots[seg], px, py, tx, ty);
                 frenet_to_cartesian(px, py, tx, ty, d, cx, cy);
@@ -582,6 +586,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
         const unsigned long long m = __ballot(off);
         if (half == 0) off_lo = m; else off_hi = m;
     }
+    FP_WSTAMP(12);
     uint32_t flags = 0;
     if (__ballot(bad_speed)) flags |= FP_FLAG_SPEED;
     if (__ballot(bad_accel)) flags |= FP_FLAG_ACCEL;
@@ -662,16 +667,24 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
                 float2 c[kU];
 #pragma unroll
                 for (int u = 0; u < kU; ++u) c[u] = L.xyf[__float_as_int(q[u].w) & 0xFF];
+                bool pass[kU], any = false;
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                     const float dx = q[u].x - c[u].x, dy = q[u].y - c[u].y;
-                    const bool pass = (dx * dx + dy * dy <= q[u].z) && (e0 + u * kWave + lane < P);
-                    const unsigned long long m = __ballot(pass);
-                    const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (pass) L.queue[qn + below] = (uint16_t)(e0 + u * kWave + lane);
-                    qn += __popcll(m);
+                    pass[u] = (dx * dx + dy * dy <= q[u].z) && (e0 + u * kWave + lane < P);
+                    any |= pass[u];
+                }
+                if (__ballot(any)) {  // (most trips keep nothing: one ballot instead of four compactions)
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const unsigned long long m = __ballot(pass[u]);
+                        const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (pass[u]) L.queue[qn + below] = (uint16_t)(e0 + u * kWave + lane);
+                        qn += __popcll(m);
+                    }
                 }
             }
+            if (e0 >= P) FP_WSTAMP(13);
             if (qn > kQueue - kU * kWave || (e0 >= P && qn > 0)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -736,12 +749,23 @@ __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
 #endif
 __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refine_kernel(FissArgs fa, int pt_rows_max, const int* perm, int* dur)
 {
+#if defined(FP_PHASE_STAMPS)
+    const long long t_begin = wall_clock64();
+#else
     const long long t_begin = dur ? wall_clock64() : 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const KernelArgs& ka = fa.ka;
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x;  // launch order: longest egos first when the host has one
+    // Timing diagnostic (tools/refine_stamps.py, -DFP_PHASE_STAMPS): thread 0 leaves 10 ns ticks since the workgroup started in
+    // columns 112.. of the last row of the ego's series block (sparse layout, stride 128); column 112 = the absolute start.
+#if defined(FP_PHASE_STAMPS)
+#define FP_RSTAMP(k) do { if (threadIdx.x == 0 && fa.io.best_traj) fa.io.best_traj[((size_t)b * FP_ARR_COUNT + 15) * fa.io.traj_stride + 112 + (k)] = (k) == 0 ? (double)(t_begin & 0xFFFFFFFFFFll) : (double)(wall_clock64() - t_begin); } while (0)
+#else
+#define FP_RSTAMP(k) do { } while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     constexpr int kThreads = kWave * kRefineWaves;
     const int32_t* ijk = fa.io.best_ijk + (size_t)b * 3;
@@ -833,19 +857,36 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
                 L.pt[e] = make_float4((float)rx, (float)ry, R2, __int_as_float((r * p.check_stride) | (j << 8)));
             }
         }
+#if defined(FP_RABL) && FP_RABL == 3  // timing ablation: staging only
+    } else if (false) {
+#else
     } else {
-        const double coarse_cost0 = analytic_cost(p, eg, target_speed, x, L.S);
+#endif
+        // The evaluations form a dependent chain (~2.3 us each on a lone wavefront), so the cost of the CURRENT point x rides along
+        // with the six probes around it (lanes >= 6 price x itself): that is the coarse winner's cost in round 0 and the previous
+        // round's step afterwards - R + 1 evaluations in the chain instead of 2 R + 1.
+        double coarse_cost0 = nan;
+        bool have_coarse = false;
+        int pending = -1;  // the lane whose trajectory (= x) still waits for its cost
         double my_x[3] = {nan, nan, nan}, my_cost = nan;  // lane c = refinement trajectory c (generation order)
         int ncand = 0;
         for (int r = 0; r < R; ++r) {
             const int dim = lane >> 1;
             double xp[3] = {x[0], x[1], x[2]};
-            if (lane < 6) xp[dim] += (lane & 1) ? res[dim] : -res[dim];
+            if (lane < 6) {
+                xp[dim] += (lane & 1) ? res[dim] : -res[dim];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) xp[m] = fmin(fmax(xp[m], lo[m]), hi[m]);  // np.clip
+                for (int m = 0; m < 3; ++m) xp[m] = fmin(fmax(xp[m], lo[m]), hi[m]);  // np.clip
+            }
             const bool bad = lane < 6 && (!(xp[0] == xp[0]) || !(xp[1] == xp[1]) || !(xp[2] == xp[2]));
             if (__ballot(bad)) break;
-            const double cp = analytic_cost(p, eg, target_speed, xp, L.S);  // lanes >= 6 price x itself (unused)
+            const double cp = analytic_cost(p, eg, target_speed, xp, L.S);  // lanes >= 6: the cost of x itself
+            {
+                const double cx0 = __shfl(cp, 6, kWave);
+                if (!have_coarse) { coarse_cost0 = cx0; have_coarse = true; }
+                if (lane == pending) my_cost = cx0;
+                pending = -1;
+            }
             for (int k = 0; k < 6; ++k) {  // hand probe k to lane ncand + k
                 const double c = __shfl(cp, k, kWave), a0 = __shfl(xp[0], k, kWave), a1 = __shfl(xp[1], k, kWave), a2 = __shfl(xp[2], k, kWave);
                 if (lane == ncand + k) { my_cost = c; my_x[0] = a0; my_x[1] = a1; my_x[2] = a2; }
@@ -870,20 +911,30 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
                 nan_step |= !(xn[m] == xn[m]);
             }
             if (nan_step) break;  // zero gradient: the reference raises inside np.arange(nan); refinement stops here
-            const double cn = analytic_cost(p, eg, target_speed, xn, L.S);
-            if (lane == ncand) { my_cost = cn; my_x[0] = xn[0]; my_x[1] = xn[1]; my_x[2] = xn[2]; }
+            if (lane == ncand) { my_x[0] = xn[0]; my_x[1] = xn[1]; my_x[2] = xn[2]; }
+            pending = ncand;  // priced with the next round's probes, or below
             ncand += 1;
             x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
+        }
+        if (!have_coarse || pending >= 0) {  // (x is the coarse winner while no round got as far as its evaluation)
+            const double cl = analytic_cost(p, eg, target_speed, x, L.S);
+            if (!have_coarse) coarse_cost0 = cl;
+            if (lane == pending) my_cost = cl;
         }
         cand[lane * 4] = my_x[0]; cand[lane * 4 + 1] = my_x[1]; cand[lane * 4 + 2] = my_x[2]; cand[lane * 4 + 3] = my_cost;
         if (lane == 0) { cand[4 * kWave] = (double)ncand; cand[4 * kWave + 1] = coarse_cost0; }
     }
+    if (wave == 0) FP_RSTAMP(1);
     __syncthreads();
+    FP_RSTAMP(2);
     double my_x[3] = {cand[lane * 4], cand[lane * 4 + 1], cand[lane * 4 + 2]};  // lane c = refinement trajectory c (generation order)
     const double my_cost = cand[lane * 4 + 3];
     const int ncand = (int)cand[4 * kWave];
     const double coarse_cost = cand[4 * kWave + 1];
     __syncthreads();  // the queues take their bytes back
+#if defined(FP_RABL) && FP_RABL == 1  // timing ablation: rounds + staging only
+    return;
+#endif
     // refined_trajs.get() in cost order (ties: generation order), :301-323.  Every wavefront holds the same candidate list;
     // the next kRefineWaves trajectories in pop order are checked SPECULATIVELY side
     // by side, one whole wavefront each, and the verdicts are then consumed in pop order exactly like the sequential loop -
@@ -891,8 +942,35 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     uint32_t* verdict = (uint32_t*)(smem + verdict_off);  // [2][kRefineWaves], double-buffered across groups
     int validated = 0, checks = 0, winner = -1;
     bool alive = lane < ncand;
+    // Pop order = ascending (cost, generation index): a strict total order unless a cost is NaN, so every lane counts the
+    // candidates in front of its own once (register reads, no cross-lane reduction per pop: four 6-step butterflies cost ~1.2 us
+    // of every group).  With a NaN cost in the list the butterfly below decides, as it always did.
+    int rank = kWave;
+    const bool ranked = !__ballot(alive && !(my_cost == my_cost));
+    if (ranked) {
+        rank = 0;
+        for (int j = 0; j < ncand; ++j) {
+            const double cj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_cost), j), __builtin_amdgcn_readlane(__double2loint(my_cost), j));
+            rank += (cj < my_cost || (cj == my_cost && j < lane)) ? 1 : 0;
+        }
+        if (!alive) rank = kWave;
+    }
+    bool open = true;  // (ranked pops) nothing has ended the loop yet
     for (int grp = 0; winner < 0; ++grp) {
         int pop[kRefineWaves];
+        if (ranked) {
+#pragma unroll
+            for (int u = 0; u < kRefineWaves; ++u) {
+                const unsigned long long m = __ballot(rank == grp * kRefineWaves + u);
+                int bl = (open && m) ? __ffsll((long long)m) - 1 : -1;
+                if (bl >= 0) {
+                    const double bc = __shfl(my_cost, bl, kWave);
+                    if (bc > coarse_cost) bl = -1;  // `cost > coarse cost` ends the loop (:303-304)
+                }
+                if (bl < 0) open = false;
+                pop[u] = bl;
+            }
+        } else
 #pragma unroll
         for (int u = 0; u < kRefineWaves; ++u) {
             double bc = alive ? my_cost : __builtin_inf();
@@ -914,10 +992,15 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
         for (int u = 1; u < kRefineWaves; ++u) mine = (wave == u) ? pop[u] : mine;
         if (mine >= 0) {
             const double cx[3] = {__shfl(my_x[0], mine, kWave), __shfl(my_x[1], mine, kWave), __shfl(my_x[2], mine, kWave)};
+#if defined(FP_PHASE_STAMPS)
+            const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane, (wave == 0 && grp == 0 && fa.io.best_traj) ? fa.io.best_traj + ((size_t)b * FP_ARR_COUNT + 15) * fa.io.traj_stride + 112 : nullptr, t_begin);
+#else
             const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane);
+#endif
             if (lane == 0) verdict[(grp & 1) * kRefineWaves + wave] = fl;
         }
         __syncthreads();
+        FP_RSTAMP(3 + (grp < 6 ? grp : 6));
         bool done = false;
 #pragma unroll
         for (int u = 0; u < kRefineWaves; ++u) {
@@ -930,6 +1013,9 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
             if (!(fl & FP_FLAG_COLLISION)) { winner = pop[u]; done = true; }
         }
         if (done) break;
+#if defined(FP_RABL) && FP_RABL >= 4  // timing ablation: at most FP_RABL - 3 validation groups
+        if (grp >= FP_RABL - 4) break;
+#endif
     }
     if (wave == 0) {
         if (fa.io.trace && lane < R * 7) {
@@ -955,6 +1041,9 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     // winner epilogue (what plan() returns) on request: the series of the refined trajectory, or of the coarse winner when no
     // refined one survived.  Every wavefront holds the same candidate list; wavefront 0 writes the series (two time points per
     // lane, no barrier), the others are done.
+#if defined(FP_RABL) && FP_RABL == 2  // timing ablation: no series
+    return;
+#endif
     if (fa.io.best_traj && wave == 0) {
         double fx[3];
 #pragma unroll
@@ -964,7 +1053,10 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
         kw.r.best_flags = fa.io.best_flags;
         kw.r.traj_stride = fa.io.traj_stride;
         kw.r.traj_sparse = fa.io.traj_sparse;
+        FP_RSTAMP(10);
         winner_series_wave(kw, b, b, true, fx[0], fx[1], fx[2], lane, SplineLds{L.knots, L.coef, nx, nx});
+        FP_RSTAMP(11);
+        FP_RSTAMP(0);
     }
 }
 
