@@ -392,7 +392,12 @@ __global__ __launch_bounds__(256) void eval_trajs_kernel(KernelArgs ka, int K, c
 // ---------------------------------------------------------------------------
 // all_C > 0: materialise EVERY lattice candidate (slot = (ego, candidate) in FOP order): the all_trajs payload.
 constexpr int kWinnerWaves = 4;
-__global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C, int n_slots, int spline_in_lds)
+#if defined(FP_WINNER_OCC)
+__global__ __launch_bounds__(kWave * kWinnerWaves, FP_WINNER_OCC) void winner_traj_kernel(
+#else
+__global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(
+#endif
+    KernelArgs ka, const double* end_states, int all_C, int n_slots, int spline_in_lds)
 {
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
@@ -424,7 +429,11 @@ __global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(Kerne
         winner_series_wave(ka, b, slot, best >= 0, d_end, v_end, T, lane, SplineLds{gk, gc, bt.nx[f], NX});
         return;
     }
+#if defined(FP_ABL_NO_SPLINE_COPY)  // timing ablation (garbage series after the first launch's leftovers)
+    if (false) {
+#else
     if (best >= 0 && T == T) {  // (wave-uniform; an ego without a winner needs no spline)
+#endif
         for (int i = lane; i < 9 * NX; i += kWave) my[i] = i < NX ? gk[i] : gc[i - NX];
     }
     const SplineLds sp{my, my + NX, bt.nx[f], NX};

@@ -10,5 +10,5 @@ dev = torch.device("cuda", 0)
 eng = FrenetEngine(0)
 wl = bench.Workload(torch, eng, synth.make_config(3, B=256), dev, torch.cuda.current_stream(dev))
 m = bench.materialize_leg(torch, eng, wl, dev, torch.cuda.current_stream(dev))
-for k in ("compact", "padded128"):
+for k in [k for k in m if isinstance(m[k], dict)]:
     v = m[k]; print(k, f"median {v['kernel_ms']:.3f} ms  min {v['kernel_ms_min']:.3f}  max {v['kernel_ms_max']:.3f}  spread {v['spread']:.2f}  written {v['achieved_GBps']:.0f} GB/s  algorithmic {v['algorithmic_GBps']:.0f} GB/s")
