@@ -392,13 +392,15 @@ __global__ __launch_bounds__(256) void eval_trajs_kernel(KernelArgs ka, int K, c
 // ---------------------------------------------------------------------------
 // all_C > 0: materialise EVERY lattice candidate (slot = (ego, candidate) in FOP order): the all_trajs payload.
 constexpr int kWinnerWaves = 4;
-#if defined(FP_WINNER_OCC)
-__global__ __launch_bounds__(kWave * kWinnerWaves, FP_WINNER_OCC) void winner_traj_kernel(
-#else
-__global__ __launch_bounds__(kWave * kWinnerWaves) void winner_traj_kernel(
+// ALL: the materialise instance (its own register budget: the winners' instance stays at 127 VGPRs, four waves per SIMD).
+#ifndef FP_WINNER_OCC
+#define FP_WINNER_OCC 1
 #endif
-    KernelArgs ka, const double* end_states, int all_C, int n_slots, int spline_in_lds)
+template <bool ALL>
+__global__ __launch_bounds__(kWave * kWinnerWaves, ALL ? FP_WINNER_OCC : 1) void winner_traj_kernel(KernelArgs ka, const double* end_states, int all_C_arg, int n_slots,
+                                                                                               int spline_in_lds)
 {
+    const int all_C = ALL ? all_C_arg : 0;
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const int lane = threadIdx.x & (kWave - 1);
@@ -453,7 +455,7 @@ static int winner_lds_bytes(const KernelArgs& ka, bool all)
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream)
 {
     const int n = ka.b.B;
-    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka, false), stream, ka, end_states, 0, n, 0);
+    hipLaunchKernelGGL(winner_traj_kernel<false>, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka, false), stream, ka, end_states, 0, n, 0);
     return hipGetLastError();
 }
 
@@ -461,7 +463,7 @@ hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
 {
     const int C = ka.p.nd * ka.p.nv * ka.p.nt;
     const unsigned n = (unsigned)ka.b.B * (unsigned)C;
-    hipLaunchKernelGGL(winner_traj_kernel, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka, true), stream, ka, nullptr, C, (int)n, winner_lds_bytes(ka, true) > 0);
+    hipLaunchKernelGGL(winner_traj_kernel<true>, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka, true), stream, ka, nullptr, C, (int)n, winner_lds_bytes(ka, true) > 0);
     return hipGetLastError();
 }
 

@@ -1005,6 +1005,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     }
     if (tid == 0 && dur && nsplit == 1) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
     FP_STAMP(10);
+#if defined(FP_PHASE_STAMPS)  // column 15: the workgroup's absolute start (10 ns ticks, low 40 bits) - the launch's occupancy over time
+    if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + 15] = (double)(t_begin & 0xFFFFFFFFFFll);
+#endif
     // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
     // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
     // stores hide behind the other workgroups' arithmetic.  ONE wavefront does it (two time points per lane, neighbours by lane
@@ -1080,7 +1083,11 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         gs = fit < 1 ? 1 : (gs > fit ? fit : gs);
     }
     const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1);
+#if defined(FP_PHASE_STAMPS)  // (the stamps travel in the series block: the three-workgroup variant leaves the series themselves unwritten)
+    bool three = gs == 1 && nsplit == 1 && b.B > 512 && L6.total <= 52 * 1024;
+#else
     bool three = gs == 1 && nsplit == 1 && !ka.r.best_traj && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
+#endif
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
 #endif

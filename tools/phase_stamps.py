@@ -46,10 +46,23 @@ print(f"{'phase':48s} {'median us':>10s} {'p90 us':>10s} {'mean us':>10s}")
 for k, name in enumerate(PHASES):
     print(f"{name:48s} {np.median(d[:, k]):10.2f} {np.percentile(d[:, k], 90):10.2f} {d[:, k].mean():10.2f}")
 print(f"{'workgroup total':48s} {np.median(stamps[:, -1]):10.2f} {np.percentile(stamps[:, -1], 90):10.2f} {stamps[:, -1].mean():10.2f}")
-print(f"sum of workgroup durations / 512 slots = {stamps[:, -1].sum() / 512:.1f} us")
+print(f"sum of workgroup durations / 512 slots = {stamps[:, -1].sum() / 512:.1f} us, / 768 slots = {stamps[:, -1].sum() / 768:.1f} us")
 # inside the 4th slice of the workgroup: stamps 11..14 after the frames / prep / B / N barriers
 sl = raw[:, 11:15]
 print("one slice (the 4th):  prep {:.2f}  B {:.2f}  N {:.2f} us (medians);  frames + lat = slice total - these".format(
     np.median(sl[:, 1] - sl[:, 0]), np.median(sl[:, 2] - sl[:, 1]), np.median(sl[:, 3] - sl[:, 2])))
 print("absolute stamps of that slice / group (us since the workgroup started): after frames+lat {:.2f}, prep {:.2f}, B {:.2f}, N {:.2f}; G ended at {:.2f}".format(
     *(np.median(sl[:, i]) for i in range(4)), np.median(raw[:, 7])))
+
+# occupancy of the launch over time: workgroups running at every instant (absolute starts in column 15)
+t0 = raw[:, 15] - raw[:, 15].min()
+t1 = t0 + stamps[:, -1]
+span = t1.max()
+grid = np.linspace(0, span, 400)
+running = ((t0[None, :] <= grid[:, None]) & (t1[None, :] > grid[:, None])).sum(axis=1)
+print(f"launch: first start to last end {span:.1f} us; workgroups running: max {running.max()}, mean {running.mean():.0f}")
+for lo, hi in ((0, 0.1), (0.1, 0.3), (0.3, 0.5), (0.5, 0.7), (0.7, 0.8), (0.8, 0.9), (0.9, 1.0)):
+    m = (grid >= lo * span) & (grid < hi * span)
+    print(f"  {lo * span:6.1f} .. {hi * span:6.1f} us: mean {running[m].mean():6.0f} running")
+order = np.argsort(t0)
+print("start time of the n-th workgroup (us):", {n: round(float(t0[order[n]]), 1) for n in (0, 255, 511, 767, 768, 1023, 1535, 2047) if n < B})
