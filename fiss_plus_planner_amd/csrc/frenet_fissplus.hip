@@ -121,14 +121,24 @@ __device__ __forceinline__ void explore(const uint4& rec, int lane, uint32_t (&G
 // W wavefronts build the tables and rank the lattice (W = 1: small lattices, wave-level synchronisation only); the walk itself is
 // one wavefront's - the others leave before it starts.  NW = 32-bit words of rank bits per lane (C <= 2048 NW).  NB = buckets
 // (a multiple of 64 W).
-template <int W, int NW>
-__global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa, int NB)
+constexpr int kMisc = 256;  // bytes of counters / per-wave extremes / jump state in front of the tables
+// CMAX: the most samples the instance is launched for (sizes the per-thread register copies of the jump's relaxation).
+template <int W, int NW, int CMAX>
+__global__ __launch_bounds__(W * kWave, W >= 8 ? 8 : 1) void fissplus_search_kernel(FissArgs fa, int NB)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = W * kWave;
     const fp_params& p = fa.ka.p;
     const fp_batch& bt = fa.ka.b;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    // Timing diagnostic (tools/refine_stamps.py, -DFP_PHASE_STAMPS): thread 0 leaves 10 ns ticks since the workgroup started in
+    // columns 96..111 of the last row of the ego's series block (sparse layout, stride 128, N <= 96)
+#if defined(FP_PHASE_STAMPS)
+    const long long t_begin = wall_clock64();
+#define FP_SSTAMP(k) do { if (threadIdx.x == 0 && fa.io.best_traj) fa.io.best_traj[((size_t)b * FP_ARR_COUNT + 15) * fa.io.traj_stride + 96 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
+#else
+#define FP_SSTAMP(k) do { } while (0)
+#endif
     const int nd = p.nd, nv = p.nv, nt = p.nt, C = nd * nv * nt;
     auto group_sync = [&]() { if constexpr (W == 1) wave_lds_sync(); else __syncthreads(); };
     auto write_none = [&](int s0, int s1, int s2, int s3) {
@@ -149,10 +159,10 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
     // keys + payloads, later the rank records) | order, rank, lim u16 [C] each | hist int [NB + 2] | cursor int [NB + 2]
     const int C32 = C + (C >> 5) + 1;
     const int C8 = (C + 7) & ~7;
-    int* s_cnt = (int*)smem;                    // [0] feasible, [1] pass constraints, [4..7] wave totals of the scan
-    double* s_wmin = (double*)(smem + 32);      // [4]
-    double* s_wmax = (double*)(smem + 64);      // [4]
-    double* X = (double*)(smem + 128);
+    int* s_cnt = (int*)smem;                    // [0] feasible, [1] pass constraints, [4..4 + W) wave totals of the scan (W <= 8)
+    double* s_wmin = (double*)(smem + 64);      // [W]
+    double* s_wmax = (double*)(smem + 128);     // [W]
+    double* X = (double*)(smem + kMisc);
     unsigned char* Y = (unsigned char*)(X + ((C32 + 1) & ~1));
     double* bkey = (double*)Y;
     uint16_t* bq = (uint16_t*)(Y + (size_t)8 * C8);
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
     int* hist = (int*)(limtab + C8);
     int* cursor = hist + NB + 2;
 
-    if (tid < 8) s_cnt[tid] = 0;
+    if (tid < 16) s_cnt[tid] = 0;
     for (int i = tid; i < NB + 2; i += T) hist[i] = 0;
     group_sync();
 
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         return;
     }
 
+    FP_SSTAMP(1);
     // ---- T2: histogram over NB buckets linear in the key (+ bucket NB: the non-finite keys)
     const double scale = kmax > kmin ? (double)NB / (kmax - kmin) : 0.0;
     auto bucket_of = [&](double key) -> int {
@@ -253,6 +264,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         }
     }
     group_sync();
+    FP_SSTAMP(3);
     // ---- T4: scatter into bucket order (the payloads were parked in the rank array, which T5 fills)
     for (int q = tid; q < C; q += T) {
         const double key = X[q];
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         bq[slot] = rank[q];
     }
     group_sync();
+    FP_SSTAMP(4);
     // ---- T5: rank inside the bucket by counting; length of the tie run behind the candidate
     const int nfin = hist[NB];
     for (int q = tid; q < C; q += T) {
@@ -285,6 +298,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         limtab[r] = (uint16_t)(r < nfin ? r + eq_after + 1 : ((mine & kPayNan) ? 0 : nfin));
     }
     group_sync();
+    FP_SSTAMP(5);
     // ---- T6: per rank: cost_est (fiss_planner.py:33-99) and the record {six neighbour ranks, bound, payload bits}
     {
         const double* smin = fa.io.samp_min + (size_t)b * 3;
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         }
     }
     group_sync();
+    FP_SSTAMP(6);
 #if defined(FP_ABL_SEARCH_NOWALK)  // timing ablation: prologue + ranking only
     return;
 #endif
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
     uint32_t* jG2 = jG1 + 64 * NW;
     uint32_t* jQ2 = jG2 + 64 * NW;
     uint16_t* lam = (uint16_t*)(jQ2 + 64 * NW);
-    int* s_j = (int*)(smem + 32);  // [0] state after iteration 1 (0 jump, 1 finished, 2 serial only) [1] its pop [2] beta [3..5] counts
+    int* s_j = (int*)(smem + 192);  // [0] state after iteration 1 (0 jump, 1 finished, 2 serial only) [1] its pop [2] beta [3..5] counts
     if (wave == 0) {
         const int st = iterate();
         if (st != 0) finish();
@@ -450,6 +465,7 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
         for (int k = 0; k < NW; ++k) jG1[lane + 64 * k] = G[k];
     }
     group_sync();
+    FP_SSTAMP(7);
     const int after_first = s_j[0];
     if (after_first == 1) return;
     if (after_first == 0) {
@@ -472,25 +488,72 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
             lam[r] = (uint16_t)((seeded && r < nfin) ? (w3 & 0xFFFFu) : 0xFFFFu);
         }
         group_sync();
-        for (;;) {
-            int changed = 0;
-            for (int r = tid; r < nfin; r += T) {
-                const uint32_t cur = lam[r];
-                const uint4 rec = REC[r];
-                const uint32_t lev = rec.w & 0xFFFFu;
-                if (cur == lev) continue;  // at its floor
-                const uint32_t n[6] = {rec.x & 0xFFFFu, rec.x >> 16, rec.y & 0xFFFFu, rec.y >> 16, rec.z & 0xFFFFu, rec.z >> 16};
-                uint32_t mn = 0xFFFFu;
+        // Every sweep is a chain of dependent LDS round trips behind a barrier, so a thread keeps the records of its own samples in
+        // registers (one round trip per sweep instead of two) and sweeps twice per barrier: the levels only ever fall towards the
+        // fixed point, in any order of the updates, and the loop ends after a barrier interval in which nobody changed anything.
+        constexpr int kPer = (CMAX + T - 1) / T;  // samples per thread
+        if constexpr (kPer <= 4) {
+            uint32_t nx[kPer], ny[kPer], nz[kPer], lv[kPer];
 #pragma unroll
-                for (int e = 0; e < 6; ++e) {
-                    const uint32_t v = lam[n[e] < (uint32_t)C ? n[e] : r];
-                    mn = v < mn ? v : mn;
+            for (int u = 0; u < kPer; ++u) {
+                const int r = tid + u * T;
+                lv[u] = 0xFFFFFFFFu;  // not mine / not finite
+                nx[u] = ny[u] = nz[u] = 0u;
+                if (r < nfin) {
+                    const uint4 rec = REC[r];
+                    // a missing neighbour (0xFFFF) reads the sample itself
+                    auto fix = [&](uint32_t w) {
+                        const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+                        return (lo < (uint32_t)C ? lo : (uint32_t)r) | ((hi < (uint32_t)C ? hi : (uint32_t)r) << 16);
+                    };
+                    nx[u] = fix(rec.x); ny[u] = fix(rec.y); nz[u] = fix(rec.z);
+                    lv[u] = rec.w & 0xFFFFu;
                 }
-                const uint32_t v = mn > lev ? mn : lev;
-                if (v < cur) { lam[r] = (uint16_t)v; changed = 1; }
             }
-            if (!__syncthreads_or(changed)) break;
+            for (;;) {
+                int changed = 0;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                    for (int u = 0; u < kPer; ++u) {
+                        if (lv[u] == 0xFFFFFFFFu) continue;
+                        const int r = tid + u * T;
+                        const uint32_t cur = lam[r];
+                        if (cur == lv[u]) continue;  // at its floor
+                        const uint32_t a0 = lam[nx[u] & 0xFFFFu], a1 = lam[nx[u] >> 16], a2 = lam[ny[u] & 0xFFFFu], a3 = lam[ny[u] >> 16],
+                                       a4 = lam[nz[u] & 0xFFFFu], a5 = lam[nz[u] >> 16];
+                        uint32_t mn = a0 < a1 ? a0 : a1;
+                        const uint32_t m2 = a2 < a3 ? a2 : a3, m3 = a4 < a5 ? a4 : a5;
+                        mn = mn < m2 ? mn : m2;
+                        mn = mn < m3 ? mn : m3;
+                        const uint32_t v = mn > lv[u] ? mn : lv[u];
+                        if (v < cur) { lam[r] = (uint16_t)v; changed = 1; }
+                    }
+                }
+                if (!__syncthreads_or(changed)) break;
+            }
+        } else {
+            for (;;) {
+                int changed = 0;
+                for (int r = tid; r < nfin; r += T) {
+                    const uint32_t cur = lam[r];
+                    const uint4 rec = REC[r];
+                    const uint32_t lev = rec.w & 0xFFFFu;
+                    if (cur == lev) continue;  // at its floor
+                    const uint32_t n[6] = {rec.x & 0xFFFFu, rec.x >> 16, rec.y & 0xFFFFu, rec.y >> 16, rec.z & 0xFFFFu, rec.z >> 16};
+                    uint32_t mn = 0xFFFFu;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        const uint32_t v = lam[n[e] < (uint32_t)C ? n[e] : r];
+                        mn = v < mn ? v : mn;
+                    }
+                    const uint32_t v = mn > lev ? mn : lev;
+                    if (v < cur) { lam[r] = (uint16_t)v; changed = 1; }
+                }
+                if (!__syncthreads_or(changed)) break;
+            }
         }
+        FP_SSTAMP(8);
         {   // beta: the smallest level of a feasible sample
             uint32_t mine = 0xFFFFu;
             for (int r = tid; r < nfin; r += T)
@@ -541,13 +604,25 @@ __global__ __launch_bounds__(W * kWave) void fissplus_search_kernel(FissArgs fa,
             ngen = lane == 0 ? s_j[5] : 0;
             rs = lowest_rank<NW>(Q);
         }
+        FP_SSTAMP(9);
     }
     if (wave != 0) return;
     int st;
     do { st = iterate(); } while (st == 0);
     finish();
+    FP_SSTAMP(10);
+#if defined(FP_PHASE_STAMPS)
+    if (lane == 0 && fa.io.best_traj) fa.io.best_traj[((size_t)b * FP_ARR_COUNT + 15) * fa.io.traj_stride + 96 + 12] = (double)(t_begin & 0xFFFFFFFFFFll);
+    if (lane == 0 && fa.io.best_traj) fa.io.best_traj[((size_t)b * FP_ARR_COUNT + 15) * fa.io.traj_stride + 96 + 11] = (double)(num_iter - (after_first == 0 ? s_j[3] : 0));  // iterations walked one by one
+#endif
 }
 
+#ifndef FP_SEARCH_WAVES
+#define FP_SEARCH_WAVES 4   // wavefronts per workgroup of the mid-size instances (C <= 2048)
+#endif
+#ifndef FP_SEARCH_NB
+#define FP_SEARCH_NB 512    // buckets (a multiple of 64 x FP_SEARCH_WAVES; 0: 256 up to 1024 samples)
+#endif
 namespace {
 int fissplus_lds_bytes(int C, int NB)
 {
@@ -556,7 +631,7 @@ int fissplus_lds_bytes(int C, int NB)
     const int NW = C <= 2048 ? 1 : 2;
     const int sort_scratch = 4 * 2 * (NB + 2);                 // histogram + cursors
     const int jump_scratch = 3 * 4 * 64 * NW + 2 * C8;         // three word arrays + the levels (they reuse the sort's bytes)
-    return 128 + 8 * ((C32 + 1) & ~1) + 16 * C8 + 3 * 2 * C8 + (sort_scratch > jump_scratch ? sort_scratch : jump_scratch) + 16;
+    return kMisc + 8 * ((C32 + 1) & ~1) + 16 * C8 + 3 * 2 * C8 + (sort_scratch > jump_scratch ? sort_scratch : jump_scratch) + 16;
 }
 }  // namespace
 
@@ -565,25 +640,32 @@ hipError_t launch_fissplus_search(const FissArgs& fa, hipStream_t stream)
     const int C = fa.ka.p.nd * fa.ka.p.nv * fa.ka.p.nt;
     FP_LDS_SLOTS(cfg_1);
     FP_LDS_SLOTS(cfg_4);
+    FP_LDS_SLOTS(cfg_4s);
     FP_LDS_SLOTS(cfg_4w);
     if (C <= 4 * kWave) {  // single wavefront: the single-ego plan cycle (5 x 5 x 5)
         const int NB = C <= kWave ? kWave : 2 * kWave;
         const int bytes = fissplus_lds_bytes(C, NB);
-        hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<1, 1>, bytes, cfg_1);
+        hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<1, 1, 256>, bytes, cfg_1);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fissplus_search_kernel<1, 1>), dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa, NB);
+        hipLaunchKernelGGL((fissplus_search_kernel<1, 1, 256>), dim3(fa.ka.b.B), dim3(kWave), bytes, stream, fa, NB);
     } else if (C <= 2048) {
-        const int NB = C <= 1024 ? 256 : 512;
+        const int NB = FP_SEARCH_NB > 0 ? FP_SEARCH_NB : (C <= 1024 ? 256 : 512);
         const int bytes = fissplus_lds_bytes(C, NB);
-        hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<4, 1>, bytes, cfg_4);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fissplus_search_kernel<4, 1>), dim3(fa.ka.b.B), dim3(4 * kWave), bytes, stream, fa, NB);
+        if (C <= 1024) {
+            hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<FP_SEARCH_WAVES, 1, 1024>, bytes, cfg_4s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fissplus_search_kernel<FP_SEARCH_WAVES, 1, 1024>), dim3(fa.ka.b.B), dim3(FP_SEARCH_WAVES * kWave), bytes, stream, fa, NB);
+        } else {
+            hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<FP_SEARCH_WAVES, 1, 2048>, bytes, cfg_4);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fissplus_search_kernel<FP_SEARCH_WAVES, 1, 2048>), dim3(fa.ka.b.B), dim3(FP_SEARCH_WAVES * kWave), bytes, stream, fa, NB);
+        }
     } else {
         const int NB = 1024;
         const int bytes = fissplus_lds_bytes(C, NB);
-        hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<4, 2>, bytes, cfg_4w);
+        hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<4, 2, 4096>, bytes, cfg_4w);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fissplus_search_kernel<4, 2>), dim3(fa.ka.b.B), dim3(4 * kWave), bytes, stream, fa, NB);
+        hipLaunchKernelGGL((fissplus_search_kernel<4, 2, 4096>), dim3(fa.ka.b.B), dim3(4 * kWave), bytes, stream, fa, NB);
     }
     return hipGetLastError();
 }

@@ -35,3 +35,19 @@ print(f"results -> series      median {np.median(ser):6.2f}  p90 {np.percentile(
 print(f"workgroup total        median {np.median(t[:, 11]):6.2f}  p90 {np.percentile(t[:, 11], 90):6.2f}  max {t[:, 11].max():6.2f}")
 end = start + t[:, 11]
 print(f"last workgroup ends {end.max():.1f} us after the first one started")
+
+# the search kernel's stamps (columns 96..111 of the same row): egos whose walk ran past its first iteration
+sr = out.best_traj[:, 15, 96:112] * 0.01
+walked = sr[:, 10] > 0
+w = sr[walked]
+print(f"\nfissplus_search_kernel: {walked.sum()} egos walk past the first iteration ({(sr[:, 7] > 0).sum()} rank their lattice)")
+names = [(1, "T1 tables (global reads) + reductions"), (3, "T2 histogram + T3 scan"), (4, "T4 scatter"), (5, "T5 rank in bucket"), (6, "T6 cost_est + records"),
+         (7, "first iteration"), (8, "jump: level relaxation"), (9, "jump: beta + state"), (10, "remaining iterations + results")]
+prev = np.zeros(len(w))
+for k, n in names:
+    cur = w[:, k]
+    print(f"  {n:40s} median {np.median(cur - prev):6.2f}  p90 {np.percentile(cur - prev, 90):6.2f}")
+    prev = cur
+print(f"  {'workgroup total':40s} median {np.median(w[:, 10]):6.2f}  p90 {np.percentile(w[:, 10], 90):6.2f}  max {w[:, 10].max():6.2f};  iterations walked one by one after the jump: median {np.median(w[:, 11] * 100):.0f}  p90 {np.percentile(w[:, 11] * 100, 90):.0f}  max {w[:, 11].max() * 100:.0f}")
+t0 = w[:, 12] * 100 * 0.01 - (w[:, 12] * 100 * 0.01).min()
+print(f"  walking workgroups start (us after the first of them): median {np.median(t0):.1f}  p90 {np.percentile(t0, 90):.1f}  max {t0.max():.1f};  the last one ends at {(t0 + w[:, 10]).max():.1f}")
