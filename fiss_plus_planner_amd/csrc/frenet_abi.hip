@@ -54,6 +54,7 @@ int fail(int code, const char* fmt, ...)
 constexpr size_t kAlign = 256;
 constexpr size_t kSmallRegion = 4u << 20;  // device bytes mirrored by the pinned host block
 constexpr size_t kSmallMax = 64u << 10;    // arrays up to this size travel through the pinned block
+constexpr size_t kZeroCopyInMax = 256u << 10;  // latency regime: inputs the kernels read straight from the pinned block (all of a call's arrays together)
 
 inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
@@ -107,6 +108,8 @@ struct fp_ctx {
     DeviceBuf parts;               // latency-mode lattice launch: [ticket counters, fixed-size region][partial argmins]
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
+    int stage_kernel = 1;          // fp_ctx_set_option("stage_kernel"): the latency regime's inputs reach the device by a copy kernel instead of a copy command
+    int zero_copy_in = 0;          // fp_ctx_set_option("zero_copy_in"): FP_MEM_HOST calls of a handful of egos read their inputs from pinned host memory
     int lattice_group = 0;         // fp_ctx_set_option("lattice_group"): 0 auto, 1 never, n >= 2: up to n slices per barrier interval
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
@@ -127,6 +130,14 @@ struct fp_ctx {
 
 namespace {
 
+// Latency regime: the pinned window goes to the arena by a copy KERNEL (16 bytes per lane, read straight from the pinned host block)
+// instead of a copy command: for ~100 KB the copy engine takes ~9 us and the kernel behind it starts ~8 us after the copy ends
+// (cross-engine dependency); a kernel-to-kernel dependency on the same queue costs ~2-3 us and the copy itself ~4 us.
+__global__ __launch_bounds__(256) void stage_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // One FP_MEM_HOST call: reserve(), in()/in_mut() for every input, flush_in(), out() for every output, launch kernels,
 // fetch_out().
 class HostStage {
@@ -136,10 +147,15 @@ class HostStage {
     // zero_copy_out (latency regime, a handful of egos): small outputs are written by the kernels straight into the pinned
     // host block (it is device-visible) - no D2H command at all after the launch, only the stream synchronisation.  Larger
     // batches keep the outputs in HBM (kernels of the same call read each other's outputs) and fetch them with one copy.
+    // The same regime reads its INPUTS from the pinned block too (zero-copy in): the host's memcpy into the block is the whole
+    // transfer, the kernels fetch what they touch over the link (a few dependent reads, ~1 us more each than from HBM) - no copy
+    // command, no blit kernel, no gap behind them: a single-ego plan cycle is ~15 us shorter.  Only while the inputs of the call
+    // stay below kZeroCopyInMax bytes in total (a kernel re-reads parts of them; beyond that the copy engine wins).
     int reserve(size_t large_bytes, bool zero_copy_out = false)
     {
         FP_TRY(ctx_->arena.reserve(kSmallRegion + large_bytes + kAlign));
         zero_copy_out_ = zero_copy_out;
+        zero_copy_in_ = zero_copy_out && ctx_->zero_copy_in;
         small_ = 0;
         large_ = kSmallRegion;
         outs_.clear();
@@ -155,7 +171,23 @@ class HostStage {
     {
         const size_t bytes = sizeof(T) * count;
         if (count == 0) { *dev = (const T*)(ctx_->arena.base + large_); return FP_OK; }
-        if (bytes <= kSmallMax && align_up(small_) + bytes <= kSmallRegion) {
+        if (zero_copy_in_ && align_up(small_) + bytes <= kZeroCopyInMax) {
+            small_ = align_up(small_);
+            memcpy(ctx_->pinned + small_, host, bytes);
+            *dev = (const T*)(ctx_->pinned + small_);
+            small_ += bytes;
+            return FP_OK;
+        }
+        if (zero_copy_in_) {  // does not fit the zero-copy window: its own copy (the mirrored window below is not flushed in this mode)
+            large_ = align_up(large_);
+            T* d = (T*)(ctx_->arena.base + large_);
+            large_ += bytes;
+            HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx_->stream));
+            *dev = d;
+            return FP_OK;
+        }
+        // (latency regime: bigger arrays too - one transfer for the whole call instead of one more copy command per array)
+        if (bytes <= (zero_copy_out_ ? kZeroCopyInMax : kSmallMax) && align_up(small_) + bytes <= kSmallRegion) {
             small_ = align_up(small_);
             memcpy(ctx_->pinned + small_, host, bytes);
             *dev = (const T*)(ctx_->arena.base + small_);
@@ -190,7 +222,16 @@ class HostStage {
     }
     int flush_in()  // the output window of the small region starts after the inputs
     {
-        if (small_ > 0) HIP_TRY(hipMemcpyAsync(ctx_->arena.base, ctx_->pinned, small_, hipMemcpyHostToDevice, ctx_->stream));
+        if (small_ > 0 && !zero_copy_in_) {
+            if (zero_copy_out_ && ctx_->stage_kernel) {
+                const int n16 = (int)((small_ + 15) / 16);  // (both blocks are 256-byte aligned and kSmallRegion long)
+                const int blocks = (n16 + 255) / 256;
+                hipLaunchKernelGGL(stage_copy_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, ctx_->stream, (uint4*)ctx_->arena.base, (const uint4*)ctx_->pinned, n16);
+                HIP_TRY(hipGetLastError());
+            } else {
+                HIP_TRY(hipMemcpyAsync(ctx_->arena.base, ctx_->pinned, small_, hipMemcpyHostToDevice, ctx_->stream));
+            }
+        }
         small_out_lo_ = small_out_hi_ = align_up(small_);
         return FP_OK;
     }
@@ -240,7 +281,7 @@ class HostStage {
         bool via_pinned;
     };
     fp_ctx* ctx_;
-    bool zero_copy_out_ = false;
+    bool zero_copy_out_ = false, zero_copy_in_ = false;
     size_t small_ = 0, large_ = 0, small_out_lo_ = 0, small_out_hi_ = 0;
     std::vector<Out> outs_;
 };
@@ -652,6 +693,16 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->fiss_jump = value;
         return FP_OK;
     }
+    if (strcmp(name, "stage_kernel") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "stage_kernel must be 0 or 1");
+        ctx->stage_kernel = value;
+        return FP_OK;
+    }
+    if (strcmp(name, "zero_copy_in") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "zero_copy_in must be 0 or 1");
+        ctx->zero_copy_in = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_group") == 0) {
         if (value < 0) return fail(FP_EINVAL, "lattice_group must be 0 (auto), 1 (never) or the number of slices per group");
         ctx->lattice_group = value;
@@ -669,7 +720,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 {
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
-        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_order", ctx->lattice_order},
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"lattice_order", ctx->lattice_order},
         {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)

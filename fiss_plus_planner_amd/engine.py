@@ -27,6 +27,21 @@ COST_WX1 = dict(cost_horizon=10.0, w_speed=1.0, w_accel=0.1, w_jerk=0.1, w_offse
 
 
 def make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
+    """fp_params of a batch.  A planner re-plans with the same batch object every cycle: the struct is cached on it, keyed on
+    every scalar it is built from."""
+    lim0 = getattr(batch, "curvature_limits", None)
+    key = (nd or batch.nd, nv or batch.nv, nt or batch.nt, batch.check_stride, batch.tick_t, batch.veh_l, batch.veh_w, batch.max_speed, batch.max_accel,
+           None if lim0 is None else tuple(lim0))
+    cached = getattr(batch, "__dict__", {}).get("_fp_cache")
+    if cached is not None and cached[0] == key:
+        return _abi.FpParams.from_buffer_copy(cached[1])  # a copy: callers may edit their struct
+    p = _make_params(batch, nd, nv, nt)
+    if hasattr(batch, "__dict__"):
+        batch.__dict__["_fp_cache"] = (key, bytes(p))
+    return p
+
+
+def _make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
     p = _abi.FpParams()
     p.nd, p.nv, p.nt = nd or batch.nd, nv or batch.nv, nt or batch.nt
     p.check_stride = int(batch.check_stride)
@@ -227,12 +242,12 @@ class FrenetEngine:
             return out
         opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
         io = _abi.FpFissIo()
-        io.samp_min, io.samp_max, io.samp_res = batch.samp_min.ctypes.data, batch.samp_max.ctypes.data, batch.samp_res.ctypes.data
-        io.prev_best_idx, io.best_ijk, io.best_cost = prev.ctypes.data, out.best_ijk.ctypes.data, out.best_cost.ctypes.data
-        io.end_state, io.refined, io.stats = out.end_state.ctypes.data, out.refined.ctypes.data, out.stats.ctypes.data
-        io.trace = out.trace.ctypes.data if out.trace is not None else None
-        io.best_flags = out.best_flags.ctypes.data if winner else None
-        io.best_traj = out.best_traj.ctypes.data if winner else None
+        io.samp_min, io.samp_max, io.samp_res = _ptr(batch.samp_min), _ptr(batch.samp_max), _ptr(batch.samp_res)
+        io.prev_best_idx, io.best_ijk, io.best_cost = _ptr(prev), _ptr(out.best_ijk), _ptr(out.best_cost)
+        io.end_state, io.refined, io.stats = _ptr(out.end_state), _ptr(out.refined), _ptr(out.stats)
+        io.trace = _ptr(out.trace) if out.trace is not None else None
+        io.best_flags = _ptr(out.best_flags) if winner else None
+        io.best_traj = _ptr(out.best_traj) if winner else None
         io.traj_stride, io.traj_sparse = int(traj_stride), int(traj_sparse)
         p = make_params(batch)
         fb = _host_batch(batch)

@@ -123,7 +123,7 @@ class FrenetTrajectory:
         """dump: [16, stride]; N = len(t); M = len(x) (points that stayed on the spline)."""
         tr = cls.__new__(cls)
         tr.__dict__.update(_TRAJ_DEFAULTS)
-        tr.idx = np.array([-1, -1, -1])
+        tr.idx = np.array((-1, -1, -1) if idx is None else idx)
         d = np.array(dump[:, :N])  # one copy; the sixteen series are views of it
         for k, name in enumerate(ARRAY_NAMES[:9]):
             tr.__dict__[name] = d[k]
@@ -135,8 +135,6 @@ class FrenetTrajectory:
         tr.cost_final = float(cost_final)
         tr.is_generated = True
         tr.end_state = end_state
-        if idx is not None:
-            tr.idx = np.array(idx)
         return tr
 
     # ordering by cost_final only (reference frenet.py:150-166)

@@ -322,18 +322,21 @@ class FissPlanner(FrenetOptimalPlanner):
         prev = None if self.prev_best_idx is None else np.asarray(self.prev_best_idx, dtype=np.int32)[None]
         out = self._engine.plan_fiss(batch, self.KIND, prev_best_idx=prev, w_heuristic=st.w_heuristic, max_refine_iters=R,
                                      decaying_factor=getattr(st, "decaying_factor", 0.5), winner=True)
-        self.stats = Stats(*[int(v) for v in out.stats[0]])
+        # (plain Python scalars from here on: every numpy call on a one-element array costs about a microsecond of the plan cycle)
+        self.stats = Stats(*out.stats[0].tolist())
         self.all_trajs.append([])
-        if plus and R > 0 and not np.isnan(out.best_cost[0]):
+        best_cost = float(out.best_cost[0])
+        found = best_cost == best_cost
+        if plus and R > 0 and found:
             self.sampling_res = self.sampling_res * st.decaying_factor ** R  # decays in place in the reference (:282)
-        if np.isnan(out.best_cost[0]):
+        if not found:
             return None
         self.prev_best_idx = out.prev_best_idx[0].copy()
-        _, N, M = unpack_flags(out.best_flags[:1])
-        es = out.end_state[0]
+        fl = int(out.best_flags[0])  # N and M ride in the flag word (FP_FLAG_N_SHIFT / FP_FLAG_M_SHIFT)
+        es = out.end_state[0].tolist()
         end = FrenetState(t=es[2], s=0.0, s_d=es[1], d=es[0])
-        idx = np.array([-1, -1, -1]) if out.refined[0] else out.best_ijk[0].copy()
-        self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], int(N[0]), int(M[0]), float(out.best_cost[0]), end, idx)
+        idx = [-1, -1, -1] if out.refined[0] else out.best_ijk[0]
+        self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], (fl >> 8) & 0xFFF, fl >> 20, best_cost, end, idx)
         return self.best_traj
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
