@@ -151,13 +151,21 @@ class FrenetEngine:
             out = self.dense_outputs(B, Cn, tables, winner, traj_stride, traj_sparse)
         if B == 0:
             return out
-        res = _abi.FpResult()
-        res.best_idx, res.best_cost, res.stats = _ptr(out.best_idx), _ptr(out.best_cost), _ptr(out.stats)
-        res.cost_tbl = _ptr(out.cost) if tables else None
-        res.flag_tbl = _ptr(out.flags) if tables else None
-        res.best_flags = _ptr(out.best_flags) if winner else None
-        res.best_traj = _ptr(out.best_traj) if winner else None
-        res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
+        # a caller that re-plans into the same `out` every cycle (planners.py) finds the fp_result of its arrays cached on it
+        # (building the struct costs several microseconds of a ~55 us plan cycle); the arrays of `out` must not be replaced then
+        key = (tables, winner, int(traj_stride), int(traj_sparse))
+        cached = out.__dict__.get("_res")
+        if cached is not None and cached[0] == key:
+            res = cached[1]
+        else:
+            res = _abi.FpResult()
+            res.best_idx, res.best_cost, res.stats = _ptr(out.best_idx), _ptr(out.best_cost), _ptr(out.stats)
+            res.cost_tbl = _ptr(out.cost) if tables else None
+            res.flag_tbl = _ptr(out.flags) if tables else None
+            res.best_flags = _ptr(out.best_flags) if winner else None
+            res.best_traj = _ptr(out.best_traj) if winner else None
+            res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
+            out.__dict__["_res"] = (key, res)
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
@@ -241,14 +249,21 @@ class FrenetEngine:
         if B == 0:
             return out
         opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
-        io = _abi.FpFissIo()
-        io.samp_min, io.samp_max, io.samp_res = _ptr(batch.samp_min), _ptr(batch.samp_max), _ptr(batch.samp_res)
-        io.prev_best_idx, io.best_ijk, io.best_cost = _ptr(prev), _ptr(out.best_ijk), _ptr(out.best_cost)
-        io.end_state, io.refined, io.stats = _ptr(out.end_state), _ptr(out.refined), _ptr(out.stats)
-        io.trace = _ptr(out.trace) if out.trace is not None else None
-        io.best_flags = _ptr(out.best_flags) if winner else None
-        io.best_traj = _ptr(out.best_traj) if winner else None
-        io.traj_stride, io.traj_sparse = int(traj_stride), int(traj_sparse)
+        # (a caller that re-plans into the same `out` with the same batch arrays finds its fp_fiss_io cached, like plan_dense's fp_result)
+        key = (winner, int(traj_stride), int(traj_sparse), id(batch.samp_min), id(batch.samp_max), id(batch.samp_res))
+        cached = out.__dict__.get("_io")
+        if cached is not None and cached[0] == key:
+            io = cached[1]
+        else:
+            io = _abi.FpFissIo()
+            io.samp_min, io.samp_max, io.samp_res = _ptr(batch.samp_min), _ptr(batch.samp_max), _ptr(batch.samp_res)
+            io.prev_best_idx, io.best_ijk, io.best_cost = _ptr(prev), _ptr(out.best_ijk), _ptr(out.best_cost)
+            io.end_state, io.refined, io.stats = _ptr(out.end_state), _ptr(out.refined), _ptr(out.stats)
+            io.trace = _ptr(out.trace) if out.trace is not None else None
+            io.best_flags = _ptr(out.best_flags) if winner else None
+            io.best_traj = _ptr(out.best_traj) if winner else None
+            io.traj_stride, io.traj_sparse = int(traj_stride), int(traj_sparse)
+            out.__dict__["_io"] = (key, io, batch.samp_min, batch.samp_max, batch.samp_res)  # (the arrays kept alive: their ids are the key)
         p = make_params(batch)
         fb = _host_batch(batch)
         _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(p), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_HOST, None))

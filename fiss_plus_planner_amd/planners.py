@@ -211,8 +211,15 @@ class FrenetOptimalPlanner:
         return np.array([batch.d_samples[i_d], batch.v_samples[0, iv], batch.t_samples[it]]), (i_d, iv, it)
 
     def _dense(self, batch: ProblemBatch, winner: bool = False):
-        out = self._engine.plan_dense(batch, tables=True, winner=winner)
-        self.last_tables = (out.cost[0], out.flags[0])
+        # the output arrays (and the fp_result over them) are allocated once per planner and reused every cycle; what outlives
+        # the call is copied out of them (last_tables here, the winner's series in FrenetTrajectory.from_dump)
+        key = (batch.C, winner)
+        outs = self.__dict__.setdefault("_dense_outs", {})
+        reuse = outs.get(key)
+        if reuse is None:
+            reuse = outs[key] = self._engine.dense_outputs(1, batch.C, True, winner)
+        out = self._engine.plan_dense(batch, tables=True, winner=winner, out=reuse)
+        self.last_tables = (out.cost[0].copy(), out.flags[0].copy())
         if self.materialize_all:  # visualisation payload (reference :102): every candidate's series in one launch
             m = self._engine.materialize_all(batch)
             _, N, M = unpack_flags(m.flags[0])
@@ -320,8 +327,12 @@ class FissPlanner(FrenetOptimalPlanner):
         plus = self.KIND == "FISS+"
         R = st.max_refine_iters if (plus and st.refine_trajectory) else 0
         prev = None if self.prev_best_idx is None else np.asarray(self.prev_best_idx, dtype=np.int32)[None]
+        outs = self.__dict__.setdefault("_fiss_outs", {})  # output arrays (+ the fp_fiss_io over them) reused every cycle
+        reuse = outs.get(R)
+        if reuse is None:
+            reuse = outs[R] = self._engine.fiss_outputs(1, R, True)
         out = self._engine.plan_fiss(batch, self.KIND, prev_best_idx=prev, w_heuristic=st.w_heuristic, max_refine_iters=R,
-                                     decaying_factor=getattr(st, "decaying_factor", 0.5), winner=True)
+                                     decaying_factor=getattr(st, "decaying_factor", 0.5), winner=True, out=reuse)
         # (plain Python scalars from here on: every numpy call on a one-element array costs about a microsecond of the plan cycle)
         self.stats = Stats(*out.stats[0].tolist())
         self.all_trajs.append([])
@@ -335,7 +346,7 @@ class FissPlanner(FrenetOptimalPlanner):
         fl = int(out.best_flags[0])  # N and M ride in the flag word (FP_FLAG_N_SHIFT / FP_FLAG_M_SHIFT)
         es = out.end_state[0].tolist()
         end = FrenetState(t=es[2], s=0.0, s_d=es[1], d=es[0])
-        idx = [-1, -1, -1] if out.refined[0] else out.best_ijk[0]
+        idx = [-1, -1, -1] if out.refined[0] else out.best_ijk[0].tolist()
         self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], (fl >> 8) & 0xFFF, fl >> 20, best_cost, end, idx)
         return self.best_traj
 
