@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 9
+FP_ABI_VERSION = 10
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
@@ -44,7 +44,8 @@ class FpBatch(C.Structure):
                 ("d_samples", C.c_void_p), ("t_samples", C.c_void_p), ("v_samples", C.c_void_p), ("target_speed", C.c_void_p),
                 ("ego", C.c_void_p), ("frame_of", C.c_void_p), ("scene_of", C.c_void_p), ("t_now", C.c_void_p),
                 ("nx", C.c_void_p), ("knots", C.c_void_p), ("coef", C.c_void_p),
-                ("obs_pose", C.c_void_p), ("obs_dims", C.c_void_p), ("final_time_step", C.c_void_p), ("skip", C.c_void_p)]
+                ("obs_pose", C.c_void_p), ("obs_dims", C.c_void_p), ("final_time_step", C.c_void_p), ("skip", C.c_void_p),
+                ("tables_tag", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class FpResult(C.Structure):

@@ -105,11 +105,14 @@ struct fp_ctx {
     DeviceBuf arena;               // [ small region (kSmallRegion) | large region ] staging of FP_MEM_HOST calls
     char* pinned = nullptr;        // kSmallRegion bytes of pinned host memory mirroring the small region
     DeviceBuf scratch;             // intermediate tables of multi-kernel entry points (fp_plan_fiss)
+    DeviceBuf tables;              // frame + scene tables of the last tagged FP_MEM_HOST call (fp_batch.tables_tag)
+    int tables_key[6] = {0, 0, 0, 0, 0, 0};  // {tag, F, NX, S, T_obs, n_obs} of what `tables` holds (tag 0: nothing)
+    size_t tables_off[6] = {0, 0, 0, 0, 0, 0};  // nx, knots, coef, obs_pose, obs_dims, final_time_step
     DeviceBuf parts;               // latency-mode lattice launch: [ticket counters, fixed-size region][partial argmins]
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
     int stage_kernel = 1;          // fp_ctx_set_option("stage_kernel"): the latency regime's inputs reach the device by a copy kernel instead of a copy command
-    int zero_copy_in = 0;          // fp_ctx_set_option("zero_copy_in"): FP_MEM_HOST calls of a handful of egos read their inputs from pinned host memory
+    int zero_copy_in = 0;          // fp_ctx_set_option("zero_copy_in"): FP_MEM_HOST calls of a handful of egos read inputs from pinned host memory: 0 never (default: even a few hundred bytes read over the link cost every kernel of the call a round trip - measured slower than the copy kernel), 1 the per-ego arrays of a call whose tables are cached (tables_tag), 2 everything
     int lattice_group = 0;         // fp_ctx_set_option("lattice_group"): 0 auto, 1 never, n >= 2: up to n slices per barrier interval
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
@@ -155,7 +158,7 @@ class HostStage {
     {
         FP_TRY(ctx_->arena.reserve(kSmallRegion + large_bytes + kAlign));
         zero_copy_out_ = zero_copy_out;
-        zero_copy_in_ = zero_copy_out && ctx_->zero_copy_in;
+        zero_copy_in_ = zero_copy_out && ctx_->zero_copy_in == 2;
         small_ = 0;
         large_ = kSmallRegion;
         outs_.clear();
@@ -165,6 +168,10 @@ class HostStage {
     // bytes a `count`-element array may add to the large region
     template <typename T>
     static size_t need(size_t count) { return align_up(sizeof(T) * count) + kAlign; }
+    fp_ctx* ctx() const { return ctx_; }
+    // (latency regime with the big tables resident on the device: the per-ego arrays that are left are a few hundred bytes - the
+    // kernels read them from the pinned block, one more microsecond in their first round of loads, and no copy is enqueued at all)
+    void small_inputs_only() { if (zero_copy_out_ && ctx_->zero_copy_in != 0) zero_copy_in_ = true; }
 
     template <typename T>
     int in(const T* host, size_t count, const T** dev)
@@ -355,6 +362,38 @@ size_t batch_need(const fp_params* p, const fp_batch* b)
 int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* dev)
 {
     *dev = *b;
+    const bool has_obs = b->S > 0 && b->n_obs > 0;
+    bool tables_resident = false;
+    if (b->tables_tag != 0) {
+        // the frame / scene tables of a tagged call live in their own device buffer across calls (fp_batch.tables_tag)
+        fp_ctx* ctx = hs.ctx();
+        const int key[6] = {b->tables_tag, b->F, b->NX, b->S, b->T_obs, has_obs ? b->n_obs : 0};
+        const void* src[6] = {b->nx, b->knots, b->coef, b->obs_pose, b->obs_dims, b->final_time_step};
+        const size_t bytes[6] = {sizeof(int32_t) * (size_t)b->F, sizeof(double) * (size_t)b->F * b->NX, sizeof(double) * (size_t)b->F * 8 * b->NX,
+                                 has_obs ? sizeof(double) * (size_t)b->S * b->T_obs * b->n_obs * 4 : 0, has_obs ? sizeof(double) * (size_t)b->S * b->n_obs * 2 : 0,
+                                 has_obs ? sizeof(int32_t) * (size_t)b->S : 0};
+        if (memcmp(key, ctx->tables_key, sizeof(key)) != 0) {
+            size_t total = 0;
+            for (int i = 0; i < 6; ++i) { ctx->tables_off[i] = total; total += align_up(bytes[i]); }
+            ctx->tables_key[0] = 0;  // (nothing valid while the upload is being set up)
+            if (total + kAlign > ctx->tables.cap) {
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                FP_TRY(ctx->tables.reserve(total + kAlign));
+            }
+            for (int i = 0; i < 6; ++i)
+                if (bytes[i]) HIP_TRY(hipMemcpyAsync(ctx->tables.base + ctx->tables_off[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream));
+            memcpy(ctx->tables_key, key, sizeof(key));
+        }
+        char* tb = ctx->tables.base;
+        dev->nx = (const int32_t*)(tb + ctx->tables_off[0]);
+        dev->knots = (const double*)(tb + ctx->tables_off[1]);
+        dev->coef = (const double*)(tb + ctx->tables_off[2]);
+        dev->obs_pose = (const double*)(tb + ctx->tables_off[3]);
+        dev->obs_dims = (const double*)(tb + ctx->tables_off[4]);
+        dev->final_time_step = (const int32_t*)(tb + ctx->tables_off[5]);
+        tables_resident = true;
+        hs.small_inputs_only();
+    }
 #define PUSH(field, count) FP_TRY(hs.in(b->field, (size_t)(count), &dev->field))
     PUSH(d_samples, p->nd);
     PUSH(t_samples, p->nt);
@@ -364,13 +403,14 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
     PUSH(frame_of, b->B);
     PUSH(scene_of, b->B);
     PUSH(t_now, b->B);
-    PUSH(nx, b->F);
-    PUSH(knots, (size_t)b->F * b->NX);
-    PUSH(coef, (size_t)b->F * 8 * b->NX);
-    const bool has_obs = b->S > 0 && b->n_obs > 0;
-    PUSH(obs_pose, has_obs ? (size_t)b->S * b->T_obs * b->n_obs * 4 : 0);
-    PUSH(obs_dims, has_obs ? (size_t)b->S * b->n_obs * 2 : 0);
-    PUSH(final_time_step, has_obs ? b->S : 0);
+    if (!tables_resident) {
+        PUSH(nx, b->F);
+        PUSH(knots, (size_t)b->F * b->NX);
+        PUSH(coef, (size_t)b->F * 8 * b->NX);
+        PUSH(obs_pose, has_obs ? (size_t)b->S * b->T_obs * b->n_obs * 4 : 0);
+        PUSH(obs_dims, has_obs ? (size_t)b->S * b->n_obs * 2 : 0);
+        PUSH(final_time_step, has_obs ? b->S : 0);
+    }
     if (b->skip) PUSH(skip, b->B);
 #undef PUSH
     if (!has_obs) dev->n_obs = 0;
@@ -645,6 +685,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     if (ctx->parts.base) (void)hipFree(ctx->parts.base);
+    if (ctx->tables.base) (void)hipFree(ctx->tables.base);
     if (ctx->curv_buf.base) (void)hipFree(ctx->curv_buf.base);
     ctx->order_lattice.release();
     ctx->order_refine.release();
@@ -699,7 +740,7 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         return FP_OK;
     }
     if (strcmp(name, "zero_copy_in") == 0) {
-        if (value < 0 || value > 1) return fail(FP_EINVAL, "zero_copy_in must be 0 or 1");
+        if (value < 0 || value > 2) return fail(FP_EINVAL, "zero_copy_in must be 0, 1 or 2");
         ctx->zero_copy_in = value;
         return FP_OK;
     }

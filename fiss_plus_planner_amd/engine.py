@@ -68,7 +68,8 @@ def _host_batch(batch: ProblemBatch) -> _abi.FpBatch:
     """FpBatch over the batch's own numpy arrays.  A planner re-plans with the same (in-place updated) arrays every cycle, so
     the struct is cached on the batch and rebuilt only when one of the arrays was replaced."""
     arrays = [getattr(batch, name) for name in _BATCH_PTRS]
-    key = tuple(map(id, arrays))
+    tag = int(getattr(batch, "tables_tag", 0) or 0)  # fp_batch.tables_tag: the frame / scene tables stay on the device between calls
+    key = tuple(map(id, arrays)) + (tag,)
     cached = batch.__dict__.get("_fb_cache")
     if cached is not None and cached[0] == key:
         return _abi.FpBatch.from_buffer_copy(cached[1])  # a copy: callers may edit their struct
@@ -76,6 +77,7 @@ def _host_batch(batch: ProblemBatch) -> _abi.FpBatch:
     fb.B, fb.F, fb.NX, fb.S, fb.T_obs, fb.n_obs = batch.B, batch.F, batch.NX, batch.S, batch.T_obs, batch.n_obs
     for name, a in zip(_BATCH_PTRS, arrays):
         setattr(fb, name, _ptr(a) if a.size else None)
+    fb.tables_tag = tag
     batch.__dict__["_fb_cache"] = (key, _abi.FpBatch.from_buffer_copy(fb), arrays)  # the arrays are kept alive with the pointers
     return fb
 

@@ -12,6 +12,8 @@ planner without a GPU / built library raises.
 """
 from __future__ import annotations
 
+import itertools
+
 import numpy as np
 
 from . import search
@@ -49,6 +51,8 @@ class Stats:
     def as_tuple(self):
         return (self.num_iter, self.num_trajs_generated, self.num_trajs_validated, self.num_collison_checks)
 
+
+_TABLE_TAGS = itertools.count(1)  # fp_batch.tables_tag values: one per (planner, centerline, obstacle list) the process ever builds
 
 class FrenetOptimalPlannerSettings:
     """reference frenet_optimal_planner.py:38-56"""
@@ -178,6 +182,11 @@ class FrenetOptimalPlanner:
                 max_speed=self.vehicle.max_speed, max_accel=self.vehicle.max_accel, tick_t=st.tick_t, check_stride=2,
                 samp_min=np.array([[-sw / 2, st.lowest_speed, st.min_t]]), samp_max=np.array([[sw / 2, 0.0, st.max_t]]),
                 samp_res=np.array([[rd, 0.0, rt]]), curvature_limits=curv)
+            # fp_batch.tables_tag: the library keeps this batch's spline and obstacle tables on the device until the planner builds
+            # a new batch (another centerline / another obstacle list) - per cycle only the start state travels.  The tables are
+            # treated as immutable while the planner holds them, like the reference's prediction objects; `cache_tables = False`
+            # on the planner uploads them every cycle instead.
+            batch.tables_tag = next(_TABLE_TAGS) if getattr(self, "cache_tables", True) else 0
             cache = [key, batch, None, sp, tab]  # sp / tab kept alive so their ids cannot be recycled
             self._batch_cache = cache
         batch = cache[1]

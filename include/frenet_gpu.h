@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 9
+#define FP_ABI_VERSION 10
 
 /* error codes */
 #define FP_OK 0
@@ -117,6 +117,14 @@ typedef struct {
     const int32_t* final_time_step; /* [S]      obstacles[0].prediction.final_time_step :173 */
     const int32_t* skip;         /* NULL or [B]: egos with skip[b] != 0 are not planned (best_idx = -1, no table rows written);
                                     the closed-loop driver passes its `done` array here */
+    /* FP_MEM_HOST only, 0 = off.  A non-zero tag is the caller's promise that the frame and scene tables of this call (nx, knots,
+     * coef, obs_pose, obs_dims, final_time_step - with F, NX, S, T_obs, n_obs) are byte for byte those of the previous
+     * FP_MEM_HOST call on this ctx that carried the same tag: the library then keeps them on the device and uploads only the
+     * per-ego arrays (a planner re-plans against the same centerline and obstacle predictions cycle after cycle; for one ego that
+     * is ~100 KB per call that need not travel, ~12 us of a ~43 us call).  A new tag (or changed sizes) uploads again; one set of
+     * tables is kept per ctx.  Ignored by FP_MEM_DEVICE calls. */
+    int32_t tables_tag;
+    int32_t reserved0;
 } fp_batch;
 
 /* Outputs of the dense lattice pass; any pointer except best_idx/best_cost may be NULL.

@@ -199,3 +199,52 @@ def test_validate_option_turns_device_faults_into_errors(engine):
     finally:
         engine.set_option("validate", 0)
     assert engine.get_option("validate") == 0
+
+
+def test_tables_tag_keeps_frames_and_scenes_on_the_device(oracle, engine):
+    """fp_batch.tables_tag (FP_MEM_HOST): the first call with a tag uploads the frame / scene tables, later calls with the same tag
+    reuse the device copy (proved by handing them garbage host tables: the results still equal the untagged call's), a new tag or
+    tag 0 uploads again.  Per-ego arrays (start state, t_now, samples) travel with every call."""
+    batch = synth.make_batch(3, 5, 5, 5, 12, 60, True, 123)
+    ref = engine.plan_dense(batch, winner=True)
+    probs = oracle.problems_from_batch(batch)
+    np.testing.assert_array_equal(ref.best_idx, [p.fop_plan().best_idx for p in probs])
+    batch.tables_tag = 41
+    first = engine.plan_dense(batch, winner=True)
+    good = {k: getattr(batch, k).copy() for k in ("knots", "coef", "obs_pose", "obs_dims")}
+    try:
+        batch.knots[...] = 7.0; batch.coef[...] = -3.0; batch.obs_pose[...] = 1e3; batch.obs_dims[...] = 50.0  # (not looked at: same tag)
+        batch.ego[:, 3] += 0.25  # the per-ego arrays DO travel (a lateral offset: other costs)
+        moved = engine.plan_dense(batch, winner=True)
+    finally:
+        for k, v in good.items():
+            getattr(batch, k)[...] = v
+    batch.tables_tag = 0
+    moved_ref = engine.plan_dense(batch, winner=True)
+    for a, b in ((first, ref), (moved, moved_ref)):
+        np.testing.assert_array_equal(a.best_idx, b.best_idx)
+        np.testing.assert_array_equal(a.cost, b.cost)
+        np.testing.assert_array_equal(a.flags, b.flags)
+        assert np.array_equal(a.best_traj, b.best_traj, equal_nan=True)
+    assert not np.array_equal(moved_ref.cost, ref.cost)
+    # a new tag uploads what the host holds now (other obstacle sizes -> other collision flags)
+    batch.tables_tag = 42
+    batch.obs_dims *= 2.5
+    try:
+        bigger = engine.plan_dense(batch)
+        batch.tables_tag = 0
+        bigger_ref = engine.plan_dense(batch)
+    finally:
+        batch.obs_dims /= 2.5
+    np.testing.assert_array_equal(bigger.flags, bigger_ref.flags)
+    assert not np.array_equal(bigger_ref.flags, moved_ref.flags)
+    # FISS+ through the same tables
+    fb = synth.make_batch(2, 5, 5, 5, 12, 60, True, 124, kind="FISS+")
+    f_ref = engine.plan_fiss(fb, winner=True)
+    fb.tables_tag = 43
+    for _ in range(2):
+        f_tag = engine.plan_fiss(fb, winner=True)
+        np.testing.assert_array_equal(f_tag.best_ijk, f_ref.best_ijk)
+        np.testing.assert_array_equal(f_tag.stats, f_ref.stats)
+        np.testing.assert_array_equal(f_tag.best_cost, f_ref.best_cost)
+        assert np.array_equal(f_tag.best_traj, f_ref.best_traj, equal_nan=True)
