@@ -111,6 +111,7 @@ struct fp_ctx {
     DeviceBuf parts;               // latency-mode lattice launch: [ticket counters, fixed-size region][partial argmins]
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
+    int inline_inputs = 1;         // fp_ctx_set_option("inline_inputs"): fp_plan_dense(FP_MEM_HOST) of a tiny batch with cached tables passes the per-ego arrays inside the lattice kernel's argument block
     int stage_kernel = 1;          // fp_ctx_set_option("stage_kernel"): the latency regime's inputs reach the device by a copy kernel instead of a copy command
     int zero_copy_in = 0;          // fp_ctx_set_option("zero_copy_in"): FP_MEM_HOST calls of a handful of egos read inputs from pinned host memory: 0 never (default: even a few hundred bytes read over the link cost every kernel of the call a round trip - measured slower than the copy kernel), 1 the per-ego arrays of a call whose tables are cached (tables_tag), 2 everything
     int lattice_group = 0;         // fp_ctx_set_option("lattice_group"): 0 auto, 1 never, n >= 2: up to n slices per barrier interval
@@ -169,6 +170,7 @@ class HostStage {
     template <typename T>
     static size_t need(size_t count) { return align_up(sizeof(T) * count) + kAlign; }
     fp_ctx* ctx() const { return ctx_; }
+    bool latency() const { return zero_copy_out_; }
     // (latency regime with the big tables resident on the device: the per-ego arrays that are left are a few hundred bytes - the
     // kernels read them from the pinned block, one more microsecond in their first round of loads, and no copy is enqueued at all)
     void small_inputs_only() { if (zero_copy_out_ && ctx_->zero_copy_in != 0) zero_copy_in_ = true; }
@@ -359,7 +361,7 @@ size_t batch_need(const fp_params* p, const fp_batch* b)
            HostStage::need<int32_t>(b->S);
 }
 
-int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* dev)
+int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* dev, fp::InlineIn* inl = nullptr)
 {
     *dev = *b;
     const bool has_obs = b->S > 0 && b->n_obs > 0;
@@ -395,14 +397,33 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
         hs.small_inputs_only();
     }
 #define PUSH(field, count) FP_TRY(hs.in(b->field, (size_t)(count), &dev->field))
-    PUSH(d_samples, p->nd);
-    PUSH(t_samples, p->nt);
-    PUSH(v_samples, (size_t)b->B * p->nv);
-    PUSH(target_speed, b->B);
-    PUSH(ego, (size_t)b->B * 6);
-    PUSH(frame_of, b->B);
-    PUSH(scene_of, b->B);
-    PUSH(t_now, b->B);
+    // Inline inputs (fp::InlineIn): with the tables resident, what is left of a tiny batch fits the kernel's argument block
+    bool inlined = false;
+    if (inl && tables_resident && hs.latency() && !b->skip) {
+        const void* src[8] = {b->d_samples, b->t_samples, b->v_samples, b->target_speed, b->ego, b->frame_of, b->scene_of, b->t_now};
+        const size_t bytes[8] = {sizeof(double) * (size_t)p->nd, sizeof(double) * (size_t)p->nt, sizeof(double) * (size_t)b->B * p->nv, sizeof(double) * (size_t)b->B,
+                                 sizeof(double) * (size_t)b->B * 6, sizeof(int32_t) * (size_t)b->B, sizeof(int32_t) * (size_t)b->B, sizeof(int32_t) * (size_t)b->B};
+        size_t off[8], total = 0;
+        for (int i = 0; i < 8; ++i) { off[i] = total; total += (bytes[i] + 7) & ~(size_t)7; }
+        if (total <= (size_t)fp::kInlineMax) {
+            for (int i = 0; i < 8; ++i) memcpy(inl->bytes + off[i], src[i], bytes[i]);
+            dev->d_samples = (const double*)off[0]; dev->t_samples = (const double*)off[1]; dev->v_samples = (const double*)off[2];
+            dev->target_speed = (const double*)off[3]; dev->ego = (const double*)off[4]; dev->frame_of = (const int32_t*)off[5];
+            dev->scene_of = (const int32_t*)off[6]; dev->t_now = (const int32_t*)off[7];
+            inl->on = 1;
+            inlined = true;
+        }
+    }
+    if (!inlined) {
+        PUSH(d_samples, p->nd);
+        PUSH(t_samples, p->nt);
+        PUSH(v_samples, (size_t)b->B * p->nv);
+        PUSH(target_speed, b->B);
+        PUSH(ego, (size_t)b->B * 6);
+        PUSH(frame_of, b->B);
+        PUSH(scene_of, b->B);
+        PUSH(t_now, b->B);
+    }
     if (!tables_resident) {
         PUSH(nx, b->F);
         PUSH(knots, (size_t)b->F * b->NX);
@@ -734,6 +755,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->fiss_jump = value;
         return FP_OK;
     }
+    if (strcmp(name, "inline_inputs") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "inline_inputs must be 0 or 1");
+        ctx->inline_inputs = value;
+        return FP_OK;
+    }
     if (strcmp(name, "stage_kernel") == 0) {
         if (value < 0 || value > 1) return fail(FP_EINVAL, "stage_kernel must be 0 or 1");
         ctx->stage_kernel = value;
@@ -761,7 +787,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 {
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
-        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"lattice_order", ctx->lattice_order},
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
         {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
@@ -810,7 +836,11 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
                       HostStage::need<double>(B * C) + HostStage::need<uint32_t>(B * C) + HostStage::need<uint32_t>(B) +
                       HostStage::need<double>(traj_doubles) + HostStage::need<int32_t>(B * 2),
                       /*zero_copy_out=*/B <= 8));
-    FP_TRY(stage_batch(hs, params, batch, &ka.b));
+    // (inline inputs need the fused kernel with the winner's series inside it: no other kernel of this call may read the batch)
+    fp::InlineIn inl;
+    const bool try_inline = ctx->inline_inputs && B <= 8 && !params->curvature_mask && ctx->lattice_kernel != 1 &&
+                            (!result->best_traj || winner_inside_lattice(ctx, batch)) && fp::lattice_group_fit(*params, *batch) >= 1;
+    FP_TRY(stage_batch(hs, params, batch, &ka.b, try_inline ? &inl : nullptr));
     FP_TRY(hs.flush_in());
     ka.r.best_idx = hs.out(result->best_idx, B);
     ka.r.best_cost = hs.out(result->best_cost, B);
@@ -833,9 +863,12 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     fp::KernelArgs kl = ka;
     if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
-    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, inl.on ? &inl : nullptr), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
-    if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
+    if (result->best_traj && !winner_done) {
+        if (inl.on) return fail(FP_EHIP, "internal: inline inputs without the series inside the lattice kernel");
+        LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
+    }
     if (d_fopplus)
         LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, d_fopplus, ka.r.stats, ctx->stream),
                    "FOP+ count kernel");

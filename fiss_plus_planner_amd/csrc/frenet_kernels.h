@@ -36,6 +36,18 @@ struct KernelArgs {
     const uint8_t* curv_tbl = nullptr;
 };
 
+// Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel
+// INSIDE the kernel argument block - kernel arguments live in device memory on this platform (the host writes them through the
+// BAR), so the kernel reads them like any other HBM data and no copy, copy kernel or dependency is enqueued for them.  on != 0:
+// the fields d_samples, t_samples, v_samples, target_speed, ego, frame_of, scene_of, t_now of KernelArgs.b hold byte OFFSETS into
+// bytes[] instead of addresses (skip must be NULL).
+constexpr int kInlineMax = 1024;
+struct InlineIn {
+    int on = 0;
+    int pad = 0;
+    unsigned char bytes[kInlineMax];
+};
+
 // Production dense-lattice kernel (profile sharing + compacted collision).  Returns hipErrorInvalidValue when the
 // problem does not fit it (LDS budget / index widths); launch_lattice then uses the lane-per-candidate kernel.
 // Arguments of the FISS / FISS+ batch kernels: the lattice arguments plus the dense tables and the fp_fiss_io arrays.
@@ -66,14 +78,15 @@ constexpr size_t kTicketBytes = 64 * 1024;
 // group: time-horizon slices per barrier interval of the collision stages (<= 1: one at a time; n: up to n, as far as
 // lattice_group_fit allows - for small lattices whose slices are latency bound).
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done = nullptr,
-                                const int* perm = nullptr, int* dur = nullptr, int group = 1);
+                                const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr);
 int lattice_group_fit(const fp_params& p, const fp_batch& b);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Curvature flags of every lattice candidate -> out [B][C] (one workgroup per ego, one lane per candidate, spline in LDS).
 hipError_t launch_curvature_flags(const KernelArgs& ka, uint8_t* out, hipStream_t stream);
 // Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
+// inl (optional, see InlineIn): only with which == 2 semantics guaranteed by the caller (the problem fits the fused kernel).
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done = nullptr,
-                          const int* perm = nullptr, int* dur = nullptr, int group = 1);
+                          const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr);
 // Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
 // end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);

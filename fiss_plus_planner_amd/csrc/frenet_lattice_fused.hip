@@ -179,9 +179,15 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
 // by the latency of those barrier intervals (a handful of wavefronts of work each), not by arithmetic: with all nt slices in one group
 // an ego costs 4 intervals instead of 4 nt and needs no split over workgroups (no ticket, no merge).
 // NTH: threads per workgroup, 512 or - the grouped latency instances, one workgroup per CU - 1024 (twice the wavefronts per pass).
+// the kernel's parameters as one struct: where InlineIn::bytes sits in the argument segment
+struct LatticeKernarg {
+    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg; InlineIn inl;
+};
+constexpr size_t kInlineOffset = offsetof(LatticeKernarg, inl) + offsetof(InlineIn, bytes);
+
 template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH>
 __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur, int gs_arg)
+                                                                   int* dur, int gs_arg, InlineIn inl)
 {
     constexpr bool kShape = ND > 0;  // (all six are set together)
     constexpr bool kGroup = GS != 1;
@@ -261,12 +267,26 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     double* s_k = (double*)(smem + L.konst);
 
     // the ego's scalars: independent global reads, all issued before the first one is waited for (a read costs ~1-2 us)
+    // the per-ego arrays: at the addresses in the batch, or (InlineIn, latency instances only) inside this kernel's own argument block
+    const double *in_d = bt.d_samples, *in_t = bt.t_samples, *in_v = bt.v_samples, *in_ts = bt.target_speed, *in_ego = bt.ego;
+    const int32_t *in_frame = bt.frame_of, *in_scene = bt.scene_of, *in_tnow = bt.t_now;
+    if constexpr (OCC <= 4) {
+        if (inl.on) {
+            // (the blob's place in this kernel's own argument segment: taking the address of the by-value parameter itself would
+            // make the compiler keep a private copy of it)
+            const unsigned char* base = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + kInlineOffset;
+            in_d = (const double*)(base + (size_t)bt.d_samples); in_t = (const double*)(base + (size_t)bt.t_samples);
+            in_v = (const double*)(base + (size_t)bt.v_samples); in_ts = (const double*)(base + (size_t)bt.target_speed);
+            in_ego = (const double*)(base + (size_t)bt.ego); in_frame = (const int32_t*)(base + (size_t)bt.frame_of);
+            in_scene = (const int32_t*)(base + (size_t)bt.scene_of); in_tnow = (const int32_t*)(base + (size_t)bt.t_now);
+        }
+    }
     const int skip_flag = bt.skip ? bt.skip[b] : 0;
-    const int f = bt.frame_of[b];
-    const int sc = bt.scene_of[b];
-    const int t_now = bt.t_now[b];
-    const double target_speed = bt.target_speed[b];
-    const double* eg = bt.ego + (size_t)b * 6;
+    const int f = in_frame[b];
+    const int sc = in_scene[b];
+    const int t_now = in_tnow[b];
+    const double target_speed = in_ts[b];
+    const double* eg = in_ego + (size_t)b * 6;
     const double s0 = eg[0], s_d0 = eg[1], s_dd0 = eg[2], d0 = eg[3], d_d0 = eg[4], d_dd0 = eg[5];
     if (skip_flag) {  // finished ego of a closed-loop batch (block-uniform exit)
         if (part == 0) {
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         // all NX columns (the copy does not wait for nx; columns >= nx hold the +inf padding / are never addressed)
         for (int i = tid; i < NX; i += kThreads) s_knots[i] = gk[i];
         for (int i = tid; i < nt + nv + nd; i += kThreads)
-            s_ts[i] = i < nt ? bt.t_samples[i] : (i < nt + nv ? bt.v_samples[(size_t)b * nv + (i - nt)] : bt.d_samples[i - nt - nv]);
+            s_ts[i] = i < nt ? in_t[i] : (i < nt + nv ? in_v[(size_t)b * nv + (i - nt)] : in_d[i - nt - nv]);
         for (int i = tid; i < 8 * NX; i += kThreads) s_coef[i] = gc[i];  // [8][NX], same layout
         if (n_obs > 0) {
             const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
@@ -1026,7 +1046,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         const int id = div_by<NT, ND * NT>(q1, inv_nt_a), it = q1 - mul24(id, nt);
         d_end = s_ds[id]; v_end = s_vs[iv]; T_end = s_ts[it];
     }
-    winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp);
+    winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp, eg);
 }
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the lane-per-candidate kernel).
@@ -1066,8 +1086,10 @@ int lattice_group_fit(const fp_params& p, const fp_batch& b)
 }
 
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
-                                int group)
+                                int group, const InlineIn* inl)
 {
+    static const InlineIn kNoInline{};
+    const InlineIn& in = inl ? *inl : kNoInline;
     if (winner_done) *winner_done = false;
     const fp_params& p = ka.p;
     const fp_batch& b = ka.b;
@@ -1088,6 +1110,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
 #else
     bool three = gs == 1 && nsplit == 1 && !ka.r.best_traj && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
 #endif
+    if (in.on) three = false;  // (inline inputs are read by the two-workgroup instances only; they belong to tiny batches anyway)
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
 #endif
@@ -1108,7 +1131,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     auto go = [&](auto kernel, int* configured, int threads = kThreads) -> hipError_t {
         hipError_t err = ensure_dynamic_lds((const void*)kernel, L.total, configured);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kernel, dim3(b.B * nsplit), dim3(threads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur, gs);
+        hipLaunchKernelGGL(kernel, dim3(b.B * nsplit), dim3(threads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur, gs, in);
         return hipGetLastError();
     };
     FP_LDS_SLOTS(cfg_generic);

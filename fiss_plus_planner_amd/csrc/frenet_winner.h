@@ -16,7 +16,7 @@ namespace fp {
 // np.arctan2 / hypot / diff chains (:121-134), truncation at the first point off the spline (:112-113).
 // Output layout: fp_result.traj_stride / traj_sparse (include/frenet_gpu.h).
 __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, int slot, bool valid, double d_end, double v_end, double T, int lane,
-                                                   const SplineLds& sp)
+                                                   const SplineLds& sp, const double* ego_row = nullptr)
 {
     typedef double double2v __attribute__((ext_vector_type(2)));
     const fp_params& p = ka.p;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
         if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
         return;
     }
-    const double* eg = bt.ego + (size_t)b * 6;
+    const double* eg = ego_row ? ego_row : bt.ego + (size_t)b * 6;  // (ego_row: the caller resolved the ego's state itself, InlineIn)
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
     const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], v_end, 0.0, T);
     double x[2] = {nan, nan}, y[2] = {nan, nan};
