@@ -187,6 +187,12 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "fiss_jump": 1 (default) = the FISS+ search walk runs its first iteration, then jumps to the state the reference's walk has
  * when the first feasible sample becomes reachable (minimax cost level, computed in parallel) and resumes there; 0 = every
  * iteration one after the other.  Identical results and Stats.
+ * "stage_kernel" (1 default), "inline_inputs" (1 default), "zero_copy_in" (0 default): how an FP_MEM_HOST call of at most 8 egos
+ * moves its inputs.  stage_kernel: the pinned staging block goes to the device by one copy KERNEL instead of copy commands (a
+ * copy command plus the cross-engine dependency behind it costs ~15 us of a single-ego call).  inline_inputs: fp_plan_dense
+ * with fp_batch.tables_tag set passes the per-ego arrays inside the lattice kernel's argument block - nothing is copied at all.
+ * zero_copy_in: the kernels read inputs from the pinned host block over the link (1: the per-ego arrays of a tagged call, 2:
+ * everything) - measured slower than the copy kernel, kept for experiments.  Identical results in every combination.
  * "fiss_stages": timing diagnostic of fp_plan_fiss, 3 (default) = the whole pipeline, 2 = stop after the search walk (no
  * refinement), 1 = stop after the dense lattice pass; with 1 or 2 the outputs of the skipped stages are NOT produced. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
