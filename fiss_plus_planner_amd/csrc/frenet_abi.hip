@@ -105,9 +105,17 @@ struct fp_ctx {
     DeviceBuf arena;               // [ small region (kSmallRegion) | large region ] staging of FP_MEM_HOST calls
     char* pinned = nullptr;        // kSmallRegion bytes of pinned host memory mirroring the small region
     DeviceBuf scratch;             // intermediate tables of multi-kernel entry points (fp_plan_fiss)
-    DeviceBuf tables;              // frame + scene tables of the last tagged FP_MEM_HOST call (fp_batch.tables_tag)
-    int tables_key[6] = {0, 0, 0, 0, 0, 0};  // {tag, F, NX, S, T_obs, n_obs} of what `tables` holds (tag 0: nothing)
-    size_t tables_off[6] = {0, 0, 0, 0, 0, 0};  // nx, knots, coef, obs_pose, obs_dims, final_time_step
+    // frame + scene tables of tagged FP_MEM_HOST calls (fp_batch.tables_tag): a few sets, least recently used one replaced - two
+    // planners that take turns on one ctx (FOP and FISS+ on the same scenario, say) both keep theirs
+    struct TableSet {
+        DeviceBuf buf;
+        int key[6] = {0, 0, 0, 0, 0, 0};       // {tag, F, NX, S, T_obs, n_obs} of what buf holds (tag 0: nothing)
+        size_t off[6] = {0, 0, 0, 0, 0, 0};    // nx, knots, coef, obs_pose, obs_dims, final_time_step
+        unsigned long used = 0;                // tick of the last call that read it
+    };
+    static constexpr int kTableSets = 4;
+    TableSet tables[kTableSets];
+    unsigned long tables_tick = 0;
     DeviceBuf parts;               // latency-mode lattice launch: [ticket counters, fixed-size region][partial argmins]
     int lattice_kernel = 0;        // fp_ctx_set_option("lattice_kernel")
     int lattice_split = 0;         // fp_ctx_set_option("lattice_split"): 0 auto, 1 never, 2 always
@@ -374,25 +382,33 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
         const size_t bytes[6] = {sizeof(int32_t) * (size_t)b->F, sizeof(double) * (size_t)b->F * b->NX, sizeof(double) * (size_t)b->F * 8 * b->NX,
                                  has_obs ? sizeof(double) * (size_t)b->S * b->T_obs * b->n_obs * 4 : 0, has_obs ? sizeof(double) * (size_t)b->S * b->n_obs * 2 : 0,
                                  has_obs ? sizeof(int32_t) * (size_t)b->S : 0};
-        if (memcmp(key, ctx->tables_key, sizeof(key)) != 0) {
+        fp_ctx::TableSet* ts = nullptr;
+        fp_ctx::TableSet* lru = &ctx->tables[0];
+        for (auto& t : ctx->tables) {
+            if (memcmp(key, t.key, sizeof(key)) == 0) { ts = &t; break; }
+            if (t.used < lru->used) lru = &t;
+        }
+        if (!ts) {  // upload into the least recently used set
+            ts = lru;
             size_t total = 0;
-            for (int i = 0; i < 6; ++i) { ctx->tables_off[i] = total; total += align_up(bytes[i]); }
-            ctx->tables_key[0] = 0;  // (nothing valid while the upload is being set up)
-            if (total + kAlign > ctx->tables.cap) {
+            for (int i = 0; i < 6; ++i) { ts->off[i] = total; total += align_up(bytes[i]); }
+            ts->key[0] = 0;  // (nothing valid while the upload is being set up)
+            if (total + kAlign > ts->buf.cap) {
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
-                FP_TRY(ctx->tables.reserve(total + kAlign));
+                FP_TRY(ts->buf.reserve(total + kAlign));
             }
             for (int i = 0; i < 6; ++i)
-                if (bytes[i]) HIP_TRY(hipMemcpyAsync(ctx->tables.base + ctx->tables_off[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream));
-            memcpy(ctx->tables_key, key, sizeof(key));
+                if (bytes[i]) HIP_TRY(hipMemcpyAsync(ts->buf.base + ts->off[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream));
+            memcpy(ts->key, key, sizeof(key));
         }
-        char* tb = ctx->tables.base;
-        dev->nx = (const int32_t*)(tb + ctx->tables_off[0]);
-        dev->knots = (const double*)(tb + ctx->tables_off[1]);
-        dev->coef = (const double*)(tb + ctx->tables_off[2]);
-        dev->obs_pose = (const double*)(tb + ctx->tables_off[3]);
-        dev->obs_dims = (const double*)(tb + ctx->tables_off[4]);
-        dev->final_time_step = (const int32_t*)(tb + ctx->tables_off[5]);
+        ts->used = ++ctx->tables_tick;
+        char* tb = ts->buf.base;
+        dev->nx = (const int32_t*)(tb + ts->off[0]);
+        dev->knots = (const double*)(tb + ts->off[1]);
+        dev->coef = (const double*)(tb + ts->off[2]);
+        dev->obs_pose = (const double*)(tb + ts->off[3]);
+        dev->obs_dims = (const double*)(tb + ts->off[4]);
+        dev->final_time_step = (const int32_t*)(tb + ts->off[5]);
         tables_resident = true;
         hs.small_inputs_only();
     }
@@ -706,7 +722,8 @@ int fp_ctx_destroy(fp_ctx* ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
     if (ctx->parts.base) (void)hipFree(ctx->parts.base);
-    if (ctx->tables.base) (void)hipFree(ctx->tables.base);
+    for (auto& t : ctx->tables)
+        if (t.buf.base) (void)hipFree(t.buf.base);
     if (ctx->curv_buf.base) (void)hipFree(ctx->curv_buf.base);
     ctx->order_lattice.release();
     ctx->order_refine.release();

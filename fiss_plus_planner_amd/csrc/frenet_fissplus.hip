@@ -642,7 +642,10 @@ hipError_t launch_fissplus_search(const FissArgs& fa, hipStream_t stream)
     FP_LDS_SLOTS(cfg_4);
     FP_LDS_SLOTS(cfg_4s);
     FP_LDS_SLOTS(cfg_4w);
-    if (C <= 4 * kWave) {  // single wavefront: the single-ego plan cycle (5 x 5 x 5)
+#ifndef FP_SEARCH_SMALL
+#define FP_SEARCH_SMALL (4 * kWave)  // lattices up to this size: one wavefront
+#endif
+    if (C <= FP_SEARCH_SMALL) {  // single wavefront: the single-ego plan cycle (5 x 5 x 5)
         const int NB = C <= kWave ? kWave : 2 * kWave;
         const int bytes = fissplus_lds_bytes(C, NB);
         hipError_t e = ensure_dynamic_lds((const void*)fissplus_search_kernel<1, 1, 256>, bytes, cfg_1);

@@ -121,8 +121,8 @@ typedef struct {
      * coef, obs_pose, obs_dims, final_time_step - with F, NX, S, T_obs, n_obs) are byte for byte those of the previous
      * FP_MEM_HOST call on this ctx that carried the same tag: the library then keeps them on the device and uploads only the
      * per-ego arrays (a planner re-plans against the same centerline and obstacle predictions cycle after cycle; for one ego that
-     * is ~100 KB per call that need not travel, ~12 us of a ~43 us call).  A new tag (or changed sizes) uploads again; one set of
-     * tables is kept per ctx.  Ignored by FP_MEM_DEVICE calls. */
+     * is ~100 KB per call that need not travel, ~12 us of a ~43 us call).  A new tag (or changed sizes) uploads again; a ctx keeps
+     * the tables of its four most recently used tags.  Ignored by FP_MEM_DEVICE calls. */
     int32_t tables_tag;
     int32_t reserved0;
 } fp_batch;

