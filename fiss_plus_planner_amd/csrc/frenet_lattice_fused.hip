@@ -207,8 +207,11 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // ticks) at the phase boundaries in columns 112.. of the last row of its best_traj block (free with traj_stride = 128, sparse, T <= 11 s).
 #if defined(FP_PHASE_STAMPS)
 #define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x / nsplit) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
+// (the one workgroup of an ego that is left after the ticket - whichever part it is - stamps columns 5, 6 and 10)
+#define FP_STAMP_LAST(k) do { if (threadIdx.x == 0 && ka.r.best_traj) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
 #else
 #define FP_STAMP(k) do { } while (0)
+#define FP_STAMP_LAST(k) do { } while (0)
 #endif
 #if defined(FP_COUNTERS)  // work statistics (tools/work_counters.py): LDS counters, left in row 14, columns 112.. of the winner block
     __shared__ int s_dbg[16];
@@ -996,6 +999,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         }
         __syncthreads();
         if (s_cnt[3] != nsplit - 1) return;
+        FP_STAMP_LAST(5);
         if (tid == 0) {
             part_count[b] = 0;  // ready for the next launch
             __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the loads below stay behind the ticket
@@ -1024,7 +1028,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         }
     }
     if (tid == 0 && dur && nsplit == 1) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
-    FP_STAMP(10);
+    if (nsplit > 1) FP_STAMP_LAST(10); else FP_STAMP(10);
 #if defined(FP_PHASE_STAMPS)  // column 15: the workgroup's absolute start (10 ns ticks, low 40 bits) - the launch's occupancy over time
     if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + 15] = (double)(t_begin & 0xFFFFFFFFFFll);
 #endif
@@ -1047,6 +1051,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         d_end = s_ds[id]; v_end = s_vs[iv]; T_end = s_ts[it];
     }
     winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp, eg);
+    FP_STAMP_LAST(6);
 }
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the lane-per-candidate kernel).

@@ -19,8 +19,9 @@ PHASES = ["scalars + spline tables + obstacle sizes", "LUT + speed bound + later
           "slices: frames / lat / prep / B / N", "assembly + argmin", "results"]
 STAMPS = [0, 1, 2, 3, 4, 7, 8, 9, 10]
 
-CONFIG = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-batch = synth.make_config(CONFIG)
+# usage: phase_stamps.py [config | "b1"] [lattice_split] [lattice_group];  b1 = one ego, 5 x 5 x 5, 27 obstacles (the plan-cycle case)
+CONFIG = sys.argv[1] if len(sys.argv) > 1 else "3"
+batch = synth.make_batch(1, 5, 5, 5, 27, 100, True, 7) if CONFIG == "b1" else synth.make_config(int(CONFIG))
 dev = torch.device("cuda", 0)
 eng = FrenetEngine(0)
 eng.set_option("lattice_winner", 1)  # the stamps travel in the winner block the lattice kernel itself writes
@@ -66,3 +67,6 @@ for lo, hi in ((0, 0.1), (0.1, 0.3), (0.3, 0.5), (0.5, 0.7), (0.7, 0.8), (0.8, 0
     print(f"  {lo * span:6.1f} .. {hi * span:6.1f} us: mean {running[m].mean():6.0f} running")
 order = np.argsort(t0)
 print("start time of the n-th workgroup (us):", {n: round(float(t0[order[n]]), 1) for n in (0, 255, 511, 767, 768, 1023, 1535, 2047) if n < B})
+if raw[:, 5].max() > 0:  # latency mode: the last workgroup of an ego to arrive (its own clock)
+    print("last workgroup of an ego (us since IT started): ticket taken {:.2f}, results written {:.2f}, series written {:.2f}".format(
+        np.median(raw[:, 5]), np.median(raw[:, 10]), np.median(raw[:, 6])))
