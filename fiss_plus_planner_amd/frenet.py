@@ -19,6 +19,9 @@ import numpy as np
 ARRAY_NAMES = ("t", "s", "s_d", "s_dd", "s_ddd", "d", "d_d", "d_dd", "d_ddd", "x", "y", "yaw", "ds", "c", "c_d", "c_dd")
 
 
+_ARRAY_INDEX = {n: i for i, n in enumerate(ARRAY_NAMES)}
+
+
 class LaneType(Enum):
     """planners/common/scenario/lane.py:8-12"""
     UNDEFINED = 0
@@ -122,24 +125,33 @@ class FrenetTrajectory:
                   idx=None) -> "FrenetTrajectory":
         """dump: [16, stride]; N = len(t); M = len(x) (points that stayed on the spline)."""
         tr = cls.__new__(cls)
-        tr.__dict__.update(_TRAJ_DEFAULTS)
-        tr.idx = np.array((-1, -1, -1) if idx is None else idx)
-        d = np.array(dump[:, :N])  # one copy; the sixteen series are views of it
-        rows = list(d)             # (one pass in C instead of sixteen indexing calls)
         dct = tr.__dict__
-        dct.update(zip(ARRAY_NAMES[:9], rows))
-        if M >= 2:
-            m1 = M - 1
-            lens = (M, M, M, m1, m1, M - 2, M - 3 if M >= 3 else 0)
-        else:
-            lens = (M, M, 0, 0, 0, 0, 0)
-        for name, row, ln in zip(ARRAY_NAMES[9:], rows[9:], lens):
-            dct[name] = row[:ln]
+        dct.update(_TRAJ_DEFAULTS)
+        tr.idx = np.array((-1, -1, -1) if idx is None else idx)
+        # one copy of the block; the sixteen series are views of it, made when they are first read (__getattr__): a plan cycle
+        # that only takes the next state out of its trajectory never builds the Cartesian rows
+        dct["_dump"] = np.array(dump[:, :N])
+        dct["_M"] = M
         tr.lane_type = LaneType.UNDEFINED
         tr.cost_final = float(cost_final)
         tr.is_generated = True
         tr.end_state = end_state
         return tr
+
+    def __getattr__(self, name):  # (only reached for names that are not in __dict__: the series of a from_dump trajectory)
+        k = _ARRAY_INDEX.get(name)
+        d = self.__dict__.get("_dump")
+        if k is None or d is None:
+            raise AttributeError(name)
+        if k < 9:
+            v = d[k]
+        else:
+            M = self.__dict__["_M"]
+            # lengths of x, y, yaw, ds, c, c_d, c_dd (frenet_optimal_planner.py:121-134)
+            ln = (M, M, M, M - 1, M - 1, M - 2, M - 3)[k - 9] if M >= 2 else (M if k < 11 else 0)
+            v = d[k, : max(ln, 0)]
+        self.__dict__[name] = v
+        return v
 
     # ordering by cost_final only (reference frenet.py:150-166)
     def __eq__(self, other):
