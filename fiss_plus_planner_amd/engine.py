@@ -82,6 +82,18 @@ def _host_batch(batch: ProblemBatch) -> _abi.FpBatch:
     return fb
 
 
+def host_structs(batch: ProblemBatch, freeze: bool = False):
+    """(fp_params, fp_batch) of a host batch.  freeze=True pins them on the batch: for a caller that owns the batch, never replaces
+    its arrays and never changes its scalars (planners.py updates the start state in place) later calls skip even the cache checks."""
+    st = batch.__dict__.get("_structs")
+    if st is not None:
+        return st
+    st = (make_params(batch), _host_batch(batch))
+    if freeze:
+        batch.__dict__["_structs"] = st
+    return st
+
+
 def device_batch(sizes, ptrs: dict) -> _abi.FpBatch:
     """FpBatch from raw device addresses (ints).  sizes: object with B, F, NX, S, T_obs, n_obs."""
     fb = _abi.FpBatch()
@@ -168,8 +180,7 @@ class FrenetEngine:
             res.best_traj = _ptr(out.best_traj) if winner else None
             res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
             out.__dict__["_res"] = (key, res)
-        p = make_params(batch)
-        fb = _host_batch(batch)
+        p, fb = host_structs(batch)
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(p), C.byref(fb), C.byref(res), _abi.FP_MEM_HOST, None))
         return out
 
@@ -266,8 +277,7 @@ class FrenetEngine:
             io.best_traj = _ptr(out.best_traj) if winner else None
             io.traj_stride, io.traj_sparse = int(traj_stride), int(traj_sparse)
             out.__dict__["_io"] = (key, io, batch.samp_min, batch.samp_max, batch.samp_res)  # (the arrays kept alive: their ids are the key)
-        p = make_params(batch)
-        fb = _host_batch(batch)
+        p, fb = host_structs(batch)
         _abi.check(self._lib.fp_plan_fiss(self._ctx, C.byref(p), C.byref(fb), C.byref(opts), C.byref(io), _abi.FP_MEM_HOST, None))
         return out
 

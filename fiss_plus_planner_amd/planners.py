@@ -18,7 +18,7 @@ import numpy as np
 
 from . import search
 from .batch import FISS_KINDS, ProblemBatch
-from .engine import TRAJ_STRIDE, FrenetEngine, unpack_flags
+from .engine import TRAJ_STRIDE, FrenetEngine, host_structs, unpack_flags
 from .frenet import FrenetState, FrenetTrajectory
 from .obstacles import ObstacleTable, flatten_obstacles, obstacles_fingerprint
 from .spline import CubicSpline2D
@@ -187,6 +187,7 @@ class FrenetOptimalPlanner:
             # treated as immutable while the planner holds them, like the reference's prediction objects; `cache_tables = False`
             # on the planner uploads them every cycle instead.
             batch.tables_tag = next(_TABLE_TAGS) if getattr(self, "cache_tables", True) else 0
+            host_structs(batch, freeze=True)  # (this batch is the planner's own: its arrays are only ever updated in place)
             cache = [key, batch, None, sp, tab]  # sp / tab kept alive so their ids cannot be recycled
             self._batch_cache = cache
         batch = cache[1]
