@@ -261,7 +261,13 @@ class FrenetEngine:
         prev = out.prev_best_idx
         if B == 0:
             return out
-        opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
+        okey = (plus, R, w_heuristic, decaying_factor)
+        ocached = out.__dict__.get("_opts")
+        if ocached is not None and ocached[0] == okey:
+            opts = ocached[1]
+        else:
+            opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
+            out.__dict__["_opts"] = (okey, opts)
         # (a caller that re-plans into the same `out` with the same batch arrays finds its fp_fiss_io cached, like plan_dense's fp_result)
         key = (winner, int(traj_stride), int(traj_sparse), id(batch.samp_min), id(batch.samp_max), id(batch.samp_res))
         cached = out.__dict__.get("_io")
