@@ -122,6 +122,7 @@ struct fp_ctx {
     int inline_inputs = 1;         // fp_ctx_set_option("inline_inputs"): fp_plan_dense(FP_MEM_HOST) of a tiny batch with cached tables passes the per-ego arrays inside the lattice kernel's argument block
     int stage_kernel = 1;          // fp_ctx_set_option("stage_kernel"): the latency regime's inputs reach the device by a copy kernel instead of a copy command
     int zero_copy_in = 0;          // fp_ctx_set_option("zero_copy_in"): FP_MEM_HOST calls of a handful of egos read inputs from pinned host memory: 0 never (default: even a few hundred bytes read over the link cost every kernel of the call a round trip - measured slower than the copy kernel), 1 the per-ego arrays of a call whose tables are cached (tables_tag), 2 everything
+    int lattice_tail = 0;          // fp_ctx_set_option("lattice_tail"): 0 auto, 1 never, n >= 2: the last n dispatch slots of a multi-round launch are cut in two workgroups
     int lattice_group = 0;         // fp_ctx_set_option("lattice_group"): 0 auto, 1 never, n >= 2: up to n slices per barrier interval
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
     int fiss_stages = 3;           // fp_ctx_set_option("fiss_stages"): timing diagnostic, 3 = the whole pipeline
@@ -522,11 +523,12 @@ int launch_order_after(LaunchOrder& o, const fp_batch* b, const int* dur, hipStr
 
 // Latency mode: a small batch cannot fill 256 CUs with one workgroup per ego, so the time-horizon slices of every ego are
 // spread over nt workgroups.  Returns the split factor and makes sure the partial-argmin buffer exists.
-int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, int* nsplit, void** parts, int* group)
+int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, int* nsplit, void** parts, int* group, int* tail)
 {
     *nsplit = 1;
     *parts = nullptr;
     *group = 1;
+    *tail = 0;
     // auto: as many workgroups per ego as keep ALL workgroups resident at once (measured on MI355X: 1.6-2.5x faster up to that
     // point, slower beyond it - a second round of workgroups costs more than the shorter critical path saves); at most one
     // workgroup per slice
@@ -552,19 +554,28 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
         *group = p->nt;
         parts_per_ego = 1;
     }
-    if (parts_per_ego < 2 || p->nt < 2) return FP_OK;
+    // Tail split (launch_lattice_fused, `tail`): a launch of several rounds of one-workgroup egos cuts its last slots in two
+    const bool want_tail = parts_per_ego < 2 && *group == 1 && ctx->lattice_tail != 1 && obstacles && p->nt >= 2 &&
+                           (ctx->lattice_tail >= 2 || b->B > ctx->resident_groups);
+    if ((parts_per_ego < 2 && !want_tail) || p->nt < 2) return FP_OK;
     // want implies a small batch or an explicit request: the counters get a fixed region in front (kTicketBytes) so that they
     // never share bytes with the partial argmins of a call with another B
     if ((size_t)b->B * 4 > fp::kTicketBytes) return FP_OK;  // (an explicitly requested split of a huge batch: not worth it)
     const size_t need = fp::kTicketBytes + (size_t)b->B * p->nt * 16 + kAlign;
     if (need > ctx->parts.cap) {
+        if (want_tail) {  // an optimisation only: never (re)allocate inside a stream capture for it
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+            if (cap != hipStreamCaptureStatusNone) return FP_OK;
+        }
         HIP_TRY(hipStreamSynchronize(stream));  // the buffer is reallocated: drain its users
         FP_TRY(ctx->parts.reserve(need));
         // ticket counters start at zero; every launch leaves them at zero
         HIP_TRY(hipMemsetAsync(ctx->parts.base, 0, fp::kTicketBytes, stream));
     }
-    *nsplit = parts_per_ego;
+    *nsplit = parts_per_ego < 2 ? 1 : parts_per_ego;
     *parts = ctx->parts.base;
+    if (want_tail) *tail = ctx->lattice_tail >= 2 ? ctx->lattice_tail : -(ctx->resident_groups / 2);  // (auto: the launcher knows the residency)
     return FP_OK;
 }
 
@@ -792,6 +803,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->lattice_group = value;
         return FP_OK;
     }
+    if (strcmp(name, "lattice_tail") == 0) {
+        if (value < 0) return fail(FP_EINVAL, "lattice_tail must be 0 (auto), 1 (never) or the number of egos cut in two");
+        ctx->lattice_tail = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_split") == 0) {
         if (value < 0 || value > 2) return fail(FP_EINVAL, "lattice_split must be 0 (auto), 1 (never) or 2 (always)");
         ctx->lattice_split = value;
@@ -804,7 +820,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 {
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
-        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
         {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
@@ -830,14 +846,14 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.r = *result;
         if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r));
         FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
-        int nsplit, group; void* parts;
-        FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group));
+        int nsplit, group, tail; void* parts;
+        FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
         bool winner_done = false;
         const int* perm; int* dur;
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
         fp::KernelArgs kl = ka;
         if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
-        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group), "lattice kernel");
+        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         if (result->fopplus)
@@ -873,14 +889,14 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     // sparse rows are only partly written by the kernels: the host block comes back with the caller's own bytes elsewhere
     if (result->traj_sparse && ka.r.best_traj) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, result->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     FP_TRY(lattice_curv_scratch(ctx, params, batch, ctx->stream, &ka.curv_tbl));
-    int nsplit, group; void* parts;
-    FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts, &group));
+    int nsplit, group, tail; void* parts;
+    FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts, &group, &tail));
     bool winner_done = false;
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     fp::KernelArgs kl = ka;
     if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
-    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, inl.on ? &inl : nullptr), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, inl.on ? &inl : nullptr, tail), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (result->best_traj && !winner_done) {
         if (inl.on) return fail(FP_EHIP, "internal: inline inputs without the series inside the lattice kernel");
@@ -1046,11 +1062,11 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         if (io->traj_sparse && fa.io.best_traj) HIP_TRY(hipMemcpyAsync(fa.io.best_traj, io->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     }
     FP_TRY(lattice_curv_scratch(ctx, params, batch, stream, &fa.ka.curv_tbl));
-    int nsplit, group; void* parts;
-    FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group));
+    int nsplit, group, tail; void* parts;
+    FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group, &tail));
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
-    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group), "lattice kernel");
+    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group, nullptr, tail), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     fa.walk_jump = ctx->fiss_jump;

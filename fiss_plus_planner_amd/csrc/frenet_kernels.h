@@ -77,8 +77,11 @@ constexpr size_t kTicketBytes = 64 * 1024;
 // workgroup leaves its ego's duration there (10 ns ticks).
 // group: time-horizon slices per barrier interval of the collision stages (<= 1: one at a time; n: up to n, as far as
 // lattice_group_fit allows - for small lattices whose slices are latency bound).
+// tail (needs part_scratch, nsplit == 1): the last `tail` dispatch slots of a multi-round launch are cut in two workgroups each (the
+// launch's tail drains faster); < 0: auto for a device of -tail compute units (half a round of resident workgroups, only when the
+// launch has more egos than stay resident); 0: off.
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done = nullptr,
-                                const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr);
+                                const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0);
 int lattice_group_fit(const fp_params& p, const fp_batch& b);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Curvature flags of every lattice candidate -> out [B][C] (one workgroup per ego, one lane per candidate, spline in LDS).
@@ -86,7 +89,7 @@ hipError_t launch_curvature_flags(const KernelArgs& ka, uint8_t* out, hipStream_
 // Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
 // inl (optional, see InlineIn): only with which == 2 semantics guaranteed by the caller (the problem fits the fused kernel).
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done = nullptr,
-                          const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr);
+                          const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0);
 // Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
 // end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);

@@ -640,11 +640,11 @@ hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint
 }
 
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done, const int* perm,
-                          int* dur, int group, const InlineIn* inl)
+                          int* dur, int group, const InlineIn* inl, int tail)
 {
     if (winner_done) *winner_done = false;
     if (which == 1) return inl && inl->on ? hipErrorInvalidValue : launch_lattice_percand(ka, stream);
-    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur, group, inl);
+    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur, group, inl, tail);
     if (e == hipErrorInvalidValue && which != 2 && !(inl && inl->on)) {
         (void)hipGetLastError();
         if (winner_done) *winner_done = false;

@@ -181,14 +181,21 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
 // NTH: threads per workgroup, 512 or - the grouped latency instances, one workgroup per CU - 1024 (twice the wavefronts per pass).
 // the kernel's parameters as one struct: where InlineIn::bytes sits in the argument segment
 struct LatticeKernarg {
-    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg; InlineIn inl;
+    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from; InlineIn inl;
 };
 constexpr size_t kInlineOffset = offsetof(LatticeKernarg, inl) + offsetof(InlineIn, bytes);
 
 template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH>
-__global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur, int gs_arg, InlineIn inl)
+__global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit_arg, Best* part_best, int* part_count, const int* perm,
+                                                                   int* dur, int gs_arg, int tail_from, InlineIn inl)
 {
+    // Dispatch slot -> (ego, part).  Uniform split (latency mode): slot = blockIdx / nsplit.  Tail split (tail_from >= 0, nsplit_arg
+    // == 1): the slots from tail_from on - the workgroups that start when the launch's last round is already draining - are cut in
+    // two like a latency-mode ego, so the launch does not end on whole egos that started last (see launch_lattice_fused).
+    const bool in_tail = tail_from >= 0 && (int)blockIdx.x >= tail_from;
+    const int nsplit = in_tail ? 2 : nsplit_arg;
+    const int slot = in_tail ? tail_from + (((int)blockIdx.x - tail_from) >> 1) : (int)blockIdx.x / nsplit_arg;
+    const int part_of_slot = in_tail ? (((int)blockIdx.x - tail_from) & 1) : (int)blockIdx.x - slot * nsplit_arg;
     constexpr bool kShape = ND > 0;  // (all six are set together)
     constexpr bool kGroup = GS != 1;
     constexpr int kThreads = NTH, kWaves = NTH / kWave;  // (shadow the file-scope defaults)
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     // launch order: longest egos first when the host has an order for this batch (perm; nsplit == 1 then)
-    const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x / nsplit, part = perm ? 0 : (int)blockIdx.x - b * nsplit;
+    const int b = perm ? perm[slot] : slot, part = part_of_slot;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
@@ -1003,7 +1010,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if (tid == 0) {
             part_count[b] = 0;  // ready for the next launch
             __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the loads below stay behind the ticket
-            Best* pb = part_best + (size_t)b * nsplit;
+            Best* pb = part_best + ((size_t)blockIdx.x - part);  // the ego's first workgroup
             auto part = [&](int w) {
                 return Best{__hip_atomic_load(&pb[w].cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                             __hip_atomic_load(&pb[w].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
@@ -1027,7 +1034,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
         }
     }
-    if (tid == 0 && dur && nsplit == 1) dur[b] = (int)(wall_clock64() - t_begin);  // 10 ns ticks: feeds the next launches' order
+    // 10 ns ticks: feeds the next launches' order (a tail ego leaves twice its last part's time: about what it would take whole)
+    if (tid == 0 && dur && (nsplit == 1 || in_tail)) dur[b] = (int)(wall_clock64() - t_begin) * nsplit;
     if (nsplit > 1) FP_STAMP_LAST(10); else FP_STAMP(10);
 #if defined(FP_PHASE_STAMPS)  // column 15: the workgroup's absolute start (10 ns ticks, low 40 bits) - the launch's occupancy over time
     if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + 15] = (double)(t_begin & 0xFFFFFFFFFFll);
@@ -1091,7 +1099,7 @@ int lattice_group_fit(const fp_params& p, const fp_batch& b)
 }
 
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
-                                int group, const InlineIn* inl)
+                                int group, const InlineIn* inl, int tail)
 {
     static const InlineIn kNoInline{};
     const InlineIn& in = inl ? *inl : kNoInline;
@@ -1126,6 +1134,21 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     int* part_count = (int*)part_scratch;
     Best* part_best = part_scratch ? (Best*)((char*)part_scratch + kTicketBytes) : nullptr;
     if (nsplit != 1) perm = nullptr;
+    // Tail split: a launch of several rounds of workgroups (one per ego) ends on the egos that happened to start last - with ~50 us
+    // per ego and the last workgroup starting ~40 us before the end, a fifth of the launch runs on a draining chip.  The last `tail`
+    // dispatch slots are cut in two (time-horizon slices it_lo .. it_hi per part, ticket + merge like the latency mode): each half
+    // repeats the ego's prologue, so only about half a round's worth of slots pays (tail < 0: auto).  Results do not depend on it.
+    int tail_from = -1;
+#if !defined(FP_PHASE_STAMPS) && !defined(FP_COUNTERS)
+    if (tail != 0 && nsplit == 1 && gs == 1 && part_scratch && p.nt >= 2 && b.S > 0 && b.n_obs > 0 && (size_t)b.B * 4 <= kTicketBytes) {
+        const int resident = (three ? 3 : 2) * (tail < 0 ? -tail : 0);  // workgroups the device holds at once (auto: tail = -compute units)
+        int n_tail = tail > 0 ? tail : (b.B > resident ? resident / 2 : 0);
+        if (n_tail > b.B - resident && tail < 0) n_tail = b.B - resident;
+        if (n_tail > b.B) n_tail = b.B;
+        if (n_tail > 0) tail_from = b.B - n_tail;
+    }
+#endif
+    const unsigned grid = tail_from >= 0 ? (unsigned)(2 * b.B - tail_from) : (unsigned)(b.B * nsplit);
     hipError_t e;
     if (p.curvature_mask) {  // optional curvature checks: their own launch, ORed into the flag words by the assembly stage
         if (!ka.curv_tbl) return hipErrorInvalidValue;
@@ -1136,7 +1159,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     auto go = [&](auto kernel, int* configured, int threads = kThreads) -> hipError_t {
         hipError_t err = ensure_dynamic_lds((const void*)kernel, L.total, configured);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kernel, dim3(b.B * nsplit), dim3(threads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur, gs, in);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur, gs, tail_from, in);
         return hipGetLastError();
     };
     FP_LDS_SLOTS(cfg_generic);
