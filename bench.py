@@ -239,7 +239,7 @@ def materialize_leg(torch, eng, main_wl, dev, stream):
     fbm = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in main_wl.dten.items()})
     fbm.B = Bm
     m_flags = torch.empty(Bm * C, dtype=torch.int32, device=dev)
-    materialize = {"kernel": "winner_traj_kernel (all candidates)", "egos": Bm, "bound": "hbm", "peak_GBps": HBM_PEAK_GBS}
+    materialize = {"kernel": "materialize_profiles_kernel (all candidates; one wavefront per ego and longitudinal profile writes its nd candidates)", "egos": Bm, "bound": "hbm", "peak_GBps": HBM_PEAK_GBS}
     # two layouts of the same payload: the compact one (rows of ceil(max T / tick) columns, only existing elements written) and
     # the round-1 layout (16 x 128 NaN-padded block per candidate).  Every launch writes into a FRESH allocation (the spread over
     # buffer placements is part of the measurement); median and maximum are both reported.

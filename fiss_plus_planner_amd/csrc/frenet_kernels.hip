@@ -442,6 +442,42 @@ __global__ __launch_bounds__(kWave * kWinnerWaves, ALL ? FP_WINNER_OCC : 1) void
     winner_series_wave(ka, b, slot, best >= 0, d_end, v_end, T, lane, sp);
 }
 
+// Materialise mode, the production kernel: one wavefront per (ego, longitudinal profile) writes the series of the nd candidates
+// that share the profile (profile_series_wave, frenet_winner.h).  Candidate (i_d, i_T, i_v) is block (i_d * nt + i_T) * nv + i_v of
+// its ego: the wavefront's nd blocks are nt * nv blocks apart.  winner_traj_kernel<true> (a wavefront per candidate) stays as the
+// A/B reference (-DFP_MAT_PER_CANDIDATE).
+#ifndef FP_MAT_OCC
+#define FP_MAT_OCC 1
+#endif
+__global__ __launch_bounds__(kWave * kWinnerWaves, FP_MAT_OCC) void materialize_profiles_kernel(KernelArgs ka, int n_tasks, int spline_in_lds)
+{
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int task = blockIdx.x * kWinnerWaves + (int)threadIdx.x / kWave;  // wave-uniform
+    if (task >= n_tasks) return;
+    const int nq = p.nt * p.nv;
+    const int b = task / nq, q = task - b * nq;
+    const int it = q / p.nv, iv = q - it * p.nv;
+    const double T = bt.t_samples[it], v_end = bt.v_samples[(size_t)b * p.nv + iv];
+    const size_t slot0 = (size_t)b * p.nd * nq + q;
+    const int f = bt.frame_of[b];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wt_smem[];
+    const int NX = bt.NX;
+    const double* gk = bt.knots + (size_t)f * NX;
+    const double* gc = bt.coef + (size_t)f * 8 * NX;
+    if (!spline_in_lds) {  // (a reference line too long for four LDS copies: the tables stay where they are)
+        profile_series_wave(ka, b, slot0, (size_t)nq, p.nd, bt.d_samples, v_end, T, lane, SplineLds{gk, gc, bt.nx[f], NX});
+        return;
+    }
+    // the wavefront's own LDS copy of the ego's spline (wave-private: no barrier), paid once per nd candidates
+    double* my = (double*)wt_smem + (size_t)((int)threadIdx.x / kWave) * 9 * NX;
+    if (T == T) {
+        for (int i = lane; i < 9 * NX; i += kWave) my[i] = i < NX ? gk[i] : gc[i - NX];
+    }
+    profile_series_wave(ka, b, slot0, (size_t)nq, p.nd, bt.d_samples, v_end, T, lane, SplineLds{my, my + NX, bt.nx[f], NX});
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -463,6 +499,14 @@ hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
 {
     const int C = ka.p.nd * ka.p.nv * ka.p.nt;
     const unsigned n = (unsigned)ka.b.B * (unsigned)C;
+#if !defined(FP_MAT_PER_CANDIDATE)
+    {
+        const unsigned n_tasks = (unsigned)ka.b.B * (unsigned)(ka.p.nt * ka.p.nv);
+        const int lds = winner_lds_bytes(ka, true);
+        hipLaunchKernelGGL(materialize_profiles_kernel, dim3((n_tasks + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), lds, stream, ka, (int)n_tasks, lds > 0);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(winner_traj_kernel<true>, dim3((n + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), winner_lds_bytes(ka, true), stream, ka, nullptr, C, (int)n, winner_lds_bytes(ka, true) > 0);
     return hipGetLastError();
 }

@@ -30,8 +30,18 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
     // elements 2l, 2l + 1 of a row that holds `len` elements: the value, NaN padding (whole block, or up to the end of the 128-byte
     // line in the sparse layout: partial-line stores cost a read-modify-write at the memory side), or nothing.  Write-once stream:
     // non-temporal stores (plain ones are 1.6x slower in the materialise mode).
+#if defined(FP_ABL_MAT_NO_STORE)  // timing ablation (tools/mat_variants.sh): the arithmetic without the stream of stores
+    double abl_sum = 0.0;
+#endif
     auto put = [&](int r, double v0, double v1, int len) {
         const int i = 2 * lane;
+#if defined(FP_ABL_MAT_NO_STORE)
+        abl_sum += (i < len ? v0 : 0.0) + (i + 1 < len ? v1 : 0.0);
+        if (r != FP_ARR_C_DD) return;
+        v0 = v1 = abl_sum;
+        len = 2 * lane == 0 ? 2 : 0;
+        if (lane != 0) return;
+#endif
         const int upto = sparse ? ((len + 15) & ~15) : FP_MAX_POINTS;
         const int lim = stride < upto ? stride : upto;
         const double a = i < len ? v0 : nan, c = i + 1 < len ? v1 : nan;
@@ -53,6 +63,15 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
         if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
         return;
     }
+#if defined(FP_ABL_MAT_STORE_ONLY)  // timing ablation: the stream of stores without the arithmetic
+    {
+        const int Ms = N - (slot & 3);
+#pragma unroll
+        for (int r = 0; r < FP_ARR_COUNT; ++r) put(r, 1.0, 2.0, r < FP_ARR_X ? N : (r <= FP_ARR_YAW ? Ms : Ms - 1));
+        if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)Ms << FP_FLAG_M_SHIFT);
+        return;
+    }
+#endif
     const double* eg = ego_row ? ego_row : bt.ego + (size_t)b * 6;  // (ego_row: the caller resolved the ego's state itself, InlineIn)
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
     const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], v_end, 0.0, T);
@@ -93,8 +112,13 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const double ddx = next(x, h) - x[h], ddy = next(y, h) - y[h];
+#if defined(FP_ABL_MAT_NO_MATH)  // timing ablation: no atan2 / hypot
+        yaw[h] = ddy + ddx;
+        ds[h] = ddx * ddy;
+#else
         yaw[h] = atan2(ddy, ddx);
         ds[h] = hypot(ddx, ddy);
+#endif
     }
     {   // the last point repeats the previous heading (:129)
         const double p0 = prev(yaw, 0), p1 = prev(yaw, 1);
@@ -115,6 +139,119 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
         uint32_t fl = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
         if (M < N) fl |= FP_FLAG_TRUNCATED;
         ka.r.best_flags[slot] = fl;
+    }
+}
+
+// Materialise mode (fp_materialize_all): one WAVEFRONT writes the series of ALL nd lattice candidates that share one longitudinal
+// profile (i_T, i_v).  Of a candidate's series everything but the lateral polynomial belongs to the profile: t, s and its
+// derivatives, the spline segment of every point, the reference-line frame (position + unit tangent) and the truncation index M -
+// computed once and kept in registers (two adjacent points per lane, as in winner_series_wave), then every lateral sample adds its
+// own quintic, offsets the frames and runs the yaw / ds / curvature difference chains.  Same arithmetic per element as
+// winner_series_wave (the tests compare the two and the oracle), a ninth of the segment searches / frame evaluations / input reads
+// per candidate in a 9-wide lattice.  slot0 = the block of lateral sample 0, slot_step = blocks between two lateral samples.
+__device__ __forceinline__ void profile_series_wave(const KernelArgs& ka, int b, size_t slot0, size_t slot_step, int n_lat, const double* d_ends,
+                                                    double v_end, double T, int lane, const SplineLds& sp)
+{
+    typedef double double2v __attribute__((ext_vector_type(2)));
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
+    const double nan = __builtin_nan("");
+    const int stride = ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS;
+    const bool sparse = ka.r.traj_sparse != 0;
+    const bool pairs = (stride & 1) == 0 && ((uintptr_t)ka.r.best_traj & 15) == 0;  // every row of every block starts on a 16-byte boundary
+    const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
+    double* out = nullptr;
+    auto put = [&](int r, double v0, double v1, int len) {  // (see winner_series_wave)
+        const int i = 2 * lane;
+        const int upto = sparse ? ((len + 15) & ~15) : FP_MAX_POINTS;
+        const int lim = stride < upto ? stride : upto;
+        const double a = i < len ? v0 : nan, c = i + 1 < len ? v1 : nan;
+        double* dst = &out[r * stride + i];
+        if (pairs) {
+            if (i < lim) __builtin_nontemporal_store(double2v{a, c}, (double2v*)dst);
+        } else {
+            if (i < lim) __builtin_nontemporal_store(a, dst);
+            if (i + 1 < lim) __builtin_nontemporal_store(c, dst + 1);
+        }
+        if (!sparse && stride > FP_MAX_POINTS)
+            for (int k = FP_MAX_POINTS + lane; k < stride; k += kWave) __builtin_nontemporal_store(nan, &out[r * stride + k]);
+    };
+    const bool lon_ok = N > 0 && N <= FP_MAX_POINTS && (v_end == v_end);  // wave-uniform
+    const double* eg = bt.ego + (size_t)b * 6;
+    double t[2], s[2], s_d[2], s_dd[2], s_ddd[2], px[2], py[2], tx[2], ty[2];
+    bool on[2] = {false, false};
+    int M = N;
+    if (lon_ok) {
+        const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], v_end, 0.0, T);
+        unsigned long long off_mask[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * lane + h;
+            bool off = false;
+            t[h] = s[h] = s_d[h] = s_dd[h] = s_ddd[h] = px[h] = py[h] = tx[h] = ty[h] = nan;
+            if (i < N) {
+                t[h] = (double)i * p.tick_t;
+                quartic_eval(lon, t[h], s[h], s_d[h], s_dd[h], s_ddd[h]);
+                const int seg = spline_segment(sp, s[h], -1);
+                off = seg < 0;  // first point off the spline truncates the Cartesian series (:112-113)
+                if (!off) {
+                    spline_frame(sp, seg, s[h] - sp.knots[seg], px[h], py[h], tx[h], ty[h]);
+                    on[h] = true;
+                }
+            }
+            off_mask[h] = __ballot(off);
+        }
+        if (off_mask[0]) M = 2 * (__ffsll((long long)off_mask[0]) - 1);
+        if (off_mask[1]) { const int m1 = 2 * (__ffsll((long long)off_mask[1]) - 1) + 1; M = m1 < M ? m1 : M; }
+    }
+    const int My = M >= 2 ? M : 0;
+    uint32_t fl = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+    if (M < N) fl |= FP_FLAG_TRUNCATED;
+    auto next = [&](const double* v, int h) { return h == 0 ? v[1] : __shfl_down(v[0], 1, kWave); };
+    auto prev = [&](const double* v, int h) { return h == 1 ? v[0] : __shfl_up(v[1], 1, kWave); };
+    for (int id = 0; id < n_lat; ++id) {
+        const size_t slot = slot0 + (size_t)id * slot_step;
+        out = ka.r.best_traj + slot * FP_ARR_COUNT * stride;
+        const double d_end = d_ends[id];
+        if (!lon_ok || !(d_end == d_end)) {  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < FP_ARR_COUNT; ++r) put(r, nan, nan, 0);
+            if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
+            continue;
+        }
+        const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
+        double x[2] = {nan, nan}, y[2] = {nan, nan}, d[2], d_d[2], d_dd[2], d_ddd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            d[h] = d_d[h] = d_dd[h] = d_ddd[h] = nan;
+            if (2 * lane + h < N) quintic_eval(lat, t[h], d[h], d_d[h], d_dd[h], d_ddd[h]);
+            if (on[h]) frenet_to_cartesian(px[h], py[h], tx[h], ty[h], d[h], x[h], y[h]);
+        }
+        put(FP_ARR_T, t[0], t[1], N);
+        put(FP_ARR_S, s[0], s[1], N); put(FP_ARR_S_D, s_d[0], s_d[1], N); put(FP_ARR_S_DD, s_dd[0], s_dd[1], N); put(FP_ARR_S_DDD, s_ddd[0], s_ddd[1], N);
+        put(FP_ARR_D, d[0], d[1], N); put(FP_ARR_D_D, d_d[0], d_d[1], N); put(FP_ARR_D_DD, d_dd[0], d_dd[1], N); put(FP_ARR_D_DDD, d_ddd[0], d_ddd[1], N);
+        double yaw[2], ds[2], c[2], cd[2], cdd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double ddx = next(x, h) - x[h], ddy = next(y, h) - y[h];
+            yaw[h] = atan2(ddy, ddx);
+            ds[h] = hypot(ddx, ddy);
+        }
+        {   // the last point repeats the previous heading (:129)
+            const double p0 = prev(yaw, 0), p1 = prev(yaw, 1);
+            if (2 * lane == M - 1) yaw[0] = p0;
+            if (2 * lane + 1 == M - 1) yaw[1] = p1;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) c[h] = (next(yaw, h) - yaw[h]) / ds[h];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) cd[h] = (next(c, h) - c[h]) / p.tick_t;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) cdd[h] = (next(cd, h) - cd[h]) / p.tick_t;
+        put(FP_ARR_X, x[0], x[1], M); put(FP_ARR_Y, y[0], y[1], M);
+        put(FP_ARR_YAW, yaw[0], yaw[1], My); put(FP_ARR_DS, ds[0], ds[1], My - 1); put(FP_ARR_C, c[0], c[1], My - 1);
+        put(FP_ARR_C_D, cd[0], cd[1], My - 2); put(FP_ARR_C_DD, cdd[0], cdd[1], My - 3);
+        if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = fl;
     }
 }
 
