@@ -78,7 +78,7 @@ constexpr size_t kTicketBytes = 64 * 1024;
 // group: time-horizon slices per barrier interval of the collision stages (<= 1: one at a time; n: up to n, as far as
 // lattice_group_fit allows - for small lattices whose slices are latency bound).
 // tail (needs part_scratch, nsplit == 1): the last `tail` dispatch slots of a multi-round launch are cut in two workgroups each (the
-// launch's tail drains faster); < 0: auto for a device of -tail compute units (half a round of resident workgroups, only when the
+// launch's tail drains faster); < 0: auto for a device of -tail compute units (a quarter of a round of resident workgroups, only when the
 // launch has more egos than stay resident); 0: off.
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done = nullptr,
                                 const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0);

@@ -449,12 +449,23 @@ __global__ __launch_bounds__(kWave * kWinnerWaves, ALL ? FP_WINNER_OCC : 1) void
 #ifndef FP_MAT_OCC
 #define FP_MAT_OCC 1
 #endif
+constexpr int kMatXcdRun = 16;
 __global__ __launch_bounds__(kWave * kWinnerWaves, FP_MAT_OCC) void materialize_profiles_kernel(KernelArgs ka, int n_tasks, int spline_in_lds)
 {
     const fp_params& p = ka.p;
     const fp_batch& bt = ka.b;
     const int lane = threadIdx.x & (kWave - 1);
-    const int task = blockIdx.x * kWinnerWaves + (int)threadIdx.x / kWave;  // wave-uniform
+    // XCD-aware dispatch: the hardware deals workgroups round-robin to the 8 XCDs, so with the plain mapping every XCD writes every
+    // eighth 53 KB piece of the output.  Here an XCD takes runs of kMatXcdRun consecutive workgroups (about one ego's profiles): its
+    // stores stream over contiguous blocks.  Measured on MI355X: padded layout 0.440 -> 0.412 ms (5.4 -> 5.8 TB/s written), compact
+    // layout 0.351 -> 0.348 ms and the spread over buffer placements 10 -> 7 % (runs of 4 ... 504 workgroups all within 1 %).
+    const int bid = (int)blockIdx.x;
+#if defined(FP_MAT_NO_XCD)  // (A/B)
+    const int wg = bid;
+#else
+    const int wg = ((bid / (8 * kMatXcdRun)) * 8 + (bid & 7)) * kMatXcdRun + ((bid >> 3) % kMatXcdRun);  // (the grid is a multiple of 8 runs)
+#endif
+    const int task = wg * kWinnerWaves + (int)threadIdx.x / kWave;  // wave-uniform
     if (task >= n_tasks) return;
     const int nq = p.nt * p.nv;
     const int b = task / nq, q = task - b * nq;
@@ -503,7 +514,8 @@ hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
     {
         const unsigned n_tasks = (unsigned)ka.b.B * (unsigned)(ka.p.nt * ka.p.nv);
         const int lds = winner_lds_bytes(ka, true);
-        hipLaunchKernelGGL(materialize_profiles_kernel, dim3((n_tasks + kWinnerWaves - 1) / kWinnerWaves), dim3(kWave * kWinnerWaves), lds, stream, ka, (int)n_tasks, lds > 0);
+        const unsigned n_wg = (n_tasks + kWinnerWaves - 1) / kWinnerWaves, unit = 8 * kMatXcdRun;
+        hipLaunchKernelGGL(materialize_profiles_kernel, dim3((n_wg + unit - 1) / unit * unit), dim3(kWave * kWinnerWaves), lds, stream, ka, (int)n_tasks, lds > 0);
         return hipGetLastError();
     }
 #endif

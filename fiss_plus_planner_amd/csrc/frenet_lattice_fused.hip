@@ -1137,12 +1137,12 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     // Tail split: a launch of several rounds of workgroups (one per ego) ends on the egos that happened to start last - with ~50 us
     // per ego and the last workgroup starting ~40 us before the end, a fifth of the launch runs on a draining chip.  The last `tail`
     // dispatch slots are cut in two (time-horizon slices it_lo .. it_hi per part, ticket + merge like the latency mode): each half
-    // repeats the ego's prologue, so only about half a round's worth of slots pays (tail < 0: auto).  Results do not depend on it.
+    // repeats the ego's prologue, so only a quarter of a round's worth of slots is cut (tail < 0: auto).  Results do not depend on it.
     int tail_from = -1;
 #if !defined(FP_PHASE_STAMPS) && !defined(FP_COUNTERS)
     if (tail != 0 && nsplit == 1 && gs == 1 && part_scratch && p.nt >= 2 && b.S > 0 && b.n_obs > 0 && (size_t)b.B * 4 <= kTicketBytes) {
         const int resident = (three ? 3 : 2) * (tail < 0 ? -tail : 0);  // workgroups the device holds at once (auto: tail = -compute units)
-        int n_tail = tail > 0 ? tail : (b.B > resident ? resident / 2 : 0);
+        int n_tail = tail > 0 ? tail : (b.B > resident ? resident / 4 : 0);  // (128 ... 384 of 768 measured within 1 %; 576: no gain; 768: slower)
         if (n_tail > b.B - resident && tail < 0) n_tail = b.B - resident;
         if (n_tail > b.B) n_tail = b.B;
         if (n_tail > 0) tail_from = b.B - n_tail;

@@ -161,8 +161,18 @@ __device__ __forceinline__ void profile_series_wave(const KernelArgs& ka, int b,
     const bool pairs = (stride & 1) == 0 && ((uintptr_t)ka.r.best_traj & 15) == 0;  // every row of every block starts on a 16-byte boundary
     const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
     double* out = nullptr;
+#if defined(FP_ABL_MAT_NO_STORE)
+    double abl_sum = 0.0;
+#endif
     auto put = [&](int r, double v0, double v1, int len) {  // (see winner_series_wave)
         const int i = 2 * lane;
+#if defined(FP_ABL_MAT_NO_STORE)
+        abl_sum += (i < len ? v0 : 0.0) + (i + 1 < len ? v1 : 0.0);
+        if (r != FP_ARR_C_DD) return;
+        v0 = v1 = abl_sum;
+        len = 2 * lane == 0 ? 2 : 0;
+        if (lane != 0) return;
+#endif
         const int upto = sparse ? ((len + 15) & ~15) : FP_MAX_POINTS;
         const int lim = stride < upto ? stride : upto;
         const double a = i < len ? v0 : nan, c = i + 1 < len ? v1 : nan;
@@ -219,6 +229,14 @@ __device__ __forceinline__ void profile_series_wave(const KernelArgs& ka, int b,
             if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = 0u;
             continue;
         }
+#if defined(FP_ABL_MAT_STORE_ONLY)
+        {
+#pragma unroll
+            for (int r = 0; r < FP_ARR_COUNT; ++r) put(r, 1.0, 2.0, r < FP_ARR_X ? N : (r <= FP_ARR_YAW ? My : My - 1));
+            if (lane == 0 && ka.r.best_flags) ka.r.best_flags[slot] = fl;
+            continue;
+        }
+#endif
         const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
         double x[2] = {nan, nan}, y[2] = {nan, nan}, d[2], d_d[2], d_dd[2], d_ddd[2];
 #pragma unroll

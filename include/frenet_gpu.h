@@ -174,7 +174,7 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * time, except for batches of at most one ego per compute unit that "lattice_split" could only cut in two: one 1024-thread
  * workgroup per ego then takes all nt slices at once, when its LDS holds their tables), 1 = always one at a time, n >= 2 = up to n
  * at a time (as many as fit).  Identical results.
- * "lattice_tail": 0 = auto (default: a launch with more one-workgroup egos than stay resident cuts the LAST half round of its
+ * "lattice_tail": 0 = auto (default: a launch with more one-workgroup egos than stay resident cuts the LAST quarter round of its
  * dispatch slots in two workgroups each - slices split, ticket + merge as in latency mode - so that it does not end on whole egos
  * that started last), 1 = never, n >= 2 = the last n slots.  Identical results.
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
