@@ -159,7 +159,8 @@ class Workload:
 
     def step(self):
         if self.fiss:
-            self.prev.fill_(-1)  # every step plans the same cycle: no history carried over
+            with self.torch.cuda.stream(self.stream):
+                self.prev.fill_(-1)  # every step plans the same cycle: no history carried over
             self.eng.plan_fiss_device(self.params, self.fb, self.opts, self.io, stream=self.stream.cuda_stream)
         else:
             # one launch: lattice + argmin + the winner's series (what plan() returns) written by the workgroup that found it
@@ -653,6 +654,39 @@ def main():
         o8["egos_with_a_feasible_candidate"] = float((w8.h_idx.numpy() >= 0).mean())
         extras[f"{other}_layout"] = o8
         del w8
+        # (d2) two contexts, two streams: the steps alternate between two engines (each its own fp_ctx and stream, what
+        # ShardedEngine(shards_per_device=2) does on the product side), so the draining tail of one launch - and the one-round search /
+        # refinement kernels of a FISS+ step - run beside the next step's lattice kernel.  Same batches, same outputs; an extra leg,
+        # never the headline (whose steps run back to back on one stream).
+        eng2 = FrenetEngine(local_rank)
+        stream2 = torch.cuda.Stream(dev)
+
+        def measure2(ws):
+            for k in range(warm_x):
+                ws[k % len(ws)].step(); ws[k % len(ws)].fetch()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps_x):
+                ws[(warm_x + k) % len(ws)].step(); ws[(warm_x + k) % len(ws)].fetch()
+            barrier()
+            el = time.perf_counter() - t0
+            return {"value": float(np.mean([w.candidates for w in ws])) * steps_x / el, "unit": "candidates/s", "ms_per_step": el / steps_x * 1e3,
+                    "steps": steps_x, "warmup": warm_x}
+
+        torch.cuda.synchronize(dev)
+        ws2 = [wls[k] if k % 2 == 0 else Workload(torch, eng2, wls[k].batch, dev, stream2) for k in range(len(wls))] if len(wls) >= 2 else \
+              [main_wl, Workload(torch, eng2, batch, dev, stream2)]
+        w4a, w4b = Workload(torch, eng, b4, dev, stream, fiss=True), Workload(torch, eng2, b4, dev, stream2, fiss=True)
+        torch.cuda.synchronize(dev)
+        o2 = measure2(ws2)
+        o2["what"] = "the headline workload with its steps alternating between two fp_ctx / two HIP streams (launches of consecutive steps overlap)"
+        o2["parity"] = gate("two_streams", ws2[1], 64)
+        o2["config4"] = measure2([w4a, w4b])
+        torch.cuda.synchronize(dev)
+        if args.cpu_seconds > 0:
+            o2["config4"]["parity"] = fiss_parity("two_streams config4", w4b, np.arange(0, B, max(1, B // 64)))
+        extras["two_streams"] = o2
+        del ws2, w4a, w4b, eng2
         # (e) many scenarios x many cycles on the device, and the PCIe-inclusive host-buffer entry
         if args.cpu_seconds > 0:
             extras["closed_loop"] = closed_loop_leg(torch, eng, dev, B, args.layout, 50, gate_threads)
