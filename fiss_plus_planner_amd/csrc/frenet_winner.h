@@ -147,7 +147,7 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
 // derivatives, the spline segment of every point, the reference-line frame (position + unit tangent) and the truncation index M -
 // computed once and kept in registers (two adjacent points per lane, as in winner_series_wave), then every lateral sample adds its
 // own quintic, offsets the frames and runs the yaw / ds / curvature difference chains.  Same arithmetic per element as
-// winner_series_wave (the tests compare the two and the oracle), a ninth of the segment searches / frame evaluations / input reads
+// winner_series_wave (the tests compare both with the CPU restatement), a ninth of the segment searches / frame evaluations / input reads
 // per candidate in a 9-wide lattice.  slot0 = the block of lateral sample 0, slot_step = blocks between two lateral samples.
 __device__ __forceinline__ void profile_series_wave(const KernelArgs& ka, int b, size_t slot0, size_t slot_step, int n_lat, const double* d_ends,
                                                     double v_end, double T, int lane, const SplineLds& sp)
