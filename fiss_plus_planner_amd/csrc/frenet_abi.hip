@@ -138,6 +138,7 @@ struct fp_ctx {
     int lattice_order = 1;
     int lattice_launches = 0, lattice_ordered_launches = 0;  // fp_ctx_get_option counters
     LaunchOrder order_lattice, order_refine;
+    DeviceBuf idx_shadow;          // [B] device copy of best_idx for the winner kernel of a dense call (KernelArgs::idx_shadow)
     DeviceBuf curv_buf;            // [B][C] curvature flag bytes of the lattice (fp_params.curvature_mask), written ahead of the fused kernel
 };
 
@@ -579,6 +580,22 @@ int lattice_split_for(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStr
     return FP_OK;
 }
 
+// Device copy of best_idx for a dense call whose winner series come from winner_traj_kernel (KernelArgs::idx_shadow); nullptr
+// when the buffer would have to grow inside a stream capture (the epilogue then reads the caller's array).
+int32_t* idx_shadow_for(fp_ctx* ctx, size_t B, hipStream_t stream)
+{
+    if (B * sizeof(int32_t) > ctx->idx_shadow.cap) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) return nullptr;
+        if (hipStreamSynchronize(stream) != hipSuccess || ctx->idx_shadow.reserve(B * sizeof(int32_t)) != FP_OK) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    return (int32_t*)ctx->idx_shadow.base;
+}
+
 // Optional curvature checks: the fused lattice kernel reads them from a [B][C] byte table that launch_lattice fills first.
 int lattice_curv_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, const uint8_t** out)
 {
@@ -736,6 +753,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     for (auto& t : ctx->tables)
         if (t.buf.base) (void)hipFree(t.buf.base);
     if (ctx->curv_buf.base) (void)hipFree(ctx->curv_buf.base);
+    if (ctx->idx_shadow.base) (void)hipFree(ctx->idx_shadow.base);
     ctx->order_lattice.release();
     ctx->order_refine.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -851,6 +869,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         bool winner_done = false;
         const int* perm; int* dur;
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
+        if (result->best_traj && !winner_inside_lattice(ctx, batch)) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
         fp::KernelArgs kl = ka;
         if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
         LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");

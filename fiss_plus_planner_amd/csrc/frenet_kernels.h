@@ -34,6 +34,10 @@ struct KernelArgs {
     // [B][C] FP_FLAG_CURVATURE / KAPPA_D / KAPPA_DD of every lattice candidate (flat FOP order), written by
     // launch_curvature_flags ahead of the fused lattice kernel when p.curvature_mask is set; nullptr otherwise
     const uint8_t* curv_tbl = nullptr;
+    // device copy of r.best_idx, written by the lattice kernels beside it and read by winner_traj_kernel (optional): the caller's
+    // best_idx may be device-mapped HOST memory (bench.py's results need no copy that way), where the epilogue's first read costs
+    // the link's round trip (winner kernel 10.9 -> 9.2 us on BASELINE configs[2])
+    int32_t* idx_shadow = nullptr;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void lattice_percand_kernel(KernelArgs ka, int
     const fp_params& p = ka.p;
     const int C = p.nd * p.nv * p.nt;
     if (ka.b.skip && ka.b.skip[b]) {  // finished ego of a closed-loop batch
-        if (threadIdx.x == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
+        if (threadIdx.x == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); if (ka.idx_shadow) ka.idx_shadow[b] = -1; }
         return;
     }
     EgoCtx e;
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(512) void lattice_percand_kernel(KernelArgs ka, int
         Best r = wave_best_slot[0];
         for (int w = 1; w < nw; ++w) r = best_merge(r, wave_best_slot[w]);
         ka.r.best_idx[b] = r.idx;
+        if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
         ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
         if (ka.r.stats) {  // frenet_optimal_planner.py:254-256
             int32_t* st = ka.r.stats + (size_t)b * 4;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(kWave * kWinnerWaves, ALL ? FP_WINNER_OCC : 1) void
     if (slot >= n_slots) return;
     const int b = all_C > 0 ? slot / all_C : slot;
     const double nan = __builtin_nan("");
-    const int best = all_C > 0 ? slot - b * all_C : (end_states ? 0 : ka.r.best_idx[b]);
+    const int best = all_C > 0 ? slot - b * all_C : (end_states ? 0 : (ka.idx_shadow ? ka.idx_shadow : ka.r.best_idx)[b]);
     double d_end = nan, v_end = nan, T = nan;
     if (end_states) {
         d_end = end_states[(size_t)b * 3]; v_end = end_states[(size_t)b * 3 + 1]; T = end_states[(size_t)b * 3 + 2];

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     if (skip_flag) {  // finished ego of a closed-loop batch (block-uniform exit)
         if (part == 0) {
             if (tid == 0 && dur) dur[b] = 0;
-            if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
+            if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); if (ka.idx_shadow) ka.idx_shadow[b] = -1; }
             if (ka.r.best_traj) {  // NaN series, flag word 0 (returns before it touches the spline or the scratch)
                 const double nan = __builtin_nan("");
                 if (wave == 0) winner_series_wave(ka, b, b, false, nan, nan, nan, lane, SplineLds{nullptr, nullptr, 0, 0});
@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     if (tid == 0) {
         const Best r = s_best[0];
         ka.r.best_idx[b] = r.idx;
+        if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
         ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
         if (ka.r.stats) {
             int32_t* st = ka.r.stats + (size_t)b * 4;
