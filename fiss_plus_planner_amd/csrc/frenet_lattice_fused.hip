@@ -323,7 +323,10 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if (rows_stage > rows_max) rows_stage = rows_max;
     }
     const double* gp = bt.obs_pose + (size_t)(sc >= 0 ? sc : 0) * bt.T_obs * n_obs_tab * 4;
-    constexpr int kPoseFlight = 2;  // pose reads in flight per lane in the group test
+#ifndef FP_POSE_FLIGHT
+#define FP_POSE_FLIGHT 2
+#endif
+    constexpr int kPoseFlight = FP_POSE_FLIGHT;  // pose reads in flight per lane in the group test
     auto fetch_poses = [&](int i0, double4* ps) {
 #pragma unroll
         for (int u = 0; u < kPoseFlight; ++u) {

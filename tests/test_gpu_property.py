@@ -72,8 +72,28 @@ def test_random_settings_vs_oracle(oracle, engine, seed):
             np.testing.assert_array_equal(out.flags[e], r.flags, err_msg=f"seed {seed} kernel {kernel} ego {e}")
             assert out.best_idx[e] == r.best_idx, (seed, kernel, e)
     engine.set_option("lattice_kernel", 0)
-    engine.set_option("lattice_split", 0)
     engine.set_option("lattice_group", 0)
+    # the tail split (the last half of the dispatch slots cut in two workgroups each) changes nothing
+    engine.set_option("lattice_split", 1)
+    engine.set_option("lattice_tail", max(2, b.B // 2))
+    try:
+        cut = engine.plan_dense(b, winner=True)
+    finally:
+        engine.set_option("lattice_split", 0)
+        engine.set_option("lattice_tail", 0)
+    np.testing.assert_array_equal(cut.best_idx, out.best_idx)
+    np.testing.assert_array_equal(cut.flags, out.flags)
+    assert np.array_equal(cut.best_traj, out.best_traj, equal_nan=True)
+    # every candidate's series by the profile-sharing materialise kernel == the winner epilogue's series of the same candidate
+    # (fp_winner_trajs: one wavefront per trajectory) and the dense table's N / M words
+    m = engine.materialize_all(b, traj_stride=128, traj_sparse=bool(seed & 1))
+    dense = engine.plan_dense(b)
+    assert np.array_equal(m.flags >> 8, dense.flags >> 8) and np.array_equal(m.flags & 8, dense.flags & 8)
+    rngc = np.random.default_rng(7000 + seed)
+    for c in rngc.choice(b.C, size=min(b.C, 6), replace=False):
+        w = engine.winner_trajs(b, np.full(b.B, c, dtype=np.int32))
+        assert np.array_equal(m.traj[:, c], w.best_traj, equal_nan=True), (seed, c)  # (the sparse layout's holes keep the host's NaN prefill)
+        np.testing.assert_array_equal(m.flags[:, c] >> 8, w.best_flags >> 8)
     # explicit end states (continuous): cost, flags and the full series
     rng = np.random.default_rng(seed)
     K = 3

@@ -15,12 +15,12 @@ if [ "$MODE" = build ]; then
   wait
   ls -la tools/_tmp/var
 else
-  SCRIPT=${1:-tools/mat_rate.py}
+  SCRIPT=${1:-tools/mat_rate.py}   # (CMD="python bench.py ..." in the environment: any command instead, its last TAIL lines are shown)
   cp fiss_plus_planner_amd/libfrenetgpu.so /tmp/plain.so
   for so in /tmp/plain.so $(ls tools/_tmp/var/*.so); do
     cp $so fiss_plus_planner_amd/libfrenetgpu.so
     echo "== $(basename $so .so)"
-    timeout 300 python $SCRIPT 2>&1 | tail -${TAIL:-4}
+    if [ -n "${CMD:-}" ]; then timeout 600 bash -c "$CMD" 2>&1 | tail -${TAIL:-4}; else timeout 300 python $SCRIPT 2>&1 | tail -${TAIL:-4}; fi
   done
   cp /tmp/plain.so fiss_plus_planner_amd/libfrenetgpu.so
 fi
