@@ -94,17 +94,19 @@ def test_device_closed_loop_batch_no_host_sync(engine):
     assert (dev.cycles > 0).any()
 
 
-@pytest.mark.parametrize("kind", ["FOP", "FISS+"])
-def test_hip_graph_replay_equals_eager_loop(engine, kind):
-    """One captured [plan -> advance] cycle replayed from a HIP graph gives the same final states as the eager loop."""
+@pytest.mark.parametrize("kind,big", [("FOP", False), ("FISS+", False), ("FOP", True), ("FISS+", True)])
+def test_hip_graph_replay_equals_eager_loop(engine, kind, big):
+    """One captured [plan -> advance] cycle replayed from a HIP graph gives the same final states as the eager loop.  big: more egos
+    than stay resident - the three-workgroups-per-CU lattice instance with its tail split (ticket counters), the winners' index copy
+    and the feedback launch order (index order inside a capture) all run inside the captured cycle."""
     from fiss_plus_planner_amd import synth
     from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
 
-    cycles = 9
+    cycles = 5 if big else 9
     goal = None
     outs = []
     for use_graph in (False, True):
-        batch = synth.make_batch(48, 5, 5, 5, 10, 100, False, 62, kind=kind)
+        batch = synth.make_config(3, B=900, kind=kind) if big else synth.make_batch(48, 5, 5, 5, 10, 100, False, 62, kind=kind)
         goal = np.stack([batch.coef[:, 0, 30], batch.coef[:, 4, 30]], axis=1)
         run = ClosedLoopRunner(engine, DeviceBatch(batch, 0), goal, kind)
         outs.append(run.run_graph(cycles) if use_graph else run.run(cycles))
