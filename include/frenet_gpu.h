@@ -25,7 +25,8 @@
  *   - a ctx is bound to one device; calls on one ctx must not overlap in time, and the work they enqueue must not either: use
  *     one stream per ctx at a time (the ctx keeps scratch buffers - partial results, launch order - that successive calls reuse
  *     in stream order).  FP_MEM_DEVICE calls may allocate or grow such a scratch buffer on first use (never inside a stream capture
- *     after a warm-up call of the same size).
+ *     after a warm-up call of the same size).  A captured graph holds the addresses of those buffers: a later call on the same ctx
+ *     with a LARGER batch may reallocate them - capture again after such a call.
  */
 #ifndef FRENET_GPU_H
 #define FRENET_GPU_H
