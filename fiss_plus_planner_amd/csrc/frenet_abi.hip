@@ -171,6 +171,7 @@ class HostStage {
         zero_copy_out_ = zero_copy_out;
         zero_copy_in_ = zero_copy_out && ctx_->zero_copy_in == 2;
         small_ = 0;
+        small_dirty_ = false;
         large_ = kSmallRegion;
         outs_.clear();
         small_out_lo_ = small_out_hi_ = 0;
@@ -211,6 +212,7 @@ class HostStage {
             memcpy(ctx_->pinned + small_, host, bytes);
             *dev = (const T*)(ctx_->arena.base + small_);
             small_ += bytes;
+            small_dirty_ = true;  // the arena's copy of the window has to be brought up to date (flush_in)
             return FP_OK;
         }
         large_ = align_up(large_);
@@ -241,7 +243,7 @@ class HostStage {
     }
     int flush_in()  // the output window of the small region starts after the inputs
     {
-        if (small_ > 0 && !zero_copy_in_) {
+        if (small_ > 0 && small_dirty_ && !zero_copy_in_) {  // (arrays the kernels address in the pinned block itself need no mirror)
             if (zero_copy_out_ && ctx_->stage_kernel) {
                 const int n16 = (int)((small_ + 15) / 16);  // (both blocks are 256-byte aligned and kSmallRegion long)
                 const int blocks = (n16 + 255) / 256;
@@ -300,7 +302,7 @@ class HostStage {
         bool via_pinned;
     };
     fp_ctx* ctx_;
-    bool zero_copy_out_ = false, zero_copy_in_ = false;
+    bool zero_copy_out_ = false, zero_copy_in_ = false, small_dirty_ = false;
     size_t small_ = 0, large_ = 0, small_out_lo_ = 0, small_out_hi_ = 0;
     std::vector<Out> outs_;
 };
@@ -371,7 +373,12 @@ size_t batch_need(const fp_params* p, const fp_batch* b)
            HostStage::need<int32_t>(b->S);
 }
 
-int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* dev, fp::InlineIn* inl = nullptr)
+// Inline inputs of a multi-kernel call (fp::InlineIn::publish): besides the eight per-ego arrays of the batch the blob carries
+// the call's other small inputs (`extra`), the lattice kernel copies it to a device mirror, and `dev_pub` / the extras' `dev`
+// get the mirror's addresses - what the kernels behind the lattice kernel read.
+struct InlineExtra { const void* src; size_t bytes; const void** dev; };
+int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* dev, fp::InlineIn* inl = nullptr,
+                fp_batch* dev_pub = nullptr, const InlineExtra* extra = nullptr, int n_extra = 0)
 {
     *dev = *b;
     const bool has_obs = b->S > 0 && b->n_obs > 0;
@@ -423,13 +430,31 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
                                  sizeof(double) * (size_t)b->B * 6, sizeof(int32_t) * (size_t)b->B, sizeof(int32_t) * (size_t)b->B, sizeof(int32_t) * (size_t)b->B};
         size_t off[8], total = 0;
         for (int i = 0; i < 8; ++i) { off[i] = total; total += (bytes[i] + 7) & ~(size_t)7; }
-        if (total <= (size_t)fp::kInlineMax) {
+        size_t total_x = total;
+        for (int i = 0; i < n_extra; ++i) total_x += (extra[i].bytes + 7) & ~(size_t)7;
+        if ((dev_pub ? total_x : total) <= (size_t)fp::kInlineMax) {
             for (int i = 0; i < 8; ++i) memcpy(inl->bytes + off[i], src[i], bytes[i]);
             dev->d_samples = (const double*)off[0]; dev->t_samples = (const double*)off[1]; dev->v_samples = (const double*)off[2];
             dev->target_speed = (const double*)off[3]; dev->ego = (const double*)off[4]; dev->frame_of = (const int32_t*)off[5];
             dev->scene_of = (const int32_t*)off[6]; dev->t_now = (const int32_t*)off[7];
             inl->on = 1;
             inlined = true;
+            if (dev_pub) {  // the device mirror the lattice kernel fills for the kernels behind it
+                const unsigned char* mirror = hs.temp<unsigned char>(fp::kInlineMax);
+                *dev_pub = *dev;
+                dev_pub->d_samples = (const double*)(mirror + off[0]); dev_pub->t_samples = (const double*)(mirror + off[1]);
+                dev_pub->v_samples = (const double*)(mirror + off[2]); dev_pub->target_speed = (const double*)(mirror + off[3]);
+                dev_pub->ego = (const double*)(mirror + off[4]); dev_pub->frame_of = (const int32_t*)(mirror + off[5]);
+                dev_pub->scene_of = (const int32_t*)(mirror + off[6]); dev_pub->t_now = (const int32_t*)(mirror + off[7]);
+                size_t o = total;
+                for (int i = 0; i < n_extra; ++i) {
+                    memcpy(inl->bytes + o, extra[i].src, extra[i].bytes);
+                    *extra[i].dev = mirror + o;
+                    o += (extra[i].bytes + 7) & ~(size_t)7;
+                }
+                inl->publish = (void*)mirror;
+                inl->n8 = (int)((total_x + 7) / 8);
+            }
         }
     }
     if (!inlined) {
@@ -453,6 +478,7 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
     if (b->skip) PUSH(skip, b->B);
 #undef PUSH
     if (!has_obs) dev->n_obs = 0;
+    if (!has_obs && dev_pub && inlined) dev_pub->n_obs = 0;
     return FP_OK;
 }
 
@@ -1047,6 +1073,8 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     const size_t traj_doubles = io->best_traj ? B * FP_ARR_COUNT * (size_t)stride : 0;
     const size_t trace_doubles = (io->trace && R > 0) ? B * (size_t)R * 7 * 4 : 0;
     HostStage hs(ctx);
+    fp::InlineIn inl;   // (host entry, latency regime: see below)
+    fp_batch lat_b;     // the batch as the lattice kernel addresses it (byte offsets into inl.bytes when inl.on)
     if (mem == FP_MEM_DEVICE) {
         fa.ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) fa.ka.b.n_obs = 0;
@@ -1061,13 +1089,24 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         }
         FP_TRY(hs.reserve(batch_need(params, batch) + 4 * HostStage::need<double>(B * 3) + 2 * HostStage::need<int32_t>(B * 3) +
                           HostStage::need<double>(B) + 2 * HostStage::need<int32_t>(B * 4) + HostStage::need<uint32_t>(B) +
-                          HostStage::need<double>(trace_doubles) + HostStage::need<double>(traj_doubles),
+                          HostStage::need<double>(trace_doubles) + HostStage::need<double>(traj_doubles) + HostStage::need<unsigned char>(fp::kInlineMax),
                           /*zero_copy_out=*/B <= 8));
-        FP_TRY(stage_batch(hs, params, batch, &fa.ka.b));
+        // Latency regime with the tables resident (fp_batch.tables_tag): the per-ego arrays and the three sampling-range arrays ride
+        // inside the lattice kernel's argument block, which also leaves them in a device mirror for the search and refinement
+        // kernels - no copy kernel, no dependency in front of the lattice kernel (a single-ego FISS+ cycle: ~5 us of ~80).
         fa.io = *io;
-        FP_TRY(hs.in(io->samp_min, B * 3, &fa.io.samp_min));
-        FP_TRY(hs.in(io->samp_max, B * 3, &fa.io.samp_max));
-        FP_TRY(hs.in(io->samp_res, B * 3, &fa.io.samp_res));
+        const bool try_inline = ctx->inline_inputs && B <= 8 && !params->curvature_mask && ctx->lattice_kernel != 1 &&
+                                fp::lattice_group_fit(*params, *batch) >= 1;
+        const InlineExtra ex[3] = {{io->samp_min, sizeof(double) * B * 3, (const void**)&fa.io.samp_min},
+                                   {io->samp_max, sizeof(double) * B * 3, (const void**)&fa.io.samp_max},
+                                   {io->samp_res, sizeof(double) * B * 3, (const void**)&fa.io.samp_res}};
+        FP_TRY(stage_batch(hs, params, batch, &lat_b, try_inline ? &inl : nullptr, &fa.ka.b, ex, 3));
+        if (!inl.on) {
+            fa.ka.b = lat_b;
+            FP_TRY(hs.in(io->samp_min, B * 3, &fa.io.samp_min));
+            FP_TRY(hs.in(io->samp_max, B * 3, &fa.io.samp_max));
+            FP_TRY(hs.in(io->samp_res, B * 3, &fa.io.samp_res));
+        }
         FP_TRY(hs.in_mut(io->prev_best_idx, B * 3, &fa.io.prev_best_idx));
         FP_TRY(hs.flush_in());
         fa.io.best_ijk = hs.out(io->best_ijk, B * 3);
@@ -1085,7 +1124,13 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group, &tail));
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
-    LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group, nullptr, tail), "lattice kernel");
+    if (inl.on) {
+        fp::KernelArgs kl = fa.ka;
+        kl.b = lat_b;
+        LAUNCH_TRY(fp::launch_lattice(kl, stream, 2, parts, nsplit, nullptr, perm, dur, group, &inl, tail), "lattice kernel");
+    } else {
+        LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group, nullptr, tail), "lattice kernel");
+    }
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     fa.walk_jump = ctx->fiss_jump;

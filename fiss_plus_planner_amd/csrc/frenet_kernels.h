@@ -45,10 +45,14 @@ struct KernelArgs {
 // BAR), so the kernel reads them like any other HBM data and no copy, copy kernel or dependency is enqueued for them.  on != 0:
 // the fields d_samples, t_samples, v_samples, target_speed, ego, frame_of, scene_of, t_now of KernelArgs.b hold byte OFFSETS into
 // bytes[] instead of addresses (skip must be NULL).
+// publish != nullptr: the lattice kernel's first workgroup also copies the first n8 8-byte words of bytes[] to that device address -
+// the later kernels of a multi-kernel call (fp_plan_fiss: search, refinement) read the same arrays from there, stream-ordered behind
+// the lattice kernel, and the call enqueues no copy of any kind.
 constexpr int kInlineMax = 1024;
 struct InlineIn {
     int on = 0;
-    int pad = 0;
+    int n8 = 0;
+    void* publish = nullptr;
     unsigned char bytes[kInlineMax];
 };
 

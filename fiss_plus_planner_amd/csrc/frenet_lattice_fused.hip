@@ -289,6 +289,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             in_v = (const double*)(base + (size_t)bt.v_samples); in_ts = (const double*)(base + (size_t)bt.target_speed);
             in_ego = (const double*)(base + (size_t)bt.ego); in_frame = (const int32_t*)(base + (size_t)bt.frame_of);
             in_scene = (const int32_t*)(base + (size_t)bt.scene_of); in_tnow = (const int32_t*)(base + (size_t)bt.t_now);
+            if (inl.publish && blockIdx.x == 0)  // (InlineIn::publish: the following kernels of the call read the arrays from device memory)
+                for (int i = threadIdx.x; i < inl.n8; i += kThreads) ((unsigned long long*)inl.publish)[i] = ((const unsigned long long*)base)[i];
         }
     }
     const int skip_flag = bt.skip ? bt.skip[b] : 0;

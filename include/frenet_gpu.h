@@ -193,8 +193,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * iteration one after the other.  Identical results and Stats.
  * "stage_kernel" (1 default), "inline_inputs" (1 default), "zero_copy_in" (0 default): how an FP_MEM_HOST call of at most 8 egos
  * moves its inputs.  stage_kernel: the pinned staging block goes to the device by one copy KERNEL instead of copy commands (a
- * copy command plus the cross-engine dependency behind it costs ~15 us of a single-ego call).  inline_inputs: fp_plan_dense
- * with fp_batch.tables_tag set passes the per-ego arrays inside the lattice kernel's argument block - nothing is copied at all.
+ * copy command plus the cross-engine dependency behind it costs ~15 us of a single-ego call).  inline_inputs: fp_plan_dense and
+ * fp_plan_fiss with fp_batch.tables_tag set pass the per-ego arrays inside the lattice kernel's argument block - nothing is copied at
+ * all (fp_plan_fiss: the lattice kernel leaves them in device memory for the kernels behind it).
  * zero_copy_in: the kernels read inputs from the pinned host block over the link (1: the per-ego arrays of a tagged call, 2:
  * everything) - measured slower than the copy kernel, kept for experiments.  Identical results in every combination.
  * "fiss_stages": timing diagnostic of fp_plan_fiss, 3 (default) = the whole pipeline, 2 = stop after the search walk (no
