@@ -105,7 +105,13 @@ class ShardedEngine:
                               t_now=np.empty(B, dtype=np.int32), cart=np.empty((B, 3)))
 
         def call(eng, sb, view, lo, hi):
-            res = ClosedLoopRunner(eng, DeviceBatch(sb, eng.device), goal[lo:hi], planner).run(max_cycles)
+            import torch
+
+            # every shard's loop runs on a HIP stream of its own (torch's current stream is per thread): several shards on ONE
+            # device overlap their cycles - a cycle of a few hundred running egos is one round of workgroups, as long as its slowest
+            # ego, and leaves most of the chip idle for the other shard
+            with torch.cuda.stream(torch.cuda.Stream(torch.device("cuda", eng.device))):
+                res = ClosedLoopRunner(eng, DeviceBatch(sb, eng.device), goal[lo:hi], planner).run(max_cycles)
             for k in ("done", "cycles", "ego", "t_now", "cart"):
                 getattr(view, k)[...] = getattr(res, k)
 
