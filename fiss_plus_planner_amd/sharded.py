@@ -15,7 +15,14 @@ lets one device's H2D staging overlap another shard's kernels).
 """
 from __future__ import annotations
 
-from concurrent.futures import ThreadPoolExecutor
+import os
+
+# Several shards on one device only overlap when their streams sit on different hardware queues; the HIP runtime's default of four
+# lets two created streams share one (their launches then serialise: a two-shard closed loop measured 270 instead of 147 us per
+# cycle).  Read once when the runtime starts, so this only helps when it has not started yet; export it yourself otherwise.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
 from types import SimpleNamespace
 
 import numpy as np
