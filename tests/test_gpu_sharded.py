@@ -45,3 +45,41 @@ def test_sharded_closed_loop_equals_single_runner(engine):
         np.testing.assert_array_equal(getattr(out, k), getattr(ref, k), err_msg=k)
     assert np.array_equal(out.ego, ref.ego) and np.array_equal(out.cart, ref.cart, equal_nan=True)
     assert out.cycles.sum() > batch.B
+
+
+@pytest.mark.parametrize("kind", ["FOP", "FISS+"])
+def test_two_contexts_on_two_streams_interleaved(engine, kind):
+    """Independent batches pipelined on one GPU (bench.py's two_streams legs): two engines, each with its own
+    fp_ctx and HIP stream, enqueue device-resident closed-loop cycles of two multi-round fleets alternately from one host thread -
+    the launches overlap on the device (three-workgroup lattice instances with their tail split and ticket counters, search and
+    refinement kernels side by side) and every fleet ends in exactly the state it reaches alone on a single stream."""
+    import torch
+
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+    from fiss_plus_planner_amd.engine import FrenetEngine
+
+    cfg, cycles, B = (3 if kind == "FOP" else 4), 6, 1000
+    fleets = [synth.make_config(cfg, B=B, ego_offset=k * B, kind=kind) for k in range(2)]
+    goal = np.full((B, 2), 1e9)
+    alone = [ClosedLoopRunner(engine, DeviceBatch(synth.make_config(cfg, B=B, ego_offset=k * B, kind=kind), 0), goal, kind).run(cycles) for k in range(2)]
+    dev = torch.device("cuda", 0)
+    other = FrenetEngine(0)
+    try:
+        parts = []
+        for k, eng in enumerate((engine, other)):
+            st = torch.cuda.Stream(dev)
+            with torch.cuda.stream(st):
+                parts.append((ClosedLoopRunner(eng, DeviceBatch(fleets[k], 0), goal, kind), st))
+        torch.cuda.synchronize(dev)
+        for _ in range(cycles):
+            for run, st in parts:
+                run.step(st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        for (run, _), ref in zip(parts, alone):
+            np.testing.assert_array_equal(run.done.cpu().numpy(), ref.done)
+            np.testing.assert_array_equal(run.cycles.cpu().numpy(), ref.cycles)
+            np.testing.assert_array_equal(run.db.t["t_now"].cpu().numpy(), ref.t_now)
+            assert np.array_equal(run.db.t["ego"].cpu().numpy(), ref.ego)
+        assert alone[0].cycles.sum() > 0 and alone[1].cycles.sum() > 0
+    finally:
+        other.close()
