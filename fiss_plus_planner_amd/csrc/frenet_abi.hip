@@ -650,9 +650,16 @@ bool winner_inside_lattice(const fp_ctx* ctx, const fp_batch* b)
 fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
 
 // FopPlusPlanner counts pops over the dense tables: when the caller did not ask for them they live in the ctx's scratch buffer.
-int fopplus_tables(fp_ctx* ctx, size_t B, size_t C, fp_result* r)
+int fopplus_tables(fp_ctx* ctx, size_t B, size_t C, fp_result* r, hipStream_t stream)
 {
-    FP_TRY(ctx->scratch.reserve(align_up(sizeof(double) * B * C) + align_up(sizeof(uint32_t) * B * C)));
+    const size_t need = align_up(sizeof(double) * B * C) + align_up(sizeof(uint32_t) * B * C);
+    if (need > ctx->scratch.cap) {  // growing the buffer frees the old one: not inside a stream capture, and not under its users
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) return fail(FP_EINVAL, "result.fopplus: the ctx's table scratch must grow - run one call of this size outside the stream capture first");
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    FP_TRY(ctx->scratch.reserve(need));
     char* sp = (char*)ctx->scratch.base;
     if (!r->cost_tbl) r->cost_tbl = (double*)sp;
     if (!r->flag_tbl) r->flag_tbl = (uint32_t*)(sp + align_up(sizeof(double) * B * C));
@@ -888,7 +895,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
-        if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r));
+        if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r, (hipStream_t)stream));
         FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
         int nsplit, group, tail; void* parts;
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
@@ -903,7 +910,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         if (result->fopplus)
             LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, result->fopplus, ka.r.stats,
-                                                (hipStream_t)stream), "FOP+ count kernel");
+                                                ka.b.skip, (hipStream_t)stream), "FOP+ count kernel");
         return FP_OK;
     }
     FP_TRY(check_batch_host(params, batch));
@@ -930,7 +937,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     ka.r.traj_stride = result->traj_stride;
     ka.r.traj_sparse = result->traj_sparse;
     int32_t* d_fopplus = hs.out(result->fopplus, B * 2);
-    if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r));
+    if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r, ctx->stream));
     // sparse rows are only partly written by the kernels: the host block comes back with the caller's own bytes elsewhere
     if (result->traj_sparse && ka.r.best_traj) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, result->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     FP_TRY(lattice_curv_scratch(ctx, params, batch, ctx->stream, &ka.curv_tbl));
@@ -948,7 +955,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
     }
     if (d_fopplus)
-        LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, d_fopplus, ka.r.stats, ctx->stream),
+        LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, d_fopplus, ka.r.stats, ka.b.skip, ctx->stream),
                    "FOP+ count kernel");
     return hs.fetch_out();
 }

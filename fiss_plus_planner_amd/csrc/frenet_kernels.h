@@ -3,18 +3,28 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "../../include/frenet_gpu.h"
 
 namespace fp {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and not free: remember the largest size configured per
-// (kernel, device).  `slot` is a function-local static array of kMaxDevices ints initialised to -1.
+// (kernel, device).  `slot` is a function-local static array of kMaxDevices ints initialised to -1.  Several host threads may
+// launch on one device (ShardedEngine(shards_per_device > 1), two contexts on two streams): the check-and-set is serialised, so
+// the recorded size is always the size the runtime was last told (a smaller request can never land after a larger one).
 constexpr int kMaxDevices = 64;
+inline std::mutex& dynamic_lds_mutex()
+{
+    static std::mutex m;
+    return m;
+}
 inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes, int* slot)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(dynamic_lds_mutex());
     if (dev < 0 || dev >= kMaxDevices) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (bytes > slot[dev]) {
         e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -102,8 +112,9 @@ hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, v
 // end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);
 // FopPlusPlanner.plan from the dense tables + the FOP argmin (one wavefront per ego): out [B][2] = {popped, tie}, stats [B][4].
+// skip (optional, fp_batch.skip): egos the lattice kernel did not plan get out = {0, 0} and keep their Stats.
 hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint32_t* flag_tbl, const int32_t* best_idx, const double* best_cost,
-                                int32_t* out, int32_t* stats, hipStream_t stream);
+                                int32_t* out, int32_t* stats, const int32_t* skip, hipStream_t stream);
 // Frenet frame construction / Cartesian -> Frenet projection (frenet_frame.hip).
 hipError_t launch_frames_build(int F, int NX, const int32_t* n, const double* points, double* knots, double* coef, hipStream_t stream);
 hipError_t launch_from_state(const fp_batch& bt, const double* states, double* ego, hipStream_t stream);

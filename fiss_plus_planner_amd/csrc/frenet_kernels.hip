@@ -652,10 +652,14 @@ hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const d
 // caller replays that ego on the host.  One wavefront per ego.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave * 4) void fopplus_count_kernel(int B, int C, const double* cost_tbl, const uint32_t* flag_tbl, const int32_t* best_idx,
-                                                                   const double* best_cost, int32_t* out, int32_t* stats)
+                                                                   const double* best_cost, int32_t* out, int32_t* stats, const int32_t* skip)
 {
     const int b = blockIdx.x * 4 + (int)threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     if (b >= B) return;
+    if (skip && skip[b]) {  // a finished ego of a closed loop: the lattice kernel wrote no table rows for it; nothing popped, no tie, Stats untouched
+        if (lane == 0) { out[2 * b] = 0; out[2 * b + 1] = 0; }
+        return;
+    }
     const int win = best_idx[b];
     const double cw = best_cost[b];
     const double* cost = cost_tbl + (size_t)b * C;
@@ -690,9 +694,9 @@ __global__ __launch_bounds__(kWave * 4) void fopplus_count_kernel(int B, int C, 
 }
 
 hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint32_t* flag_tbl, const int32_t* best_idx, const double* best_cost,
-                                int32_t* out, int32_t* stats, hipStream_t stream)
+                                int32_t* out, int32_t* stats, const int32_t* skip, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fopplus_count_kernel, dim3((B + 3) / 4), dim3(kWave * 4), 0, stream, B, C, cost_tbl, flag_tbl, best_idx, best_cost, out, stats);
+    hipLaunchKernelGGL(fopplus_count_kernel, dim3((B + 3) / 4), dim3(kWave * 4), 0, stream, B, C, cost_tbl, flag_tbl, best_idx, best_cost, out, stats, skip);
     return hipGetLastError();
 }
 

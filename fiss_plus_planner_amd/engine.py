@@ -103,6 +103,25 @@ def device_batch(sizes, ptrs: dict) -> _abi.FpBatch:
     return fb
 
 
+def fiss_rounds(kind, max_refine_iters: int) -> int:
+    """Refinement rounds a plan_fiss call runs (the rule FrenetEngine.plan_fiss applies): FISS+ by name or by its ABI constant."""
+    return int(max_refine_iters) if kind in ("FISS+", _abi.FP_FISS_PLUS) else 0
+
+
+def _check_out(out: SimpleNamespace, B: int, spec: dict) -> None:
+    """Caller-provided output arrays cross the C ABI as bare addresses: every array the call writes must be a writable,
+    C-contiguous array of the dtype and shape [B, ...] the engine would have allocated itself (a strided or wrong-dtype array
+    would be written out of bounds by the C side)."""
+    for k, want in spec.items():
+        if want is None:
+            continue
+        dtype, tail = np.dtype(want[0]), (B,) + tuple(want[1])
+        a = getattr(out, k, None)
+        if not isinstance(a, np.ndarray) or a.shape != tail or a.dtype != dtype or not a.flags.c_contiguous or not a.flags.writeable:
+            raise ValueError(f"out.{k}: need a writable C-contiguous {dtype} array of shape {tail}, got "
+                             f"{type(a).__name__ if not isinstance(a, np.ndarray) else (str(a.dtype), a.shape, bool(a.flags.c_contiguous))}")
+
+
 def unpack_flags(flags: np.ndarray):
     """flag word -> (bits, N, M)."""
     return flags & 0xFF, (flags >> _abi.FLAG_N_SHIFT) & 0xFFF, (flags >> _abi.FLAG_M_SHIFT) & 0xFFF
@@ -163,6 +182,10 @@ class FrenetEngine:
         B, Cn = batch.B, batch.C
         if out is None:  # (out: arrays of dense_outputs' shapes, e.g. contiguous slices of a bigger batch's outputs)
             out = self.dense_outputs(B, Cn, tables, winner, traj_stride, traj_sparse)
+        elif "_res" not in out.__dict__:  # caller's arrays, first use: they cross the ABI as bare addresses
+            _check_out(out, B, dict(best_idx=("int32", ()), best_cost=("float64", ()), stats=("int32", (4,)),
+                                    cost=("float64", (Cn,)) if tables else None, flags=("uint32", (Cn,)) if tables else None,
+                                    best_flags=("uint32", ()) if winner else None, best_traj=("float64", (16, traj_stride)) if winner else None))
         if B == 0:
             return out
         # a caller that re-plans into the same `out` every cycle (planners.py) finds the fp_result of its arrays cached on it
@@ -254,9 +277,13 @@ class FrenetEngine:
         """
         B = batch.B
         plus = kind in ("FISS+", _abi.FP_FISS_PLUS)
-        R = max_refine_iters if plus else 0
+        R = fiss_rounds(kind, max_refine_iters)
         if out is None:
             out = self.fiss_outputs(B, R, winner, trace, traj_stride, traj_sparse)
+        elif "_io" not in out.__dict__:
+            _check_out(out, B, dict(prev_best_idx=("int32", (3,)), best_ijk=("int32", (3,)), best_cost=("float64", ()), end_state=("float64", (3,)),
+                                    refined=("int32", ()), stats=("int32", (4,)), trace=("float64", (max(R, 1) * 7, 4)) if trace and R > 0 else None,
+                                    best_flags=("uint32", ()) if winner else None, best_traj=("float64", (16, traj_stride)) if winner else None))
         out.prev_best_idx[...] = -1 if prev_best_idx is None else np.asarray(prev_best_idx, dtype=np.int32)
         prev = out.prev_best_idx
         if B == 0:

@@ -20,14 +20,37 @@ import numpy as np
 
 @dataclass
 class ObstacleTable:
+    """Immutability contract: a planner that is handed an ObstacleTable keeps its device copy across plan() calls (the tables do
+    not travel every cycle).  While a planner holds the table its arrays are FROZEN (numpy write flag off): an in-place update
+    raises instead of silently planning against stale device tables.  To change the scene build a new table, or call
+    ``update(pose=..., dims=..., final_time_step=...)``, which swaps the arrays and bumps ``version`` - the planners key their
+    device cache on (table, version) and upload again."""
     pose: np.ndarray           # [T_obs, n_obs, 4]
     dims: np.ndarray           # [n_obs, 2]
     final_time_step: int       # obstacles[0].prediction.final_time_step
+    version: int = 0           # bumped by update(); part of the planners' cache key
 
     def __post_init__(self):
         self.pose = np.ascontiguousarray(self.pose, dtype=np.float64)
         self.dims = np.ascontiguousarray(self.dims, dtype=np.float64)
         assert self.pose.ndim == 3 and self.pose.shape[2] == 4 and self.dims.shape == (self.pose.shape[1], 2)
+
+    def freeze(self) -> None:
+        """Called by a planner when it caches the table on the device: writes through these arrays raise from now on."""
+        self.pose.setflags(write=False)
+        self.dims.setflags(write=False)
+
+    def update(self, pose=None, dims=None, final_time_step=None) -> "ObstacleTable":
+        """Replace (never edit) the arrays; every planner that cached the old content uploads the new one on its next plan()."""
+        if pose is not None:
+            self.pose = np.array(pose, dtype=np.float64, order="C")
+        if dims is not None:
+            self.dims = np.array(dims, dtype=np.float64, order="C")
+        if final_time_step is not None:
+            self.final_time_step = int(final_time_step)
+        assert self.pose.ndim == 3 and self.pose.shape[2] == 4 and self.dims.shape == (self.pose.shape[1], 2)
+        self.version += 1
+        return self
 
 
 def _shape_vertices(poly):

@@ -106,12 +106,22 @@ def _engine_for(device: int) -> FrenetEngine:
 
 
 class FrenetOptimalPlanner:
-    """FOP: exhaustive lattice, argmin over the feasible candidates (reference frenet_optimal_planner.py:58-278)."""
+    """FOP: exhaustive lattice, argmin over the feasible candidates (reference frenet_optimal_planner.py:58-278).
+
+    Table caching (``cache_tables=True``, the default): the reference-line spline and the flattened obstacle table of a plan()
+    call stay on the device until the planner sees ANOTHER centerline / obstacle list / ``ObstacleTable`` (or the same table
+    after ``ObstacleTable.update()``); per cycle only the start state travels.  The cached numpy arrays are frozen (write flag
+    off) while the planner holds them, so editing an ``ObstacleTable`` or the spline tables in place raises ``ValueError``
+    instead of silently checking collisions against stale device data.  A list of obstacle OBJECTS is re-flattened whenever the
+    list holds other objects or another horizon (``obstacles_fingerprint``); mutating such an object in place is not visible -
+    pass ``cache_tables=False`` to flatten nothing ahead and upload every cycle, as the planner did before round 3."""
 
     KIND = "FOP"
 
     def __init__(self, planner_settings: FrenetOptimalPlannerSettings, ego_vehicle: Vehicle, scenario=None, *,
-                 device: int = 0, engine: FrenetEngine | None = None, materialize_all: bool = False, frame_on: str = "device"):
+                 device: int = 0, engine: FrenetEngine | None = None, materialize_all: bool = False, frame_on: str = "device",
+                 cache_tables: bool = True):
+        self.cache_tables = cache_tables
         self.settings = planner_settings
         self.vehicle = ego_vehicle
         self.cubic_spline = None
@@ -146,6 +156,8 @@ class FrenetOptimalPlanner:
             return None  # has_collision: empty list -> no collision (:170-171)
         # The flattened table is reused only while the list holds the SAME obstacle objects (element identities + horizon); the
         # cache keeps them alive, so a recycled address cannot alias a different obstacle.
+        if not self.cache_tables:  # re-read every object every cycle (in-place updates of the obstacle objects are seen)
+            return flatten_obstacles(obstacles)
         key = obstacles_fingerprint(obstacles)
         if self._obs_cache[0] != key:
             self._obs_cache = (key, flatten_obstacles(obstacles), list(obstacles))
@@ -164,7 +176,8 @@ class FrenetOptimalPlanner:
         tab = self._obstacle_table(obstacles)
         sp = self.cubic_spline
         curv = (self.vehicle.max_curvature, self.vehicle.max_kappa_d, self.vehicle.max_kappa_dd) if getattr(st, "check_curvature", False) else None
-        key = (id(sp), id(tab), st.num_width, st.num_speed, st.num_t, st.min_t, st.max_t, st.tick_t, st.max_road_width, st.lowest_speed,
+        cache_tables = getattr(self, "cache_tables", True)
+        key = (id(sp), id(tab), getattr(tab, "version", 0), cache_tables, st.num_width, st.num_speed, st.num_t, st.min_t, st.max_t, st.tick_t, st.max_road_width, st.lowest_speed,
                self.vehicle.l, self.vehicle.w, self.vehicle.max_speed, self.vehicle.max_accel, curv)
         cache = getattr(self, "_batch_cache", None)
         if cache is None or cache[0] != key:
@@ -183,10 +196,15 @@ class FrenetOptimalPlanner:
                 samp_min=np.array([[-sw / 2, st.lowest_speed, st.min_t]]), samp_max=np.array([[sw / 2, 0.0, st.max_t]]),
                 samp_res=np.array([[rd, 0.0, rt]]), curvature_limits=curv)
             # fp_batch.tables_tag: the library keeps this batch's spline and obstacle tables on the device until the planner builds
-            # a new batch (another centerline / another obstacle list) - per cycle only the start state travels.  The tables are
-            # treated as immutable while the planner holds them, like the reference's prediction objects; `cache_tables = False`
-            # on the planner uploads them every cycle instead.
-            batch.tables_tag = next(_TABLE_TAGS) if getattr(self, "cache_tables", True) else 0
+            # a new batch (another centerline / another obstacle list / ObstacleTable.update()) - per cycle only the start state
+            # travels.  Contract (class docstring): the cached arrays are frozen, so an in-place edit raises instead of going stale;
+            # `cache_tables=False` uploads them every cycle and freezes nothing.
+            batch.tables_tag = next(_TABLE_TAGS) if cache_tables else 0
+            if cache_tables:
+                if tab is not None:
+                    tab.freeze()
+                sp.knots.setflags(write=False)
+                sp.coef.setflags(write=False)
             host_structs(batch, freeze=True)  # (this batch is the planner's own: its arrays are only ever updated in place)
             cache = [key, batch, None, sp, tab]  # sp / tab kept alive so their ids cannot be recycled
             self._batch_cache = cache

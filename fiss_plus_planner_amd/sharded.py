@@ -15,25 +15,109 @@ lets one device's H2D staging overlap another shard's kernels).
 """
 from __future__ import annotations
 
+import logging
 import os
-
-# Several shards on one device only overlap when their streams sit on different hardware queues; the HIP runtime's default of four
-# lets two created streams share one (their launches then serialise: a two-shard closed loop measured 270 instead of 147 us per
-# cycle).  Read once when the runtime starts, so this only helps when it has not started yet; export it yourself otherwise.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+from concurrent.futures import ThreadPoolExecutor
 from types import SimpleNamespace
 
 import numpy as np
 
+from . import _abi
 from .batch import ProblemBatch
-from .engine import TRAJ_STRIDE, FrenetEngine, device_count
+from .engine import TRAJ_STRIDE, FrenetEngine, device_count, fiss_rounds
+
+_log = logging.getLogger(__name__)
 
 
 def _rows(ns: SimpleNamespace, lo: int, hi: int) -> SimpleNamespace:
     """The same output object restricted to egos [lo, hi): contiguous views, written in place by the shard's call."""
     return SimpleNamespace(**{k: (v[lo:hi] if isinstance(v, np.ndarray) else v) for k, v in vars(ns).items()})
+
+
+class ShardedDeviceBatch:
+    """A problem batch cut into contiguous ego ranges and uploaded ONCE: shard r's rows of every per-ego array, and the frame /
+    scene tables its egos reference, live in the HBM of shard r's device (`device_batch.DeviceBatch`), next to the shard's output
+    buffers; every shard owns a HIP stream.  Per-ego results (index, cost, Stats, flag word; the FISS arrays) land in PINNED host
+    arrays covering the whole batch - rank r's slice is written by rank r only, nothing is gathered or concatenated, no collective.
+    Shards on one device write those results straight through the device mapping of the pinned block (no copy command on the
+    stream); with several devices every shard brings its packed results home with one asynchronous copy.  Big outputs (dense
+    tables, winner series) stay in HBM per shard (`shard.cost_tbl`, `.flag_tbl`, `.best_traj` torch tensors) and are fetched on
+    demand (`fetch_tables`, `fetch_series`)."""
+
+    def __init__(self, eng: "ShardedEngine", batch: ProblemBatch, tables: bool = False, winner: bool = False, fiss_rounds_max: int = 3,
+                 traj_stride: int | None = None):
+        import torch
+
+        from .device_batch import DeviceBatch
+
+        self.torch, self.eng, self.B, self.C = torch, eng, batch.B, batch.C
+        self.tables, self.winner = bool(tables), bool(winner)
+        self.traj_stride = int(traj_stride) if traj_stride else (int(np.ceil(batch.t_samples.max() / batch.tick_t)) + 15) // 16 * 16
+        self.R = int(fiss_rounds_max)
+        B, W = batch.B, eng.world
+        one_device = len(set(eng.devices)) == 1
+        self.zero_copy = one_device  # results written through the pinned block's device mapping (see class docstring)
+        i32, f64 = torch.int32, torch.float64
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()  # noqa: E731
+        # whole-batch pinned results; numpy views of the same memory are what the plan calls return
+        self._pinned = dict(best_idx=pin(B, i32), best_cost=pin(B, f64), stats=pin((B, 4), i32), best_flags=pin(B, i32),
+                            best_ijk=pin((B, 3), i32), end_state=pin((B, 3), f64), refined=pin(B, i32), prev_best_idx=pin((B, 3), i32))
+        self.host = SimpleNamespace(**{k: v.numpy() for k, v in self._pinned.items()})
+        self.host.best_flags = self.host.best_flags.view(np.uint32)
+        self.shards = []
+        for r, (lo, hi) in enumerate(eng.bounds(B, W)):
+            if hi <= lo:
+                continue
+            sb = batch.shard(r, W)
+            dev = eng.devices[r]
+            with torch.cuda.device(dev):
+                db = DeviceBatch(sb, dev)
+                n = hi - lo
+                sh = SimpleNamespace(rank=r, lo=lo, hi=hi, engine=eng.engines[r], db=db, stream=torch.cuda.Stream(torch.device("cuda", dev)))
+                d = torch.device("cuda", dev)
+                sh.cost_tbl = torch.empty((n, batch.C), dtype=f64, device=d) if tables else None
+                sh.flag_tbl = torch.empty((n, batch.C), dtype=i32, device=d) if tables else None
+                sh.best_traj = torch.full((n, 16, self.traj_stride), float("nan"), dtype=f64, device=d) if winner else None
+                sh.prev = torch.full((n, 3), -1, dtype=i32, device=d)
+                sh.trace = None
+                if self.zero_copy:
+                    sh.res = {k: v[lo:hi] for k, v in self._pinned.items()}  # device-visible views of the pinned rows
+                else:
+                    sh.res = {k: torch.empty((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=d) for k, v in self._pinned.items()}
+                sh.res["prev_best_idx"] = sh.prev  # (in / out history: always in HBM, copied home after the call)
+            self.shards.append(sh)
+
+    # -- plumbing
+    def _home(self, sh, names):
+        """Results of one shard -> the pinned rows (only when they were not written there directly)."""
+        for k in names:
+            if not self.zero_copy or k == "prev_best_idx":
+                self._pinned[k][sh.lo:sh.hi].copy_(sh.res[k], non_blocking=True)
+
+    def synchronize(self):
+        for sh in self.shards:
+            sh.stream.synchronize()
+
+    def reset_state(self, batch: ProblemBatch):
+        """Upload the start states / time steps of `batch` again (a closed loop advances the resident ones in place)."""
+        torch = self.torch
+        for sh in self.shards:
+            with torch.cuda.stream(sh.stream):
+                sh.db.t["ego"].copy_(torch.from_numpy(np.ascontiguousarray(batch.ego[sh.lo:sh.hi])), non_blocking=False)
+                sh.db.t["t_now"].copy_(torch.from_numpy(np.ascontiguousarray(batch.t_now[sh.lo:sh.hi])), non_blocking=False)
+        self.synchronize()
+
+    def fetch_tables(self):
+        """(cost [B, C], flags [B, C]) from the shards' HBM (requires upload(..., tables=True) and a plan_dense(tables=True) call)."""
+        self.synchronize()
+        cost = np.concatenate([sh.cost_tbl.cpu().numpy() for sh in self.shards])
+        flags = np.concatenate([sh.flag_tbl.cpu().numpy().view(np.uint32) for sh in self.shards])
+        return cost, flags
+
+    def fetch_series(self):
+        """best_traj [B, 16, traj_stride] (compact layout: elements past a row's length are whatever the buffer held - NaN here)."""
+        self.synchronize()
+        return np.concatenate([sh.best_traj.cpu().numpy() for sh in self.shards])
 
 
 class ShardedEngine:
@@ -43,6 +127,13 @@ class ShardedEngine:
         if not devices:
             raise RuntimeError("ShardedEngine: no GPU visible (the engine has no CPU path)")
         self.devices = [int(d) for d in devices for _ in range(max(1, int(shards_per_device)))]
+        if int(shards_per_device) > 1 and "GPU_MAX_HW_QUEUES" not in os.environ:
+            # Several shards on one device only overlap when their streams sit on different hardware queues; the HIP runtime's default
+            # of four lets two created streams share one (a two-shard closed loop measured 270 instead of 147 us per cycle).  The
+            # runtime reads the variable once, when it starts: this helps only if no HIP call was made yet - export it otherwise.
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+            _log.info("ShardedEngine(shards_per_device=%d): set GPU_MAX_HW_QUEUES=8 (takes effect only if the HIP runtime has not started)",
+                      int(shards_per_device))
         self.engines = [engine_factory(d) for d in self.devices]
         self._pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="frenet-shard")
 
@@ -84,23 +175,23 @@ class ShardedEngine:
         return out
 
     # ------------------------------------------------------------------ the FrenetEngine surface, for the whole batch
-    def plan_dense(self, batch: ProblemBatch, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+    def _plan_dense_host(self, batch: ProblemBatch, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """FrenetOptimalPlanner.plan() for every ego (frenet_optimal_planner.py:247-270), sharded: the result object of
         FrenetEngine.plan_dense for the whole batch."""
         out = FrenetEngine.dense_outputs(batch.B, batch.C, tables, winner, traj_stride, traj_sparse)
         return self._run(batch, out, lambda eng, sb, view, lo, hi: eng.plan_dense(sb, tables, winner, traj_stride, traj_sparse, out=view))
 
-    def plan_fiss(self, batch: ProblemBatch, kind: str = "FISS+", prev_best_idx=None, w_heuristic: float = 10.0, max_refine_iters: int = 3,
+    def _plan_fiss_host(self, batch: ProblemBatch, kind: str = "FISS+", prev_best_idx=None, w_heuristic: float = 10.0, max_refine_iters: int = 3,
                   decaying_factor: float = 0.5, winner: bool = False, trace: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """FissPlanner.plan / FissPlusPlanner.plan for every ego (fiss_planner.py:190-270, fiss_plus_planner.py:61-170), sharded."""
-        R = max_refine_iters if kind in ("FISS+",) else 0
+        R = fiss_rounds(kind, max_refine_iters)
         out = FrenetEngine.fiss_outputs(batch.B, R, winner, trace, traj_stride, traj_sparse)
         prev = None if prev_best_idx is None else np.ascontiguousarray(prev_best_idx, dtype=np.int32)
         return self._run(batch, out, lambda eng, sb, view, lo, hi: eng.plan_fiss(
             sb, kind, None if prev is None else prev[lo:hi], w_heuristic, max_refine_iters, decaying_factor, winner, trace, traj_stride,
             traj_sparse, out=view))
 
-    def closed_loop(self, batch: ProblemBatch, goal_xy: np.ndarray, planner: str = "FOP", max_cycles: int = 100):
+    def _closed_loop_host(self, batch: ProblemBatch, goal_xy: np.ndarray, planner: str = "FOP", max_cycles: int = 100):
         """The closed loop of planners/benchmark/planning.py:120-162 for every ego, device-resident: every shard uploads its egos
         once, steps [plan -> advance] max_cycles times on its own GPU without a host round trip (device_batch.ClosedLoopRunner) and
         only the final states come back, merged in ego order."""
@@ -123,3 +214,113 @@ class ShardedEngine:
                 getattr(view, k)[...] = getattr(res, k)
 
         return self._run(batch, out, call)
+
+    # ------------------------------------------------------------------ entry points: host batch (staged per call) or resident shards
+    def plan_dense(self, batch, *args, **kw):
+        """FrenetOptimalPlanner.plan() for every ego (frenet_optimal_planner.py:247-270).  `batch`: a ProblemBatch (host arrays,
+        staged through FP_MEM_HOST on every call: `_plan_dense_host`) or a ShardedDeviceBatch from `upload` (resident:
+        `_plan_dense_resident`, the call only enqueues kernels)."""
+        return (self._plan_dense_resident if isinstance(batch, ShardedDeviceBatch) else self._plan_dense_host)(batch, *args, **kw)
+
+    def plan_fiss(self, batch, *args, **kw):
+        """FissPlanner.plan / FissPlusPlanner.plan for every ego; host batch (`_plan_fiss_host`) or resident shards
+        (`_plan_fiss_resident`)."""
+        return (self._plan_fiss_resident if isinstance(batch, ShardedDeviceBatch) else self._plan_fiss_host)(batch, *args, **kw)
+
+    def closed_loop(self, batch, *args, **kw):
+        """The closed loop of planning.py:120-162 for every ego; host batch (uploaded for the loop: `_closed_loop_host`) or resident
+        shards (`_closed_loop_resident`: the resident states are advanced in place)."""
+        return (self._closed_loop_resident if isinstance(batch, ShardedDeviceBatch) else self._closed_loop_host)(batch, *args, **kw)
+
+    # ------------------------------------------------------------------ resident shards: upload once, plan many times
+    # (the *_host methods above re-stage the batch through FP_MEM_HOST on every call - the PCIe-inclusive path, ~30x below the
+    # resident rate on BASELINE configs[2])
+    def upload(self, batch: ProblemBatch, tables: bool = False, winner: bool = False, fiss_rounds_max: int = 3, traj_stride: int | None = None) -> ShardedDeviceBatch:
+        """Cut `batch` into the engine's shards and make every shard resident on its device (see ShardedDeviceBatch)."""
+        return ShardedDeviceBatch(self, batch, tables, winner, fiss_rounds_max, traj_stride)
+
+    def _each(self, sdb: ShardedDeviceBatch, call, sync: bool):
+        """call(shard) for every shard.  One shard: in the caller's thread (a thread hop costs more than the enqueue); several: one
+        host thread each, so the enqueues of different devices do not queue up behind each other."""
+        if len(sdb.shards) == 1:
+            call(sdb.shards[0])
+        else:
+            for f in [self._pool.submit(call, sh) for sh in sdb.shards]:
+                f.result()
+        if sync:
+            sdb.synchronize()
+
+    def _plan_dense_resident(self, sdb: ShardedDeviceBatch, tables: bool = False, winner: bool = False, sync: bool = True):
+        """fp_plan_dense on every resident shard (FP_MEM_DEVICE: the call only enqueues kernels on the shard's stream).  Returns
+        sdb.host (numpy views of the pinned result block: best_idx, best_cost, stats, best_flags); with sync=False the arrays are
+        valid after sdb.synchronize().  tables / winner: the dense tables / the winners' series are written to the shard's HBM
+        buffers (upload(..., tables=True / winner=True))."""
+        if (tables and not sdb.tables) or (winner and not sdb.winner):
+            raise ValueError("upload(batch, tables=..., winner=...) did not reserve the buffers this call asks for")
+        torch = sdb.torch
+
+        def call(sh):
+            r = sh.res
+            with torch.cuda.device(sh.db.dev):
+                sh.engine.plan_dense_device(sh.db.params, sh.db.fb, r["best_idx"].data_ptr(), r["best_cost"].data_ptr(), r["stats"].data_ptr(),
+                                            sh.cost_tbl.data_ptr() if tables else 0, sh.flag_tbl.data_ptr() if tables else 0,
+                                            stream=sh.stream.cuda_stream, best_flags=r["best_flags"].data_ptr() if winner else 0,
+                                            best_traj=sh.best_traj.data_ptr() if winner else 0, traj_stride=sdb.traj_stride, traj_sparse=True)
+                with torch.cuda.stream(sh.stream):
+                    sdb._home(sh, ("best_idx", "best_cost", "stats") + (("best_flags",) if winner else ()))
+
+        self._each(sdb, call, sync)
+        return sdb.host
+
+    def _plan_fiss_resident(self, sdb: ShardedDeviceBatch, kind="FISS+", prev_best_idx=None, w_heuristic: float = 10.0, max_refine_iters: int = 3,
+                            decaying_factor: float = 0.5, winner: bool = False, sync: bool = True):
+        """fp_plan_fiss on every resident shard.  prev_best_idx [B, 3] (-1 = None): uploaded when given, else the history the
+        previous call left on the device is used (None on the first call = no history).  Returns sdb.host (best_ijk, best_cost,
+        end_state, refined, stats, prev_best_idx (+ best_flags)); the series go to shard.best_traj."""
+        if winner and not sdb.winner:
+            raise ValueError("upload(batch, winner=True) did not reserve the series buffers")
+        torch = sdb.torch
+        R = fiss_rounds(kind, max_refine_iters)
+        plus = kind in ("FISS+", _abi.FP_FISS_PLUS)
+        prev = None if prev_best_idx is None else np.ascontiguousarray(prev_best_idx, dtype=np.int32).reshape(sdb.B, 3)
+
+        def call(sh):
+            r = sh.res
+            with torch.cuda.device(sh.db.dev), torch.cuda.stream(sh.stream):
+                if prev is not None:
+                    sh.prev.copy_(torch.from_numpy(prev[sh.lo:sh.hi]), non_blocking=False)
+                opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
+                io = _abi.FpFissIo()
+                io.samp_min, io.samp_max, io.samp_res = (sh.db.t[k].data_ptr() for k in ("samp_min", "samp_max", "samp_res"))
+                io.prev_best_idx, io.best_ijk, io.best_cost = sh.prev.data_ptr(), r["best_ijk"].data_ptr(), r["best_cost"].data_ptr()
+                io.end_state, io.refined, io.stats, io.trace = r["end_state"].data_ptr(), r["refined"].data_ptr(), r["stats"].data_ptr(), None
+                io.best_flags = r["best_flags"].data_ptr() if winner else None
+                io.best_traj = sh.best_traj.data_ptr() if winner else None
+                io.traj_stride, io.traj_sparse = sdb.traj_stride, 1
+                sh.engine.plan_fiss_device(sh.db.params, sh.db.fb, opts, io, stream=sh.stream.cuda_stream)
+                sdb._home(sh, ("best_ijk", "best_cost", "end_state", "refined", "stats", "prev_best_idx") + (("best_flags",) if winner else ()))
+
+        self._each(sdb, call, sync)
+        return sdb.host
+
+    def _closed_loop_resident(self, sdb: ShardedDeviceBatch, goal_xy: np.ndarray, planner: str = "FOP", max_cycles: int = 100):
+        """The device-resident closed loop (planning.py:120-162) on shards that are ALREADY resident: no upload, the resident start
+        states are advanced in place (sdb.reset_state(batch) rewinds them)."""
+        from .device_batch import ClosedLoopRunner
+
+        torch = sdb.torch
+        goal = np.ascontiguousarray(goal_xy, dtype=np.float64).reshape(sdb.B, 2)
+        B = sdb.B
+        out = SimpleNamespace(done=np.empty(B, dtype=np.int32), cycles=np.empty(B, dtype=np.int32), ego=np.empty((B, 6)),
+                              t_now=np.empty(B, dtype=np.int32), cart=np.empty((B, 3)))
+
+        def call(sh):
+            with torch.cuda.device(sh.db.dev), torch.cuda.stream(sh.stream):
+                sh.db.fb.skip = None
+                res = ClosedLoopRunner(sh.engine, sh.db, goal[sh.lo:sh.hi], planner).run(max_cycles)
+                sh.db.fb.skip = None  # (the runner's `done` array dies with it)
+            for k in ("done", "cycles", "ego", "t_now", "cart"):
+                getattr(out, k)[sh.lo:sh.hi] = getattr(res, k)
+
+        self._each(sdb, call, True)
+        return out

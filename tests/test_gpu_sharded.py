@@ -83,3 +83,94 @@ def test_two_contexts_on_two_streams_interleaved(engine, kind):
         assert alone[0].cycles.sum() > 0 and alone[1].cycles.sum() > 0
     finally:
         other.close()
+
+
+def test_out_arrays_are_checked_before_they_cross_the_abi(engine):
+    """plan_dense(out=...) hands bare addresses to the C side: a strided / wrong-dtype array must be refused, not written through."""
+    from fiss_plus_planner_amd.engine import FrenetEngine
+
+    batch = synth.make_config(2, B=8)
+    out = FrenetEngine.dense_outputs(batch.B, batch.C, True, False)
+    out.cost = np.empty((batch.B, 2 * batch.C))[:, ::2]
+    with pytest.raises(ValueError, match="out.cost"):
+        engine.plan_dense(batch, tables=True, out=out)
+    out = FrenetEngine.dense_outputs(batch.B, batch.C, True, False)
+    out.best_idx = np.empty(batch.B, dtype=np.int64)
+    with pytest.raises(ValueError, match="out.best_idx"):
+        engine.plan_dense(batch, tables=True, out=out)
+    with ShardedEngine(devices=[0], shards_per_device=2) as eng:  # kind as the ABI constant sizes the outputs like the name does
+        fb = synth.make_config(4, B=16)
+        a, b = eng.plan_fiss(fb, 1, trace=True), eng.plan_fiss(fb, "FISS+", trace=True)
+        assert a.trace is not None and np.array_equal(a.trace, b.trace, equal_nan=True)
+
+
+# ---- resident shards (ShardedEngine.upload): BASELINE configs[4] size, 8 logical shards on the one device of the box
+CONFIG5_B, CONFIG5_W = 16384, 8
+
+
+@pytest.fixture(scope="module")
+def sharded8():
+    with ShardedEngine(devices=[0], shards_per_device=CONFIG5_W) as eng:
+        yield eng
+
+
+def test_resident_shards_config5_fop(engine, sharded8):
+    """16 384 egos uploaded once, eight resident shards: index / cost / Stats / flag tables / winner series bit-equal to the single
+    engine's host-buffer call; a second resident call (nothing uploaded) gives the same again."""
+    batch = synth.make_config(5, B=CONFIG5_B)
+    ref = engine.plan_dense(batch, tables=True, winner=True, traj_stride=112, traj_sparse=True)
+    sdb = sharded8.upload(batch, tables=True, winner=True, traj_stride=112)
+    assert len(sdb.shards) == CONFIG5_W and [(s.lo, s.hi) for s in sdb.shards] == ShardedEngine.bounds(CONFIG5_B, CONFIG5_W)
+    for rep in range(2):
+        out = sharded8.plan_dense(sdb, tables=True, winner=True)
+        for k in ("best_idx", "best_cost", "stats", "best_flags"):
+            assert np.array_equal(getattr(out, k), getattr(ref, k), equal_nan=True), (k, rep)
+        cost, flags = sdb.fetch_tables()
+        assert np.array_equal(cost, ref.cost, equal_nan=True) and np.array_equal(flags, ref.flags)
+        assert np.array_equal(sdb.fetch_series(), ref.best_traj, equal_nan=True)
+    # asynchronous form: enqueue twice, synchronise once
+    sdb.host.best_idx[:] = -7
+    sharded8.plan_dense(sdb, sync=False)
+    sharded8.plan_dense(sdb, sync=False)
+    sdb.synchronize()
+    np.testing.assert_array_equal(sdb.host.best_idx, ref.best_idx)
+    with pytest.raises(ValueError):
+        sharded8.plan_dense(sharded8.upload(synth.make_config(2, B=16)), tables=True)
+
+
+def test_resident_shards_config5_fissplus(engine, sharded8):
+    fb = synth.make_config(4, B=CONFIG5_B)
+    rng = np.random.default_rng(5)
+    prev = np.where(rng.uniform(size=(fb.B, 1)) < 0.5, -1, np.column_stack([rng.integers(0, fb.nd, fb.B), rng.integers(0, fb.nv, fb.B),
+                                                                           rng.integers(0, fb.nt, fb.B)])).astype(np.int32)
+    ref = engine.plan_fiss(fb, "FISS+", prev_best_idx=prev, winner=True, traj_stride=112, traj_sparse=True)
+    sdb = sharded8.upload(fb, winner=True, traj_stride=112)
+    out = sharded8.plan_fiss(sdb, "FISS+", prev_best_idx=prev, winner=True)
+    for k in ("best_ijk", "stats", "refined", "prev_best_idx", "best_flags", "best_cost", "end_state"):
+        assert np.array_equal(getattr(out, k), getattr(ref, k), equal_nan=True), k
+    assert np.array_equal(sdb.fetch_series(), ref.best_traj, equal_nan=True)
+    # the history stays resident: a second call without prev_best_idx continues from the first one's winners
+    ref2 = engine.plan_fiss(fb, "FISS+", prev_best_idx=ref.prev_best_idx)
+    out2 = sharded8.plan_fiss(sdb, "FISS+")
+    for k in ("best_ijk", "stats", "refined", "prev_best_idx", "best_cost", "end_state"):
+        assert np.array_equal(getattr(out2, k), getattr(ref2, k), equal_nan=True), k
+
+
+@pytest.mark.parametrize("planner", ["FOP", "FISS+"])
+def test_resident_shards_config5_closed_loop(engine, sharded8, planner):
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+
+    cfg, cycles = (5 if planner == "FOP" else 4), 4
+    batch = synth.make_config(cfg, B=CONFIG5_B, kind=planner)
+    goal = np.full((batch.B, 2), 1e9)
+    ref = ClosedLoopRunner(engine, DeviceBatch(batch, 0), goal, planner).run(cycles)
+    sdb = sharded8.upload(batch)
+    out = sharded8.closed_loop(sdb, goal, planner, max_cycles=cycles)
+    for k in ("done", "cycles", "t_now"):
+        np.testing.assert_array_equal(getattr(out, k), getattr(ref, k), err_msg=k)
+    assert np.array_equal(out.ego, ref.ego) and np.array_equal(out.cart, ref.cart, equal_nan=True)
+    assert out.cycles.sum() > batch.B
+    # the resident states moved; rewound, a dense pass equals the single engine's on the original batch
+    sdb.reset_state(batch)
+    if planner == "FOP":
+        np.testing.assert_array_equal(sharded8.plan_dense(sdb).best_idx, engine.plan_dense(batch, tables=False).best_idx)
