@@ -77,6 +77,15 @@ __device__ __forceinline__ int div_by(int e, float inv_d)
     }
 }
 
+// Orders the LDS accesses of ONE wavefront for the compiler (the hardware executes a wavefront's LDS instructions in program order):
+// what lanes wrote before it, other lanes of the same wavefront read after it.  No instruction is emitted.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 #if defined(FP_ABL_NO_SLICE_SYNC)  // timing ablation: the slice loop without its barriers (results are wrong)
 #define SLICE_SYNC() do { } while (0)
 #else
@@ -110,18 +119,36 @@ struct Layout {
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
 
+// Two organisations of the collision stages share the kernel's prologue (FP_SLICE_LOOP selects the older one for A/B runs):
+//   walk (default)  every wavefront takes one lon profile (T, v) at a time and does everything for it by itself - frames, fan
+//                   half-widths, broad phase, narrow phase - with NO workgroup barrier; the per-slice tables (frames, half-widths,
+//                   hit list) are per WAVEFRONT, the lateral bounds and coefficients of all slices are computed once per ego
+//   slice loop      all wavefronts work on one time-horizon slice (or a group of gs slices) per barrier interval
+#if defined(FP_SLICE_LOOP)
+constexpr bool kWalk = false;
+#else
+constexpr bool kWalk = true;
+#endif
 // gs = time-horizon slices the collision stages work on per barrier interval (1: one at a time; the per-slice tables are gs deep)
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs)
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs, int nwaves)
 {
     Layout L;
     int o = 0;
     L.dim = o;      o = align16(o + 32 * n_obs);
     L.pose = o;     o = align16(o + 32 * kItemCap);  // poses of the group test's survivors (x, y, cos, sin), in list order
-    L.frames = o;   o = align16(o + 32 * gs * nv * hp);
-    L.lat = o;      o = align16(o + 8 * gs * nd * hp);
-    L.dmax = o;     o = align16(o + 2 * 4 * gs * hp);   // float, rounded up; two buffers (group parity): LDS atomic max in phase A
-    L.ddmax = o;    o = align16(o + 2 * 4 * gs * hp);
-    L.wfat = o;     o = align16(o + 4 * gs * nv * hp);  // float, rounded up
+    if (kWalk) {
+        L.frames = o;   o = align16(o + 32 * nwaves * hp);   // [wavefront][point]: the profile the wavefront is working on
+        L.lat = o;
+        L.dmax = o;     o = align16(o + 4 * nt * hp);        // [slice][point] float, rounded up: max |d| over the lateral samples
+        L.ddmax = o;    o = align16(o + 4 * nt * hp);        // max |d(i + 1) - d(i)|
+        L.wfat = o;     o = align16(o + 4 * nwaves * (rows > 0 ? rows : 1));  // [wavefront][row] float, rounded up
+    } else {
+        L.frames = o;   o = align16(o + 32 * gs * nv * hp);
+        L.lat = o;      o = align16(o + 8 * gs * nd * hp);
+        L.dmax = o;     o = align16(o + 2 * 4 * gs * hp);   // float, rounded up; two buffers (group parity): LDS atomic max in phase A
+        L.ddmax = o;    o = align16(o + 2 * 4 * gs * hp);
+        L.wfat = o;     o = align16(o + 4 * gs * nv * hp);  // float, rounded up
+    }
     L.grp = o;      o = align16(o + 32 * (rows > 0 ? rows : 1));       // per checked pose row: circle enclosing all lon profiles' points
     L.iqueue = o;   o = align16(o + 2 * kItemCap);                           // (row, obstacle) items that pass the group test
     L.samples = o;  o = align16(o + 8 * (nt + nv + nd));  // t / v / d sample grids (read all over the kernel: keep them out of HBM latency)
@@ -129,12 +156,15 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.lat_sum = o;  o = align16(o + 24 * nd * nt);   // sum_ad, sum_jd, sum_d
     L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
     L.qlon = o;     o = align16(o + 16 * nt * nv);   // a3, a4 of every lon profile (a0..a2 are the ego state)
-    L.qlat = o;     o = align16(o + 24 * gs * nd);   // a3, a4, a5 of the CURRENT slices' lat profiles
+    L.qlat = o;     o = align16(o + 24 * (kWalk ? nt : gs) * nd);   // a3, a4, a5 of the lat profiles (walk: of every slice; else of the CURRENT slices)
     L.box = o;      o = align16(o + 16 * (rows > 0 ? rows : 1));  // per checked pose row: bounding box of the slice's reference points (ordered-uint fp32)
-    L.coll = o;     o = align16(o + nd * nv * nt);
+    L.coll = o;     o = align16(o + (kWalk ? 8 * nt * nv : nd * nv * nt));  // walk: one bit per lateral sample, a 64-bit word per lon profile; else a byte per candidate
     // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
     L.queue = o;    L.pows = o;
-    o = align16(o + (4 * kHitCap > 88 * nt ? 4 * kHitCap : 88 * nt));
+    {
+        const int q = kWalk ? 4 * 64 * nwaves : 4 * kHitCap;
+        o = align16(o + (q > 88 * nt ? q : 88 * nt));
+    }
     L.cnt = o;      o = align16(o + 32);  // list counters (monotone) + scan mask + ticket + two fp32 bounds
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * 16);  // (up to 16 wavefronts)
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const int n_obs_tab = kShape ? NOBS : bt.n_obs;  // obstacles per scene of the table
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs);
+    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs, kWaves);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
@@ -268,6 +298,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     double* s_qlat = (double*)(smem + L.qlat);  // [gs][nd][3]
     uint4* s_box = (uint4*)(smem + L.box);      // [rows] {min x, max x, min y, max y} relative to the first knot
     unsigned char* s_coll = smem + L.coll;
+    uint32_t* s_collmask = (uint32_t*)(smem + L.coll);  // walk: [lon profile][2], bit id = lateral sample id of the profile collides
     uint32_t* s_hits = (uint32_t*)(smem + L.queue);
     int* s_cnt = (int*)(smem + L.cnt);
     int* s_nslice = (int*)(smem + L.nslice);
@@ -424,11 +455,16 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         rows = (h + stride - 1) / stride;
         if (rows_stage < rows) rows = rows_stage;
     }
-    for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
+    if constexpr (kWalk) {
+        for (int c = tid; c < 2 * nt * nv; c += kThreads) s_collmask[c] = 0u;
+    } else {
+        for (int c = tid; c < C; c += kThreads) s_coll[c] = 0;
+    }
     for (int r = tid; r < rows; r += kThreads) {
         s_box[r] = make_uint4(kOrdPosInf, kOrdNegInf, kOrdPosInf, kOrdNegInf);  // empty
     }
-    for (int i = tid; i < 2 * gs * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
+    if constexpr (!kWalk)
+        for (int i = tid; i < 2 * gs * hp_max; i += kThreads) { s_dmax2[i] = 0.0f; s_ddmax2[i] = 0.0f; }
     // points whose frame the collision stage can touch: 0 .. hp-1 (pose k needs point k+1 for its heading)
     const int pose_limit = rows * stride < horizon_cap ? rows * stride : horizon_cap;  // poses k < pose_limit (and k < M)
     int hp = pose_limit > 0 ? pose_limit + 1 : 0;
@@ -601,6 +637,15 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // per trajectory point
     const float inv_nd_g = 1.0f / (float)nd;
     auto fill_group_lat = [&](int it0) {  // the group of slices that starts at it0: [slice in group][lateral sample]
+        if constexpr (kWalk) {  // every slice of this workgroup, [slice][lateral sample] (absolute slice index)
+            for (int e = kThreads - 1 - tid; e < mul24(n_it, nd); e += kThreads) {
+                const int itl = div_small(e, inv_nd_g), id = e - mul24(itl, nd);
+                const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, s_ts[it_lo + itl]);
+                double* o = s_qlat + 3 * (mul24(it_lo + itl, nd) + id);
+                o[0] = q.a3; o[1] = q.a4; o[2] = q.a5;
+            }
+            return;
+        }
         const int idg = kThreads - 1 - tid;  // the last threads: they have the least prep work
         if (idg < mul24(gs, nd)) {
             const int itl = kGroup ? div_small(idg, inv_nd_g) : 0, id = idg - mul24(itl, nd);
@@ -613,6 +658,34 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     fill_group_lat(it_lo);
     __syncthreads();
     FP_STAMP(3);
+    if constexpr (kWalk) {
+        // ---- lateral fan bounds of EVERY slice (walk): lane = (slice, point inside the collision horizon), loop over the lateral
+        // samples: fan half-width max|d| and largest lateral step max|d(i + 1) - d(i)|, float_above: never below the fp64 value.
+        // (The first threads: the circles below take the last ones.)
+        if (n_obs > 0 && hp > 0) {
+            const float inv_hp = 1.0f / (float)hp;
+            for (int e = tid; e < mul24(n_it, hp); e += kThreads) {
+                const int itl = div_small(e, inv_hp), i = e - mul24(itl, hp);
+                const int it = it_lo + itl;
+                const int np_i = hp < s_nslice[it] ? hp : s_nslice[it];
+                if (i >= np_i) continue;
+                const double t = (double)i * tick, tn = (double)(i + 1) * tick;
+                float dm = 0.0f, ddm = 0.0f;
+                for (int id = 0; id < nd; ++id) {
+                    const double* ql = s_qlat + 3 * (mul24(it, nd) + id);
+                    const double a3 = ql[0], a4 = ql[1], a5 = ql[2];
+                    const double d = fma(fma(fma(fma(fma(a5, t, a4), t, a3), t, d_dd0 * 0.5), t, d_d0), t, d0);
+                    const double dn = fma(fma(fma(fma(fma(a5, tn, a4), tn, a3), tn, d_dd0 * 0.5), tn, d_d0), tn, d0);
+                    // (a NaN offset must poison the bound like the integer atomic max on bit patterns did: NaN is the largest pattern)
+                    const float fd = float_above(fabs(d)), fdd = float_above(fabs(dn - d));
+                    dm = __float_as_uint(fd) > __float_as_uint(dm) ? fd : dm;
+                    ddm = __float_as_uint(fdd) > __float_as_uint(ddm) ? fdd : ddm;
+                }
+                s_dmax2[mul24(it, hp_max) + i] = dm;
+                s_ddmax2[mul24(it, hp_max) + i] = i + 1 < np_i ? ddm : 0.0f;
+            }
+        }
+    }
     // ---- ranges -> circles: every reference point of the row lies within  v_max * (half the range)  of the line's point at
     // the middle of the range (v_max >= |P'(s)| everywhere); + ego reach + the largest lateral offset.  One test per
     // (row, obstacle) item then prunes the item for every profile of every slice at once.
@@ -725,6 +798,183 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             // No survivor (block-uniform: empty surroundings, obstacles out of reach): nothing can collide, the slices are skipped.
             // (Skipping only the rows without a survivor was tried: a lane that skips its point saves nothing while its wavefront's
             // other lanes work, and the bookkeeping cost 3 % on dense scenes.)
+            if constexpr (kWalk) {
+                // ---- WALK: every wavefront takes lon profiles (slice, end speed) from a counter and handles each one on its own, in four
+                // wave-local steps with no workgroup barrier between them (a wavefront's LDS accesses execute in program order):
+                //   frames   lane = trajectory point inside the collision horizon: reference-line frame -> the wavefront's frame table
+                //   prep     lane = checked pose row: the fan's half-width along the reference normal (fp32, rounded outwards)
+                //   B        lane = surviving item, in list (= time) order, 64 at a time: fattened circle + separating axes n_k, t_k;
+                //            the passing items are compacted into the wavefront's hit list (ballot + popcount, no atomics)
+                //   N        lane = (hit, lateral sample), floor(64 / nd) hits per round: exact circle + 4-axis separating-axis test.
+                // The collision state of the profile's nd candidates is ONE wave-uniform bit mask: a lane skips candidates that have
+                // collided, and the walk of a profile ENDS when all nd have (later items cannot change anything) - items are in time
+                // order, so a blocked profile ends after its first hits instead of testing every pose of the horizon.
+                if (n_surv > 0) {
+                    __syncthreads();  // the survivors' (cos, sin), the item list and the lateral bounds are visible to every wavefront
+                    Frame* wfr = s_frames + mul24(wave, hp_max);
+                    float* wwf = s_wfat + mul24(wave, rows_max > 0 ? rows_max : 1);
+                    uint32_t* wh = s_hits + wave * kWave;
+                    constexpr int kHpwC = ND > 0 ? kWave / ND : 1;
+                    const int hpw = kShape ? kHpwC : kWave / nd;  // hits per narrow-phase round
+                    const int hh_l = div_by<ND, kWave>(lane, inv_ndf), id_l = lane - mul24(hh_l, nd);
+                    const unsigned long long full = nd >= 64 ? ~0ull : ((1ull << nd) - 1ull);
+                    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+                    const int n_prof = mul24(n_it, nv);
+                    const float inv_stride = 1.0f / (float)stride;
+                    // Profiles are dealt to the wavefronts round-robin (wave w takes w, w + 8, ...: a mix of end speeds each).  A shared
+                    // counter was tried first: `if (lane == 0) atomicAdd` + readfirstlane inside a loop whose only exit is a break gets
+                    // restructured by the compiler so that lanes 1..63 spin on their own (a hang, not a slowdown) - the loop below has
+                    // a wave-uniform scalar trip count and no divergent branch around a cross-lane operation.
+                    for (int pq = __builtin_amdgcn_readfirstlane(wave); pq < n_prof; pq += kWaves) {
+                        const int itl = div_by<NV, NT * NV>(pq, inv_nvf), iv = pq - mul24(itl, nv);
+                        const int it = it_lo + itl, qg = mul24(it, nv) + iv;
+                        const int M = __builtin_amdgcn_readfirstlane(s_lon_meta[qg].x);  // (M <= N; wave-uniform -> scalar registers)
+                        // a trajectory of fewer than two points has no heading: no pair (M == 1 is the assembly's business)
+                        if (M < 2) continue;
+                        const int n_pts = __builtin_amdgcn_readfirstlane(s_nslice[it]);
+                        const int np = hp < n_pts ? hp : n_pts;
+                        const int npm = np < M ? np : M;
+                        const double a3 = s_qlon[2 * qg], a4 = s_qlon[2 * qg + 1];
+    // [section FRAMES]
+                        for (int i = lane; i < npm; i += kWave) {
+                            const double t = (double)i * tick;
+                            const double s = fma(fma(fma(fma(a4, t, a3), t, s_dd0 * 0.5), t, s_d0), t, s0);
+                            const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
+                            Frame fr;
+                            spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
+                            wfr[i] = fr;
+                        }
+    // [/section FRAMES]
+                        wave_lds_sync();
+                        const float* dm = s_dmax2 + mul24(it, hp_max);
+                        const float* ddm = s_ddmax2 + mul24(it, hp_max);
+                        {   // prep (see the slice loop's comment for the bound): conservative, fp32
+                            const float r_ego_f = float_above(s_k[4]), hl_f = float_above(s_k[2]), hw_f = float_above(s_k[3]);
+    // [section PREP]
+                            for (int r = lane; r < rows; r += kWave) {
+                                const int k = mul24(r, stride);
+                                const bool row_ok = k < n_pts && k < hp;
+                                float wl = r_ego_f;
+                                if (k + 1 < M && k + 1 < hp) {
+                                    const Frame f0 = wfr[k], f1 = wfr[k + 1];
+                                    const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
+                                    const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
+                                    const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
+                                    const double nn = fma(f1.tx, f0.tx, f1.ty * f0.ty);   // n_{k+1} . n_k
+                                    const double nt_ = fma(f1.tx, f0.ty, -f1.ty * f0.tx); // n_{k+1} . t_k
+                                    const double dm1 = (double)dm[k + 1];
+                                    const float num = (float)(fabs(a_n) + (double)ddm[k] + dm1 * fabs(1.0 - nn));
+                                    const float den = (float)(fabs(a_t) - dm1 * fabs(nt_));
+                                    if (den > 1e-30f) {  // v_rcp_f32: 1 ulp; the factor covers it and the two roundings to nearest
+                                        const float sigma = vmin_f32(1.0f, num * __builtin_amdgcn_rcpf(den) * (1.0f + 4e-6f) + 1e-9f);
+                                        wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
+                                    }
+                                }
+                                wwf[r] = row_ok ? (dm[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
+                            }
+    // [/section PREP]
+                        }
+                        wave_lds_sync();
+                        // candidates of this profile that collided in an earlier item chunk (crowded scenes only; else 0)
+                        unsigned long long coll = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_collmask[2 * qg + 1]) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)s_collmask[2 * qg]);
+                        const double* qlat = s_qlat + 3 * mul24(it, nd);
+#if defined(FP_ABL_NO_BN)
+                        const int n_walk = 0;
+#else
+                        const int n_walk = n_surv;
+#endif
+                        for (int c0 = 0; c0 < n_walk && coll != full; c0 += kWave) {
+                            const int si = c0 + lane;
+                            bool pass = false;
+                            uint32_t code = 0;
+                            if (si < n_walk) {
+                                const int item = s_items[si];
+                                const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
+                                const int k = mul24(r, stride);
+                                const ObsPose op = s_spose[si];
+                                const ObsDim od = s_dim[j];
+                                const Frame fr = wfr[k];  // (stale beyond the profile's M: the test below excludes those poses)
+                                const double r_ego_b = s_k[4];
+                                const double fat = (r_ego_b + od.r + (double)dm[k]) * (1.0 + 1e-12);
+                                const double dx = op.x - fr.px, dy = op.y - fr.py;
+                                // (1) circle around the reference point; (2) separating axis n_k: lateral offset of the obstacle centre
+                                // vs the fan half-width + the obstacle's own reach along n_k; (3) separating axis t_k: every ego centre
+                                // of the fan lies ON the normal line, so along t_k the fan reaches no further than the ego box's
+                                // half-diagonal.  A NaN pose passes all three (-> "collision").
+                                const double w = fma(dy, fr.tx, -dx * fr.ty), u = fma(dx, fr.tx, dy * fr.ty);
+                                const double a_n = fabs(fma(op.s, fr.tx, -op.c * fr.ty)), a_t = fabs(fma(op.c, fr.tx, op.s * fr.ty));
+                                const double reach = fma(od.hl, a_n, od.hw * a_t), reach_t = fma(od.hl, a_t, od.hw * a_n);
+                                pass = k < M && !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)wwf[r] + reach) &&
+                                       !(fabs(u) > r_ego_b * (1.0 + 1e-12) + reach_t);
+                                code = (uint32_t)k | ((uint32_t)si << 8);  // k < 128, si < 512
+                            }
+                            const unsigned long long m = __ballot(pass);
+                            if (lane == 0) { FP_COUNT(1, 1); FP_COUNT(2, __popcll(m)); }
+                            if (!m) continue;
+                            const int n_hits = __popcll(m);
+                            if (pass) wh[__popcll(m & lt_mask)] = code;
+                            wave_lds_sync();
+                            // ---- N: exact narrow phase, hpw hits x nd lateral samples per round
+#if defined(FP_ABL_NO_N)
+                            const int n_exact = 0;
+#else
+                            const int n_exact = n_hits;
+#endif
+                            for (int h0 = 0; h0 < n_exact; h0 += hpw) {
+                                const int h = h0 + hh_l;
+                                bool hit = false;
+                                if (hh_l < hpw && h < n_exact && !((coll >> id_l) & 1ull)) {
+                                    const uint32_t hc = wh[h];
+                                    const int k = hc & 0xFF, si2 = hc >> 8;
+                                    const int j = (int)s_items[si2] - mul24(div_by<STRIDE, FP_MAX_POINTS>(k, inv_stride), n_obs);  // item = row * n_obs + obstacle
+                                    FP_COUNT(3, 1);
+                                    // heading of pose k: forward difference, or the previous one for the last point (:127-129)
+                                    const int ka_ = (k + 1 < M) ? k : k - 1;
+                                    const Frame f0 = wfr[ka_], f1 = wfr[ka_ + 1];
+                                    const double* ql = qlat + mul24(id_l, 3);
+                                    const double b3 = ql[0], b4 = ql[1], b5 = ql[2];
+                                    const double ta = (double)ka_ * tick, tb = (double)(ka_ + 1) * tick;
+                                    const double da = fma(fma(fma(fma(fma(b5, ta, b4), ta, b3), ta, d_dd0 * 0.5), ta, d_d0), ta, d0);
+                                    const double db = fma(fma(fma(fma(fma(b5, tb, b4), tb, b3), tb, d_dd0 * 0.5), tb, d_d0), tb, d0);
+                                    double xa, ya, xb, yb;
+                                    frenet_to_cartesian(f0.px, f0.py, f0.tx, f0.ty, da, xa, ya);
+                                    frenet_to_cartesian(f1.px, f1.py, f1.tx, f1.ty, db, xb, yb);
+                                    Obb ego;
+                                    step_heading(xb - xa, yb - ya, ego.c, ego.s);
+                                    ego.x = (ka_ == k) ? xa : xb;
+                                    ego.y = (ka_ == k) ? ya : yb;
+                                    ego.hl = s_k[2];
+                                    ego.hw = s_k[3];
+                                    const ObsPose op = s_spose[si2];
+                                    const ObsDim od = s_dim[j];
+                                    if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
+                                        hit = true;  // polygon construction fails in the reference -> collision (:178-182)
+                                    } else {
+                                        const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
+                                        const double dx = op.x - ego.x, dy = op.y - ego.y;
+                                        hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                    }
+                                    if (hit) FP_COUNT(5, 1);
+                                }
+                                if (lane == 0) FP_COUNT(6, 1);
+                                unsigned long long hm = __ballot(hit);
+                                // fold the round's hits onto the nd lateral samples (scalar arithmetic on the ballot)
+                                if (nd >= kWave) coll |= hm;
+                                else
+                                    for (; hm; hm >>= nd) coll |= hm & full;
+                                if (coll == full) { if (lane == 0) FP_COUNT(7, 1); break; }
+                            }
+                        }
+                        if (lane == 0) { s_collmask[2 * qg] = (uint32_t)coll; s_collmask[2 * qg + 1] = (uint32_t)(coll >> 32); }
+                    }
+                    // every wavefront's collision masks are visible to the assembly (and every wavefront is done with this chunk's item
+                    // list before G overwrites it: crowded scenes walk the profiles again over the next chunk's survivors)
+                    __syncthreads();
+                }
+                i0 = i1;
+                continue;
+            }
             int par = 0;  // which of the two fan-bound buffers this group fills (the other one is zeroed meanwhile)
             for (int it0 = it_lo; n_surv > 0 && it0 < it_hi; it0 += gs) {
                 // ---- a GROUP of g slices (g = 1 in the throughput instances): profile index q = (slice in group) * nv + iv and
@@ -962,7 +1212,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         const int2 meta = s_lon_meta[mul24(it, nv) + iv];
         const int M = meta.x;
         uint32_t flags = (uint32_t)meta.y;
-        bool hit = s_coll[c] != 0;
+        bool hit;
+        if constexpr (kWalk) hit = (s_collmask[2 * (mul24(it, nv) + iv) + (id >> 5)] >> (id & 31)) & 1u;
+        else hit = s_coll[c] != 0;
         if (n_obs > 0 && M == 1 && horizon_cap >= 1) hit = true;  // traj.yaw is empty -> IndexError -> collision (:178-182)
         if (hit) flags |= FP_FLAG_COLLISION;
         if (M < N) flags |= FP_FLAG_TRUNCATED;
@@ -1098,7 +1350,7 @@ int lattice_group_fit(const fp_params& p, const fp_batch& b)
     if (!fused_shape(p, b, &rows, &hp)) return 0;
     int gs = 0;
     for (int g = 1; g <= p.nt; ++g) {
-        if (g * p.nv > 256 || make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), g).total > kLdsLimit) break;
+        if (g * p.nv > 256 || make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), g, FP_GROUP_THREADS / kWave).total > kLdsLimit) break;
         gs = g;
     }
     return gs;
@@ -1123,7 +1375,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         const int fit = lattice_group_fit(p, b);
         gs = fit < 1 ? 1 : (gs > fit ? fit : gs);
     }
-    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1);
+    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1, kThreads / kWave);
 #if defined(FP_PHASE_STAMPS)  // (the stamps travel in the series block: the three-workgroup variant leaves the series themselves unwritten)
     bool three = gs == 1 && nsplit == 1 && b.B > 512 && L6.total <= 52 * 1024;
 #else
@@ -1133,7 +1385,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
 #endif
-    const Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs);
+    const Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (nsplit > p.nt) nsplit = p.nt;
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
