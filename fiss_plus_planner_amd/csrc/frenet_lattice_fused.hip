@@ -250,6 +250,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
 #define FP_STAMP(k) do { } while (0)
 #define FP_STAMP_LAST(k) do { } while (0)
 #endif
+#if defined(FP_PHASE_STAMPS)
+    __shared__ unsigned int s_walk_t[2];  // when the first / the last wavefront of the workgroup finished its profiles
+#endif
 #if defined(FP_COUNTERS)  // work statistics (tools/work_counters.py): LDS counters, left in row 14, columns 112.. of the winner block
     __shared__ int s_dbg[16];
     if (threadIdx.x < 16) s_dbg[threadIdx.x] = 0;
@@ -379,6 +382,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         // [0], [1]: list counters; [2]: slices whose lon profiles need the point-by-point scan; [3]: ticket; [5], [6]: fp32 bit patterns
         // of the spline's speed bound and of the largest lateral offset
         if (tid < 8) s_cnt[tid] = 0;
+#if defined(FP_PHASE_STAMPS)
+        if (tid == 0) { s_walk_t[0] = 0xFFFFFFFFu; s_walk_t[1] = 0u; }
+#endif
         // all NX columns (the copy does not wait for nx; columns >= nx hold the +inf padding / are never addressed)
         for (int i = tid; i < NX; i += kThreads) s_knots[i] = gk[i];
         for (int i = tid; i < nt + nv + nd; i += kThreads)
@@ -659,10 +665,20 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     __syncthreads();
     FP_STAMP(3);
     if constexpr (kWalk) {
-        // ---- lateral fan bounds of EVERY slice (walk): lane = (slice, point inside the collision horizon), loop over the lateral
-        // samples: fan half-width max|d| and largest lateral step max|d(i + 1) - d(i)|, float_above: never below the fp64 value.
-        // (The first threads: the circles below take the last ones.)
+        // ---- lateral fan bounds of EVERY slice (walk): lane = (slice, point inside the collision horizon): fan half-width max|d| and
+        // largest lateral step max|d(i + 1) - d(i)| over the lateral samples, float_above: never below the fp64 value.  For a fixed
+        // horizon the quintic is AFFINE in its end offset (Hermite form, see the lateral bound above): d(t; d_end) = b(t) + d_end g(t),
+        // so |d| and |d(i + 1) - d(i)| are convex in d_end and their maxima over the samples sit at the smallest and the largest
+        // sample - two profiles are evaluated instead of nd (the rounding of the other samples' own evaluations, ~1e-16 relative,
+        // is far inside float_above's 2^-22).  (The first threads: the circles below take the last ones.)
         if (n_obs > 0 && hp > 0) {
+            int id_lo = 0, id_hi = 0;  // (any order of d_samples: the reference passes np.linspace, the ABI does not require it)
+            for (int id = 1; id < nd; ++id) {
+                id_lo = s_ds[id] < s_ds[id_lo] ? id : id_lo;
+                id_hi = s_ds[id] > s_ds[id_hi] ? id : id_hi;
+            }
+            bool d_nan = false;
+            for (int id = 0; id < nd; ++id) d_nan = d_nan || !(s_ds[id] == s_ds[id]);
             const float inv_hp = 1.0f / (float)hp;
             for (int e = tid; e < mul24(n_it, hp); e += kThreads) {
                 const int itl = div_small(e, inv_hp), i = e - mul24(itl, hp);
@@ -671,16 +687,18 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 if (i >= np_i) continue;
                 const double t = (double)i * tick, tn = (double)(i + 1) * tick;
                 float dm = 0.0f, ddm = 0.0f;
-                for (int id = 0; id < nd; ++id) {
-                    const double* ql = s_qlat + 3 * (mul24(it, nd) + id);
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const double* ql = s_qlat + 3 * (mul24(it, nd) + (side ? id_hi : id_lo));
                     const double a3 = ql[0], a4 = ql[1], a5 = ql[2];
                     const double d = fma(fma(fma(fma(fma(a5, t, a4), t, a3), t, d_dd0 * 0.5), t, d_d0), t, d0);
                     const double dn = fma(fma(fma(fma(fma(a5, tn, a4), tn, a3), tn, d_dd0 * 0.5), tn, d_d0), tn, d0);
-                    // (a NaN offset must poison the bound like the integer atomic max on bit patterns did: NaN is the largest pattern)
+                    // (a NaN offset poisons the bound: as an unsigned bit pattern NaN is the largest)
                     const float fd = float_above(fabs(d)), fdd = float_above(fabs(dn - d));
                     dm = __float_as_uint(fd) > __float_as_uint(dm) ? fd : dm;
                     ddm = __float_as_uint(fdd) > __float_as_uint(ddm) ? fdd : ddm;
                 }
+                if (d_nan) dm = ddm = __builtin_nanf("");  // a NaN sample: its own profile is NaN everywhere -> every pair passes
                 s_dmax2[mul24(it, hp_max) + i] = dm;
                 s_ddmax2[mul24(it, hp_max) + i] = i + 1 < np_i ? ddm : 0.0f;
             }
@@ -821,10 +839,13 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                     const unsigned long long lt_mask = (1ull << lane) - 1ull;
                     const int n_prof = mul24(n_it, nv);
                     const float inv_stride = 1.0f / (float)stride;
-                    // Profiles are dealt to the wavefronts round-robin (wave w takes w, w + 8, ...: a mix of end speeds each).  A shared
-                    // counter was tried first: `if (lane == 0) atomicAdd` + readfirstlane inside a loop whose only exit is a break gets
-                    // restructured by the compiler so that lanes 1..63 spin on their own (a hang, not a slowdown) - the loop below has
-                    // a wave-uniform scalar trip count and no divergent branch around a cross-lane operation.
+                    // Profiles are dealt to the wavefronts round-robin (wave w takes w, w + 8, ...: a mix of end speeds each); the first
+                    // wavefront to run out waits ~3 of the walk's 24 us for the last one.  Dealing them from a shared LDS counter instead was
+                    // built and measured: no difference (153.1 / 154.4 against 155.1 / 154.1 us per step in same-box runs) - the waiting
+                    // wavefronts cost no issue slots and the CU's other workgroups fill them.  (Its C++ spelling, `if (lane == 0) t =
+                    // atomicAdd(...)` + readfirstlane inside a loop whose only exit is a break, was restructured by the compiler so that lanes
+                    // 1..63 spun on their own - a hang; it took an inline-asm block with EXEC narrowed by hand.)  The loop below has a
+                    // wave-uniform scalar trip count and no divergent branch around a cross-lane operation.
                     for (int pq = __builtin_amdgcn_readfirstlane(wave); pq < n_prof; pq += kWaves) {
                         const int itl = div_by<NV, NT * NV>(pq, inv_nvf), iv = pq - mul24(itl, nv);
                         const int it = it_lo + itl, qg = mul24(it, nv) + iv;
@@ -968,9 +989,18 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         }
                         if (lane == 0) { s_collmask[2 * qg] = (uint32_t)coll; s_collmask[2 * qg + 1] = (uint32_t)(coll >> 32); }
                     }
+#if defined(FP_PHASE_STAMPS)  // when the first and the last wavefront finished their profiles (columns 11, 12): the walk's imbalance
+                    if (lane == 0) { atomicMin(&s_walk_t[0], (unsigned int)(wall_clock64() - t_begin)); atomicMax(&s_walk_t[1], (unsigned int)(wall_clock64() - t_begin)); }
+#endif
                     // every wavefront's collision masks are visible to the assembly (and every wavefront is done with this chunk's item
                     // list before G overwrites it: crowded scenes walk the profiles again over the next chunk's survivors)
                     __syncthreads();
+#if defined(FP_PHASE_STAMPS)
+                    if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) {
+                        double* row = ka.r.best_traj + ((size_t)(perm ? perm[blockIdx.x] : blockIdx.x / nsplit) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112;
+                        row[11] = (double)s_walk_t[0]; row[12] = (double)s_walk_t[1];
+                    }
+#endif
                 }
                 i0 = i1;
                 continue;

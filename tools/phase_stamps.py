@@ -48,7 +48,10 @@ for k, name in enumerate(PHASES):
     print(f"{name:48s} {np.median(d[:, k]):10.2f} {np.percentile(d[:, k], 90):10.2f} {d[:, k].mean():10.2f}")
 print(f"{'workgroup total':48s} {np.median(stamps[:, -1]):10.2f} {np.percentile(stamps[:, -1], 90):10.2f} {stamps[:, -1].mean():10.2f}")
 print(f"sum of workgroup durations / 512 slots = {stamps[:, -1].sum() / 512:.1f} us, / 768 slots = {stamps[:, -1].sum() / 768:.1f} us")
-# inside the 4th slice of the workgroup: stamps 11..14 after the frames / prep / B / N barriers
+# the walk's imbalance: when the first / the last wavefront of the workgroup ran out of profiles (columns 11, 12)
+print("walk: first wavefront done at {:.2f} us, last at {:.2f} us after the workgroup's start (medians); G ended at {:.2f}: the walk takes {:.2f}, of which {:.2f} is waiting for the slowest wavefront".format(
+    np.median(raw[:, 11]), np.median(raw[:, 12]), np.median(raw[:, 7]), np.median(raw[:, 12] - raw[:, 7]), np.median(raw[:, 12] - raw[:, 11])))
+# (slice-loop builds, -DFP_SLICE_LOOP) inside the 4th slice of the workgroup: stamps 11..14 after the frames / prep / B / N barriers
 sl = raw[:, 11:15]
 print("one slice (the 4th):  prep {:.2f}  B {:.2f}  N {:.2f} us (medians);  frames + lat = slice total - these".format(
     np.median(sl[:, 1] - sl[:, 0]), np.median(sl[:, 2] - sl[:, 1]), np.median(sl[:, 3] - sl[:, 2])))

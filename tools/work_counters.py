@@ -36,7 +36,10 @@ eng.plan_dense_device(params, fb, bi.data_ptr(), bc.data_ptr(), stream=st.cuda_s
                       traj_stride=128, traj_sparse=True)
 torch.cuda.synchronize()
 c = bt[:, 14, 112:128].cpu().numpy()
-names = ["G survivors (items)", "B pairs tested", "B pairs passed (hits)", "N items", "N items, candidate already collided", "N new collisions"]
+names = ["G survivors (items)", "B wave rounds (64 items of one profile each)", "B pairs passed (hits)", "N lane tests (live candidates only)", "-",
+         "N lane tests that found a collision", "N wave rounds (floor(64 / nd) hits each)", "profiles whose walk ended early (all nd collided)"]
+if os.environ.get("FP_SLICE_LOOP"):  # the counters of the older slice-loop build
+    names = ["G survivors (items)", "B pairs tested", "B pairs passed (hits)", "N items", "N items, candidate already collided", "N new collisions"]
 print(f"config {config}, layout {layout}: per ego, {B} egos")
 for k, n in enumerate(names):
     print(f"  {n:40s} mean {c[:, k].mean():9.1f}  median {np.median(c[:, k]):9.1f}  p90 {np.percentile(c[:, k], 90):9.1f}  max {c[:, k].max():9.0f}")
