@@ -472,6 +472,7 @@ __global__ __launch_bounds__(W * kWave) void fiss_search_kernel(FissArgs fa, int
 namespace {
 
 constexpr int kQueue = 5 * kWave;  // survivor queue entries per wavefront (refinement kernel): drained above kWave, filled 4 kWave at a time
+constexpr int kHot = 12;           // remembered collision pairs per ego; each is tried with its 2 time steps either side: 5 kHot <= kWave lanes
 
 struct RefineLds {
     double* S;      // [FP_MAX_POINTS + 1][11]
@@ -482,6 +483,9 @@ struct RefineLds {
     float4* pt;     // [rows][n_obs] {x - ox, y - oy, (padded bounding-circle sum)^2 or -1 when absent, (step | obstacle << 8) as int bits}
     float2* xyf;    // [FP_MAX_POINTS] this wavefront's poses relative to (ox, oy), fp32
     uint16_t* queue;  // [kQueue] this wavefront's broad-phase survivors (pair table indices)
+    // pairs (pair table indices) at which earlier trajectories of this ego collided: the refined trajectories are neighbours in end
+    // state space, so the next one most likely collides at the same obstacle a step or two away - tried first (kHot entries + count)
+    int* hot;
     double ox, oy;  // first knot of the reference line: keeps the fp32 coordinates small
     int scene, t_now, horizon_cap;  // per-ego scene facts read once (scene < 0: none; horizon_cap = final_time_step - t_now)
 };
@@ -562,6 +566,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const double seg_scale = (double)(nx - 1) / (knot_last - knot0);  // (NaN / inf / <= 0: spline_segment divides per point instead)
     unsigned long long off_lo = 0, off_hi = 0;
     bool bad_speed = false, bad_accel = false;
+    const int need_xy = p.curvature_mask ? FP_MAX_POINTS : ((L.scene >= 0 && bt.n_obs > 0) ? L.horizon_cap : -1);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int i = lane + half * kWave;
@@ -573,7 +578,9 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
             bad_speed |= s_d > p.max_speed;
             bad_accel |= fabs(s_dd) > p.max_accel;
             off = !(s >= knot0) || !(s < knot_last);
-            if (!off) {
+            // Cartesian points: the collision checks read poses k < min(M, horizon) and the point after each (heading); the optional
+            // curvature checks read all of them.  The rest of the trajectory only needs its masks and the range test above.
+            if (!off && i <= need_xy) {
                 const double d = fma(fma(fma(fma(fma(lat.a5, t, lat.a4), t, lat.a3), t, lat.a2), t, lat.a1), t, lat.a0);
                 const int seg = spline_segment(sp, s, -1, seg_scale < 1e300 ? seg_scale : 0.0);
                 double px, py, tx, ty, cx, cy;
@@ -655,6 +662,22 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
         // conservative (radius padded far beyond the fp32 rounding).  Survivors are compacted into this wavefront's queue and
         // take the exact fp64 test one per lane, so their pose reads (L2 / HBM, ~1-2 us) are all in flight together
         constexpr int kU = 4;  // table reads in flight per lane: branch-free (clamped index) so the LDS latencies overlap
+        // (0) the pairs at which earlier trajectories of this ego collided, with two checked steps either side (same obstacle): one
+        // exact pass; a hit ends the trajectory before its ~1250 pairs are scanned.  (A collision is a collision whichever pair shows it.)
+        const int n_hot = L.hot[kHot] < kHot ? L.hot[kHot] : kHot;
+        if (n_hot > 0) {
+            const int hh = lane / 5, dr = lane - 5 * hh - 2;
+            bool hit = false;
+            if (hh < n_hot) {
+                const int e = L.hot[hh] + dr * n_obs;
+                if (e >= 0 && e < P) {
+                    const uint32_t kj = (uint32_t)__float_as_int(L.pt[e].w);
+                    const int kk = kj & 0xFF, j = kj >> 8;
+                    hit = pair_hits(kk, j, *(const double4*)(scene + ((size_t)(kk + t_now) * n_obs + j) * 4));
+                }
+            }
+            if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
+        }
         int qn = 0;
         for (int e0 = 0; e0 < P + kU * kWave; e0 += kU * kWave) {  // one extra trip drains what is left: the (large) exact test
             if (e0 < P) {                                            // is inlined once
@@ -685,19 +708,30 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
                 }
             }
             if (e0 >= P) FP_WSTAMP(13);
-            if (qn > kQueue - kU * kWave || (e0 >= P && qn > 0)) {
+            // survivors are tested as soon as a trip leaves any (the table is in time order: a trajectory that collides early is
+            // done before the rest of its horizon is scanned)
+            if (qn > 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 bool hit = false;
+                int hit_e = -1;
                 for (int slot = lane; slot < qn; slot += kWave) {  // survivors: exact fp64 test, their pose reads in flight together
-                    const uint32_t kj = (uint32_t)__float_as_int(L.pt[L.queue[slot]].w);
+                    const int e = L.queue[slot];
+                    const uint32_t kj = (uint32_t)__float_as_int(L.pt[e].w);
                     const int kk = kj & 0xFF, j = kj >> 8;
-                    hit |= pair_hits(kk, j, *(const double4*)(scene + ((size_t)(kk + t_now) * n_obs + j) * 4));
+                    if (pair_hits(kk, j, *(const double4*)(scene + ((size_t)(kk + t_now) * n_obs + j) * 4))) { hit = true; hit_e = e; }
                 }
                 qn = 0;
                 __builtin_amdgcn_wave_barrier();
-                if (__ballot(hit)) return flags | FP_FLAG_COLLISION;
+                const unsigned long long hm = __ballot(hit);
+                if (hm) {
+                    if (lane == __ffsll((long long)hm) - 1) {  // remember the pair for the ego's next trajectories
+                        const int pos = atomicAdd(&L.hot[kHot], 1);
+                        if (pos < kHot) L.hot[pos] = hit_e;
+                    }
+                    return flags | FP_FLAG_COLLISION;
+                }
             }
         }
         return flags;
@@ -741,7 +775,7 @@ __host__ __device__ constexpr int refine_spline_off() { return kRefineS + 3 * FP
 __host__ __device__ constexpr int refine_pt_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
 __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
 {
-    return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 2 * kQueue;
+    return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 2 * kQueue + 4 * (kHot + 4);
 }
 
 #ifndef FP_REFINE_OCC
@@ -785,13 +819,15 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     }
     const int f = bt.frame_of[b];
     const int nx = bt.nx[f];
-    const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 2 * kQueue;
+    const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 2 * kQueue - 4 * (kHot + 4);
     RefineLds L;
     L.S = (double*)smem;
     L.xy = (double2*)(L.S + kRefineS) + wave * FP_MAX_POINTS;  // one Cartesian scratch row per wavefront
     L.xyf = (float2*)(L.S + kRefineS + 2 * FP_MAX_POINTS * kRefineWaves) + wave * FP_MAX_POINTS;
     L.knots = L.S + refine_spline_off();
     L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * kQueue;
+    L.hot = (int*)(smem + verdict_off + 32 + kRefineWaves * 2 * kQueue);  // [kHot] pairs + [1] count
+    if (tid == 0) L.hot[kHot] = 0;  // (the barrier behind the rounds orders it before the first validation)
     L.coef = L.knots + nx;
     // Order of the prologue: wavefront 0 runs the refinement rounds (they only need the ego state: the power sums of a probe's
     // horizon come in closed form) WHILE wavefronts 1..3 stage the spline and the pair table; then the candidate list goes through
