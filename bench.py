@@ -215,10 +215,18 @@ def timed_run(torch, workloads, steps, warmup, stream, barrier, ev_every=None):
     return elapsed, [a.elapsed_time(b) for a, b in ev]
 
 
-def roofline_obj(bytes_launch, kern_ms, kernel, traffic=None, note=None):
+def roofline_obj(bytes_launch, kern_ms, kernel, traffic=None, note=None, fp64=None):
+    """The contract's roofline object for the HBM bound (north_star asks for HBM GB/s) and, when the PMC pass of this build is at hand,
+    the bound that actually binds: executed FP64 VALU work against the vector FP64 peak.  `binding` names which of the two is closer
+    to its roof; the top-level keys stay the HBM figures the contract defines."""
     ach = bytes_launch / (kern_ms * 1e-3) / 1e9
-    o = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-         "kernel": kernel, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch}
+    hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+           "algorithmic_bytes_per_launch": bytes_launch}
+    o = {"bound": "hbm", **hbm, "kernel": kernel, "kernel_ms": kern_ms}
+    if fp64:
+        o["binding"] = "valu_fp64" if fp64["frac"] > hbm["frac"] else "hbm"
+        o["hbm"] = dict(hbm)
+        o["valu_fp64"] = fp64
     if note:
         o["note"] = note
     return o
@@ -300,6 +308,28 @@ def fop_parity(leg, batch, egos, g_idx, g_cost, threads):
         parity_fail(leg, f"best cost differs by {err:.3e}")
     return {"checked_egos": int(len(egos)), "index_exact": True, "max_abs_cost_err": err, "cost_tolerance": COST_TOL,
             "egos_with_a_winner": int(ok.sum()), "oracle": "oracle/libfrenet_oracle.so orc_fop_plan"}
+
+
+def tables_parity(leg, batch, egos, g_cost_tbl, g_flag_tbl, g_stats):
+    """The per-candidate outputs SURVEY 8(d)'s metric counts - cost_tbl / flag_tbl rows and Stats - of `egos` against the oracle:
+    every flag word (feasibility bits, N, M) exact, every cost within the tolerance."""
+    from oracle import oracle as O
+
+    egos = np.asarray(egos)
+    ref = [pr.fop_plan() for pr in O.problems_from_batch(batch, egos)]
+    r_flags, r_cost = np.stack([r.flags for r in ref]), np.stack([r.cost for r in ref])
+    r_stats = np.stack([r.stats for r in ref])
+    if not np.array_equal(g_flag_tbl[egos], r_flags):
+        bad = np.argwhere(g_flag_tbl[egos] != r_flags)[:4]
+        parity_fail(leg, f"flag words differ at (ego, candidate) {[(int(egos[a]), int(c)) for a, c in bad]}")
+    both = np.isfinite(r_cost)
+    err = float(np.abs(g_cost_tbl[egos][both] - r_cost[both]).max())
+    if not err <= COST_TOL or not np.array_equal(np.isnan(g_cost_tbl[egos]), np.isnan(r_cost)):
+        parity_fail(leg, f"cost table differs by {err:.3e}")
+    if not np.array_equal(g_stats[egos], r_stats):
+        parity_fail(leg, "Stats differ")
+    return {"checked_egos": int(len(egos)), "checked_candidates": int(r_flags.size), "flag_words_exact": True, "stats_exact": True,
+            "max_abs_cost_err": err, "cost_tolerance": COST_TOL, "oracle": "oracle/libfrenet_oracle.so orc_fop_plan (per-candidate tables)"}
 
 
 def fiss_parity(leg, wl, egos):
@@ -657,6 +687,59 @@ def main():
         eng.set_option("lattice_order", 1)
         extras["lattice_order_on"] = {"launches_of_the_main_run": launches, "of_them_in_feedback_order": ordered,
                                       "note": f"the main run cycles {n_rot} distinct batches, so an order is always one learnt on a DIFFERENT batch"}
+        # (a2) what SURVEY 8(d)'s metric definition counts in full: the per-candidate cost / flag tables written (12 B per candidate) and
+        # the Stats brought to the host every step, next to index / cost / series as in the headline
+        wt = [Workload(torch, eng, w.batch, dev, stream, tables=True) for w in wls]
+        h_stats = [torch.empty((B, 4), dtype=torch.int32).pin_memory() for _ in wt]
+        for w, hs in zip(wt, h_stats):
+            w.fetch = (lambda w=w, hs=hs: hs.copy_(w.stats, non_blocking=True))  # stats D2H on the launch stream, every step
+        ot = measure(wt, "lattice_fused_kernel (tables written) + winner_traj_kernel")
+        ot["what"] = "the headline workload with cost_tbl + flag_tbl written to HBM (tables_written: true) and stats fetched to pinned host memory every step"
+        ot["tables_written"] = True
+        if args.cpu_seconds > 0:
+            wt[0].step(); torch.cuda.synchronize(dev)
+            ot["parity"] = tables_parity("tables_written", wt[0].batch, np.arange(0, B, max(1, B // 48)), wt[0].cost_tbl.cpu().numpy(),
+                                         wt[0].flag_tbl.cpu().numpy().view(np.uint32), wt[0].stats.cpu().numpy())
+        extras["tables_written"] = ot
+        del wt, h_stats
+        # (a3) the resident sharded entry point (ShardedEngine.upload + plan_dense on resident shards): the same four batches, one shard
+        # on this GPU, enqueue-only calls; must sit within a few percent of the headline (it is the same launches behind one more
+        # Python layer)
+        from fiss_plus_planner_amd.sharded import ShardedEngine
+        with ShardedEngine(devices=[local_rank]) as seng:
+            sdbs = [seng.upload(w.batch, winner=True) for w in wls]
+            for k in range(warm_x):
+                seng.plan_dense(sdbs[k % len(sdbs)], winner=True, sync=False)
+            for sd in sdbs:
+                sd.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps_x):
+                seng.plan_dense(sdbs[(warm_x + k) % len(sdbs)], winner=True, sync=False)
+            for sd in sdbs:
+                sd.synchronize()
+            el = time.perf_counter() - t0
+            osr = {"value": float(np.mean([w.candidates for w in wls])) * steps_x / el, "unit": "candidates/s", "ms_per_step": el / steps_x * 1e3,
+                   "steps": steps_x, "warmup": warm_x, "shards": seng.world,
+                   "what": "ShardedEngine(devices=[0]).upload(batch) once per batch, then plan_dense(resident shards, winner=True, sync=False) per step"}
+            osr["vs_headline"] = osr["ms_per_step"] / (elapsed / args.steps * 1e3)
+            if args.cpu_seconds > 0:
+                seng.plan_dense(sdbs[-1], winner=True)
+                osr["parity"] = fop_parity("sharded_resident", wls[-1].batch, np.arange(0, B, max(1, B // 64)), sdbs[-1].host.best_idx, sdbs[-1].host.best_cost, gate_threads)
+            extras["sharded_resident"] = osr
+            del sdbs
+        # (a4) BASELINE configs[4] on ONE GPU: all 16 384 egos in one launch (21 rounds of workgroups: the tail of the last round
+        # amortised over eight times the work of the headline launch)
+        if B == 2048:
+            b5 = synth.make_config(5, layout=args.layout)
+            w5 = Workload(torch, eng, b5, dev, stream)
+            steps_keep, steps_x = steps_x, min(steps_x, 12)
+            o5 = measure([w5], "lattice_fused_kernel + winner_traj_kernel, 16384 egos in one launch", ev_every=1)
+            steps_x = steps_keep
+            o5["workload"] = f"BASELINE.json configs[4] on one GPU: {b5.B} egos x 9x9x7, 50 dynamic obstacles (the 8-GPU configuration's whole batch)"
+            o5["parity"] = gate("config5_single_gpu", w5, 96)
+            extras["config5_single_gpu"] = o5
+            del w5, b5
         # (b) BASELINE configs[1]: 256 egos x 5x5x5 x 10 static obstacles; parity on ALL egos
         b2 = synth.make_config(2, layout=args.layout)
         w2 = Workload(torch, eng, b2, dev, stream)
@@ -748,7 +831,7 @@ def main():
         # executed VALU work of the dominant kernel from the committed PMC pass (a property of kernel + input, not of the run);
         # the rates use this run's kernel time
         valu_issue = fp64_exec = None
-        pmc = load_profile_json(f"r03_config3_{args.layout}_pmc_summary.json")
+        pmc = load_profile_json(f"r04_config3_{args.layout}_pmc_summary.json")  # (collected on THIS build: profiles/README.md)
         if pmc and not fiss and config == 3 and B == 2048:
             try:
                 k = next(v for kk, v in pmc.items() if "lattice_fused" in kk)
@@ -756,11 +839,13 @@ def main():
                 peak = 256 * 4 * 2.4e9 / 4.0
                 valu_issue = {"wave_instructions_per_launch": insts, "rate": insts / (kern_ms * 1e-3), "peak": peak,
                               "unit": "wave-instructions/s", "frac": insts / (kern_ms * 1e-3) / peak,
-                              "source": "SQ_INSTS_VALU from profiles/r03_config3_*_pmc_summary.json (rocprofv3 --pmc), this run's kernel time; "
+                              "source": "SQ_INSTS_VALU from profiles/r04_config3_*_pmc_summary.json (rocprofv3 --pmc, this build), this run's kernel time; "
                                         "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
                 flops = 64.0 * (2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_TRANS_F64"])
-                fp64_exec = {"executed_flops_per_launch": flops, "rate": flops / (kern_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                             "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                fp64_exec = {"executed_flops_per_launch": flops, "achieved": flops / (kern_ms * 1e-3) / 1e12, "rate": flops / (kern_ms * 1e-3) / 1e12,
+                             "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                             "fp64_share_of_valu_instructions": (k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] +
+                                                                 k["SQ_INSTS_VALU_TRANS_F64"]) / insts,
                              "source": "64 lanes x (2 FMA + MUL + ADD + TRANS) wave-level FP64 instructions from the same PMC pass (inactive lanes counted: upper bound)"}
             except Exception:
                 valu_issue = fp64_exec = None
@@ -780,7 +865,8 @@ def main():
                        "input_digest": batch.digest()[:16], "input_digests": [w.batch.digest()[:16] for w in wls]},
             "parity": parity_main,
             "roofline": roofline_obj(bytes_launch, kern_ms, kname, traffic,
-                                     "the kernel is VALU-issue bound, not HBM bound: see valu_issue / valu_fp64_executed (PMC instruction counts)"),
+                                     "the kernel is VALU-issue bound, not HBM bound: `binding` / `valu_fp64` carry the executed FP64 work of the PMC pass "
+                                     "of this build (profiles/r04_*), `valu_issue` the instruction issue rate", fp64_exec),
             "host_enqueue_ms_per_step": enqueue_ms,
             "kernel_ms_stats": {"mean": kern_ms, "min": float(np.min(kern_list)), "median": float(np.median(kern_list)), "max": float(np.max(kern_list)),
                                 "launches_timed": len(kern_list)},

@@ -37,7 +37,7 @@ def _rows(ns: SimpleNamespace, lo: int, hi: int) -> SimpleNamespace:
 class ShardedDeviceBatch:
     """A problem batch cut into contiguous ego ranges and uploaded ONCE: shard r's rows of every per-ego array, and the frame /
     scene tables its egos reference, live in the HBM of shard r's device (`device_batch.DeviceBatch`), next to the shard's output
-    buffers; every shard owns a HIP stream.  Per-ego results (index, cost, Stats, flag word; the FISS arrays) land in PINNED host
+    buffers; every shard of the ENGINE owns one HIP stream, shared by all batches uploaded to it.  Per-ego results (index, cost, Stats, flag word; the FISS arrays) land in PINNED host
     arrays covering the whole batch - rank r's slice is written by rank r only, nothing is gathered or concatenated, no collective.
     Shards on one device write those results straight through the device mapping of the pinned block (no copy command on the
     stream); with several devices every shard brings its packed results home with one asynchronous copy.  Big outputs (dense
@@ -73,7 +73,9 @@ class ShardedDeviceBatch:
             with torch.cuda.device(dev):
                 db = DeviceBatch(sb, dev)
                 n = hi - lo
-                sh = SimpleNamespace(rank=r, lo=lo, hi=hi, engine=eng.engines[r], db=db, stream=torch.cuda.Stream(torch.device("cuda", dev)))
+                # the stream belongs to the SHARD (one fp_ctx = one stream at a time, include/frenet_gpu.h): every batch uploaded to
+                # this engine enqueues on it, so calls on different resident batches of one shard stay in order
+                sh = SimpleNamespace(rank=r, lo=lo, hi=hi, engine=eng.engines[r], db=db, stream=eng.shard_stream(r))
                 d = torch.device("cuda", dev)
                 sh.cost_tbl = torch.empty((n, batch.C), dtype=f64, device=d) if tables else None
                 sh.flag_tbl = torch.empty((n, batch.C), dtype=i32, device=d) if tables else None
@@ -138,6 +140,15 @@ class ShardedEngine:
         self._pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="frenet-shard")
 
     world = property(lambda self: len(self.engines))
+
+    def shard_stream(self, r: int):
+        """The HIP stream (torch handle) shard r's resident calls enqueue on; created on first use, one per shard for the engine's life."""
+        streams = self.__dict__.setdefault("_streams", {})
+        if r not in streams:
+            import torch
+
+            streams[r] = torch.cuda.Stream(torch.device("cuda", self.devices[r]))
+        return streams[r]
 
     def close(self):
         pool, self._pool = getattr(self, "_pool", None), None

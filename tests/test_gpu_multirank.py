@@ -61,6 +61,14 @@ def test_bench_single_gpu_line_has_every_configuration():
         assert line[key]["value"] > 0 and 0 < line[key]["roofline"]["frac"] < 1, key
         assert line[key]["parity"]["index_exact"] and line[key]["parity"]["max_abs_cost_err"] <= 1e-6, key
     assert line["config2"]["parity"]["checked_egos"] == 256
+    # SURVEY 8(d)'s full metric: per-candidate tables written + Stats fetched; the resident sharded entry point; configs[4] on one GPU
+    tw = line["tables_written"]
+    assert tw["tables_written"] and tw["value"] > 0 and tw["parity"]["flag_words_exact"] and tw["parity"]["stats_exact"]
+    assert tw["parity"]["max_abs_cost_err"] <= 1e-6 and tw["parity"]["checked_candidates"] >= 40 * 567
+    sr = line["sharded_resident"]
+    assert sr["value"] > 0 and sr["parity"]["index_exact"] and 0.5 < sr["vs_headline"] < 1.3
+    c5 = line["config5_single_gpu"]
+    assert c5["value"] > 0 and c5["parity"]["index_exact"] and "16384" in c5["workload"]
     assert line["config4"]["parity"]["stats_exact"] and line["config4"]["parity"]["checked_egos"] >= 64
     assert set(line["config4"]["stage_ms"]) == {"lattice_fused_kernel (dense tables)", "fissplus_search_kernel",
                                                 "fiss_refine_kernel (3 rounds + validation + winner series)"}
