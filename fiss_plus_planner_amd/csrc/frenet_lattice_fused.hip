@@ -597,7 +597,12 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         }
     }
     // [section MASKS]
+#if defined(FP_ABL_NO_SCAN)  // timing ablation: no point-by-point mask scan (results are wrong)
+    const uint32_t scan_mask = 0u;
+#else
     const uint32_t scan_mask = (uint32_t)s_cnt[2];
+#endif
+    if (tid == 0) FP_COUNT(9, __popc(scan_mask));
     for (int it = it_lo; it < it_hi; ++it) {
         if (!((scan_mask >> ((it - it_lo) & 31)) & 1u)) continue;  // every lon profile of the slice is proven clean
         const int N = arange_len(s_ts[it], tick);

@@ -43,4 +43,4 @@ if os.environ.get("FP_SLICE_LOOP"):  # the counters of the older slice-loop buil
 print(f"config {config}, layout {layout}: per ego, {B} egos")
 for k, n in enumerate(names):
     print(f"  {n:40s} mean {c[:, k].mean():9.1f}  median {np.median(c[:, k]):9.1f}  p90 {np.percentile(c[:, k], 90):9.1f}  max {c[:, k].max():9.0f}")
-print("  first-collision marks by pose index (k // 8):", np.round(c[:, 8:16].mean(axis=0), 1).tolist())
+print("  slices whose lon profiles needed the point-by-point mask scan: mean", round(float(c[:, 9].mean()), 2), "of", batch.nt)
