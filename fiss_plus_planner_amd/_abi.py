@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 10
+FP_ABI_VERSION = 11
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND = 128, 512, 4096
@@ -27,7 +27,7 @@ _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option", "fp_ctx_get_option",
-                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_frames_build", "fp_from_state", "fp_materialize_all")
+                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_plan_step", "fp_frames_build", "fp_from_state", "fp_materialize_all")
 
 
 class FpParams(C.Structure):
@@ -65,10 +65,11 @@ class FpFissIo(C.Structure):
 
 
 class FpLoopIo(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ego", "t_now", "done", "cycles", "goal_xy", "cart_state")]
+    _fields_ = [(n, C.c_void_p) for n in ("ego", "t_now", "done", "cycles", "goal_xy", "cart_state", "goal_poly", "goal_nv", "goal_intervals")] + \
+               [("goal_max_vertices", C.c_int32), ("reserved0", C.c_int32)]
 
 
-RUNNING, DONE_GOAL, DONE_END_OF_LINE, DONE_NO_SOLUTION = 0, 1, 2, 3
+RUNNING, DONE_GOAL, DONE_END_OF_LINE, DONE_NO_SOLUTION, DONE_GOAL_REGION = 0, 1, 2, 3, 4
 
 
 class FrenetGpuError(RuntimeError):
@@ -112,6 +113,7 @@ def load() -> C.CDLL:
                                 C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
     L.fp_plan_fiss.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpFissOpts), C.POINTER(FpFissIo), C.c_int, C.c_void_p]
     L.fp_advance.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.POINTER(FpLoopIo), C.c_int, C.c_void_p]
+    L.fp_plan_step.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpResult), C.POINTER(FpLoopIo), C.c_int, C.c_void_p]
     L.fp_frames_build.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fp_from_state.argtypes = [C.c_void_p, C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fp_materialize_all.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p]

@@ -1166,6 +1166,7 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
     FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if ((best_idx == nullptr) == (end_state == nullptr)) return fail(FP_EINVAL, "exactly one of best_idx / end_state must be given");
     if (!io || !io->ego || !io->t_now || !io->done || !io->cycles || !io->goal_xy) return fail(FP_EINVAL, "fp_loop_io has a NULL mandatory array");
+    if (io->goal_poly && (!io->goal_nv || io->goal_max_vertices < 3)) return fail(FP_EINVAL, "fp_loop_io.goal_poly needs goal_nv and goal_max_vertices >= 3");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t B = (size_t)batch->B;
@@ -1179,8 +1180,9 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
     }
     FP_TRY(check_batch_host(params, batch));
     HostStage hs(ctx);
-    FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<double>(B * 6) + 4 * HostStage::need<int32_t>(B) + HostStage::need<double>(B * 2) +
-                      2 * HostStage::need<double>(B * 3)));
+    const size_t goal_v = io->goal_poly && io->goal_max_vertices >= 3 ? (size_t)io->goal_max_vertices : 0;
+    FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<double>(B * 6) + 5 * HostStage::need<int32_t>(B) + HostStage::need<double>(B * 2) +
+                      2 * HostStage::need<double>(B * 3) + HostStage::need<double>(B * goal_v * 2) + HostStage::need<double>(B * 6)));
     FP_TRY(stage_batch(hs, params, batch, &ka.b));
     fp_loop_io dio = *io;
     FP_TRY(hs.in_mut(io->ego, B * 6, &dio.ego));
@@ -1188,6 +1190,13 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
     FP_TRY(hs.in_mut(io->done, B, &dio.done));
     FP_TRY(hs.in_mut(io->cycles, B, &dio.cycles));
     FP_TRY(hs.in(io->goal_xy, B * 2, &dio.goal_xy));
+    if (io->goal_poly && io->goal_nv && io->goal_max_vertices >= 3) {
+        FP_TRY(hs.in(io->goal_poly, B * (size_t)io->goal_max_vertices * 2, &dio.goal_poly));
+        FP_TRY(hs.in(io->goal_nv, B, &dio.goal_nv));
+        if (io->goal_intervals) FP_TRY(hs.in(io->goal_intervals, B * 6, &dio.goal_intervals));
+    } else {
+        dio.goal_poly = nullptr;
+    }
     const int32_t* d_idx = nullptr;
     const double* d_es = nullptr;
     if (best_idx) FP_TRY(hs.in(best_idx, B, &d_idx));
@@ -1197,6 +1206,65 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
     if (dio.cart_state) HIP_TRY(hipMemsetAsync(dio.cart_state, 0xFF, sizeof(double) * B * 3, ctx->stream));  // NaN for egos that do not move
     LAUNCH_TRY(fp::launch_advance(ka, d_idx, d_es, dio, ctx->stream), "advance kernel");
     return hs.fetch_out();
+}
+
+int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, const fp_loop_io* io, int mem, void* stream)
+{
+    FP_TRY(common_checks(ctx, params, batch, mem, stream));
+    if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");
+    if (result->best_traj && !result->best_flags) return fail(FP_EINVAL, "result.best_traj requires result.best_flags");
+    if (result->fopplus) return fail(FP_EINVAL, "fp_plan_step plans with FrenetOptimalPlanner's rule: result.fopplus must be NULL");
+    if (!io || !io->ego || !io->t_now || !io->done || !io->cycles || !io->goal_xy) return fail(FP_EINVAL, "fp_loop_io has a NULL mandatory array");
+    if (io->goal_poly && (!io->goal_nv || io->goal_max_vertices < 3)) return fail(FP_EINVAL, "fp_loop_io.goal_poly needs goal_nv and goal_max_vertices >= 3");
+    if (batch->B == 0) return FP_OK;
+    if (mem != FP_MEM_DEVICE) {
+        // host buffers: the two staged calls (every array travels anyway; the fused launch is for resident loops)
+        fp_batch bb = *batch;
+        bb.skip = io->done;
+        FP_TRY(fp_plan_dense(ctx, params, &bb, result, mem, stream));
+        return fp_advance(ctx, params, batch, result->best_idx, nullptr, io, mem, stream);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch->B;
+    fp::KernelArgs ka;
+    ka.p = *params;
+    ka.b = *batch;
+    ka.b.skip = io->done;
+    if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
+    ka.r = *result;
+    FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
+    int nsplit, group, tail; void* parts;
+    FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
+    const int* perm; int* dur;
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
+    // the hand-over rides in the lattice launch unless that launch cannot write the series it is asked for itself (the standalone
+    // epilogue reads the ego's state, so it has to run BEFORE the state moves on) or the lane-per-candidate kernel is asked for
+    const bool series_elsewhere = result->best_traj && !winner_inside_lattice(ctx, batch);
+    bool try_fused = !series_elsewhere && ctx->lattice_kernel != 1, launched = false, fused = false;
+    bool winner_done = false;
+    if (try_fused) {
+        fp::KernelArgs kl = ka;
+        kl.loop = *io;
+        kl.has_loop = 1;
+        hipError_t e = fp::launch_lattice_fused(kl, (hipStream_t)stream, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail, &fused);
+        if (e == hipErrorInvalidValue) {  // the problem does not fit the fused kernel
+            (void)hipGetLastError();
+        } else if (e != hipSuccess) {
+            return fail(FP_EHIP, "lattice kernel: %s", hipGetErrorString(e));
+        } else {
+            launched = true;  // (fused: the instance handed the egos over itself; else advance_kernel follows below)
+        }
+    }
+    if (!launched) {
+        if (series_elsewhere) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
+        fp::KernelArgs kl = ka;
+        if (series_elsewhere) kl.r.best_traj = nullptr;
+        LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");
+    }
+    FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
+    if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
+    if (!fused) LAUNCH_TRY(fp::launch_advance(ka, ka.r.best_idx, nullptr, *io, (hipStream_t)stream), "advance kernel");
+    return FP_OK;
 }
 
 int fp_frames_build(fp_ctx* ctx, int32_t F, int32_t NX, const int32_t* n, const double* points, double* knots, double* coef, int mem,

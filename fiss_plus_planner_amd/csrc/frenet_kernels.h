@@ -48,6 +48,10 @@ struct KernelArgs {
     // best_idx may be device-mapped HOST memory (bench.py's results need no copy that way), where the epilogue's first read costs
     // the link's round trip (winner kernel 10.9 -> 9.2 us on BASELINE configs[2])
     int32_t* idx_shadow = nullptr;
+    // fp_plan_step (fused lattice kernel only): the workgroup that finds an ego's argmin also hands the ego over to its next state
+    // (advance_ego, frenet_advance.h) - has_loop != 0: `loop` holds the caller's fp_loop_io (device addresses), b.skip = loop.done
+    fp_loop_io loop = {};
+    int has_loop = 0;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel
@@ -98,8 +102,11 @@ constexpr size_t kTicketBytes = 64 * 1024;
 // tail (needs part_scratch, nsplit == 1): the last `tail` dispatch slots of a multi-round launch are cut in two workgroups each (the
 // launch's tail drains faster); < 0: auto for a device of -tail compute units (a quarter of a round of resident workgroups, only when the
 // launch has more egos than stay resident); 0: off.
+// *step_done (optional, ka.has_loop set): the launched instance hands the egos over to their next states itself (fp_plan_step); false:
+// the caller launches advance_kernel behind it.
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done = nullptr,
-                                const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0);
+                                const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0,
+                                bool* step_done = nullptr);
 int lattice_group_fit(const fp_params& p, const fp_batch& b);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Curvature flags of every lattice candidate -> out [B][C] (one workgroup per ego, one lane per candidate, spline in LDS).

@@ -12,6 +12,7 @@
 #include "frenet_device.h"
 #include "frenet_kernels.h"
 #include "frenet_winner.h"
+#include "frenet_advance.h"
 
 namespace fp {
 
@@ -567,74 +568,7 @@ __global__ void advance_kernel(KernelArgs ka, const int32_t* best_idx, const dou
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= ka.b.B) return;
-    if (io.done[b] != FP_RUNNING) return;
-    const fp_params& p = ka.p;
-    const fp_batch& bt = ka.b;
-    const double nan = __builtin_nan("");
-    double d_end = nan, v_end = nan, T = nan;
-    if (end_state) {
-        d_end = end_state[(size_t)b * 3]; v_end = end_state[(size_t)b * 3 + 1]; T = end_state[(size_t)b * 3 + 2];
-    } else {
-        const int best = best_idx[b];
-        if (best >= 0) {
-            const int iv = best % p.nv, it = (best / p.nv) % p.nt, id = best / (p.nv * p.nt);
-            d_end = bt.d_samples[id]; v_end = bt.v_samples[(size_t)b * p.nv + iv]; T = bt.t_samples[it];
-        }
-    }
-    if (!(T == T) || !(d_end == d_end) || !(v_end == v_end)) {  // plan() returned None (:131-133)
-        io.done[b] = FP_DONE_NO_SOLUTION;
-        return;
-    }
-    double* eg = io.ego + (size_t)b * 6;
-    const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
-    const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], v_end, 0.0, T);
-    const int f = bt.frame_of[b];
-    const int nx = bt.nx[f];
-    const double* knots = bt.knots + (size_t)f * bt.NX;
-    SplineLds sp{knots, bt.coef + (size_t)f * 8 * bt.NX, nx, bt.NX};
-    // points 0, 1, 2 of the trajectory: state_at_time_step(1) needs x[1], y[1], yaw[1] (:135)
-    double xs[3], ys[3], st[3][8];
-    int M = 3;
-    const int N = arange_len(T, p.tick_t);
-    for (int i = 0; i < 3; ++i) {
-        const double t = (double)i * p.tick_t;
-        quartic_eval(lon, t, st[i][0], st[i][1], st[i][2], st[i][3]);
-        quintic_eval(lat, t, st[i][4], st[i][5], st[i][6], st[i][7]);
-        const int seg = (i < N) ? spline_segment(sp, st[i][0], -1) : -1;
-        if (seg < 0) { M = i; break; }
-        double px, py, tx, ty;
-        spline_frame(sp, seg, st[i][0] - knots[seg], px, py, tx, ty);
-        frenet_to_cartesian(px, py, tx, ty, st[i][4], xs[i], ys[i]);
-    }
-    if (M < 2) {  // the reference indexes x[1] of a trajectory that left the spline at once: IndexError -> the run ends
-        io.done[b] = FP_DONE_NO_SOLUTION;
-        return;
-    }
-    // yaw[1]: forward difference, or the repeated last heading when point 2 is off the spline (:127-129)
-    const double yaw = (M >= 3) ? atan2(ys[2] - ys[1], xs[2] - xs[1]) : atan2(ys[1] - ys[0], xs[1] - xs[0]);
-    eg[0] = st[1][0]; eg[1] = st[1][1]; eg[2] = st[1][2];
-    eg[3] = st[1][4]; eg[4] = st[1][5]; eg[5] = st[1][6];
-    io.t_now[b] += 1;
-    io.cycles[b] += 1;
-    if (io.cart_state) {
-        io.cart_state[(size_t)b * 3] = xs[1]; io.cart_state[(size_t)b * 3 + 1] = ys[1]; io.cart_state[(size_t)b * 3 + 2] = yaw;
-    }
-    // stop rules (:154-161); the end of the map is the last point of np.arange(0, s_last, 0.1)
-    const double gx = io.goal_xy[(size_t)b * 2], gy = io.goal_xy[(size_t)b * 2 + 1];
-    if (hypot(xs[1] - gx, ys[1] - gy) <= 0.5 * p.veh_l) {
-        io.done[b] = FP_DONE_GOAL;
-        return;
-    }
-    const double s_last = knots[nx - 1];
-    int n_ref = (int)ceil(s_last / 0.1);
-    if (n_ref < 1) n_ref = 1;
-    const double s_ref = (double)(n_ref - 1) * 0.1;
-    const int seg = spline_segment(sp, s_ref, -1);
-    if (seg >= 0) {
-        double px, py, tx, ty;
-        spline_frame(sp, seg, s_ref - knots[seg], px, py, tx, ty);
-        if (hypot(xs[1] - px, ys[1] - py) <= 3.0) io.done[b] = FP_DONE_END_OF_LINE;
-    }
+    advance_ego(ka, b, best_idx ? best_idx[b] : -1, end_state, io);
 }
 
 hipError_t launch_advance(const KernelArgs& ka, const int32_t* best_idx, const double* end_state, const fp_loop_io& io, hipStream_t stream)

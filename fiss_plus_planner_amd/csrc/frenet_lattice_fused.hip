@@ -37,6 +37,7 @@
 #include "frenet_device.h"
 #include "frenet_kernels.h"
 #include "frenet_winner.h"
+#include "frenet_advance.h"
 
 namespace fp {
 
@@ -1340,8 +1341,17 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
 #if defined(FP_ABL_NO_WINNER)
     return;
 #endif
+    // fp_plan_step: the ego's hand-over to its next state (point 1 of the winner, stop rules) by the thread that published the argmin -
+    // after the series below where this workgroup writes them (they describe the trajectory from the OLD state).  Every other
+    // workgroup of the ego (latency mode, tail split) has read the state before it posted its partial argmin.
+    // (The three-workgroup instances never do it: the hand-over needs ~110 registers - atan2, hypot, the spline search through global
+    // memory - against their 80, and an instance that spills there also changes its code elsewhere; their launcher reports it and
+    // advance_kernel follows the launch.)
     if constexpr (OCC > 4) return;  // (this variant is only launched when the series come from winner_traj_kernel)
-    if (!ka.r.best_traj) return;
+    if (!ka.r.best_traj) {
+        if (ka.has_loop && tid == 0) advance_ego(ka, b, s_best[0].idx, nullptr, ka.loop);
+        return;
+    }
     __syncthreads();
     if (wave != 0) return;
     const int win = s_best[0].idx;
@@ -1353,6 +1363,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     }
     winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp, eg);
     FP_STAMP_LAST(6);
+    if (ka.has_loop && tid == 0) advance_ego(ka, b, win, nullptr, ka.loop);
 }
 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the lane-per-candidate kernel).
@@ -1392,8 +1403,9 @@ int lattice_group_fit(const fp_params& p, const fp_batch& b)
 }
 
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
-                                int group, const InlineIn* inl, int tail)
+                                int group, const InlineIn* inl, int tail, bool* step_done)
 {
+    if (step_done) *step_done = false;
     static const InlineIn kNoInline{};
     const InlineIn& in = inl ? *inl : kNoInline;
     if (winner_done) *winner_done = false;
@@ -1486,6 +1498,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
 #endif
     if (e != hipSuccess) return e;
     if (winner_done) *winner_done = ka.r.best_traj != nullptr && !three;
+    if (step_done) *step_done = ka.has_loop != 0 && !three;  // (ka.has_loop: the two-per-CU instances hand the egos over themselves)
     return hipSuccess;
 }
 

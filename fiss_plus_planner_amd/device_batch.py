@@ -48,9 +48,14 @@ class DeviceBatch:
 class ClosedLoopRunner:
     """[plan -> advance] for a whole batch on the device.  planner: "FOP" (fp_plan_dense) or "FISS"/"FISS+" (fp_plan_fiss)."""
 
-    def __init__(self, engine: FrenetEngine, dbatch: DeviceBatch, goal_xy: np.ndarray, planner: str = "FOP"):
+    def __init__(self, engine: FrenetEngine, dbatch: DeviceBatch, goal_xy: np.ndarray, planner: str = "FOP", fused: bool = True,
+                 goal_poly: np.ndarray | None = None, goal_nv: np.ndarray | None = None, goal_intervals: np.ndarray | None = None):
+        """fused: an FOP cycle is ONE launch (fp_plan_step: the workgroup that finds an ego's argmin advances the ego); False = the two
+        calls fp_plan_dense + fp_advance (same results; the A/B of tests and bench).
+        goal_poly [B, V, 2] + goal_nv [B] (+ goal_intervals [B, 6] = time_step / velocity / orientation lo, hi; NaN = undefined): the
+        goal region of goal_region.is_reached() (planning.py:150-153), see fp_loop_io in include/frenet_gpu.h."""
         torch = dbatch.torch
-        self.eng, self.db, self.planner = engine, dbatch, planner
+        self.eng, self.db, self.planner, self.fused = engine, dbatch, planner, fused
         B = dbatch.B
         i32, f64 = torch.int32, torch.float64
         self.best_idx = dbatch.empty(B, i32)
@@ -65,6 +70,14 @@ class ClosedLoopRunner:
         self.io.ego, self.io.t_now = dbatch.t["ego"].data_ptr(), dbatch.t["t_now"].data_ptr()
         self.io.done, self.io.cycles = self.done.data_ptr(), self.cycles.data_ptr()
         self.io.goal_xy, self.io.cart_state = self.goal.data_ptr(), self.cart.data_ptr()
+        if goal_poly is not None:
+            gp = np.ascontiguousarray(goal_poly, dtype=np.float64).reshape(B, -1, 2)
+            self.goal_poly = torch.from_numpy(gp).to(dbatch.dev)
+            self.goal_nv = torch.from_numpy(np.ascontiguousarray(goal_nv, dtype=np.int32).reshape(B)).to(dbatch.dev)
+            self.io.goal_poly, self.io.goal_nv, self.io.goal_max_vertices = self.goal_poly.data_ptr(), self.goal_nv.data_ptr(), gp.shape[1]
+            if goal_intervals is not None:
+                self.goal_iv = torch.from_numpy(np.ascontiguousarray(goal_intervals, dtype=np.float64).reshape(B, 6)).to(dbatch.dev)
+                self.io.goal_intervals = self.goal_iv.data_ptr()
         if planner != "FOP":
             self.prev = torch.full((B, 3), -1, dtype=i32, device=dbatch.dev)
             self.ijk = dbatch.empty((B, 3), i32)
@@ -82,7 +95,9 @@ class ClosedLoopRunner:
         import ctypes as C
 
         lib, ctx = self.eng._lib, self.eng._ctx
-        if self.planner == "FOP":
+        if self.planner == "FOP" and self.fused:
+            self.eng.plan_step_device(self.db.params, self.db.fb, self.io, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
+        elif self.planner == "FOP":
             self.eng.plan_dense_device(self.db.params, self.db.fb, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
             _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), self.best_idx.data_ptr(), None, C.byref(self.io),
                                       _abi.FP_MEM_DEVICE, stream or None))

@@ -365,6 +365,16 @@ class FrenetEngine:
         res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
         _abi.check(self._lib.fp_plan_dense(self._ctx, C.byref(params), C.byref(fb), C.byref(res), _abi.FP_MEM_DEVICE, stream or None))
 
+    def plan_step_device(self, params: _abi.FpParams, fb: _abi.FpBatch, io: _abi.FpLoopIo, best_idx: int, best_cost: int, stats: int = 0,
+                         stream: int = 0, best_flags: int = 0, best_traj: int = 0, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+        """One cycle of the simulation loop (planning.py:120-162) for every running ego in ONE launch (fp_plan_step): the dense FOP
+        pass, and the workgroup that finds an ego's argmin hands the ego over to its next state.  Device addresses throughout."""
+        res = _abi.FpResult()
+        res.best_idx, res.best_cost, res.stats = best_idx, best_cost, stats or None
+        res.best_flags, res.best_traj = best_flags or None, best_traj or None
+        res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
+        _abi.check(self._lib.fp_plan_step(self._ctx, C.byref(params), C.byref(fb), C.byref(res), C.byref(io), _abi.FP_MEM_DEVICE, stream or None))
+
     def winner_trajs(self, batch: ProblemBatch, best_idx: np.ndarray, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
         """The standalone winner epilogue (fp_winner_trajs): series of lattice candidate best_idx[b] for every ego
         -> best_flags [B], best_traj [B,16,128] (NaN rows and flag 0 where best_idx < 0)."""

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 10
+#define FP_ABI_VERSION 11
 
 /* error codes */
 #define FP_OK 0
@@ -301,14 +301,18 @@ int fp_from_state(fp_ctx* ctx, const fp_batch* batch, const double* states, doub
  * (planners/benchmark/planning.py:131-162): next FrenetState = point 1 of the returned trajectory
  * (frenet.py:185-196), time_step_now += 1, stop when there is no solution (:131-133), when the new position is within
  * l/2 of the goal-lanelet centre (:154-157) or within 3 m of the end of the 0.1 m-resampled reference line (:158-161).
- * (goal_region.is_reached(), :151, needs commonroad's goal geometry and is not evaluated.)
+ * goal_region.is_reached() (:150-153) is evaluated when the caller supplies the goal geometry (goal_poly below); commonroad itself is
+ * not a dependency: the rule is restated from commonroad-io's GoalRegion.is_reached / Shape.contains_point (closed point-in-polygon
+ * test + the optional time-step / velocity / orientation intervals of the goal state).
  * The chosen trajectory is given either as a lattice index (best_idx, FOP order) or as explicit end states
  * (end_state [B][3] = d, v, T; NaN = no solution) - exactly one of the two pointers is non-NULL.
- * Plan + advance can be enqueued back to back on one stream for as many cycles as wanted: no host round trip. */
+ * Plan + advance can be enqueued back to back on one stream for as many cycles as wanted: no host round trip; fp_plan_step does
+ * both in ONE launch. */
 #define FP_RUNNING 0
 #define FP_DONE_GOAL 1
 #define FP_DONE_END_OF_LINE 2
 #define FP_DONE_NO_SOLUTION 3
+#define FP_DONE_GOAL_REGION 4   /* goal_region.is_reached(state)                                      planning.py:150-153 */
 
 typedef struct {
     double* ego;            /* [B][6] in/out  (aliases fp_batch.ego) */
@@ -317,10 +321,30 @@ typedef struct {
     int32_t* cycles;        /* [B]    in/out  number of completed plan cycles */
     const double* goal_xy;  /* [B][2] centre vertex of the goal lanelet                      planning.py:54-58 */
     double* cart_state;     /* NULL or [B][3] out: x, y, yaw of the new state                planning.py:135 */
+    /* Optional goal region (NULL = the rule is skipped, as before ABI 11).  One goal state per ego: its position is a simple polygon
+     * (a lanelet's left bound + reversed right bound, a rectangle's corners, ...; either orientation, closing vertex not repeated),
+     * reached when the new position lies inside or ON the boundary (commonroad's Shape.contains_point is shapely's `intersects`).
+     * goal_intervals (NULL or [B][6]) = the goal state's time_step / velocity / orientation intervals as lo, hi pairs; a NaN bound
+     * means the goal state does not define that attribute.  time_step is compared with the cycle index i = t_now BEFORE the
+     * increment (state.time_step = i, planning.py:138), velocity with s_d, orientation with yaw[1] (closed intervals). */
+    const double* goal_poly;       /* NULL or [B][goal_max_vertices][2] */
+    const int32_t* goal_nv;        /* [B] vertices of the ego's polygon (< 3: this ego has no goal region) */
+    const double* goal_intervals;  /* NULL or [B][6] */
+    int32_t goal_max_vertices;
+    int32_t reserved0;
 } fp_loop_io;
 
 int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, const double* end_state,
                const fp_loop_io* io, int mem, void* stream);
+
+/* fp_plan_step = one cycle of the simulation loop for B egos (planning.py:120-162): fp_plan_dense (FrenetOptimalPlanner.plan) and
+ * fp_advance in ONE launch - the workgroup that finds an ego's argmin hands the ego over to its next state itself (io->ego / t_now /
+ * done / cycles / cart_state updated in place; egos with done != FP_RUNNING are skipped: batch->skip is ignored, io->done is used).
+ * result: as for fp_plan_dense (best_idx / best_cost mandatory; the tables and the winner's series optional - the series describe the
+ * trajectory the ego just left behind).  A problem that does not fit the fused lattice kernel, or a multi-round launch that also asks
+ * for the series, takes the two-launch path (same results).  Identical to fp_plan_dense + fp_advance in every output. */
+int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, const fp_loop_io* io, int mem,
+                 void* stream);
 
 #ifdef __cplusplus
 }

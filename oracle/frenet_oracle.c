@@ -1030,6 +1030,48 @@ static double unify_angle(double a)
     return a;
 }
 
+/* ---- goal_region.is_reached(state) (planners/benchmark/planning.py:150-153) --------------------------------------------------
+   commonroad-io is not a dependency of this repo (and absent from the image: PARITY UNPINNED against the real package); restated
+   from its published GoalRegion.is_reached / Shape.contains_point: a state reaches a goal state when its position lies in the goal
+   shape - shapely `polygon.intersects(Point)`, i.e. inside OR on the boundary - and every attribute the goal state defines
+   (time_step, velocity, orientation: closed intervals) contains the state's value.  Decided exactly: binary128 orientation signs
+   (orient_sign above) and the winding number, an algorithm independent of the kernels' crossing-number test. */
+static int on_segment_exact(const double* a, const double* b, const double* q)
+{
+    if (orient_sign(a, b, q) != 0) return 0;
+    return q[0] >= fmin(a[0], b[0]) && q[0] <= fmax(a[0], b[0]) && q[1] >= fmin(a[1], b[1]) && q[1] <= fmax(a[1], b[1]);
+}
+
+int orc_point_in_polygon_closed(const double* poly, int32_t nv, double x, double y)
+{
+    if (nv < 3 || !(x == x) || !(y == y)) return 0;
+    const double q[2] = {x, y};
+    int wn = 0;
+    for (int i = 0; i < nv; ++i) {
+        const double* a = poly + 2 * i;
+        const double* b = poly + 2 * ((i + 1) % nv);
+        if (on_segment_exact(a, b, q)) return 1;
+        if (a[1] <= y) {
+            if (b[1] > y && orient_sign(a, b, q) > 0) ++wn;   /* upward crossing, q strictly left */
+        } else {
+            if (b[1] <= y && orient_sign(a, b, q) < 0) --wn;  /* downward crossing, q strictly right */
+        }
+    }
+    return wn != 0;
+}
+
+static int in_goal_interval(double v, double lo, double hi) { return (lo != lo || hi != hi) ? 1 : (v >= lo && v <= hi); }
+
+/* intervals (may be NULL): time_step lo, hi, velocity lo, hi, orientation lo, hi; NaN = not defined by the goal state */
+int orc_goal_reached(const double* poly, int32_t nv, const double* intervals, double x, double y, int32_t time_step, double velocity,
+                     double orientation)
+{
+    if (intervals && !(in_goal_interval((double)time_step, intervals[0], intervals[1]) && in_goal_interval(velocity, intervals[2], intervals[3]) &&
+                       in_goal_interval(orientation, intervals[4], intervals[5])))
+        return 0;
+    return orc_point_in_polygon_closed(poly, nv, x, y);
+}
+
 int orc_from_state(const double* state, int32_t n, const double* pl, int32_t ld, double* out)
 {
     double sx = state[0], sy = state[1], syaw = state[2], sv = state[3];

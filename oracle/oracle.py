@@ -76,6 +76,8 @@ def lib():
         L.orc_eval_traj.argtypes = [PP, C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_int32, _ip, _ip, _dp, _up]
         L.orc_dense_tables.argtypes = [PP, _dp, _up]
         L.orc_fop_plan.argtypes = [PP, _ip, _dp, _ip, _dp, _up]
+        L.orc_goal_reached.argtypes = [_dp, C.c_int32, _dp, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_double]
+        L.orc_point_in_polygon_closed.argtypes = [_dp, C.c_int32, C.c_double, C.c_double]
         L.orc_fopplus_plan.argtypes = [PP, _ip, _dp, _ip]
         L.orc_fiss_plan.argtypes = [PP, C.c_double, _ip, _ip, _dp, _ip]
         L.orc_fissplus_plan.argtypes = [PP, C.c_double, C.c_int32, C.c_double, _ip, _ip, _dp, _ip, _ip, _dp, _dp]
@@ -169,6 +171,13 @@ def box_vertices(box):
     out = np.empty(8)
     rc = lib().orc_box_vertices(*[float(v) for v in box], _p(out))
     return None if rc else out.reshape(4, 2)
+
+
+def goal_reached(poly, x, y, time_step=0, velocity=0.0, orientation=0.0, intervals=None):
+    """goal_region.is_reached for one goal state: poly [n, 2], intervals None or [6] (time_step / velocity / orientation lo, hi; NaN = undefined)."""
+    pl = _f64(poly).reshape(-1, 2)
+    iv = None if intervals is None else _f64(intervals).reshape(6)
+    return bool(lib().orc_goal_reached(_p(pl), len(pl), None if iv is None else _p(iv), float(x), float(y), int(time_step), float(velocity), float(orientation)))
 
 
 def from_state(x, y, yaw, v, polyline):

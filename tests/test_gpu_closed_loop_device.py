@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
+from fiss_plus_planner_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -116,3 +117,63 @@ def test_hip_graph_replay_equals_eager_loop(engine, kind, big):
     np.testing.assert_array_equal(a.t_now, b.t_now)
     np.testing.assert_array_equal(a.ego, b.ego)
     assert (a.cycles > 0).any()
+
+
+# ---- fp_plan_step (ABI 11): plan + hand-over in one launch, and the goal region rule
+@pytest.mark.parametrize("B,cfg", [(7, 2), (300, 2), (900, 3)])
+def test_plan_step_equals_plan_dense_plus_advance(engine, B, cfg):
+    """One launch per cycle (the workgroup that finds an ego's argmin advances the ego) == fp_plan_dense + fp_advance, bit for bit, in
+    the latency instances (B = 7), the two-per-CU ones (300) and the three-per-CU ones with their tail split (900)."""
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+
+    goal = np.full((B, 2), 1e9)
+    runs = []
+    for fused in (False, True):
+        batch = synth.make_config(cfg, B=B)
+        runs.append(ClosedLoopRunner(engine, DeviceBatch(batch, 0), goal, "FOP", fused=fused).run(9, trace=True))
+    a, b = runs
+    for k in ("done", "cycles", "t_now"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k), err_msg=k)
+    assert np.array_equal(a.ego, b.ego) and np.array_equal(a.cart, b.cart, equal_nan=True)
+    assert len(a.trace) == len(b.trace) and a.cycles.sum() > B
+    for ra, rb in zip(a.trace, b.trace):
+        assert np.array_equal(ra.cost, rb.cost, equal_nan=True) and np.array_equal(ra.done, rb.done) and np.array_equal(ra.stats, rb.stats)
+
+
+def test_goal_region_rule_against_the_oracle(oracle, engine):
+    """goal_region.is_reached() on the device (fp_loop_io.goal_poly / goal_intervals) against the oracle's exact predicate: every ego
+    gets a polygon placed around, beside or exactly ON the position it reaches after one cycle, with and without intervals."""
+    from fiss_plus_planner_amd import _abi
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+
+    B = 240
+    goal = np.full((B, 2), 1e9)
+    free = ClosedLoopRunner(engine, DeviceBatch(synth.make_config(2, B=B), 0), goal, "FOP").run(1)   # where every ego lands
+    moved = free.cycles == 1
+    assert moved.sum() > B // 3
+    rng = np.random.default_rng(8)
+    V = 6
+    poly = np.zeros((B, V, 2)); nv = np.zeros(B, dtype=np.int32); iv = np.full((B, 6), np.nan)
+    for b in range(B):
+        x, y = (free.cart[b, 0], free.cart[b, 1]) if moved[b] else (0.0, 0.0)
+        kind = b % 6
+        w = 2.0 ** rng.integers(-2, 3)          # dyadic sizes: "on the boundary" is exact in fp64
+        if kind == 0:    ring = [[x - w, y - w], [x + w, y - w], [x + w, y + w], [x - w, y + w]]                      # around
+        elif kind == 1:  ring = [[x + w, y - w], [x + 3 * w, y - w], [x + 3 * w, y + w], [x + w, y + w]]              # beside
+        elif kind == 2:  ring = [[x, y - w], [x + w, y - w], [x + w, y + w], [x, y + w]]                              # position ON the left edge
+        elif kind == 3:  ring = [[x, y], [x + w, y], [x + w, y + w], [x, y + w]][::-1]                                # ON a vertex, clockwise
+        elif kind == 4:  ring = [[x - w, y - w], [x + w, y - w], [x + w, y + w], [x, y + w], [x, y + w / 2], [x - w, y + w / 2]]  # non-convex, inside
+        else:            ring = [[x - w, y - w], [x + w, y - w], [x + w, y + 2 * w]]                                  # triangle, half a width inside its long edge
+        nv[b] = len(ring)
+        poly[b, :len(ring)] = ring
+        if b % 4 == 1: iv[b, 0:2] = (0, 0)          # the cycle index of the first cycle is 0
+        if b % 4 == 2: iv[b, 0:2] = (1, 5)          # too early
+        if b % 4 == 3: iv[b, 2:4] = (free.ego[b, 1] - 1e-3, free.ego[b, 1] + 1e-3) if b % 8 == 3 else (free.ego[b, 1] + 1.0, free.ego[b, 1] + 2.0)
+    for fused in (True, False):
+        run = ClosedLoopRunner(engine, DeviceBatch(synth.make_config(2, B=B), 0), goal, "FOP", fused=fused, goal_poly=poly, goal_nv=nv, goal_intervals=iv).run(1)
+        np.testing.assert_array_equal(run.cycles, free.cycles)
+        want = np.array([moved[b] and oracle.goal_reached(poly[b, :nv[b]], free.cart[b, 0], free.cart[b, 1], 0, free.ego[b, 1], free.cart[b, 2], iv[b]) for b in range(B)])
+        got = run.done == _abi.DONE_GOAL_REGION
+        np.testing.assert_array_equal(got, want)
+        assert want.sum() > 20 and (moved & ~want).sum() > 20
+        np.testing.assert_array_equal(run.done[~want], free.done[~want])   # the other rules are untouched
