@@ -50,8 +50,11 @@ class FpBatch(C.Structure):
 
 class FpResult(C.Structure):
     _fields_ = [("best_idx", C.c_void_p), ("best_cost", C.c_void_p), ("cost_tbl", C.c_void_p), ("flag_tbl", C.c_void_p),
-                ("stats", C.c_void_p), ("best_flags", C.c_void_p), ("best_traj", C.c_void_p), ("fopplus", C.c_void_p),
+                ("stats", C.c_void_p), ("best_flags", C.c_void_p), ("best_traj", C.c_void_p), ("fopplus", C.c_void_p), ("audit", C.c_void_p),
                 ("traj_stride", C.c_int32), ("traj_sparse", C.c_int32)]
+
+
+AUDIT_NEAR_TIE, AUDIT_CONTACT, AUDIT_REORDERED = 1, 2, 4
 
 
 class FpFissOpts(C.Structure):

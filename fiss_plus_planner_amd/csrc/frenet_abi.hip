@@ -647,7 +647,7 @@ bool winner_inside_lattice(const fp_ctx* ctx, const fp_batch* b)
     return b->B <= ctx->resident_groups;
 }
 
-fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
+fp_result no_result() { return fp_result{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
 
 // FopPlusPlanner counts pops over the dense tables: when the caller did not ask for them they live in the ctx's scratch buffer.
 int fopplus_tables(fp_ctx* ctx, size_t B, size_t C, fp_result* r, hipStream_t stream)
@@ -884,6 +884,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");
     if (result->best_traj && !result->best_flags) return fail(FP_EINVAL, "result.best_traj requires result.best_flags");
+    if (result->audit && result->fopplus) return fail(FP_EINVAL, "result.audit settles FrenetOptimalPlanner's argmin: not together with result.fopplus");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t C = (size_t)params->nd * params->nv * params->nt, B = (size_t)batch->B;
@@ -895,18 +896,21 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
-        if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r, (hipStream_t)stream));
+        if ((result->fopplus || result->audit) && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r, (hipStream_t)stream));
         FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
         int nsplit, group, tail; void* parts;
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
         bool winner_done = false;
         const int* perm; int* dur;
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
-        if (result->best_traj && !winner_inside_lattice(ctx, batch)) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
+        // (the audit pass may move the winner: the series are written after it, by their own launch)
+        const bool inside = winner_inside_lattice(ctx, batch) && !result->audit;
+        if (result->best_traj && !inside) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
         fp::KernelArgs kl = ka;
-        if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
+        if (!inside) kl.r.best_traj = nullptr;
         LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
+        if (result->audit) LAUNCH_TRY(fp::launch_audit(ka, result->audit, (hipStream_t)stream), "audit kernel");
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         if (result->fopplus)
             LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, result->fopplus, ka.r.stats,
@@ -919,12 +923,12 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<int32_t>(B * 4) + 2 * HostStage::need<double>(B) + HostStage::need<int32_t>(B) +
                       HostStage::need<double>(B * C) + HostStage::need<uint32_t>(B * C) + HostStage::need<uint32_t>(B) +
-                      HostStage::need<double>(traj_doubles) + HostStage::need<int32_t>(B * 2),
+                      HostStage::need<double>(traj_doubles) + HostStage::need<int32_t>(B * 2) + HostStage::need<uint32_t>(B),
                       /*zero_copy_out=*/B <= 8));
     // (inline inputs need the fused kernel with the winner's series inside it: no other kernel of this call may read the batch)
     fp::InlineIn inl;
     const bool try_inline = ctx->inline_inputs && B <= 8 && !params->curvature_mask && ctx->lattice_kernel != 1 &&
-                            (!result->best_traj || winner_inside_lattice(ctx, batch)) && fp::lattice_group_fit(*params, *batch) >= 1;
+                            (!result->best_traj || winner_inside_lattice(ctx, batch)) && !result->audit && fp::lattice_group_fit(*params, *batch) >= 1;
     FP_TRY(stage_batch(hs, params, batch, &ka.b, try_inline ? &inl : nullptr));
     FP_TRY(hs.flush_in());
     ka.r.best_idx = hs.out(result->best_idx, B);
@@ -937,7 +941,8 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     ka.r.traj_stride = result->traj_stride;
     ka.r.traj_sparse = result->traj_sparse;
     int32_t* d_fopplus = hs.out(result->fopplus, B * 2);
-    if (result->fopplus && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r, ctx->stream));
+    uint32_t* d_audit = hs.out(result->audit, B);
+    if ((result->fopplus || result->audit) && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r, ctx->stream));
     // sparse rows are only partly written by the kernels: the host block comes back with the caller's own bytes elsewhere
     if (result->traj_sparse && ka.r.best_traj) HIP_TRY(hipMemcpyAsync(ka.r.best_traj, result->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     FP_TRY(lattice_curv_scratch(ctx, params, batch, ctx->stream, &ka.curv_tbl));
@@ -947,9 +952,10 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     fp::KernelArgs kl = ka;
-    if (!winner_inside_lattice(ctx, batch)) kl.r.best_traj = nullptr;
+    if (!winner_inside_lattice(ctx, batch) || result->audit) kl.r.best_traj = nullptr;
     LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, inl.on ? &inl : nullptr, tail), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
+    if (d_audit) LAUNCH_TRY(fp::launch_audit(ka, d_audit, ctx->stream), "audit kernel");
     if (result->best_traj && !winner_done) {
         if (inl.on) return fail(FP_EHIP, "internal: inline inputs without the series inside the lattice kernel");
         LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, ctx->stream), "winner epilogue");
@@ -1213,7 +1219,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");
     if (result->best_traj && !result->best_flags) return fail(FP_EINVAL, "result.best_traj requires result.best_flags");
-    if (result->fopplus) return fail(FP_EINVAL, "fp_plan_step plans with FrenetOptimalPlanner's rule: result.fopplus must be NULL");
+    if (result->fopplus || result->audit) return fail(FP_EINVAL, "fp_plan_step: result.fopplus / result.audit must be NULL (use fp_plan_dense + fp_advance)");
     if (!io || !io->ego || !io->t_now || !io->done || !io->cycles || !io->goal_xy) return fail(FP_EINVAL, "fp_loop_io has a NULL mandatory array");
     if (io->goal_poly && (!io->goal_nv || io->goal_max_vertices < 3)) return fail(FP_EINVAL, "fp_loop_io.goal_poly needs goal_nv and goal_max_vertices >= 3");
     if (batch->B == 0) return FP_OK;

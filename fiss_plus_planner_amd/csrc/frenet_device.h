@@ -296,6 +296,21 @@ __device__ __forceinline__ bool obb_overlap(const Obb& a, const Obb& b)
     return true;
 }
 
+// The same four axes as a signed distance: max over the axes of (centre distance along the axis - the two boxes' reach along it).
+// <= 0: the boxes overlap (obb_overlap is `obb_gap <= 0` with early exits); > 0: separated by at least that much along the best
+// axis (a lower bound of the true distance).  The audit pass (audit_kernel) calls a decision "thin" when |gap| is below its tolerance.
+__device__ __forceinline__ double obb_gap(const Obb& a, const Obb& b)
+{
+    const double dx = b.x - a.x, dy = b.y - a.y;
+    const double C = fabs(fma(a.c, b.c, a.s * b.s));
+    const double S = fabs(fma(a.s, b.c, -a.c * b.s));
+    const double g0 = fabs(fma(dx, a.c, dy * a.s)) - (a.hl + fma(b.hl, C, b.hw * S));
+    const double g1 = fabs(fma(dy, a.c, -dx * a.s)) - (a.hw + fma(b.hl, S, b.hw * C));
+    const double g2 = fabs(fma(dx, b.c, dy * b.s)) - (b.hl + fma(a.hl, C, a.hw * S));
+    const double g3 = fabs(fma(dy, b.c, -dx * b.s)) - (b.hw + fma(a.hl, S, a.hw * C));
+    return fmax(fmax(g0, g1), fmax(g2, g3));
+}
+
 // heading unit vector of the step (dx,dy): cos/sin(atan2(dy,dx)); atan2(0,0) = 0 -> (1,0).
 // An axis-parallel step gives exactly (+-1, 0) / (0, +-1), as cos / sin of atan2's exact 0, pi, +-pi/2 do after shapely's snap
 // (see sincos_snapped): boxes that touch exactly are then decided by exact arithmetic, like in the reference.

@@ -122,6 +122,9 @@ hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hi
 // skip (optional, fp_batch.skip): egos the lattice kernel did not plan get out = {0, 0} and keep their Stats.
 hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint32_t* flag_tbl, const int32_t* best_idx, const double* best_cost,
                                 int32_t* out, int32_t* stats, const int32_t* skip, hipStream_t stream);
+// fp_result.audit: near-tie / thin-contact bits of every ego from its dense tables (ka.r.cost_tbl / flag_tbl / best_idx / best_cost must be
+// set; best_idx / best_cost are rewritten where a near tie is settled by point-by-point sums).  One workgroup per ego.
+hipError_t launch_audit(const KernelArgs& ka, uint32_t* audit, hipStream_t stream);
 // Frenet frame construction / Cartesian -> Frenet projection (frenet_frame.hip).
 hipError_t launch_frames_build(int F, int NX, const int32_t* n, const double* points, double* knots, double* coef, hipStream_t stream);
 hipError_t launch_from_state(const fp_batch& bt, const double* states, double* ego, hipStream_t stream);

@@ -309,6 +309,163 @@ __global__ __launch_bounds__(512) void lattice_percand_kernel(KernelArgs ka, int
 }
 
 // ---------------------------------------------------------------------------
+// audit pass (fp_result.audit): how thin are the margins under an ego's answer?  One workgroup per ego over its dense tables.
+//   (1) near ties: feasible candidates whose cost lies within FP_AUDIT_COST_TOL of the winner's.  The lattice kernel prices candidates
+//       by closed-form sums (~1e-12 from the reference's point-by-point sums): among near-tied candidates the closed form may order
+//       them differently than the reference does.  They - and the winner - are re-priced by traj_eval (one term per trajectory point,
+//       in the reference's order) and the argmin rule (:263-268, `>=`: the last minimum wins) is applied to those sums.
+//   (2) thin contacts: for the winner and for every candidate at most as expensive that was rejected ONLY for colliding, the deepest
+//       overlap / closest miss over all checked poses and obstacles (obb_gap); |gap| < FP_AUDIT_GAP_TOL: the verdict hangs on the
+//       last places of the geometry (GEOS's exact predicates, another compiler's rounding could decide it differently).
+// Opt-in and off the throughput path: lane per candidate, sequential loops, like the lane-per-candidate kernel it shares code with.
+// ---------------------------------------------------------------------------
+// signed gap of the ego box at pose k against every obstacle present at that step: the smallest (most negative = deepest overlap).
+// +inf when no obstacle is near; -inf when the reference would raise (non-finite pose: "collision" regardless of geometry).
+__device__ double pose_min_gap(const KernelArgs& ka, const EgoCtx& e, int i, double x, double y, double c, double s)
+{
+    if (!(x == x) || !(y == y) || !(c == c)) return -__builtin_inf();
+    Obb ego{x, y, c, s, 0.5 * ka.p.veh_l, 0.5 * ka.p.veh_w};
+    const double r_e = sqrt(fma(ego.hl, ego.hl, ego.hw * ego.hw));
+    const int n = e.n_obs;
+    const int ts = i + e.t_now;
+    double g = __builtin_inf();
+    if (ts < 0 || ts >= e.T_obs) return g;
+    const double* row = e.obs_glb + (size_t)ts * n * 4;
+    for (int j = 0; j < n; ++j) {
+        if (row[4 * j + 3] == 0.0) continue;
+        const double ox = row[4 * j], oy = row[4 * j + 1];
+        const double R = r_e + e.obs_dim[4 * j + 2] + 2.0 * FP_AUDIT_GAP_TOL;  // beyond it the boxes miss by more than the tolerance
+        const double dx = ox - x, dy = oy - y;
+        if (!(fma(dx, dx, dy * dy) <= R * R)) {
+            if (!(dx == dx) || !(dy == dy)) g = -__builtin_inf();  // NaN pose: polygon construction fails -> collision
+            continue;
+        }
+        double oc, os;
+        sincos_snapped(row[4 * j + 2], os, oc);
+        g = fmin(g, obb_gap(ego, Obb{ox, oy, oc, os, e.obs_dim[4 * j], e.obs_dim[4 * j + 1]}));
+    }
+    return g;
+}
+
+// smallest gap of one candidate over its checked poses (has_collision's poses, :168-195); out_of_geometry: the collision flag does not
+// come from geometry (M == 1: the reference's IndexError)
+__device__ double candidate_min_gap(const KernelArgs& ka, const EgoCtx& e, double d_end, double v_end, double T_end)
+{
+    const fp_params& p = ka.p;
+    const int N = arange_len(T_end, p.tick_t);
+    if (N <= 0 || N > FP_MAX_POINTS || e.n_obs <= 0) return __builtin_inf();
+    const Quintic lat = quintic_bvp(e.d0, e.d_d0, e.d_dd0, d_end, 0.0, 0.0, T_end);
+    const Quartic lon = quartic_bvp(e.s0, e.s_d0, e.s_dd0, v_end, 0.0, T_end);
+    int seg = -1, M = N;
+    double xp = 0, yp = 0, hc = 1.0, hs = 0.0, g = __builtin_inf();
+    const int cs = p.check_stride;
+    for (int i = 0; i < N; ++i) {
+        const double t = (double)i * p.tick_t;
+        const double sv = fma(fma(fma(fma(lon.a4, t, lon.a3), t, lon.a2), t, lon.a1), t, lon.a0);
+        seg = spline_segment(e.sp, sv, seg);
+        if (seg < 0) { M = i; break; }
+        const double dv = fma(fma(fma(fma(fma(lat.a5, t, lat.a4), t, lat.a3), t, lat.a2), t, lat.a1), t, lat.a0);
+        double px, py, tx, ty, x, y;
+        spline_frame(e.sp, seg, sv - e.sp.knots[seg], px, py, tx, ty);
+        frenet_to_cartesian(px, py, tx, ty, dv, x, y);
+        if (i >= 1) {
+            step_heading(x - xp, y - yp, hc, hs);
+            const int k = i - 1;
+            if ((k % cs) == 0 && k < e.horizon_cap) g = fmin(g, pose_min_gap(ka, e, k, xp, yp, hc, hs));
+        }
+        xp = x; yp = y;
+    }
+    if (M >= 2) {
+        const int k = M - 1;  // the last pose repeats the previous heading (:129)
+        if ((k % cs) == 0 && k < e.horizon_cap) g = fmin(g, pose_min_gap(ka, e, k, xp, yp, hc, hs));
+    } else if (M == 1 && e.horizon_cap >= 1) {
+        g = -__builtin_inf();  // traj.yaw is empty -> IndexError -> collision: not a matter of geometry
+    }
+    return g;
+}
+
+constexpr int kAuditThreads = 256;
+constexpr int kAuditTies = 64;  // near-tied candidates re-priced per ego (more than that: the first 64 in index order, bit still set)
+__global__ __launch_bounds__(kAuditThreads) void audit_kernel(KernelArgs ka, int lds_doubles, uint32_t* audit)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int s_ties[kAuditTies + 1];
+    __shared__ Best s_wbest[kAuditThreads / kWave];
+    __shared__ int s_thin;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const fp_params& p = ka.p;
+    const int C = p.nd * p.nv * p.nt;
+    if (ka.b.skip && ka.b.skip[b]) {
+        if (tid == 0) audit[b] = 0u;
+        return;
+    }
+    if (tid == 0) { s_ties[kAuditTies] = 0; s_thin = 0; }
+    EgoCtx e;
+    stage_ego(ka, b, lds, e, lds_doubles);  // (ends with a barrier)
+    const double* cost = ka.r.cost_tbl + (size_t)b * C;
+    const uint32_t* flag = ka.r.flag_tbl + (size_t)b * C;
+    const double* vs = ka.b.v_samples + (size_t)b * p.nv;
+    const int win = ka.r.best_idx[b];
+    const double cw = win >= 0 ? cost[win] : __builtin_inf();
+    auto end_state = [&](int c, double& d_end, double& v_end, double& T_end) {
+        const int iv = c % p.nv, it = (c / p.nv) % p.nt, id = c / (p.nv * p.nt);
+        d_end = ka.b.d_samples[id]; v_end = vs[iv]; T_end = ka.b.t_samples[it];
+    };
+    // (1) near ties, in index order (kAuditTies slots)
+    if (win >= 0) {
+        for (int c = tid; c < C; c += kAuditThreads) {
+            if (c == win || (flag[c] & FP_FLAG_INFEASIBLE) || !(cost[c] == cost[c])) continue;
+            if (fabs(cost[c] - cw) <= FP_AUDIT_COST_TOL) {
+                const int pos = atomicAdd(&s_ties[kAuditTies], 1);
+                if (pos < kAuditTies - 1) s_ties[pos] = c;
+            }
+        }
+    }
+    // (2) thin contacts: the winner + every candidate at most as expensive that only the collision check rejected (no winner: every
+    // candidate only the collision check rejected - any of them flipping would give the ego a solution)
+    for (int c = tid; c < C; c += kAuditThreads) {
+        const uint32_t fl = flag[c] & FP_FLAG_INFEASIBLE;
+        const bool in_set = c == win || (fl == FP_FLAG_COLLISION && cost[c] == cost[c] && (win < 0 || cost[c] <= cw + FP_AUDIT_COST_TOL));
+        if (!in_set) continue;
+        double d_end, v_end, T_end;
+        end_state(c, d_end, v_end, T_end);
+        const double g = candidate_min_gap(ka, e, d_end, v_end, T_end);
+        if (fabs(g) < FP_AUDIT_GAP_TOL) atomicOr(&s_thin, 1);
+    }
+    __syncthreads();
+    const int n_ties = s_ties[kAuditTies] < kAuditTies - 1 ? s_ties[kAuditTies] : kAuditTies - 1;
+    uint32_t bits = s_thin ? FP_AUDIT_CONTACT : 0u;
+    if (n_ties > 0) {
+        bits |= FP_AUDIT_NEAR_TIE;
+        // re-price the tied candidates and the winner point by point; the argmin rule on those sums
+        if (tid == 0) s_ties[n_ties] = win;
+        __syncthreads();
+        Best mine{0.0, -1};
+        if (tid <= n_ties) {
+            const int c = s_ties[tid];
+            double d_end, v_end, T_end;
+            end_state(c, d_end, v_end, T_end);
+            const TrajOut o = traj_eval<false, false>(ka, e, d_end, v_end, T_end, false, nullptr, 0);
+            if (o.cost == o.cost) mine = Best{o.cost, c};
+        }
+        mine = wave_best(mine);
+        if ((tid & (kWave - 1)) == 0) s_wbest[tid / kWave] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            Best r = s_wbest[0];
+            for (int w = 1; w < kAuditThreads / kWave; ++w) r = best_merge(r, s_wbest[w]);
+            if (r.idx >= 0 && r.idx != win) {
+                bits |= FP_AUDIT_REORDERED;
+                ka.r.best_idx[b] = r.idx;
+                if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
+            }
+            if (r.idx >= 0) ka.r.best_cost[b] = r.cost;  // the point-by-point sum of the (possibly new) winner
+        }
+    }
+    if (tid == 0) audit[b] = bits;
+}
+
+// ---------------------------------------------------------------------------
 // optional curvature checks of the whole lattice (fp_params.curvature_mask): one workgroup per ego, one lane per candidate,
 // the ego's spline in LDS.  Runs ahead of the fused lattice kernel, which ORs the bytes into its flag words (the checks need
 // every Cartesian point of every candidate - exactly the per-candidate work the fused kernel is built to avoid - so they live
@@ -537,6 +694,17 @@ static int ego_lds_bytes(const fp_params& p, const fp_batch& b, int max_bytes, i
     long use = full * 8 <= max_bytes ? full : base;  // obstacle rows stay in HBM/L2 when they do not fit
     *lds_doubles = (int)use;
     return (int)(use * 8);
+}
+
+hipError_t launch_audit(const KernelArgs& ka, uint32_t* audit, hipStream_t stream)
+{
+    int lds_doubles = 0;
+    const int bytes = ego_lds_bytes(ka.p, ka.b, 0, &lds_doubles)  /* spline + sizes only: the poses are read from the scene table */;
+    FP_LDS_SLOTS(configured);
+    hipError_t err = ensure_dynamic_lds((const void*)audit_kernel, bytes, configured);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(audit_kernel, dim3(ka.b.B), dim3(kAuditThreads), bytes, stream, ka, lds_doubles, audit);
+    return hipGetLastError();
 }
 
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream)

@@ -162,9 +162,11 @@ class FrenetEngine:
 
     # ------------------------------------------------------------------ host arrays
     @staticmethod
-    def dense_outputs(B: int, Cn: int, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False):
+    def dense_outputs(B: int, Cn: int, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False,
+                      audit: bool = False):
         """Output arrays of plan_dense for B egos (ShardedEngine allocates them once and hands every shard its slice)."""
         return SimpleNamespace(
+            audit=np.zeros(B, dtype=np.uint32) if audit else None,
             best_idx=np.empty(B, dtype=np.int32), best_cost=np.empty(B), stats=np.empty((B, 4), dtype=np.int32),
             cost=np.empty((B, Cn)) if tables else None, flags=np.empty((B, Cn), dtype=np.uint32) if tables else None,
             best_flags=np.empty(B, dtype=np.uint32) if winner else None,
@@ -172,16 +174,18 @@ class FrenetEngine:
             best_traj=(np.full((B, 16, traj_stride), np.nan) if traj_sparse else np.empty((B, 16, traj_stride))) if winner else None)
 
     def plan_dense(self, batch: ProblemBatch, tables: bool = True, winner: bool = False, traj_stride: int = TRAJ_STRIDE, traj_sparse: bool = False,
-                   out: SimpleNamespace | None = None):
+                   out: SimpleNamespace | None = None, audit: bool = False):
         """FrenetOptimalPlanner.plan() for every ego of the batch (reference frenet_optimal_planner.py:247-270).
 
         Returns best_idx [B] (flat (i_d*nt+i_T)*nv+i_v, -1 = none), best_cost [B], stats [B,4] and, with
         tables=True, cost [B,C] and flags [B,C]; with winner=True also best_flags [B] and best_traj [B,16,128]
-        (the argmin's full series, written by the lattice kernel itself).
+        (the argmin's full series, written by the lattice kernel itself).  audit=True: also `audit` [B] (FP_AUDIT_* bits: another
+        feasible candidate within 1e-9 of the winner's cost - settled by point-by-point sums -, a collision verdict within 1e-9 m of
+        contact; include/frenet_gpu.h).
         """
         B, Cn = batch.B, batch.C
         if out is None:  # (out: arrays of dense_outputs' shapes, e.g. contiguous slices of a bigger batch's outputs)
-            out = self.dense_outputs(B, Cn, tables, winner, traj_stride, traj_sparse)
+            out = self.dense_outputs(B, Cn, tables, winner, traj_stride, traj_sparse, audit)
         elif "_res" not in out.__dict__:  # caller's arrays, first use: they cross the ABI as bare addresses
             _check_out(out, B, dict(best_idx=("int32", ()), best_cost=("float64", ()), stats=("int32", (4,)),
                                     cost=("float64", (Cn,)) if tables else None, flags=("uint32", (Cn,)) if tables else None,
@@ -190,7 +194,7 @@ class FrenetEngine:
             return out
         # a caller that re-plans into the same `out` every cycle (planners.py) finds the fp_result of its arrays cached on it
         # (building the struct costs several microseconds of a ~55 us plan cycle); the arrays of `out` must not be replaced then
-        key = (tables, winner, int(traj_stride), int(traj_sparse))
+        key = (tables, winner, int(traj_stride), int(traj_sparse), bool(audit))
         cached = out.__dict__.get("_res")
         if cached is not None and cached[0] == key:
             res = cached[1]
@@ -201,6 +205,7 @@ class FrenetEngine:
             res.flag_tbl = _ptr(out.flags) if tables else None
             res.best_flags = _ptr(out.best_flags) if winner else None
             res.best_traj = _ptr(out.best_traj) if winner else None
+            res.audit = _ptr(out.audit) if audit else None
             res.traj_stride, res.traj_sparse = int(traj_stride), int(traj_sparse)
             out.__dict__["_res"] = (key, res)
         p, fb = host_structs(batch)

@@ -145,6 +145,9 @@ typedef struct {
                             [b][1] = 1 when an exact cost tie (or a NaN cost) at the decision point leaves the outcome to the
                             reference's heap order - replay that ego on the host (fiss_plus_planner_amd/search.py:fopplus_search) -
                             else 0: best_idx / best_cost ARE FopPlusPlanner's answer */
+    uint32_t* audit;     /* NULL or [B]: how thin the margins under this ego's answer are (FP_AUDIT_* bits, see below).  Asking for it
+                            adds a pass over the ego's tables (one more launch) and, where FP_AUDIT_NEAR_TIE is found, settles the
+                            choice among the tied candidates by the reference's own point-by-point sums. */
     int32_t traj_stride; /* columns per series row; 0 = FP_MAX_POINTS.  Must be >= the largest N = ceil(T / tick_t) of the batch
                             (e.g. 100 for T <= 10 s at 0.1 s): a smaller stride is FP_EINVAL (host) / truncates the rows (device) */
     int32_t traj_sparse; /* 0: every element of the [16][traj_stride] block is written (NaN where a row has no element).
@@ -154,6 +157,24 @@ typedef struct {
                             block and the blocks of egos without a winner (best_flags = 0) are left untouched.  Bytes written =
                             the algorithmic bytes rounded up to lines: ~6 % more at N ~ 90.  Use traj_stride = 112 for T <= 10 s */
 } fp_result;
+
+/* fp_result.audit bits.  The kernels sum the cost terms in closed form (~1e-12 from the reference's point-by-point sums) and decide box
+ * overlaps in fp64 (they can differ from shapely / GEOS's exact predicates for boxes closer than ~1e-13 m to touching), so "the
+ * selected index is exact" holds with a margin.  These bits say when the margin is gone:
+ *   FP_AUDIT_NEAR_TIE    another FEASIBLE candidate's cost lies within FP_AUDIT_COST_TOL of the winner's.  The tied candidates (and
+ *                        the winner) were then re-priced with the reference's summation (one term per trajectory point, in order)
+ *                        and the argmin rule (:263-268, last minimum wins) applied to those sums; best_idx / best_cost are the outcome.
+ *   FP_AUDIT_REORDERED   ... and that changed the winner.
+ *   FP_AUDIT_CONTACT     the collision verdict of the winner, or of a candidate at most as expensive that was rejected ONLY for
+ *                        colliding, hangs on a pair of boxes within FP_AUDIT_GAP_TOL metres of touching (their deepest overlap over
+ *                        all checked poses and obstacles is shallower than that, or their closest miss nearer): a different
+ *                        rounding of the same geometry - GEOS, another compiler - could decide this ego differently.
+ * No bit set: every comparison behind best_idx was decided by more than the tolerances. */
+#define FP_AUDIT_NEAR_TIE 1u
+#define FP_AUDIT_CONTACT 2u
+#define FP_AUDIT_REORDERED 4u
+#define FP_AUDIT_COST_TOL 1e-9
+#define FP_AUDIT_GAP_TOL 1e-9
 
 int fp_abi_version(void);
 const char* fp_last_error(void);

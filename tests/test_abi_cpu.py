@@ -120,4 +120,4 @@ def test_integration_md_stub_matches_the_binding():
         doc, ours = ns[name], getattr(_abi, name)
         assert [(f[0], C.sizeof(f[1])) for f in doc._fields_] == [(f[0], C.sizeof(f[1])) for f in ours._fields_], name
         assert C.sizeof(doc) == C.sizeof(ours)
-    assert "best_traj.ctypes.data, None, 0, 0)" in txt  # the call site passes all ten fields
+    assert "best_traj.ctypes.data, None, None, 0, 0)" in txt  # the call site passes all eleven fields
