@@ -10,6 +10,8 @@ little-endian float64 / int32 arrays, one row per ego / frame / scene.
     frames    nx [F], knots [F, NX] (+inf padded), coef [F, 8, NX] (ax bx cx dx ay by cy dy)
     scenes    obs_pose [S, T_obs, n_obs, 4] = x, y, yaw, valid;  obs_dims [S, n_obs, 2] = length, width
               final_time_step [S]  (= obstacles[0].prediction.final_time_step, frenet_optimal_planner.py:173)
+              optional obs_nvert [S, n_obs] + obs_poly [S, n_obs, PV, 2]: convex-polygon columns (0 vertices = the rectangle of
+              obs_dims; else a counter-clockwise ring relative to the column's rotation centre, obs_dims = the box that holds it)
 
 The three sample vectors are produced with numpy.linspace on the host, as the
 reference does (frenet_optimal_planner.py:75,78,89; fiss_planner.py:47,59,69), so the
@@ -76,6 +78,9 @@ class ProblemBatch:
     # (max_curvature, max_kappa_d, max_kappa_dd): turns on the curvature checks the reference carries commented out
     # (frenet_optimal_planner.py:145-150); None = off = the reference's behaviour
     curvature_limits: tuple | None = None
+    # obstacle columns that are convex polygons instead of rectangles (fp_batch.obs_poly / obs_nvert); None = rectangles only
+    obs_poly: np.ndarray | None = None   # [S, n_obs, PV, 2]
+    obs_nvert: np.ndarray | None = None  # [S, n_obs] int32
     meta: dict = field(default_factory=dict)
 
     def __post_init__(self):
@@ -95,6 +100,12 @@ class ProblemBatch:
         for name in ("samp_min", "samp_max", "samp_res"):
             if getattr(self, name) is not None:
                 setattr(self, name, f8(getattr(self, name)))
+        if self.obs_nvert is not None and not np.any(np.asarray(self.obs_nvert)):
+            self.obs_poly = self.obs_nvert = None  # no polygon column after all
+        if self.obs_nvert is not None:
+            self.obs_poly, self.obs_nvert = f8(self.obs_poly), i4(self.obs_nvert)
+            assert self.obs_nvert.shape == (self.S, self.n_obs) and self.obs_poly.ndim == 4
+            assert self.obs_poly.shape[:2] == (self.S, self.n_obs) and self.obs_poly.shape[3] == 2 and self.obs_poly.shape[2] >= 3
 
     B = property(lambda self: self.ego.shape[0])
     nd = property(lambda self: self.d_samples.shape[0])
@@ -106,6 +117,7 @@ class ProblemBatch:
     S = property(lambda self: self.obs_pose.shape[0])
     T_obs = property(lambda self: self.obs_pose.shape[1])
     n_obs = property(lambda self: self.obs_pose.shape[2])
+    poly_stride = property(lambda self: 0 if self.obs_nvert is None else self.obs_poly.shape[2])
 
     def points_per_candidate(self) -> np.ndarray:
         """N(T) = len(np.arange(0, T, tick_t)) for each T sample."""
@@ -130,6 +142,8 @@ class ProblemBatch:
             samp_min=None if self.samp_min is None else self.samp_min[sel],
             samp_max=None if self.samp_max is None else self.samp_max[sel],
             samp_res=None if self.samp_res is None else self.samp_res[sel], curvature_limits=self.curvature_limits,
+            obs_poly=None if self.obs_nvert is None else self.obs_poly[keep_s],
+            obs_nvert=None if self.obs_nvert is None else self.obs_nvert[keep_s],
             meta=dict(self.meta, **(meta or {})))
 
     def shard(self, rank: int, world: int) -> "ProblemBatch":
@@ -144,4 +158,8 @@ class ProblemBatch:
                      "knots", "coef", "obs_pose", "obs_dims", "final_time_step"):
             a = getattr(self, name)
             h.update(name.encode()); h.update(str(a.shape).encode()); h.update(np.ascontiguousarray(a).tobytes())
+        if self.obs_nvert is not None:  # (rectangle-only batches keep the digests pinned before ABI 12)
+            for name in ("obs_poly", "obs_nvert"):
+                a = getattr(self, name)
+                h.update(name.encode()); h.update(str(a.shape).encode()); h.update(np.ascontiguousarray(a).tobytes())
         return h.hexdigest()

@@ -8,7 +8,9 @@ Replaces, for the reference's demo inputs, `CommonRoadFileReader(...).open()` (p
   (the reference asks commonroad-route-planner for it; all five demo scenarios have a unique such route - SURVEY.md 8f);
   like the reference (:68-75) the first successor of the last lanelet is appended when there is one;
 * centerline = concatenated centre vertices with duplicates removed, first occurrence kept (:79-82);
-* dynamic rectangle obstacles -> pose table [T, n, 4] = x, y, yaw, valid + dims [n, 2] (what has_collision() reads).
+* dynamic obstacles -> pose table [T, n, 4] = x, y, yaw, valid + dims [n, 2] (what has_collision() reads); shapes other than
+  centred rectangles - rectangles with a centre / orientation, circles, polygons - become polygon columns (obstacles.shape_columns:
+  `obstacle_shape.shapely_object` is any polygon in the reference, frenet_optimal_planner.py:189-191).
 
 Route choice parity with commonroad-route-planner is unpinned (package not installable offline).
 """
@@ -20,7 +22,9 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .obstacles import ObstacleTable
+from types import SimpleNamespace
+
+from .obstacles import ObstacleTable, buffer_circle_ring, shape_columns
 
 
 @dataclass
@@ -55,7 +59,36 @@ def _inside(poly: np.ndarray, x: float, y: float) -> bool:
     return inside
 
 
-def load_scenario(path: str) -> Scenario:
+def _shape(node, circle_buffer_factor: float):
+    """<shape> of a CommonRoad obstacle -> the object shape_columns() reads (what commonroad-io's Shape classes expose)."""
+    kinds = [c for c in node if c.tag in ("rectangle", "circle", "polygon")]
+    if not kinds:
+        raise ValueError("obstacle without a rectangle / circle / polygon shape")
+
+    def one(c):
+        ctr = c.find("center")
+        center = np.array([float(ctr.find("x").text), float(ctr.find("y").text)]) if ctr is not None else np.zeros(2)
+        if c.tag == "rectangle":
+            l, w = float(c.find("length").text), float(c.find("width").text)
+            o = c.find("orientation")
+            theta = float(o.find("exact").text if o.find("exact") is not None else o.text) if o is not None else 0.0
+            if theta == 0.0 and not center.any():
+                return SimpleNamespace(length=l, width=w)
+            # commonroad Rectangle.shapely_object: the corners turned by the orientation, then moved to the centre
+            corners = np.array([(-0.5 * l, -0.5 * w), (-0.5 * l, 0.5 * w), (0.5 * l, 0.5 * w), (0.5 * l, -0.5 * w)])
+            rot = np.array([[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]])
+            return SimpleNamespace(vertices=corners @ rot.T + center)
+        if c.tag == "circle":
+            # commonroad-io's Circle.shapely_object is `Point(center).buffer(radius / 2)` in the releases of the reference's era
+            # (recalled, not checkable offline - like the vehicle constants; circle_buffer_factor=1.0 for a full-radius polygon)
+            return SimpleNamespace(vertices=buffer_circle_ring(circle_buffer_factor * float(c.find("radius").text), center[0], center[1]))
+        return SimpleNamespace(vertices=_points(c))
+
+    shapes = [one(c) for c in kinds]
+    return shapes[0] if len(shapes) == 1 else SimpleNamespace(shapes=shapes)  # several shapes under one <shape>: a ShapeGroup
+
+
+def load_scenario(path: str, circle_buffer_factor: float = 0.5) -> Scenario:
     root = ET.parse(path).getroot()
     lanelets = {}
     for ll in root.findall("lanelet"):
@@ -112,23 +145,27 @@ def load_scenario(path: str) -> Scenario:
 
     obs, T = [], 0
     for ob in root.findall("dynamicObstacle"):
-        rect = ob.find("shape/rectangle")
-        if rect is None:
-            raise ValueError("only rectangle obstacles are supported (all demo scenarios use rectangles)")
         states = {}
         for st in [ob.find("initialState")] + ob.find("trajectory").findall("state"):
             states[int(st.find("time/exact").text)] = (float(st.find("position/point/x").text), float(st.find("position/point/y").text),
                                                        float(st.find("orientation/exact").text))
-        obs.append((float(rect.find("length").text), float(rect.find("width").text), states))
+        for col in shape_columns(_shape(ob.find("shape"), circle_buffer_factor)):  # (one column per convex piece, same states)
+            obs.append((col, states))
         T = max(T, max(states) + 1)
     if not obs:
         raise ValueError("scenario has no dynamic obstacle (the reference reads dynamic_obstacles[0], planning.py:70)")
     pose = np.zeros((T, len(obs), 4))
     dims = np.zeros((len(obs), 2))
-    for j, (l, w, states) in enumerate(obs):
+    pv = max([len(c[4]) for c, _ in obs if c[4] is not None], default=0)
+    poly = np.zeros((len(obs), max(pv, 3), 2)) if pv else None
+    nvert = np.zeros(len(obs), dtype=np.int32) if pv else None
+    for j, ((l, w, cx, cy, ring), states) in enumerate(obs):
         dims[j] = (l, w)
+        if ring is not None:
+            poly[j, :len(ring)] = ring
+            nvert[j] = len(ring)
         for t, (x, y, yaw) in states.items():
-            pose[t, j] = (x, y, yaw, 1.0)
-    fts = max(obs[0][2])  # dynamic_obstacles[0].prediction.final_time_step
+            pose[t, j] = (x + cx, y + cy, yaw, 1.0)
+    fts = max(obs[0][1])  # dynamic_obstacles[0].prediction.final_time_step
     return Scenario(root.get("benchmarkID"), float(root.get("timeStepSize")), route, centerline,
-                    ObstacleTable(pose[:max(fts, 1)], dims, fts), init, goal_lanelet, np.asarray(goal_center), goal_speed)
+                    ObstacleTable(pose[:max(fts, 1)], dims, fts, poly=poly, nvert=nvert), init, goal_lanelet, np.asarray(goal_center), goal_speed)

@@ -109,8 +109,8 @@ struct fp_ctx {
     // planners that take turns on one ctx (FOP and FISS+ on the same scenario, say) both keep theirs
     struct TableSet {
         DeviceBuf buf;
-        int key[6] = {0, 0, 0, 0, 0, 0};       // {tag, F, NX, S, T_obs, n_obs} of what buf holds (tag 0: nothing)
-        size_t off[6] = {0, 0, 0, 0, 0, 0};    // nx, knots, coef, obs_pose, obs_dims, final_time_step
+        int key[7] = {0, 0, 0, 0, 0, 0, 0};    // {tag, F, NX, S, T_obs, n_obs, poly_stride (0: rectangles only)} of what buf holds (tag 0: nothing)
+        size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // nx, knots, coef, obs_pose, obs_dims, final_time_step, obs_poly, obs_nvert
         unsigned long used = 0;                // tick of the last call that read it
     };
     static constexpr int kTableSets = 4;
@@ -139,6 +139,7 @@ struct fp_ctx {
     int lattice_launches = 0, lattice_ordered_launches = 0;  // fp_ctx_get_option counters
     LaunchOrder order_lattice, order_refine;
     DeviceBuf idx_shadow;          // [B] device copy of best_idx for the winner kernel of a dense call (KernelArgs::idx_shadow)
+    DeviceBuf epi_flags;           // [B] hand-over flags of the epilogue workgroups appended to a multi-round lattice launch (KernelArgs::epi_flag); zero between launches
     DeviceBuf curv_buf;            // [B][C] curvature flag bytes of the lattice (fp_params.curvature_mask), written ahead of the fused kernel
 };
 
@@ -344,6 +345,10 @@ int check_batch(const fp_batch* b)
         return fail(FP_EINVAL, "batch has a NULL array");
     if (b->S > 0 && b->n_obs > 0 && (!b->obs_pose || !b->obs_dims || !b->final_time_step))
         return fail(FP_EINVAL, "batch has obstacles but a NULL obstacle array");
+    if (b->S > 0 && b->n_obs > 0 && b->obs_nvert) {
+        if (!b->obs_poly) return fail(FP_EINVAL, "obs_nvert is set but obs_poly is NULL");
+        if (b->poly_stride < 3 || b->poly_stride > FP_MAX_POLY_VERTS) return fail(FP_ELIMIT, "poly_stride=%d outside 3..FP_MAX_POLY_VERTS", b->poly_stride);
+    }
     return FP_OK;
 }
 
@@ -361,6 +366,25 @@ int check_batch_host(const fp_params* p, const fp_batch* b)
         const double n = b->t_samples[k] / p->tick_t;
         if (!(n > 0) || n > FP_MAX_POINTS) return fail(FP_ELIMIT, "t_samples[%d]=%g needs more than FP_MAX_POINTS points", k, b->t_samples[k]);
     }
+    if (b->S > 0 && b->n_obs > 0 && b->obs_nvert) {  // polygon columns: vertex count, ring orientation, and the box the broad phases test
+        for (long c = 0; c < (long)b->S * b->n_obs; ++c) {
+            const int n = b->obs_nvert[c];
+            if (n == 0) continue;
+            if (n < 3 || n > b->poly_stride) return fail(FP_EINVAL, "obs_nvert[%ld]=%d outside 3..poly_stride=%d", c, n, b->poly_stride);
+            const double* v = b->obs_poly + (size_t)c * 2 * b->poly_stride;
+            double mx = 0.0, my = 0.0, area2 = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double* a = v + 2 * i;
+                const double* q = v + 2 * ((i + 1) % n);
+                if (!(a[0] == a[0]) || !(a[1] == a[1])) return fail(FP_EINVAL, "obs_poly column %ld has a NaN vertex", c);
+                mx = fmax(mx, fabs(a[0])); my = fmax(my, fabs(a[1]));
+                area2 += a[0] * q[1] - a[1] * q[0];
+            }
+            if (!(area2 > 0.0)) return fail(FP_EINVAL, "obs_poly column %ld is not counter-clockwise (twice its signed area = %g)", c, area2);
+            if (!(b->obs_dims[2 * c] >= 2.0 * mx) || !(b->obs_dims[2 * c + 1] >= 2.0 * my))
+                return fail(FP_EINVAL, "obs_dims of polygon column %ld (%g x %g) does not contain its vertices (needs %g x %g)", c, b->obs_dims[2 * c], b->obs_dims[2 * c + 1], 2.0 * mx, 2.0 * my);
+        }
+    }
     return FP_OK;
 }
 
@@ -370,7 +394,7 @@ size_t batch_need(const fp_params* p, const fp_batch* b)
     return HostStage::need<double>(p->nd) + HostStage::need<double>(p->nt) + HostStage::need<double>(B * p->nv) + HostStage::need<double>(B) +
            HostStage::need<double>(B * 6) + 4 * HostStage::need<int32_t>(B) + HostStage::need<int32_t>(b->F) + HostStage::need<double>(fn) +
            HostStage::need<double>(fn * 8) + HostStage::need<double>(so * b->T_obs * 4) + HostStage::need<double>(so * 2) +
-           HostStage::need<int32_t>(b->S);
+           HostStage::need<int32_t>(b->S) + (b->obs_nvert ? HostStage::need<double>(so * 2 * b->poly_stride) + HostStage::need<int32_t>(so) : 0);
 }
 
 // Inline inputs of a multi-kernel call (fp::InlineIn::publish): besides the eight per-ego arrays of the batch the blob carries
@@ -382,15 +406,18 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
 {
     *dev = *b;
     const bool has_obs = b->S > 0 && b->n_obs > 0;
+    const bool has_poly = has_obs && b->obs_nvert != nullptr;
+    if (!has_poly) { dev->obs_poly = nullptr; dev->obs_nvert = nullptr; dev->poly_stride = 0; }
     bool tables_resident = false;
     if (b->tables_tag != 0) {
         // the frame / scene tables of a tagged call live in their own device buffer across calls (fp_batch.tables_tag)
         fp_ctx* ctx = hs.ctx();
-        const int key[6] = {b->tables_tag, b->F, b->NX, b->S, b->T_obs, has_obs ? b->n_obs : 0};
-        const void* src[6] = {b->nx, b->knots, b->coef, b->obs_pose, b->obs_dims, b->final_time_step};
-        const size_t bytes[6] = {sizeof(int32_t) * (size_t)b->F, sizeof(double) * (size_t)b->F * b->NX, sizeof(double) * (size_t)b->F * 8 * b->NX,
+        const int key[7] = {b->tables_tag, b->F, b->NX, b->S, b->T_obs, has_obs ? b->n_obs : 0, has_poly ? b->poly_stride : 0};
+        const void* src[8] = {b->nx, b->knots, b->coef, b->obs_pose, b->obs_dims, b->final_time_step, b->obs_poly, b->obs_nvert};
+        const size_t bytes[8] = {sizeof(int32_t) * (size_t)b->F, sizeof(double) * (size_t)b->F * b->NX, sizeof(double) * (size_t)b->F * 8 * b->NX,
                                  has_obs ? sizeof(double) * (size_t)b->S * b->T_obs * b->n_obs * 4 : 0, has_obs ? sizeof(double) * (size_t)b->S * b->n_obs * 2 : 0,
-                                 has_obs ? sizeof(int32_t) * (size_t)b->S : 0};
+                                 has_obs ? sizeof(int32_t) * (size_t)b->S : 0, has_poly ? sizeof(double) * (size_t)b->S * b->n_obs * 2 * b->poly_stride : 0,
+                                 has_poly ? sizeof(int32_t) * (size_t)b->S * b->n_obs : 0};
         fp_ctx::TableSet* ts = nullptr;
         fp_ctx::TableSet* lru = &ctx->tables[0];
         for (auto& t : ctx->tables) {
@@ -400,13 +427,13 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
         if (!ts) {  // upload into the least recently used set
             ts = lru;
             size_t total = 0;
-            for (int i = 0; i < 6; ++i) { ts->off[i] = total; total += align_up(bytes[i]); }
+            for (int i = 0; i < 8; ++i) { ts->off[i] = total; total += align_up(bytes[i]); }
             ts->key[0] = 0;  // (nothing valid while the upload is being set up)
             if (total + kAlign > ts->buf.cap) {
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
                 FP_TRY(ts->buf.reserve(total + kAlign));
             }
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 8; ++i)
                 if (bytes[i]) HIP_TRY(hipMemcpyAsync(ts->buf.base + ts->off[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream));
             memcpy(ts->key, key, sizeof(key));
         }
@@ -418,6 +445,7 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
         dev->obs_pose = (const double*)(tb + ts->off[3]);
         dev->obs_dims = (const double*)(tb + ts->off[4]);
         dev->final_time_step = (const int32_t*)(tb + ts->off[5]);
+        if (has_poly) { dev->obs_poly = (const double*)(tb + ts->off[6]); dev->obs_nvert = (const int32_t*)(tb + ts->off[7]); }
         tables_resident = true;
         hs.small_inputs_only();
     }
@@ -474,6 +502,10 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
         PUSH(obs_pose, has_obs ? (size_t)b->S * b->T_obs * b->n_obs * 4 : 0);
         PUSH(obs_dims, has_obs ? (size_t)b->S * b->n_obs * 2 : 0);
         PUSH(final_time_step, has_obs ? b->S : 0);
+        if (has_poly) {
+            PUSH(obs_poly, (size_t)b->S * b->n_obs * 2 * b->poly_stride);
+            PUSH(obs_nvert, (size_t)b->S * b->n_obs);
+        }
     }
     if (b->skip) PUSH(skip, b->B);
 #undef PUSH
@@ -620,6 +652,36 @@ int32_t* idx_shadow_for(fp_ctx* ctx, size_t B, hipStream_t stream)
         }
     }
     return (int32_t*)ctx->idx_shadow.base;
+}
+
+// Hand-over flags for the epilogue workgroups a multi-round fused lattice launch appends to its grid (KernelArgs::epi_flag): zero when
+// allocated, and every launch leaves them zero.  nullptr when the buffer would have to grow inside a stream capture (the series then
+// come from winner_traj_kernel).
+int32_t* epi_flags_for(fp_ctx* ctx, size_t B, hipStream_t stream)
+{
+    if (B * sizeof(int32_t) > ctx->epi_flags.cap) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) return nullptr;
+        if (hipStreamSynchronize(stream) != hipSuccess || ctx->epi_flags.reserve(B * sizeof(int32_t)) != FP_OK ||
+            hipMemsetAsync(ctx->epi_flags.base, 0, ctx->epi_flags.cap, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    return (int32_t*)ctx->epi_flags.base;
+}
+
+// Who writes the winner's series of a dense call that does not write them inside the lattice workgroups: with "lattice_winner" = 0
+// (auto) the epilogue workgroups appended to the lattice grid (launch_lattice_fused takes them when the launch is a three-per-CU one;
+// otherwise it reports winner_done = false and winner_traj_kernel follows).
+void offer_epilogue(fp_ctx* ctx, const fp::KernelArgs& ka, fp::KernelArgs* kl, size_t B, hipStream_t stream)
+{
+    if (ctx->lattice_winner != 0 || !ka.r.best_traj || !ka.idx_shadow) return;
+    int32_t* flags = epi_flags_for(ctx, B, stream);
+    if (!flags) return;
+    kl->r.best_traj = ka.r.best_traj;
+    kl->epi_flag = flags;
 }
 
 // Optional curvature checks: the fused lattice kernel reads them from a [B][C] byte table that launch_lattice fills first.
@@ -787,6 +849,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
         if (t.buf.base) (void)hipFree(t.buf.base);
     if (ctx->curv_buf.base) (void)hipFree(ctx->curv_buf.base);
     if (ctx->idx_shadow.base) (void)hipFree(ctx->idx_shadow.base);
+    if (ctx->epi_flags.base) (void)hipFree(ctx->epi_flags.base);
     ctx->order_lattice.release();
     ctx->order_refine.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -908,6 +971,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         if (result->best_traj && !inside) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
         fp::KernelArgs kl = ka;
         if (!inside) kl.r.best_traj = nullptr;
+        if (!inside && !result->audit) offer_epilogue(ctx, ka, &kl, B, (hipStream_t)stream);
         LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->audit) LAUNCH_TRY(fp::launch_audit(ka, result->audit, (hipStream_t)stream), "audit kernel");
@@ -952,7 +1016,13 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     fp::KernelArgs kl = ka;
-    if (!winner_inside_lattice(ctx, batch) || result->audit) kl.r.best_traj = nullptr;
+    if (!winner_inside_lattice(ctx, batch) || result->audit) {
+        kl.r.best_traj = nullptr;
+        if (result->best_traj && !result->audit && !inl.on) {
+            ka.idx_shadow = kl.idx_shadow = idx_shadow_for(ctx, B, ctx->stream);
+            offer_epilogue(ctx, ka, &kl, B, ctx->stream);
+        }
+    }
     LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, inl.on ? &inl : nullptr, tail), "lattice kernel");
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
     if (d_audit) LAUNCH_TRY(fp::launch_audit(ka, d_audit, ctx->stream), "audit kernel");

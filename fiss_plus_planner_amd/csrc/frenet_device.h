@@ -311,6 +311,75 @@ __device__ __forceinline__ double obb_gap(const Obb& a, const Obb& b)
     return fmax(fmax(g0, g1), fmax(g2, g3));
 }
 
+// ---------------------------------------------------------------------------
+// Convex-polygon obstacles (fp_batch.obs_poly / obs_nvert): `obstacle_shape.shapely_object` is any polygon in the reference
+// (frenet_optimal_planner.py:189-191); a commonroad Circle is one too (a 64-gon from shapely's buffer()).  An obstacle column carries
+// n vertices u_i relative to its rotation centre, counter-clockwise; at a pose (x, y, yaw) vertex i sits at (x, y) + R(yaw) u_i - what
+// affinity.translate + rotate(origin='center') give a polygon whose bounding box is centred on the origin.  Polygon.intersects of two
+// convex polygons is the closed separating-axis test over the edge normals of both: the ego box's two axes + the n edge normals.
+// The test runs in the EGO's frame (ego = [-hl, hl] x [-hw, hw] at the origin): few live values, one pass over the vertices.
+// Signed gap like obb_gap: <= 0 overlap (touching counts), > 0 separated by at least that much along the best axis.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double poly_gap(const Obb& ego, double ox, double oy, double oc, double os, const double* __restrict__ v, int n)
+{
+    const double dx = ox - ego.x, dy = oy - ego.y;
+    const double px = fma(dx, ego.c, dy * ego.s), py = fma(dy, ego.c, -dx * ego.s);   // obstacle centre in the ego frame
+    const double C = fma(oc, ego.c, os * ego.s), S = fma(os, ego.c, -oc * ego.s);     // cos / sin of (obstacle yaw - ego yaw)
+    double ux = v[2 * (n - 1)], uy = v[2 * (n - 1) + 1];
+    double qpx = px + fma(C, ux, -S * uy), qpy = py + fma(S, ux, C * uy);             // previous vertex
+    double minx = qpx, maxx = qpx, miny = qpy, maxy = qpy;
+    double g = -__builtin_inf();
+    for (int i = 0; i < n; ++i) {
+        ux = v[2 * i]; uy = v[2 * i + 1];
+        const double qx = px + fma(C, ux, -S * uy), qy = py + fma(S, ux, C * uy);
+        minx = fmin(minx, qx); maxx = fmax(maxx, qx); miny = fmin(miny, qy); maxy = fmax(maxy, qy);
+        // edge q_prev -> q, outward normal (counter-clockwise ring) n = (ey, -ex): the ego's lowest point along n against the edge
+        const double ex = qx - qpx, ey = qy - qpy;
+        const double len2 = fma(ex, ex, ey * ey);
+        if (len2 > 0.0) {  // (a repeated vertex spans no half plane)
+            const double sep = -fma(ey, qpx, -ex * qpy) - fma(ego.hl, fabs(ey), ego.hw * fabs(ex));
+            g = fmax(g, sep * rsqrt_nr(len2));
+        }
+        qpx = qx; qpy = qy;
+    }
+    g = fmax(g, fmax(minx, -maxx) - ego.hl);
+    g = fmax(g, fmax(miny, -maxy) - ego.hw);
+    return g;
+}
+
+// the same test as a verdict: separated only when some axis separates STRICTLY (sign of the un-normalised value: no division)
+__device__ __forceinline__ bool poly_overlap(const Obb& ego, double ox, double oy, double oc, double os, const double* __restrict__ v, int n)
+{
+    const double dx = ox - ego.x, dy = oy - ego.y;
+    const double px = fma(dx, ego.c, dy * ego.s), py = fma(dy, ego.c, -dx * ego.s);
+    const double C = fma(oc, ego.c, os * ego.s), S = fma(os, ego.c, -oc * ego.s);
+    double ux = v[2 * (n - 1)], uy = v[2 * (n - 1) + 1];
+    double qpx = px + fma(C, ux, -S * uy), qpy = py + fma(S, ux, C * uy);
+    double minx = qpx, maxx = qpx, miny = qpy, maxy = qpy;
+    bool separated = false;
+    for (int i = 0; i < n; ++i) {
+        ux = v[2 * i]; uy = v[2 * i + 1];
+        const double qx = px + fma(C, ux, -S * uy), qy = py + fma(S, ux, C * uy);
+        minx = fmin(minx, qx); maxx = fmax(maxx, qx); miny = fmin(miny, qy); maxy = fmax(maxy, qy);
+        const double ex = qx - qpx, ey = qy - qpy;
+        separated = separated || -fma(ey, qpx, -ex * qpy) - fma(ego.hl, fabs(ey), ego.hw * fabs(ex)) > 0.0;
+        qpx = qx; qpy = qy;
+    }
+    return !(separated || minx > ego.hl || maxx < -ego.hl || miny > ego.hw || maxy < -ego.hw);
+}
+
+// The narrow phase of one (ego pose, obstacle) pair whatever the obstacle's shape: the box test on the obstacle's dims (for a polygon:
+// the centred box that contains it, a necessary condition), then the polygon itself.  nvert == nullptr: every obstacle is a rectangle.
+__device__ __forceinline__ bool shape_overlap(const Obb& ego, const Obb& ob, const int32_t* nvert, const double* poly, int poly_stride, size_t col)
+{
+    if (!obb_overlap(ego, ob)) return false;
+    if (nvert) {
+        const int n = nvert[col];
+        if (n > 0) return poly_overlap(ego, ob.x, ob.y, ob.c, ob.s, poly + col * 2 * (size_t)poly_stride, n);
+    }
+    return true;
+}
+
 // heading unit vector of the step (dx,dy): cos/sin(atan2(dy,dx)); atan2(0,0) = 0 -> (1,0).
 // An axis-parallel step gives exactly (+-1, 0) / (0, +-1), as cos / sin of atan2's exact 0, pi, +-pi/2 do after shapely's snap
 // (see sincos_snapped): boxes that touch exactly are then decided by exact arithmetic, like in the reference.

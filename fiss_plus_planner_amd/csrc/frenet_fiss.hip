@@ -655,7 +655,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
         ego.x = pc.x; ego.y = pc.y; ego.hl = veh_hl; ego.hw = veh_hw;
         double oc, os;
         sincos_snapped(ps.z, os, oc);
-        return obb_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw});
+        return shape_overlap(ego, Obb{ps.x, ps.y, oc, os, hl, hw}, bt.obs_nvert, bt.obs_poly, bt.poly_stride, (size_t)sc * n_obs + j);
     };
     if (L.pt) {
         // every (checked pose, obstacle) pair is independent: lanes run over the flattened pair table; the fp32 circle test is

@@ -52,6 +52,10 @@ struct KernelArgs {
     // (advance_ego, frenet_advance.h) - has_loop != 0: `loop` holds the caller's fp_loop_io (device addresses), b.skip = loop.done
     fp_loop_io loop = {};
     int has_loop = 0;
+    // Epilogue workgroups appended to a multi-round fused lattice launch (three workgroups per CU): [B] ints, zero between launches.
+    // The workgroup that publishes an ego's argmin sets its flag; the appended workgroups - dispatched last, i.e. into the slots the
+    // draining launch leaves empty - wait for it, write the winner's series (r.best_traj) and clear it.  Needs idx_shadow.
+    int32_t* epi_flag = nullptr;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

@@ -30,6 +30,7 @@ struct EgoCtx {
     const double* obs_dim;   // [n_obs][4] = hl, hw, bounding radius, unused
     const double* obs_glb;   // global pose table of the scene (fallback when LDS is too small)
     int n_obs, T_obs, rows, t_now, horizon_cap;  // horizon_cap = final_time_step - t_now
+    size_t col0;             // first obstacle column of the ego's scene (scene * n_obs): index base of obs_nvert / obs_poly
 };
 
 struct TrajOut {
@@ -76,6 +77,7 @@ __device__ void stage_ego(const KernelArgs& ka, int b, double* lds, EgoCtx& e, i
     e.obs_glb = nullptr;
     e.rows = 0;
     e.horizon_cap = 0;
+    e.col0 = (size_t)(sc >= 0 ? sc : 0) * bt.n_obs;
     if (e.n_obs > 0) {
         const int n = e.n_obs;
         e.horizon_cap = bt.final_time_step[sc] - e.t_now;
@@ -138,7 +140,7 @@ __device__ __forceinline__ bool pose_collides(const KernelArgs& ka, const EgoCtx
             const double dx = ox - x, dy = oy - y;
             if (!(fma(dx, dx, dy * dy) <= R * R)) continue;  // also skips NaN (no state)
             Obb ob{ox, oy, row[4 * j + 2], row[4 * j + 3], e.obs_dim[4 * j], e.obs_dim[4 * j + 1]};
-            if (obb_overlap(ego, ob)) return true;
+            if (shape_overlap(ego, ob, ka.b.obs_nvert, ka.b.obs_poly, ka.b.poly_stride, e.col0 + j)) return true;
         }
     } else {
         const int ts = i + e.t_now;
@@ -153,7 +155,7 @@ __device__ __forceinline__ bool pose_collides(const KernelArgs& ka, const EgoCtx
             double oc, os;
             sincos_snapped(row[4 * j + 2], os, oc);
             Obb ob{ox, oy, oc, os, e.obs_dim[4 * j], e.obs_dim[4 * j + 1]};
-            if (obb_overlap(ego, ob)) return true;
+            if (shape_overlap(ego, ob, ka.b.obs_nvert, ka.b.obs_poly, ka.b.poly_stride, e.col0 + j)) return true;
         }
     }
     return false;
@@ -342,7 +344,11 @@ __device__ double pose_min_gap(const KernelArgs& ka, const EgoCtx& e, int i, dou
         }
         double oc, os;
         sincos_snapped(row[4 * j + 2], os, oc);
-        g = fmin(g, obb_gap(ego, Obb{ox, oy, oc, os, e.obs_dim[4 * j], e.obs_dim[4 * j + 1]}));
+        // (a polygon column: the larger of the two gaps - its box is a necessary condition, the polygon itself decides)
+        double gj = obb_gap(ego, Obb{ox, oy, oc, os, e.obs_dim[4 * j], e.obs_dim[4 * j + 1]});
+        const int nvert = ka.b.obs_nvert ? ka.b.obs_nvert[e.col0 + j] : 0;
+        if (nvert > 0) gj = fmax(gj, poly_gap(ego, ox, oy, oc, os, ka.b.obs_poly + (e.col0 + j) * 2 * (size_t)ka.b.poly_stride, nvert));
+        g = fmin(g, gj);
     }
     return g;
 }

@@ -212,14 +212,66 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
 // NTH: threads per workgroup, 512 or - the grouped latency instances, one workgroup per CU - 1024 (twice the wavefronts per pass).
 // the kernel's parameters as one struct: where InlineIn::bytes sits in the argument segment
 struct LatticeKernarg {
-    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from; InlineIn inl;
+    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from, epi_from; InlineIn inl;
 };
 constexpr size_t kInlineOffset = offsetof(LatticeKernarg, inl) + offsetof(InlineIn, bytes);
 
-template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH>
+// POLY: the scene may hold convex-polygon obstacle columns (fp_batch.obs_nvert != NULL).  Only the run-time-shape instances exist with
+// POLY = true: the polygon branch in the narrow phase costs the rectangle-only instances 26 more spilled SGPRs and 2 % of the headline
+// step (same-box A/B), and scenes with polygons are not what the shaped instances were made for.
+template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH, bool POLY = false>
 __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit_arg, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur, int gs_arg, int tail_from, InlineIn inl)
+                                                                   int* dur, int gs_arg, int tail_from, int epi_from, InlineIn inl)
 {
+    // ---------------------------------------------------------------- appended epilogue workgroups (blockIdx >= epi_from)
+    // The three-workgroups-per-CU instances cannot write the winner's series themselves (the slot time of a one-wavefront dependent
+    // chain, and 125 registers), and a winner_traj_kernel behind the launch costs ~9.5 us of a ~155 us step in which the last ~25 us
+    // run on a draining chip.  So the series are written INSIDE the drain: the grid carries B / 4 more workgroups at its end - the
+    // hardware dispatches workgroups in index order, so they become resident when every lattice workgroup has been dispatched and
+    // slots fall free - each of which takes four dispatch slots (in launch order: the egos that started first), waits for their argmins
+    // (flag per ego, set by the workgroup that published it; relaxed agent-scope atomics, see the ticket's ordering argument below)
+    // and writes the four series, two wavefronts per trajectory (winner_series_pair: one point per lane, 80 registers).
+    // No deadlock: an epilogue workgroup only ever waits for lattice workgroups, and a workgroup distributor (one per XCD, each
+    // taking every eighth workgroup) starts its workgroups in index order: when an epilogue workgroup holds a slot, every lattice
+    // workgroup of the same XCD has been started, and those of the other XCDs do not depend on this XCD's slots.  Should that
+    // ever not hold the wait gives up after ~2 s and traps (a failed call instead of a hung device).
+    if constexpr (OCC > 4) {
+        if (epi_from >= 0 && (int)blockIdx.x >= epi_from) {
+            extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+            constexpr int kPairs = NTH / (2 * kWave);  // trajectories per workgroup
+            double* scratch = (double*)esm;                         // [kPairs][4][FP_MAX_POINTS]
+            int* s_m = (int*)(esm + kPairs * 4 * FP_MAX_POINTS * 8);  // [kPairs][2] first point off the spline per wavefront
+            int* s_idx = s_m + 2 * kPairs;                           // [kPairs] the egos' argmins
+            const int pair = (int)threadIdx.x / (2 * kWave), i = (int)threadIdx.x - pair * 2 * kWave;
+            const int eslot = ((int)blockIdx.x - epi_from) * kPairs + pair;
+            const bool have = eslot < ka.b.B;
+            const int eb = have ? (perm ? perm[eslot] : eslot) : 0;
+            if (have && i == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(&ka.epi_flag[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1 << 23)) __builtin_trap();
+                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the index is read after the flag
+                s_idx[pair] = __hip_atomic_load(&ka.idx_shadow[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ka.epi_flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+            __syncthreads();
+            const fp_params& pp = ka.p;
+            const fp_batch& bb = ka.b;
+            const int win = have ? s_idx[pair] : -1;
+            double d_end = __builtin_nan(""), v_end = d_end, T_end = d_end;
+            if (win >= 0) {
+                const int iv = win % pp.nv, it = (win / pp.nv) % pp.nt, id = win / (pp.nv * pp.nt);
+                d_end = bb.d_samples[id]; v_end = bb.v_samples[(size_t)eb * pp.nv + iv]; T_end = bb.t_samples[it];
+            }
+            const int ef = bb.frame_of[eb];
+            // (a pair beyond the batch still runs the barriers; it writes nothing)
+            winner_series_pair(ka, eb, eb, win >= 0, d_end, v_end, T_end, i, SplineLds{bb.knots + (size_t)ef * bb.NX, bb.coef + (size_t)ef * 8 * bb.NX, bb.nx[ef], bb.NX},
+                               scratch + pair * 4 * FP_MAX_POINTS, s_m + 2 * pair, have);
+            return;
+        }
+    }
     // Dispatch slot -> (ego, part).  Uniform split (latency mode): slot = blockIdx / nsplit.  Tail split (tail_from >= 0, nsplit_arg
     // == 1): the slots from tail_from on - the workgroups that start when the launch's last round is already draining - are cut in
     // two like a latency-mode ego, so the launch does not end on whole egos that started last (see launch_lattice_fused).
@@ -338,7 +390,21 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     if (skip_flag) {  // finished ego of a closed-loop batch (block-uniform exit)
         if (part == 0) {
             if (tid == 0 && dur) dur[b] = 0;
-            if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); if (ka.idx_shadow) ka.idx_shadow[b] = -1; }
+            if (tid == 0) { ka.r.best_idx[b] = -1; ka.r.best_cost[b] = __builtin_nan(""); }
+            if constexpr (OCC > 4) {
+                if (ka.epi_flag) {  // (the appended epilogue workgroups write the NaN series / the zero flag word of a skipped ego too)
+                    if (tid == 0) {
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        __hip_atomic_store(&ka.idx_shadow[b], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        __builtin_amdgcn_s_waitcnt(0);
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        __hip_atomic_store(&ka.epi_flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return;
+                }
+            }
+            if (tid == 0 && ka.idx_shadow) ka.idx_shadow[b] = -1;
             if (ka.r.best_traj) {  // NaN series, flag word 0 (returns before it touches the spline or the scratch)
                 const double nan = __builtin_nan("");
                 if (wave == 0) winner_series_wave(ka, b, b, false, nan, nan, nan, lane, SplineLds{nullptr, nullptr, 0, 0});
@@ -980,7 +1046,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                     } else {
                                         const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
                                         const double dx = op.x - ego.x, dy = op.y - ego.y;
-                                        hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                        if constexpr (POLY) hit = fma(dx, dx, dy * dy) <= R * R && shape_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, bt.obs_nvert, bt.obs_poly, bt.poly_stride, (size_t)sc * n_obs + j);
+                                        else hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
                                     }
                                     if (hit) FP_COUNT(5, 1);
                                 }
@@ -1208,7 +1275,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                             } else {
                                 const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
                                 const double dx = op.x - ego.x, dy = op.y - ego.y;
-                                hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                if constexpr (POLY) hit = fma(dx, dx, dy * dy) <= R * R && shape_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, bt.obs_nvert, bt.obs_poly, bt.poly_stride, (size_t)sc * n_obs + j);
+                                        else hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
                             }
                             if (hit) { s_coll[cand] = 1; FP_COUNT(5, 1); FP_COUNT(8 + (k >> 3), 1); }
                         }
@@ -1321,7 +1389,17 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     if (tid == 0) {
         const Best r = s_best[0];
         ka.r.best_idx[b] = r.idx;
-        if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
+        if constexpr (OCC > 4) {
+            if (ka.epi_flag) {  // hand the ego to the appended epilogue workgroups: index first, acknowledged by L2, then the flag
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __hip_atomic_store(&ka.idx_shadow[b], r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __builtin_amdgcn_s_waitcnt(0);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __hip_atomic_store(&ka.epi_flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
+        } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
         ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
         if (ka.r.stats) {
             int32_t* st = ka.r.stats + (size_t)b * 4;
@@ -1423,17 +1501,28 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         gs = fit < 1 ? 1 : (gs > fit ? fit : gs);
     }
     const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1, kThreads / kWave);
-#if defined(FP_PHASE_STAMPS)  // (the stamps travel in the series block: the three-workgroup variant leaves the series themselves unwritten)
+    // the series of a three-per-CU launch: by epilogue workgroups appended to the grid (ka.epi_flag + ka.idx_shadow from the caller), if
+    // there are fewer of them than resident slots (see the kernel); else the caller launches winner_traj_kernel behind this launch
+    constexpr int kEpiPairs = kThreads / (2 * kWave);
+    constexpr int kEpiLds = kEpiPairs * 4 * FP_MAX_POINTS * 8 + kEpiPairs * 3 * 4 + 16;
+#if defined(FP_PHASE_STAMPS) || defined(FP_COUNTERS)  // (the stamps travel in the series block: the three-workgroup variant leaves the series themselves unwritten)
+    const bool can_epi = false;
     bool three = gs == 1 && nsplit == 1 && b.B > 512 && L6.total <= 52 * 1024;
 #else
-    bool three = gs == 1 && nsplit == 1 && !ka.r.best_traj && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
+    const bool can_epi = ka.r.best_traj && ka.epi_flag && ka.idx_shadow && !ka.has_loop;
+    // (series asked of THIS kernel pin it to the two-per-CU instances; series offered to the epilogue workgroups do not)
+    bool three = gs == 1 && nsplit == 1 && (!ka.r.best_traj || ka.epi_flag) && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
 #endif
     if (in.on) three = false;  // (inline inputs are read by the two-workgroup instances only; they belong to tiny batches anyway)
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
 #endif
-    const Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave);
+    const bool epilogue = three && can_epi;
+    KernelArgs kx = ka;  // (epilogue workgroups offered but not taken: the caller's winner_traj_kernel writes the series)
+    if (ka.epi_flag && !epilogue) { kx.r.best_traj = nullptr; kx.epi_flag = nullptr; }
+    Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
+    if (epilogue && L.total < kEpiLds) L.total = kEpiLds;  // (every workgroup of a launch gets the same dynamic LDS)
     if (nsplit > p.nt) nsplit = p.nt;
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
     int* part_count = (int*)part_scratch;
@@ -1453,7 +1542,9 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         if (n_tail > 0) tail_from = b.B - n_tail;
     }
 #endif
-    const unsigned grid = tail_from >= 0 ? (unsigned)(2 * b.B - tail_from) : (unsigned)(b.B * nsplit);
+    const unsigned lattice_grid = tail_from >= 0 ? (unsigned)(2 * b.B - tail_from) : (unsigned)(b.B * nsplit);
+    const int epi_from = epilogue ? (int)lattice_grid : -1;
+    const unsigned grid = lattice_grid + (epilogue ? (unsigned)((b.B + kEpiPairs - 1) / kEpiPairs) : 0u);
     hipError_t e;
     if (p.curvature_mask) {  // optional curvature checks: their own launch, ORed into the flag words by the assembly stage
         if (!ka.curv_tbl) return hipErrorInvalidValue;
@@ -1464,7 +1555,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     auto go = [&](auto kernel, int* configured, int threads = kThreads) -> hipError_t {
         hipError_t err = ensure_dynamic_lds((const void*)kernel, L.total, configured);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, stream, ka, rows, hp, nsplit, part_best, part_count, perm, dur, gs, tail_from, in);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, stream, kx, rows, hp, nsplit, part_best, part_count, perm, dur, gs, tail_from, epi_from, in);
         return hipGetLastError();
     };
     FP_LDS_SLOTS(cfg_generic);
@@ -1476,13 +1567,20 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_generic_g);
     FP_LDS_SLOTS(cfg_997_g);
     FP_LDS_SLOTS(cfg_555_g);
+    FP_LDS_SLOTS(cfg_poly);
+    FP_LDS_SLOTS(cfg_poly6);
+    FP_LDS_SLOTS(cfg_poly_g);
     auto is = [&](int nd, int nv, int nt, int stride, int n_obs, int r) {
         return p.nd == nd && p.nv == nv && p.nt == nt && p.check_stride == stride && b.n_obs == n_obs && rows == r;
     };
 #if defined(FP_NO_SHAPES)  // (A/B diagnostic: the run-time instance for every shape)
-    e = gs > 1 ? go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS>, cfg_generic_g, FP_GROUP_THREADS) : go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 1, 512>, cfg_generic);
+    e = gs > 1 ? go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS, true>, cfg_generic_g, FP_GROUP_THREADS) : go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 1, 512, true>, cfg_generic);
 #else
-    if (gs > 1) {
+    if (b.obs_nvert && b.n_obs > 0) {  // convex-polygon columns: the run-time-shape instances with the polygon narrow phase
+        if (gs > 1) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS, true>, cfg_poly_g, FP_GROUP_THREADS);
+        else if (three) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, true>, cfg_poly6);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 1, 512, true>, cfg_poly);
+    } else if (gs > 1) {
         if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 4, 0, FP_GROUP_THREADS>, cfg_997_g, FP_GROUP_THREADS);
         else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4, 0, FP_GROUP_THREADS>, cfg_555_g, FP_GROUP_THREADS);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS>, cfg_generic_g, FP_GROUP_THREADS);
@@ -1497,7 +1595,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     }
 #endif
     if (e != hipSuccess) return e;
-    if (winner_done) *winner_done = ka.r.best_traj != nullptr && !three;
+    if (winner_done) *winner_done = kx.r.best_traj != nullptr && (!three || epilogue);
     if (step_done) *step_done = ka.has_loop != 0 && !three;  // (ka.has_loop: the two-per-CU instances hand the egos over themselves)
     return hipSuccess;
 }

@@ -142,6 +142,105 @@ __device__ __forceinline__ void winner_series_wave(const KernelArgs& ka, int b, 
     }
 }
 
+// The same series written by TWO wavefronts, one time point per lane (point i = 64 * (wavefront of the pair) + lane): half the live values
+// of winner_series_wave (its two-points-per-lane body needs ~125 VGPRs; this one fits the 80 of the three-workgroups-per-CU lattice
+// instances, whose appended epilogue workgroups run it - see lattice_fused_kernel).  The neighbour elements of the difference chains
+// travel through `scratch` (LDS, 5 x FP_MAX_POINTS doubles of this trajectory) between workgroup barriers: EVERY thread of the
+// workgroup must call this function (the same number of barriers), whatever its trajectory.  Element for element the arithmetic of
+// winner_series_wave (bit-identical output).  write = false: no stores at all (the thread only keeps the barriers' count).
+__device__ __forceinline__ void winner_series_pair(const KernelArgs& ka, int b, int slot, bool valid, double d_end, double v_end, double T, int i,
+                                                   const SplineLds& sp, double* scratch, int* m_scratch, bool write = true)
+{
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
+    const double nan = __builtin_nan("");
+    const int stride = ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS;
+    const bool sparse = ka.r.traj_sparse != 0;
+    double* out = ka.r.best_traj + (size_t)slot * FP_ARR_COUNT * stride;
+    const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
+    const bool ok = valid && N > 0 && N <= FP_MAX_POINTS && (d_end == d_end) && (v_end == v_end);  // uniform over the pair
+    auto put = [&](int r, double v, int len) {  // element i of a row that holds `len` elements (see winner_series_wave)
+        const int upto = sparse ? ((len + 15) & ~15) : FP_MAX_POINTS;
+        const int lim = stride < upto ? stride : upto;
+        if (!write) return;  // (a thread without a trajectory only takes part in the barriers)
+        if (i < lim) __builtin_nontemporal_store(i < len ? v : nan, &out[r * stride + i]);
+        if (!sparse && stride > FP_MAX_POINTS)
+            for (int k = FP_MAX_POINTS + i; k < stride; k += 2 * kWave) __builtin_nontemporal_store(nan, &out[r * stride + k]);
+    };
+    double* xs = scratch;
+    double* ys = scratch + FP_MAX_POINTS;
+    double* ws = scratch + 2 * FP_MAX_POINTS;  // yaw, then c_d
+    double* cs = scratch + 3 * FP_MAX_POINTS;  // c
+    double x = nan, y = nan;
+    bool off = false;
+    if (ok) {
+        const double* eg = bt.ego + (size_t)b * 6;
+        double t = nan, s = nan, s_d = nan, s_dd = nan, s_ddd = nan, d = nan, d_d = nan, d_dd = nan, d_ddd = nan;
+        if (i < N) {
+            const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], d_end, 0.0, 0.0, T);
+            const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], v_end, 0.0, T);
+            t = (double)i * p.tick_t;
+            quartic_eval(lon, t, s, s_d, s_dd, s_ddd);
+            quintic_eval(lat, t, d, d_d, d_dd, d_ddd);
+            const int seg = spline_segment(sp, s, -1);
+            off = seg < 0;  // first point off the spline truncates the Cartesian series (:112-113)
+            if (!off) {
+                double px, py, tx, ty;
+                spline_frame(sp, seg, s - sp.knots[seg], px, py, tx, ty);
+                frenet_to_cartesian(px, py, tx, ty, d, x, y);
+            }
+        }
+        put(FP_ARR_T, t, N);
+        put(FP_ARR_S, s, N); put(FP_ARR_S_D, s_d, N); put(FP_ARR_S_DD, s_dd, N); put(FP_ARR_S_DDD, s_ddd, N);
+        put(FP_ARR_D, d, N); put(FP_ARR_D_D, d_d, N); put(FP_ARR_D_DD, d_dd, N); put(FP_ARR_D_DDD, d_ddd, N);
+    } else {  // no trajectory: NaN rows in the dense layout, nothing in the sparse one
+#pragma unroll
+        for (int r = 0; r < FP_ARR_COUNT; ++r) put(r, nan, 0);
+    }
+    xs[i] = x; ys[i] = y;
+    {   // first point off the spline over both wavefronts of the pair
+        const unsigned long long m = __ballot(off);
+        if ((i & (kWave - 1)) == 0) m_scratch[i >> 6] = m ? (i & ~(kWave - 1)) + __ffsll((long long)m) - 1 : FP_MAX_POINTS;
+    }
+    __syncthreads();
+    int M = N;
+    {
+        const int m0 = m_scratch[0], m1 = m_scratch[1];
+        const int mf = m0 < m1 ? m0 : m1;
+        M = mf < M ? mf : M;
+    }
+    const bool last = i + 1 >= FP_MAX_POINTS;  // (element 128 does not exist: the value is never used)
+    const double xn = last ? nan : xs[i + 1], yn = last ? nan : ys[i + 1];
+    const double ddx = xn - x, ddy = yn - y;
+    const double yaw_raw = atan2(ddy, ddx), ds = hypot(ddx, ddy);
+    ws[i] = yaw_raw;
+    __syncthreads();
+    // the last point repeats the previous heading (:129): yaw[M - 1] = yaw[M - 2]
+    const double yaw = (i == M - 1 && i >= 1) ? ws[i - 1] : yaw_raw;
+    const double yaw_next = last ? nan : ((i + 1 == M - 1) ? yaw_raw : ws[i + 1]);
+    const double c = (yaw_next - yaw) / ds;
+    cs[i] = c;
+    __syncthreads();
+    const double cd = ((last ? nan : cs[i + 1]) - c) / p.tick_t;
+    ws[i] = cd;  // (every thread is past its reads of the headings: they happened before the barrier above)
+    __syncthreads();
+    const double cdd = ((last ? nan : ws[i + 1]) - cd) / p.tick_t;
+    if (ok) {
+        const int My = M >= 2 ? M : 0;  // x, y keep their M points; the difference chains need two
+        put(FP_ARR_X, x, M); put(FP_ARR_Y, y, M);
+        put(FP_ARR_YAW, yaw, My); put(FP_ARR_DS, ds, My - 1); put(FP_ARR_C, c, My - 1);
+        put(FP_ARR_C_D, cd, My - 2); put(FP_ARR_C_DD, cdd, My - 3);
+    }
+    if (i == 0 && ka.r.best_flags && write) {
+        uint32_t fl = 0u;
+        if (ok) {
+            fl = ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
+            if (M < N) fl |= FP_FLAG_TRUNCATED;
+        }
+        ka.r.best_flags[slot] = fl;
+    }
+}
+
 // Materialise mode (fp_materialize_all): one WAVEFRONT writes the series of ALL nd lattice candidates that share one longitudinal
 // profile (i_T, i_v).  Of a candidate's series everything but the lateral polynomial belongs to the profile: t, s and its
 // derivatives, the spline segment of every point, the reference-line frame (position + unit tangent) and the truncation index M -

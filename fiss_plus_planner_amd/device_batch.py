@@ -27,11 +27,11 @@ class DeviceBatch:
         self.host = batch
         self.dev = torch.device("cuda", device)
         self.t = {k: torch.from_numpy(np.ascontiguousarray(getattr(batch, k))).to(self.dev) for k in _NAMES}
-        for k in ("samp_min", "samp_max", "samp_res"):
-            if getattr(batch, k) is not None:
+        for k in ("samp_min", "samp_max", "samp_res", "obs_poly", "obs_nvert"):
+            if getattr(batch, k, None) is not None:
                 self.t[k] = torch.from_numpy(getattr(batch, k)).to(self.dev)
         self.params = make_params(batch)
-        self.fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in self.t.items() if k in _NAMES})
+        self.fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in self.t.items() if k in _NAMES + ("obs_poly", "obs_nvert")})
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.dev)

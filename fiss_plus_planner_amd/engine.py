@@ -68,8 +68,9 @@ def _host_batch(batch: ProblemBatch) -> _abi.FpBatch:
     """FpBatch over the batch's own numpy arrays.  A planner re-plans with the same (in-place updated) arrays every cycle, so
     the struct is cached on the batch and rebuilt only when one of the arrays was replaced."""
     arrays = [getattr(batch, name) for name in _BATCH_PTRS]
+    poly = [batch.obs_poly, batch.obs_nvert] if getattr(batch, "obs_nvert", None) is not None else []
     tag = int(getattr(batch, "tables_tag", 0) or 0)  # fp_batch.tables_tag: the frame / scene tables stay on the device between calls
-    key = tuple(map(id, arrays)) + (tag,)
+    key = tuple(map(id, arrays + poly)) + (tag,)
     cached = batch.__dict__.get("_fb_cache")
     if cached is not None and cached[0] == key:
         return _abi.FpBatch.from_buffer_copy(cached[1])  # a copy: callers may edit their struct
@@ -78,7 +79,9 @@ def _host_batch(batch: ProblemBatch) -> _abi.FpBatch:
     for name, a in zip(_BATCH_PTRS, arrays):
         setattr(fb, name, _ptr(a) if a.size else None)
     fb.tables_tag = tag
-    batch.__dict__["_fb_cache"] = (key, _abi.FpBatch.from_buffer_copy(fb), arrays)  # the arrays are kept alive with the pointers
+    if poly and batch.S > 0 and batch.n_obs > 0:  # convex-polygon obstacle columns (fp_batch.obs_poly / obs_nvert)
+        fb.obs_poly, fb.obs_nvert, fb.poly_stride = _ptr(poly[0]), _ptr(poly[1]), int(poly[0].shape[2])
+    batch.__dict__["_fb_cache"] = (key, _abi.FpBatch.from_buffer_copy(fb), arrays + poly)  # the arrays are kept alive with the pointers
     return fb
 
 
@@ -100,6 +103,8 @@ def device_batch(sizes, ptrs: dict) -> _abi.FpBatch:
     fb.B, fb.F, fb.NX, fb.S, fb.T_obs, fb.n_obs = sizes.B, sizes.F, sizes.NX, sizes.S, sizes.T_obs, sizes.n_obs
     for name in _BATCH_PTRS:
         setattr(fb, name, ptrs.get(name) or None)
+    if ptrs.get("obs_nvert"):
+        fb.obs_poly, fb.obs_nvert, fb.poly_stride = ptrs["obs_poly"], ptrs["obs_nvert"], int(sizes.poly_stride)
     return fb
 
 

@@ -194,7 +194,9 @@ class FrenetOptimalPlanner:
                 obs_pose=pose, obs_dims=dims, final_time_step=fts, veh_l=self.vehicle.l, veh_w=self.vehicle.w,
                 max_speed=self.vehicle.max_speed, max_accel=self.vehicle.max_accel, tick_t=st.tick_t, check_stride=2,
                 samp_min=np.array([[-sw / 2, st.lowest_speed, st.min_t]]), samp_max=np.array([[sw / 2, 0.0, st.max_t]]),
-                samp_res=np.array([[rd, 0.0, rt]]), curvature_limits=curv)
+                samp_res=np.array([[rd, 0.0, rt]]), curvature_limits=curv,
+                obs_poly=None if tab is None or tab.nvert is None else tab.poly[None],
+                obs_nvert=None if tab is None or tab.nvert is None else tab.nvert[None])
             # fp_batch.tables_tag: the library keeps this batch's spline and obstacle tables on the device until the planner builds
             # a new batch (another centerline / another obstacle list / ObstacleTable.update()) - per cycle only the start state
             # travels.  Contract (class docstring): the cached arrays are frozen, so an in-place edit raises instead of going stale;

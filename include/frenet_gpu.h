@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 11
+#define FP_ABI_VERSION 12
 
 /* error codes */
 #define FP_OK 0
@@ -55,6 +55,7 @@ extern "C" {
 #define FP_MAX_POINTS 128   /* N = ceil(T / tick_t) per trajectory */
 #define FP_MAX_KNOTS 512    /* reference-line knots per frame */
 #define FP_MAX_CAND 4096    /* nd*nv*nt */
+#define FP_MAX_POLY_VERTS 128 /* vertices of one convex-polygon obstacle column (shapely's buffer() circle has 64) */
 
 /* candidate flag word: low bits = why a candidate is infeasible, then N and M */
 #define FP_FLAG_SPEED 1u      /* any(s_d > max_speed)       frenet_optimal_planner.py:152 */
@@ -114,7 +115,7 @@ typedef struct {
     const double* knots;         /* [F][NX]     cumulative chord length, +inf padded   cubic_spline.py:162-168 */
     const double* coef;          /* [F][8][NX]  ax bx cx dx ay by cy dy                cubic_spline.py:30-43 */
     const double* obs_pose;      /* [S][T_obs][n_obs][4]  x, y, yaw, valid(0/1) */
-    const double* obs_dims;      /* [S][n_obs][2]         length, width */
+    const double* obs_dims;      /* [S][n_obs][2]         length, width (a polygon column: the centred box that contains it, see obs_poly) */
     const int32_t* final_time_step; /* [S]      obstacles[0].prediction.final_time_step :173 */
     const int32_t* skip;         /* NULL or [B]: egos with skip[b] != 0 are not planned (best_idx = -1, no table rows written);
                                     the closed-loop driver passes its `done` array here */
@@ -125,7 +126,19 @@ typedef struct {
      * is ~100 KB per call that need not travel, ~12 us of a ~43 us call).  A new tag (or changed sizes) uploads again; a ctx keeps
      * the tables of its four most recently used tags.  Ignored by FP_MEM_DEVICE calls. */
     int32_t tables_tag;
-    int32_t reserved0;
+    /* Obstacle shapes other than rectangles (ABI 12).  has_collision hands `obstacle.obstacle_shape.shapely_object` - ANY polygon - to
+     * construct_polygon and Polygon.intersects (frenet_optimal_planner.py:162-166, :189-191).  obs_nvert == NULL: every column is the
+     * rectangle of obs_dims.  Else obs_nvert[s][j] = 0 for a rectangle, or the number of vertices (3 .. poly_stride) of a CONVEX
+     * polygon whose ring is obs_poly[s][j][0 .. nvert): (x, y) relative to the column's rotation centre - the centre of the shape's
+     * bounding box, about which affinity.rotate(origin='center') turns it; the column's poses carry that centre - in COUNTER-CLOCKWISE
+     * order, closing vertex not repeated.  At a pose (x, y, yaw) vertex i sits at (x, y) + R(yaw) (u_x, u_y).  obs_dims of such a column
+     * MUST be (2 max|u_x|, 2 max|u_y|) or larger (the broad phases test that box; FP_MEM_HOST calls check it).  A circle is the polygon
+     * shapely's buffer() makes of it; a non-convex shape or a group of shapes is several columns with the same poses, one convex piece
+     * each, every piece relative to the WHOLE shape's centre (fiss_plus_planner_amd/obstacles.py does all of this).  Part of the
+     * scene tables as far as tables_tag is concerned. */
+    int32_t poly_stride;          /* vertices per column of obs_poly (<= FP_MAX_POLY_VERTS); ignored when obs_nvert == NULL */
+    const double* obs_poly;       /* NULL or [S][n_obs][poly_stride][2] */
+    const int32_t* obs_nvert;     /* NULL or [S][n_obs] */
 } fp_batch;
 
 /* Outputs of the dense lattice pass; any pointer except best_idx/best_cost may be NULL.

@@ -500,6 +500,93 @@ int orc_box_vertices(double l, double w, double x, double y, double yaw, double*
     return 0;
 }
 
+/* ---- obstacle shapes other than rectangles.  `obstacle_shape.shapely_object` is any polygon (frenet_optimal_planner.py:189-191); a
+   problem's column j with obs_nvert[j] >= 3 carries a convex counter-clockwise ring relative to its rotation centre (the centre of the
+   shape's bounding box, which the column's poses carry).  construct_polygon (:162-166) on it: translate every vertex by the pose,
+   rotate about (x0, y0) = the pose position with shapely's affine arithmetic (cos / sin snapped below 2.5e-16). */
+static int make_ring(const double* u, int n, double x, double y, double yaw, double* out)
+{
+    if (!isfinite(x) || !isfinite(y) || !isfinite(yaw)) return -1;
+    double cosp = cos(yaw), sinp = sin(yaw);
+    if (fabs(cosp) < 2.5e-16) cosp = 0.0;
+    if (fabs(sinp) < 2.5e-16) sinp = 0.0;
+    const double x0 = x, y0 = y;
+    const double xoff = x0 - x0 * cosp + y0 * sinp;
+    const double yoff = y0 - x0 * sinp - y0 * cosp;
+    for (int k = 0; k < n; ++k) {
+        const double tx = u[2 * k] + x, ty = u[2 * k + 1] + y;
+        if (!isfinite(tx) || !isfinite(ty)) return -1;
+        out[2 * k] = cosp * tx - sinp * ty + xoff;
+        out[2 * k + 1] = sinp * tx + cosp * ty + yoff;
+    }
+    return 0;
+}
+
+/* Polygon.intersects for two convex polygons (rings of na / nb vertices): closed-set separating-axis test over the edge normals of
+   both (touching counts as intersecting) - quads_intersect for any vertex count. */
+static int convex_intersect(const double* A, int na, const double* B, int nb)
+{
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* P = pass ? B : A;
+        const int np_ = pass ? nb : na;
+        for (int k = 0; k < np_; ++k) {
+            const int k1 = (k + 1) % np_;
+            const double ex = P[2 * k1] - P[2 * k], ey = P[2 * k1 + 1] - P[2 * k + 1];
+            const double ax = -ey, ay = ex;
+            double amin = INFINITY, amax = -INFINITY, bmin = INFINITY, bmax = -INFINITY;
+            for (int v = 0; v < na; ++v) {
+                const double pa = A[2 * v] * ax + A[2 * v + 1] * ay;
+                if (pa < amin) amin = pa;
+                if (pa > amax) amax = pa;
+            }
+            for (int v = 0; v < nb; ++v) {
+                const double pb = B[2 * v] * ax + B[2 * v + 1] * ay;
+                if (pb < bmin) bmin = pb;
+                if (pb > bmax) bmax = pb;
+            }
+            if (amax < bmin || bmax < amin) return 0;
+        }
+    }
+    return 1;
+}
+
+/* the same predicate decided exactly (see quads_intersect_exact) */
+static int convex_intersect_exact(const double* A, int na, const double* B, int nb)
+{
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* P = pass ? B : A;
+        const double* Q = pass ? A : B;
+        const int np_ = pass ? nb : na, nq = pass ? na : nb;
+        for (int k = 0; k < np_; ++k) {
+            const double* p0 = P + 2 * k;
+            const double* p1 = P + 2 * ((k + 1) % np_);
+            int inside = 0;
+            for (int m = 2; m < np_ && inside == 0; ++m) inside = orient_sign(p0, p1, P + 2 * ((k + m) % np_));
+            if (inside == 0) continue; /* degenerate edge: no half plane */
+            int all_out = 1;
+            for (int v = 0; v < nq && all_out; ++v) {
+                const int o = orient_sign(p0, p1, Q + 2 * v);
+                if (o == 0 || o == inside) all_out = 0;
+            }
+            if (all_out) return 0;
+        }
+    }
+    return 1;
+}
+
+/* Ego box (l, w at x, y, yaw) against a convex ring `u` (n vertices relative to its rotation centre) at pose (ox, oy, oyaw):
+   1 / 0 / -1 (a polygon could not be built).  exact = 0: the float test, 1: the exact one.  world (may be NULL): the ring's 2 n
+   world coordinates, for the audit's second implementation in python. */
+int orc_box_ring_intersect(double l, double w, double x, double y, double yaw, const double* u, int32_t n, double ox, double oy,
+                           double oyaw, int32_t exact, double* world)
+{
+    double A[4][2], B[2 * ORC_MAX_POLY_VERTS];
+    if (n < 3 || n > ORC_MAX_POLY_VERTS) return -1;
+    if (make_box(l, w, x, y, yaw, A) || make_ring(u, n, ox, oy, oyaw, B)) return -1;
+    if (world) memcpy(world, B, sizeof(double) * 2 * (size_t)n);
+    return exact ? convex_intersect_exact(&A[0][0], 4, B, n) : convex_intersect(&A[0][0], 4, B, n);
+}
+
 /* has_collision, frenet_optimal_planner.py:168-195 */
 static int traj_has_collision(const orc_problem* p, const traj_t* t)
 {
@@ -517,6 +604,14 @@ static int traj_has_collision(const orc_problem* p, const traj_t* t)
             if (t_step < 0 || t_step >= p->T_obs) continue; /* state_at_time -> None */
             const double* ps = p->obs_pose + ((size_t)t_step * (size_t)p->n_obs + (size_t)j) * 4;
             if (ps[3] == 0.0) continue; /* :187-188 */
+            const int nvert = p->obs_nvert ? p->obs_nvert[j] : 0;
+            if (nvert >= 3) { /* a polygon column: the ring itself (obs_dims only holds the box around it) */
+                double ring[2 * ORC_MAX_POLY_VERTS];
+                if (nvert > ORC_MAX_POLY_VERTS) return -1;
+                if (make_ring(p->obs_poly + (size_t)j * 2 * (size_t)p->poly_stride, nvert, ps[0], ps[1], ps[2], ring)) continue;
+                if (convex_intersect(&ego[0][0], 4, ring, nvert)) return 1;
+                continue;
+            }
             double ob[4][2];
             if (make_box(p->obs_dims[2 * j], p->obs_dims[2 * j + 1], ps[0], ps[1], ps[2], ob)) continue;
             if (quads_intersect(ego, ob)) return 1;

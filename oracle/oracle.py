@@ -42,6 +42,7 @@ class OrcProblem(C.Structure):
         ("n_obs", C.c_int32), ("T_obs", C.c_int32), ("obs_pose", _dp), ("obs_dims", _dp),
         ("final_time_step", C.c_int32), ("t_now", C.c_int32), ("check_stride", C.c_int32),
         ("curvature_mask", C.c_int32), ("max_curvature", C.c_double), ("max_kappa_d", C.c_double), ("max_kappa_dd", C.c_double),
+        ("obs_poly", _dp), ("obs_nvert", _ip), ("poly_stride", C.c_int32),
     ]
 
 
@@ -90,6 +91,8 @@ def lib():
         L.orc_boxes_intersect_exact.restype = C.c_int
         L.orc_boxes_intersect_batch.argtypes = [C.c_int32, _dp, _dp, C.c_int32, C.c_int32, C.POINTER(C.c_int8)]
         L.orc_box_vertices.argtypes = [C.c_double] * 5 + [_dp]
+        L.orc_box_ring_intersect.argtypes = [C.c_double] * 5 + [_dp, C.c_int32] + [C.c_double] * 3 + [C.c_int32, _dp]
+        L.orc_box_ring_intersect.restype = C.c_int
         _lib = L
     return _lib
 
@@ -173,6 +176,17 @@ def box_vertices(box):
     return None if rc else out.reshape(4, 2)
 
 
+def box_ring_intersect(box, ring, pose, exact=False, world=False):
+    """Ego box (l, w, x, y, yaw) against a convex counter-clockwise ring [n, 2] (relative to its rotation centre) at pose (x, y, yaw):
+    construct_polygon + Polygon.intersects for a polygon obstacle.  True / False / None; world=True also returns the ring's world
+    coordinates [n, 2]."""
+    u = _f64(ring).reshape(-1, 2)
+    w = np.empty_like(u)
+    rc = lib().orc_box_ring_intersect(*[float(v) for v in box], _p(u), len(u), *[float(v) for v in pose], int(exact), _p(w))
+    res = None if rc < 0 else bool(rc)
+    return (res, w) if world else res
+
+
 def goal_reached(poly, x, y, time_step=0, velocity=0.0, orientation=0.0, intervals=None):
     """goal_region.is_reached for one goal state: poly [n, 2], intervals None or [6] (time_step / velocity / orientation lo, hi; NaN = undefined)."""
     pl = _f64(poly).reshape(-1, 2)
@@ -196,7 +210,7 @@ class Problem:
 
     def __init__(self, *, d_samples, v_samples, t_samples, tick_t, target_speed, veh_l, veh_w, max_speed, max_accel,
                  ego, knots, coef_x, coef_y, obs_pose=None, obs_dims=None, final_time_step=0, t_now=0, check_stride=2,
-                 samp_min=None, samp_max=None, samp_res=None, curvature_limits=None):
+                 samp_min=None, samp_max=None, samp_res=None, curvature_limits=None, obs_poly=None, obs_nvert=None):
         self._keep = k = SimpleNamespace()
         k.d = _f64(d_samples); k.v = _f64(v_samples); k.t = _f64(t_samples)
         k.knots = _f64(knots); k.cx = _f64(coef_x); k.cy = _f64(coef_y)
@@ -226,6 +240,10 @@ class Problem:
         if curvature_limits is not None:  # (max_curvature, max_kappa_d, max_kappa_dd): turns the optional checks on
             P.curvature_mask = 1
             P.max_curvature, P.max_kappa_d, P.max_kappa_dd = (float(v) for v in curvature_limits)
+        if obs_nvert is not None and k.pose.size:  # convex-polygon obstacle columns: [n_obs, PV, 2] rings + [n_obs] vertex counts
+            k.poly = _f64(obs_poly); k.nvert = np.ascontiguousarray(obs_nvert, dtype=np.int32)
+            assert k.nvert.shape == (P.n_obs,) and k.poly.shape[0] == P.n_obs and k.poly.shape[2] == 2
+            P.obs_poly = _p(k.poly); P.obs_nvert = k.nvert.ctypes.data_as(_ip); P.poly_stride = k.poly.shape[1]
         self.c = P
 
     @property
@@ -317,7 +335,9 @@ def problems_from_batch(batch, egos=None, d_samples=None):
             samp_min=batch.samp_min[b] if getattr(batch, "samp_min", None) is not None else None,
             samp_max=batch.samp_max[b] if getattr(batch, "samp_max", None) is not None else None,
             samp_res=batch.samp_res[b] if getattr(batch, "samp_res", None) is not None else None,
-            curvature_limits=getattr(batch, "curvature_limits", None)))
+            curvature_limits=getattr(batch, "curvature_limits", None),
+            obs_poly=batch.obs_poly[sc] if has_obs and getattr(batch, "obs_nvert", None) is not None else None,
+            obs_nvert=batch.obs_nvert[sc] if has_obs and getattr(batch, "obs_nvert", None) is not None else None))
     return out
 
 

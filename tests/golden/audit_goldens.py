@@ -3,7 +3,7 @@
 
     python tests/golden/audit_goldens.py [--out /tmp/golden_audit] [--skip-generate]
 
-Regenerates every fixture whose generation calls Polygon.intersects (g3 g4 g5 g6 g9 g10 g11) into --out, with
+Regenerates every fixture whose generation calls Polygon.intersects (g3 g4 g5 g6 g9 g10 g11 g12) into --out, with
 refshim.Polygon.intersects = the EXACT predicate behind a float filter, compares every array of every regenerated .npz with the
 committed file bit for bit, and writes tests/golden/collision_audit.json: per generator the number of intersects calls, how many of
 them were within 1e-9 (relative) of contact and went to rational arithmetic, and how many of THOSE the plain fp64 separating-axis
@@ -19,7 +19,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GENS = ["g3", "g4", "g5", "g6", "g9", "g10", "g11"]
+GENS = ["g3", "g4", "g5", "g6", "g9", "g10", "g11", "g12"]
 
 
 def main():

@@ -752,8 +752,151 @@ def g10():
     save("g10_generated_order.npz", **out)
 
 
+# ---------------------------------------------------------------------------
+# G12: obstacle shapes that are not rectangles.  has_collision hands obstacle.obstacle_shape.shapely_object - ANY polygon - to
+# construct_polygon / intersects (frenet_optimal_planner.py:186-193).  The scenes keep synth's obstacle MOTION and swap the shapes:
+def g12_shapes():
+    """name -> own-frame geometry (a ring, or a list of rings for a group).  None: the scene's own rectangle (length, width)."""
+    ang = -np.arange(64) * (2.0 * np.pi / 64)  # shapely's Point.buffer(r): 64 vertices, clockwise from (r, 0)
+    c, sn = np.cos(ang), np.sin(ang)
+    c[np.abs(c) < 5e-16] = 0.0; sn[np.abs(sn) < 5e-16] = 0.0
+    rot = np.array([[np.cos(0.5), -np.sin(0.5)], [np.sin(0.5), np.cos(0.5)]])
+    rect = np.array([(-2.25, -0.95), (2.25, -0.95), (2.25, 0.95), (-2.25, 0.95)])
+    return [
+        ("circle", 1.6 * np.stack([c, sn], axis=1)),                                   # a commonroad Circle's shapely_object
+        ("triangle", np.array([(-2.4, -1.0), (2.4, -1.0), (0.0, 1.2)])),
+        ("rotated_rect", rect @ rot.T),                                                # a Rectangle with orientation 0.5
+        ("L", np.array([(0, 0), (4.2, 0), (4.2, 1.2), (1.3, 1.2), (1.3, 3.0), (0, 3.0)], dtype=float)),  # non-convex, off-centre
+        ("pentagon", np.array([(1.0, 0.0), (3.0, 0.5), (3.5, 2.0), (2.0, 3.0), (0.5, 1.8)])),           # convex, off-centre
+        ("rectangle", None),
+        ("group", [np.array([(-3.0, -0.5), (-1.0, -0.5), (-1.0, 0.5), (-3.0, 0.5)]), np.array([(1.0, -0.8), (3.0, 0.0), (1.0, 0.8)])]),
+    ]
+
+
+def g12_scene(b: ProblemBatch, seed: int) -> ProblemBatch:
+    """synth spreads its obstacles over +-4 m and 120 m: few verdicts would hang on a shape.  Here every obstacle drives slowly in
+    or beside the ego's lane, a few car lengths ahead, at a heading a little off the lane's - the ego's candidates brush past their
+    corners within the horizon."""
+    rng = np.random.default_rng(seed)
+    S, T, n = b.obs_pose.shape[:3]
+    tt = np.arange(T) * b.tick_t
+    pose = np.zeros_like(b.obs_pose)
+    for sc in range(S):
+        e = int(np.nonzero(b.scene_of == sc)[0][0])
+        s0 = b.ego[e, 0] + 14.0 + 11.0 * rng.permutation(n) + rng.uniform(-3, 3, n)
+        v = rng.uniform(0.0, 3.5, n)
+        side = np.where(rng.uniform(size=n) < 0.5, -1.0, 1.0)
+        d = side * rng.uniform(1.9, 3.3, n)
+        s_t = (s0[None, :] + v[None, :] * tt[:, None])[None]
+        f = int(b.frame_of[e])
+        px, py, yaw = synth.sample_frames(b.knots[f:f + 1], b.coef[f:f + 1], s_t)
+        px, py, yaw = px[0], py[0], yaw[0]
+        pose[sc, :, :, 0] = px - d[None, :] * np.sin(yaw)
+        pose[sc, :, :, 1] = py + d[None, :] * np.cos(yaw)
+        pose[sc, :, :, 2] = yaw + rng.uniform(-0.6, 0.6, n)[None, :] + 0.02 * tt[:, None] * rng.uniform(-1, 1, n)[None, :]
+        pose[sc, :, :, 3] = 1.0
+    return with_overrides(b, obs_pose=pose)
+
+
+def g12_obstacles(b: ProblemBatch, e: int):
+    sc = int(b.scene_of[e])
+    pose, dims, fts = b.obs_pose[sc], b.obs_dims[sc], int(b.final_time_step[sc])
+    out = []
+    for j, (_, geom) in enumerate(g12_shapes()):
+        p = pose[:, j, :3].copy()
+        p[pose[:, j, 3] == 0.0] = np.nan
+        if geom is None:
+            out.append(refshim.StubObstacle(dims[j, 0], dims[j, 1], p, fts))
+        elif isinstance(geom, list):
+            out.append(refshim.StubShapeObstacle(refshim.MultiPolygon(geom), p, fts))
+        else:
+            out.append(refshim.StubShapeObstacle(refshim.Polygon(geom), p, fts))
+    return out
+
+
+def g12():
+    """Per case: the raw inputs (synth batch = motion + the rectangle's sizes, the shape rings), the reference's per-candidate
+    has_collision verdicts and the four planners' answers with those shapes, and - for the tests' sanity - the verdicts the same
+    scene gives when every shape is replaced by its bounding box (what the build did before ABI 12): they must differ."""
+    out = {}
+    names = []
+    shapes = g12_shapes()
+    rings = np.full((len(shapes), 2, 64, 2), np.nan)
+    ring_n = np.zeros((len(shapes), 2), dtype=np.int32)
+    for j, (_, geom) in enumerate(shapes):
+        for k, ring in enumerate([] if geom is None else (geom if isinstance(geom, list) else [geom])):
+            rings[j, k, :len(ring)] = ring
+            ring_n[j, k] = len(ring)
+    out["shape_names"] = np.array([n for n, _ in shapes])
+    out["shape_rings"] = rings
+    out["shape_ring_n"] = ring_n
+    # (scene seeds picked with the oracle so that the shapes decide: verdicts and the selected index differ from the boxed scene's)
+    b5, b9 = synth.make_batch(3, 5, 5, 5, 7, 60, True, 9112), synth.make_batch(2, 9, 9, 7, 7, 50, True, 9113)
+    cases = [("p555", g12_scene(b5, 3)), ("p555b", g12_scene(b5, 4)), ("p997", g12_scene(b9, 11)), ("p997b", g12_scene(b9, 4))]
+    for name, b in cases:
+        names.append(name)
+        C = b.C
+        coll = np.zeros((b.B, C), dtype=bool); coll_box = np.zeros((b.B, C), dtype=bool); cost = np.empty((b.B, C))
+        for e in range(b.B):
+            pl = make_planner("FOP", b, e)
+            pl.settings.highest_speed = float(b.target_speed[e])
+            obstacles = g12_obstacles(b, e)
+            boxes = []
+            for ob in obstacles:  # the bounding-box stand-in of every shape
+                so = ob.obstacle_shape.shapely_object
+                minx, miny, maxx, maxy = so.bounds
+                bx = refshim.StubShapeObstacle(refshim.Polygon([(minx, miny), (maxx, miny), (maxx, maxy), (minx, maxy)]), ob.poses, ob.prediction.final_time_step)
+                boxes.append(bx)
+            fpl = pl.calc_global_paths(pl.calc_frenet_paths(ego_state(b, e)))
+            for i, fp in enumerate(fpl):
+                cost[e, i] = fp.cost_final
+                coll[e, i] = pl.has_collision(fp, obstacles, int(b.t_now[e]), 2)[0]
+                coll_box[e, i] = pl.has_collision(fp, boxes, int(b.t_now[e]), 2)[0]
+        out.update(batch_to_dict(b, f"{name}_in_"))
+        out.update({f"{name}_coll": coll, f"{name}_coll_box": coll_box, f"{name}_cost": cost})
+        print(f"  g12 {name}: coll={coll.mean():.3f} box={coll_box.mean():.3f} differ={int((coll != coll_box).sum())} of {coll.size}")
+        for kind in ("FOP", "FOP+", "FISS", "FISS+"):
+            bb = b
+            if kind in ("FISS", "FISS+"):
+                sw = 3.5 - b.veh_w + 0.3
+                d, rd = np.linspace(-sw / 2, sw / 2, b.nd, retstep=True)
+                smin = b.samp_min.copy(); smax = b.samp_max.copy(); sres = b.samp_res.copy()
+                smin[:, 0] = -sw / 2; smax[:, 0] = sw / 2; sres[:, 0] = rd
+                bb = with_overrides(b, d_samples=d, samp_min=smin, samp_max=smax, samp_res=sres)
+            key = f"{name}_{kind}"
+            B = bb.B
+            idx = np.full((B, 3), -1, dtype=np.int32); flat = np.full(B, -1, dtype=np.int32)
+            pcost = np.full(B, np.nan); stats = np.zeros((B, 4), dtype=np.int32); end = np.full((B, 3), np.nan)
+            found = np.zeros(B, dtype=bool)
+            for e in range(B):
+                pl = make_planner(kind, bb, e)
+                best = pl.plan(ego_state(bb, e), float(bb.target_speed[e]), g12_obstacles(bb, e), int(bb.t_now[e]))
+                stats[e] = [pl.stats.num_iter, pl.stats.num_trajs_generated, pl.stats.num_trajs_validated, pl.stats.num_collison_checks]
+                if best is None:
+                    continue
+                found[e] = True
+                pcost[e] = best.cost_final
+                if kind in ("FOP", "FOP+"):
+                    pl2 = make_planner("FOP", bb, e)
+                    pl2.settings.highest_speed = float(bb.target_speed[e])
+                    fpl = pl2.calc_frenet_paths(ego_state(bb, e))
+                    hits = [i for i, fp in enumerate(fpl) if np.array_equal(fp.d, best.d) and np.array_equal(fp.s, best.s)]
+                    assert len(hits) == 1, (key, e, hits)
+                    flat[e] = hits[0]
+                else:
+                    idx[e] = best.idx
+                    es = best.end_state
+                    end[e] = [es.d, es.s_d, es.t]
+            if kind in ("FISS", "FISS+"):
+                out.update({f"{key}_in_d_samples": bb.d_samples, f"{key}_in_samp_min": bb.samp_min, f"{key}_in_samp_max": bb.samp_max, f"{key}_in_samp_res": bb.samp_res})
+            out.update({f"{key}_flat": flat, f"{key}_idx": idx, f"{key}_cost": pcost, f"{key}_stats": stats, f"{key}_end": end, f"{key}_found": found})
+            print(f"  g12 {key}: found={found.tolist()} stats={stats.tolist()}")
+    out["names"] = np.array(names)
+    save("g12_shapes.npz", **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10", "g11", "g12"]
     for g in todo:
         t0 = time.time()
         print(f"== {g}")

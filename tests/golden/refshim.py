@@ -44,8 +44,21 @@ AUDIT = {"calls": 0, "near_contact": 0, "float_differs_from_exact": 0}  # of Pol
 # --------------------------------------------------------------------------
 # mini "shapely": convex polygons only
 # --------------------------------------------------------------------------
+def _ring_is_convex(pts: np.ndarray) -> bool:
+    e = np.roll(pts, -1, axis=0) - pts
+    cr = e[:, 0] * np.roll(e[:, 1], -1) - e[:, 1] * np.roll(e[:, 0], -1)
+    if np.any(cr > 0.0) and np.any(cr < 0.0):
+        return False
+    for d in (e[:, 0], e[:, 1]):  # winds once: two direction changes along either axis
+        sg = np.sign(d[d != 0.0])
+        if sg.size and np.count_nonzero(sg != np.roll(sg, 1)) > 2:
+            return False
+    return True
+
+
 class Polygon:
-    """Convex polygon given by its exterior ring (closing point optional)."""
+    """Simple polygon given by its exterior ring (closing point optional).  Convex polygons - everything the reference's own demo
+    inputs produce - take the separating-axis path; any other simple polygon is decided by exact segment / containment tests."""
 
     def __init__(self, coords):
         pts = np.asarray(coords, dtype=float).reshape(-1, 2)
@@ -56,6 +69,11 @@ class Polygon:
         if not np.all(np.isfinite(pts)):
             raise ValueError("non-finite polygon coordinate")
         self.pts = pts
+        self.convex = _ring_is_convex(pts)
+
+    @property
+    def exterior(self):
+        return SimpleNamespace(coords=[tuple(p) for p in self.pts] + [tuple(self.pts[0])])
 
     @property
     def bounds(self):
@@ -106,12 +124,60 @@ class Polygon:
                     return False
         return True
 
-    def intersects(self, other: "Polygon") -> bool:
+    def intersects_general_exact(self, other: "Polygon") -> bool:
+        """Closed-set intersection of two SIMPLE polygons, exactly (rational arithmetic): some edge of one meets some edge of the
+        other, or one polygon holds a vertex of the other (then, with no edges meeting, it holds all of it)."""
+        A = [(Fraction(float(x)), Fraction(float(y))) for x, y in self.pts]
+        B = [(Fraction(float(x)), Fraction(float(y))) for x, y in other.pts]
+
+        def orient(a, b, c):
+            v = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+            return (v > 0) - (v < 0)
+
+        def on_seg(a, b, q):  # q collinear with a-b: inside the closed segment?
+            return min(a[0], b[0]) <= q[0] <= max(a[0], b[0]) and min(a[1], b[1]) <= q[1] <= max(a[1], b[1])
+
+        def seg_meet(a, b, c, d):
+            o1, o2, o3, o4 = orient(a, b, c), orient(a, b, d), orient(c, d, a), orient(c, d, b)
+            if o1 != o2 and o3 != o4:
+                return True
+            return (o1 == 0 and on_seg(a, b, c)) or (o2 == 0 and on_seg(a, b, d)) or (o3 == 0 and on_seg(c, d, a)) or (o4 == 0 and on_seg(c, d, b))
+
+        def holds(P, q):  # closed point-in-polygon: boundary counts; crossing number otherwise
+            n = len(P)
+            inside = False
+            for i in range(n):
+                a, b = P[i], P[(i + 1) % n]
+                if orient(a, b, q) == 0 and on_seg(a, b, q):
+                    return True
+                if (a[1] > q[1]) != (b[1] > q[1]):
+                    xi = a[0] + (q[1] - a[1]) * (b[0] - a[0]) / (b[1] - a[1])
+                    if q[0] < xi:
+                        inside = not inside
+            return inside
+
+        na, nb = len(A), len(B)
+        for i in range(na):
+            for j in range(nb):
+                if seg_meet(A[i], A[(i + 1) % na], B[j], B[(j + 1) % nb]):
+                    return True
+        return holds(B, A[0]) or holds(A, B[0])
+
+    def intersects(self, other) -> bool:
         """Polygon.intersects as the goldens see it: the EXACT predicate, reached through a float filter - when every axis
         overlaps, or some axis separates, by a margin far above any rounding (1e-9 relative), the float test's answer is the exact
         one; everything nearer to contact is decided in rational arithmetic.  AUDIT counts the calls, the near-contact calls and
         how often the plain float test would have answered differently (tests/golden/collision_audit.json)."""
+        if isinstance(other, MultiPolygon):
+            return other.intersects(self)
         AUDIT["calls"] += 1
+        if not (self.convex and other.convex):  # (no separating-axis filter for a non-convex operand: bounding boxes, then the exact test)
+            a, b = self.bounds, other.bounds
+            pad = 1e-9 * (1.0 + max(float(np.abs(self.pts).max()), float(np.abs(other.pts).max())))
+            if a[2] + pad < b[0] or b[2] + pad < a[0] or a[3] + pad < b[1] or b[3] + pad < a[1]:
+                return False
+            AUDIT["general_exact"] = AUDIT.get("general_exact", 0) + 1
+            return self.intersects_general_exact(other)
         scale = 1.0 + max(float(np.abs(self.pts).max()), float(np.abs(other.pts).max()))
         worst = -math.inf  # largest separation over the axes, in units of the tolerance
         for ax in np.concatenate([self._axes(), other._axes()]):
@@ -131,13 +197,30 @@ class Polygon:
         return exact
 
 
+class MultiPolygon:
+    """Several polygons as one geometry (a commonroad ShapeGroup's shapely_object): bounds of the whole, intersects = any part."""
+
+    def __init__(self, polygons):
+        self.geoms = [g if isinstance(g, Polygon) else Polygon(g) for g in polygons]
+
+    @property
+    def bounds(self):
+        b = np.array([g.bounds for g in self.geoms])
+        return (b[:, 0].min(), b[:, 1].min(), b[:, 2].max(), b[:, 3].max())
+
+    def intersects(self, other) -> bool:
+        return any(g.intersects(other) for g in self.geoms)
+
+
 class _Affinity:
     @staticmethod
-    def translate(geom: Polygon, xoff=0.0, yoff=0.0, zoff=0.0) -> Polygon:
+    def translate(geom, xoff=0.0, yoff=0.0, zoff=0.0):
+        if isinstance(geom, MultiPolygon):
+            return MultiPolygon([_Affinity.translate(g, xoff, yoff) for g in geom.geoms])
         return Polygon(geom.pts + np.array([xoff, yoff], dtype=float))
 
     @staticmethod
-    def rotate(geom: Polygon, angle, origin="center", use_radians=False) -> Polygon:
+    def rotate(geom, angle, origin="center", use_radians=False):
         if not use_radians:
             angle = angle * math.pi / 180.0
         cosp = math.cos(angle)
@@ -153,9 +236,13 @@ class _Affinity:
         y0 = (miny + maxy) / 2.0
         xoff = x0 - x0 * cosp + y0 * sinp
         yoff = y0 - x0 * sinp - y0 * cosp
-        x = geom.pts[:, 0]
-        y = geom.pts[:, 1]
-        return Polygon(np.stack([cosp * x - sinp * y + xoff, sinp * x + cosp * y + yoff], axis=1))
+        def turn(g):
+            x = g.pts[:, 0]
+            y = g.pts[:, 1]
+            return Polygon(np.stack([cosp * x - sinp * y + xoff, sinp * x + cosp * y + yoff], axis=1))
+
+        # (the affine matrix comes from the bounds of the WHOLE geometry: a multi-part geometry turns about its common centre)
+        return MultiPolygon([turn(g) for g in geom.geoms]) if isinstance(geom, MultiPolygon) else turn(geom)
 
 
 affinity = _Affinity()
@@ -190,6 +277,17 @@ class StubObstacle:
             return None
         x, y, yaw = self.poses[t]
         return SimpleNamespace(position=np.array([x, y]), orientation=float(yaw), time_step=t)
+
+
+class StubShapeObstacle(StubObstacle):
+    """An obstacle whose shape is any polygon-like `shapely_object` (what obstacle_shape.shapely_object may be in the reference,
+    frenet_optimal_planner.py:189): a Polygon, or a MultiPolygon for a group of shapes."""
+
+    def __init__(self, shapely_object, poses: np.ndarray, final_time_step: int | None = None):
+        super().__init__(1.0, 1.0, poses, final_time_step)
+        self.obstacle_shape = SimpleNamespace(shapely_object=shapely_object)
+        if isinstance(shapely_object, MultiPolygon):  # commonroad's ShapeGroup exposes its parts
+            self.obstacle_shape.shapes = [SimpleNamespace(shapely_object=g) for g in shapely_object.geoms]
 
 
 def obstacles_from_table(pose: np.ndarray, dims: np.ndarray, final_time_step: int) -> list:
@@ -244,6 +342,7 @@ def install():
     sh.affinity = affinity
     sh.geometry = sh_g
     sh_g.Polygon = Polygon
+    sh_g.MultiPolygon = MultiPolygon
     for name, mod in [
         ("commonroad", cr),
         ("commonroad.scenario", cr_s),

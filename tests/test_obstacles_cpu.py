@@ -13,7 +13,7 @@ from conftest import GOLDEN
 sys.path.insert(0, GOLDEN)
 from refshim import Polygon, StubObstacle  # noqa: E402
 
-from fiss_plus_planner_amd.obstacles import flatten_obstacles, obstacles_fingerprint  # noqa: E402
+from fiss_plus_planner_amd.obstacles import buffer_circle_ring, flatten_obstacles, obstacles_fingerprint, shape_columns  # noqa: E402
 
 
 def test_flatten_walks_state_at_time_and_the_first_obstacles_horizon():
@@ -51,13 +51,88 @@ def test_off_centre_rectangle_is_displaced_by_its_unrotated_offset():
     np.testing.assert_array_equal(tab.pose[0, 0], [13.0, 21.0, 0.3, 1.0])
 
 
-def test_non_rectangles_warn_and_use_the_bounding_box():
-    with pytest.warns(RuntimeWarning, match="bounding box"):
-        tab = flatten_obstacles([_poly_obstacle([(-2, -1), (2, -1), (0, 3)])])  # a triangle
+def test_convex_shapes_become_polygon_columns_about_their_bounding_box_centre():
+    """obstacle_shape.shapely_object is ANY polygon in the reference (:189-191): a convex one is one column - counter-clockwise ring
+    relative to the centre of its bounding box (the point affinity.rotate(origin='center') turns it about), dims = that box."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # (no bounding-box fallback, no warning)
+        tab = flatten_obstacles([_poly_obstacle([(-2, -1), (2, -1), (0, 3)])])  # a triangle, bounding box [-2, 2] x [-1, 3]
     np.testing.assert_array_equal(tab.dims, [[4.0, 4.0]])
     np.testing.assert_array_equal(tab.pose[0, 0, :2], [10.0, 21.0])
-    with pytest.warns(RuntimeWarning):
-        flatten_obstacles([_poly_obstacle([(1, 0), (0, 1), (-1, 0), (0, -1)])])   # a diamond: 4 vertices, not axis-aligned
+    np.testing.assert_array_equal(tab.nvert, [3])
+    np.testing.assert_array_equal(tab.poly[0, :3], [(-2, -2), (2, -2), (0, 2)])
+    tab = flatten_obstacles([_poly_obstacle([(1, 0), (0, -1), (-1, 0), (0, 1)])])   # a diamond given CLOCKWISE: the ring is reversed
+    np.testing.assert_array_equal(tab.nvert, [4])
+    v = tab.poly[0, :4]
+    assert np.sum(v[:, 0] * np.roll(v[:, 1], -1) - v[:, 1] * np.roll(v[:, 0], -1)) > 0
+    np.testing.assert_array_equal(tab.dims, [[2.0, 2.0]])
+
+
+def test_rectangles_and_polygons_share_a_table():
+    rect = StubObstacle(4.0, 2.0, np.tile([1.0, 2.0, 0.1], (3, 1)), 2)
+    tab = flatten_obstacles([rect, _poly_obstacle([(-2, -1), (2, -1), (0, 3)])])
+    np.testing.assert_array_equal(tab.nvert, [0, 3])
+    assert tab.poly.shape == (2, 3, 2)
+    only_rects = flatten_obstacles([rect])
+    assert only_rects.nvert is None and only_rects.poly is None
+
+
+def test_a_circle_is_the_polygon_shapely_makes_of_it():
+    ring = buffer_circle_ring(1.5, 0.25, -0.5)
+    assert ring.shape == (64, 2)
+    np.testing.assert_allclose(ring[0], [1.75, -0.5])
+    np.testing.assert_allclose(ring[1], [0.25 + 1.5 * np.cos(np.pi / 32), -0.5 - 1.5 * np.sin(np.pi / 32)], rtol=0, atol=1e-15)  # clockwise
+    assert ring[16, 0] == 0.25 and ring[32, 1] == -0.5  # snapped quarter points
+    ob = _poly_obstacle([(0, 0), (1, 0), (0, 1)])
+    ob.obstacle_shape = SimpleNamespace(radius=1.5, center=np.array([0.25, -0.5]))  # no shapely_object: the library builds the ring
+    tab = flatten_obstacles([ob])
+    np.testing.assert_array_equal(tab.nvert, [64])
+    np.testing.assert_array_equal(tab.pose[0, 0, :2], [10.25, 19.5])
+    np.testing.assert_allclose(tab.dims, [[3.0, 3.0]], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(np.hypot(tab.poly[0, :, 0], tab.poly[0, :, 1]), 1.5, rtol=0, atol=1e-15)
+
+
+def test_non_convex_shapes_and_groups_are_cut_into_convex_pieces_about_the_common_centre():
+    L = [(0, 0), (4.2, 0), (4.2, 1.2), (1.3, 1.2), (1.3, 3.0), (0, 3.0)]
+    tab = flatten_obstacles([_poly_obstacle(L)])
+    assert tab.pose.shape[1] == 2 and list(tab.nvert) == [4, 4]          # two convex quadrilaterals, same poses
+    np.testing.assert_array_equal(tab.pose[:, 0], tab.pose[:, 1])
+    np.testing.assert_array_equal(tab.pose[0, 0, :2], [10.0 + 2.1, 20.0 + 1.5])
+    area = 0.0
+    for k in range(2):
+        v = tab.poly[k, :tab.nvert[k]]
+        a2 = np.sum(v[:, 0] * np.roll(v[:, 1], -1) - v[:, 1] * np.roll(v[:, 0], -1))
+        assert a2 > 0
+        area += 0.5 * a2
+        assert tab.dims[k, 0] >= 2 * np.abs(v[:, 0]).max() and tab.dims[k, 1] >= 2 * np.abs(v[:, 1]).max()
+    np.testing.assert_allclose(area, 4.2 * 1.2 + 1.3 * 1.8)
+    # the pieces' vertices are the shape's own vertices, relative to the centre of the WHOLE shape's bounding box
+    want = {(x - 2.1, y - 1.5) for x, y in L}
+    got = {(float(x), float(y)) for k in range(2) for x, y in tab.poly[k, :tab.nvert[k]]}
+    assert got <= {(float(np.float64(x)), float(np.float64(y))) for x, y in want}
+    group = _poly_obstacle(L)
+    parts = [Polygon([(-3.0, -0.5), (-1.0, -0.5), (-1.0, 0.5), (-3.0, 0.5)]), Polygon([(1.0, -0.8), (3.0, 0.0), (1.0, 0.8)])]
+    group.obstacle_shape = SimpleNamespace(shapes=[SimpleNamespace(shapely_object=p) for p in parts])
+    tab = flatten_obstacles([group])
+    assert list(tab.nvert) == [4, 3]
+    np.testing.assert_array_equal(tab.pose[0, 0, :2], [10.0, 20.0])       # the group's box is [-3, 3] x [-0.8, 0.8]: centred
+    np.testing.assert_array_equal(tab.poly[0, :4], parts[0].pts)
+
+
+def test_random_simple_polygons_partition_into_convex_pieces_of_the_same_area():
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n = int(rng.integers(4, 15))
+        while True:
+            ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+            if np.max(np.diff(np.concatenate([ang, [ang[0] + 2 * np.pi]]))) < np.pi - 0.05:
+                break
+        r = rng.uniform(0.5, 2.0, n)
+        ring = np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1)
+        cols = shape_columns(SimpleNamespace(shapely_object=Polygon(ring)))
+        area = sum(0.5 * np.sum(c[4][:, 0] * np.roll(c[4][:, 1], -1) - c[4][:, 1] * np.roll(c[4][:, 0], -1)) for c in cols)
+        want = 0.5 * np.sum(ring[:, 0] * np.roll(ring[:, 1], -1) - ring[:, 1] * np.roll(ring[:, 0], -1))
+        np.testing.assert_allclose(area, want, rtol=1e-12)
 
 
 def test_fingerprint_follows_the_objects_not_the_list():
