@@ -112,6 +112,17 @@ struct __attribute__((aligned(16))) ObsPose {
 struct __attribute__((aligned(16))) ObsDim {
     double hl, hw, r, pad;
 };
+// A table of 32-byte records {a, b, c, d} kept as two arrays of 16-byte halves.  Consecutive lanes reading consecutive records as two
+// ds_read_b128 at a 32-byte stride touch only half of the LDS banks per instruction (every fourth lane lands on the same banks: a 2-way
+// conflict on every read of a frame or a survivor's pose); at a 16-byte stride the same reads are conflict free.  Same bytes in total.
+template <typename T>
+struct SplitTab {
+    double2* lo;
+    double2* hi;
+    __device__ __forceinline__ T get(int i) const { const double2 a = lo[i], b = hi[i]; return T{a.x, a.y, b.x, b.y}; }
+    __device__ __forceinline__ void set(int i, double a, double b, double c, double d) const { lo[i] = make_double2(a, b); hi[i] = make_double2(c, d); }
+    __device__ __forceinline__ SplitTab at(int off) const { return SplitTab{lo + off, hi + off}; }
+};
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
@@ -332,11 +343,19 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
-    ObsDim* s_dim = (ObsDim*)(smem + L.dim);
+    // obstacle sizes: (half length, half width) pairs and the bounding radii in their own array (a lane reads another obstacle's record
+    // than its neighbour: 24 useful bytes per lane instead of a 32-byte record)
+    struct DimTab {
+        double2* hlw;
+        double* rad;
+        __device__ __forceinline__ ObsDim get(int j) const { const double2 a = hlw[j]; return ObsDim{a.x, a.y, rad[j], 0.0}; }
+    };
+    const DimTab s_dim{(double2*)(smem + L.dim), (double*)(smem + L.dim) + 2 * n_obs_tab};
     // poses of the (row, obstacle) items that survive the group test, in the order of the item list: the table itself is read from
     // global memory exactly once (registers -> group test), only the ~7 % the slices can touch are kept
-    ObsPose* s_spose = (ObsPose*)(smem + L.pose);
-    Frame* s_frames = (Frame*)(smem + L.frames);
+    const SplitTab<ObsPose> s_spose{(double2*)(smem + L.pose), (double2*)(smem + L.pose) + kItemCap};
+    const int n_frames = kWalk ? mul24(kWaves, hp_max) : mul24(mul24(gs, kShape ? NV : p.nv), hp_max);  // records of the frame table
+    const SplitTab<Frame> s_frames{(double2*)(smem + L.frames), (double2*)(smem + L.frames) + n_frames};
     double* s_lat = (double*)(smem + L.lat);
     float* s_dmax2 = (float*)(smem + L.dmax);    // [2][gs][hp_max]
     float* s_ddmax2 = (float*)(smem + L.ddmax);  // [2][gs][hp_max]
@@ -461,7 +480,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
             for (int j = tid; j < n_obs; j += kThreads) {
                 const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
-                s_dim[j] = ObsDim{hl, hw, sqrt(fma(hl, hl, hw * hw)), 0.0};
+                s_dim.hlw[j] = make_double2(hl, hw);
+                s_dim.rad[j] = sqrt(fma(hl, hl, hw * hw));
             }
         }
     }
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         const int r = div_by<NOBS, ROWS * NOBS>(e, inv_nobs), j = e - mul24(r, n_obs);
                         const int k = mul24(r, stride);
                         const ObsDim g = s_grp[r];
-                        const double dx = ps[u].x - g.hl, dy = ps[u].y - g.hw, R = g.r + s_dim[j].r;
+                        const double dx = ps[u].x - g.hl, dy = ps[u].y - g.hw, R = g.r + s_dim.rad[j];
                         keep = k < pose_limit && ps[u].w != 0.0 && (ps[u].x == ps[u].x) && !(g.r < 0.0) && !(fma(dx, dx, dy * dy) > R * R);
                     }
                     const unsigned long long m = __ballot(keep);
@@ -861,7 +881,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         const int pos = __builtin_amdgcn_readlane(base, first) - item_base + __popcll(m & ((1ull << lane) - 1ull));
                         if (keep && pos < kItemCap) {
                             s_items[pos] = (unsigned short)e;
-                            s_spose[pos] = ObsPose{ps[u].x, ps[u].y, ps[u].z, 0.0};
+                            s_spose.set(pos, ps[u].x, ps[u].y, ps[u].z, 0.0);
                         }
                     }
                 }
@@ -880,9 +900,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             // the survivors' orientations -> (cos, sin), with shapely's snap (frenet_device.h); every item belongs to one chunk
             for (int si = tid; si < n_surv; si += kThreads) {
                 double sn, cs;
-                sincos_snapped(s_spose[si].c, sn, cs);
-                s_spose[si].c = cs;
-                s_spose[si].s = sn;
+                sincos_snapped(s_spose.hi[si].x, sn, cs);
+                s_spose.hi[si] = make_double2(cs, sn);
             }
             // (the slice loop's first barrier orders these writes before stage B reads them)
             // No survivor (block-uniform: empty surroundings, obstacles out of reach): nothing can collide, the slices are skipped.
@@ -901,7 +920,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 // order, so a blocked profile ends after its first hits instead of testing every pose of the horizon.
                 if (n_surv > 0) {
                     __syncthreads();  // the survivors' (cos, sin), the item list and the lateral bounds are visible to every wavefront
-                    Frame* wfr = s_frames + mul24(wave, hp_max);
+                    const SplitTab<Frame> wfr = s_frames.at(mul24(wave, hp_max));
                     float* wwf = s_wfat + mul24(wave, rows_max > 0 ? rows_max : 1);
                     uint32_t* wh = s_hits + wave * kWave;
                     constexpr int kHpwC = ND > 0 ? kWave / ND : 1;
@@ -935,7 +954,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                             const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
                             Frame fr;
                             spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
-                            wfr[i] = fr;
+                            wfr.set(i, fr.px, fr.py, fr.tx, fr.ty);
                         }
     // [/section FRAMES]
                         wave_lds_sync();
@@ -949,7 +968,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                 const bool row_ok = k < n_pts && k < hp;
                                 float wl = r_ego_f;
                                 if (k + 1 < M && k + 1 < hp) {
-                                    const Frame f0 = wfr[k], f1 = wfr[k + 1];
+                                    const Frame f0 = wfr.get(k), f1 = wfr.get(k + 1);
                                     const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
                                     const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
                                     const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
@@ -985,9 +1004,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                 const int item = s_items[si];
                                 const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
                                 const int k = mul24(r, stride);
-                                const ObsPose op = s_spose[si];
-                                const ObsDim od = s_dim[j];
-                                const Frame fr = wfr[k];  // (stale beyond the profile's M: the test below excludes those poses)
+                                const ObsPose op = s_spose.get(si);
+                                const ObsDim od = s_dim.get(j);
+                                const Frame fr = wfr.get(k);  // (stale beyond the profile's M: the test below excludes those poses)
                                 const double r_ego_b = s_k[4];
                                 const double fat = (r_ego_b + od.r + (double)dm[k]) * (1.0 + 1e-12);
                                 const double dx = op.x - fr.px, dy = op.y - fr.py;
@@ -1024,7 +1043,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                     FP_COUNT(3, 1);
                                     // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                                     const int ka_ = (k + 1 < M) ? k : k - 1;
-                                    const Frame f0 = wfr[ka_], f1 = wfr[ka_ + 1];
+                                    const Frame f0 = wfr.get(ka_), f1 = wfr.get(ka_ + 1);
                                     const double* ql = qlat + mul24(id_l, 3);
                                     const double b3 = ql[0], b4 = ql[1], b5 = ql[2];
                                     const double ta = (double)ka_ * tick, tb = (double)(ka_ + 1) * tick;
@@ -1039,8 +1058,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                     ego.y = (ka_ == k) ? ya : yb;
                                     ego.hl = s_k[2];
                                     ego.hw = s_k[3];
-                                    const ObsPose op = s_spose[si2];
-                                    const ObsDim od = s_dim[j];
+                                    const ObsPose op = s_spose.get(si2);
+                                    const ObsDim od = s_dim.get(j);
                                     if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
                                         hit = true;  // polygon construction fails in the reference -> collision (:178-182)
                                     } else {
@@ -1105,7 +1124,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
                         Frame fr;
                         spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
-                        s_frames[mul24(q, hp_max) + i] = fr;
+                        s_frames.set(mul24(q, hp_max) + i, fr.px, fr.py, fr.tx, fr.ty);
                     }
                 }
     // [/section FRAMES]
@@ -1162,7 +1181,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         const float* dm = s_dmax + mul24(itl, hp_max);
                         float wl = r_ego_f;
                         if (k + 1 < M && k + 1 < hp) {
-                            const Frame f0 = s_frames[mul24(q, hp_max) + k], f1 = s_frames[mul24(q, hp_max) + k + 1];
+                            const Frame f0 = s_frames.get(mul24(q, hp_max) + k), f1 = s_frames.get(mul24(q, hp_max) + k + 1);
                             const double dpx = f1.px - f0.px, dpy = f1.py - f0.py;
                             const double a_n = fma(dpy, f0.tx, -dpx * f0.ty);     // dP . n_k,  n_k = (-ty, tx)
                             const double a_t = fma(dpx, f0.tx, dpy * f0.ty);      // dP . t_k
@@ -1200,9 +1219,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                             const int item = s_items[si];
                             const int r = div_by<NOBS, ROWS * NOBS>(item, inv_nobs), j = item - mul24(r, n_obs);
                             const int k = mul24(r, stride);
-                            const ObsPose op = s_spose[si];
-                            const ObsDim od = s_dim[j];
-                            const Frame fr = s_frames[mul24(q, hp_max) + k];
+                            const ObsPose op = s_spose.get(si);
+                            const ObsDim od = s_dim.get(j);
+                            const Frame fr = s_frames.get(mul24(q, hp_max) + k);
                             // Poses beyond a profile's M hold stale frames, and a trajectory of fewer than two points has no heading: no
                             // pair (the narrow phase relies on it)
                             const int Mp = s_lon_meta[q0 + q].x;
@@ -1255,7 +1274,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                             const int M = s_lon_meta[q0 + q].x;
                             // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                             const int ka_ = (k + 1 < M) ? k : k - 1;
-                            const Frame f0 = s_frames[mul24(q, hp_max) + ka_], f1 = s_frames[mul24(q, hp_max) + ka_ + 1];
+                            const Frame f0 = s_frames.get(mul24(q, hp_max) + ka_), f1 = s_frames.get(mul24(q, hp_max) + ka_ + 1);
                             const double* lt = s_lat + mul24(mul24(itl, nd) + id, hp_max) + ka_;
                             const double da = lt[0], db = lt[1];
                             double xa, ya, xb, yb;
@@ -1267,8 +1286,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                             ego.y = (ka_ == k) ? ya : yb;
                             ego.hl = s_k[2];
                             ego.hw = s_k[3];
-                            const ObsPose op = s_spose[si];
-                            const ObsDim od = s_dim[j];
+                            const ObsPose op = s_spose.get(si);
+                            const ObsDim od = s_dim.get(j);
                             bool hit;
                             if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
                                 hit = true;  // polygon construction fails in the reference -> collision (:178-182)

@@ -26,7 +26,7 @@ except Exception as e:
     print(f"variant [{sys.argv[2]}] FAILED: {e}"); print(open(sys.argv[1].replace('.json', '.err')).read()[-800:])
 PY
   if [ "${PMC:-0}" = "1" ]; then
-    (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_INT32 SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_$i -o p -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-latency --no-extras ${BENCH_ARGS:-} > $OUT/pmc_$i.log 2>&1)
+    (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_INT32 SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_$i -o p -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-latency --no-extras ${BENCH_ARGS:-} > $OUT/pmc_$i.log 2>&1)
     python - $OUT/pmc_$i <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)
