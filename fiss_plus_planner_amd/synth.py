@@ -137,3 +137,38 @@ def make_config(config: int, B: int | None = None, ego_offset: int = 0, kind: st
     if config == 5:
         return make_batch(B or 16384, 9, 9, 7, 50, 50, True, CONFIG_SEEDS[5], kind or "FOP", ego_offset=ego_offset, layout=layout)
     raise ValueError(f"unknown config {config}")
+
+
+def random_convex_ring(rng, n: int, rx: float, ry: float) -> np.ndarray:
+    """n vertices on an ellipse (rx, ry) at sorted random angles: a convex counter-clockwise ring around the origin."""
+    while True:
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        if np.max(np.diff(np.concatenate([ang, [ang[0] + 2 * np.pi]]))) < np.pi - 0.2:
+            break
+    return np.stack([rx * np.cos(ang), ry * np.sin(ang)], axis=1)
+
+
+def with_random_shapes(batch: ProblemBatch, seed: int, frac: float = 0.6, max_vertices: int = 12) -> ProblemBatch:
+    """The same batch with a fraction of its rectangle columns turned into random convex polygons that fit the rectangle they replace
+    (fp_batch.obs_poly / obs_nvert: rings centred on their own bounding box - the pose is the rotation centre - and obs_dims = that
+    box).  Collisions can only disappear against the rectangle scene; the motion, the lattice and the egos are untouched."""
+    rng = np.random.default_rng(seed)
+    S, n = batch.S, batch.n_obs
+    poly = np.zeros((S, n, max_vertices, 2))
+    nvert = np.zeros((S, n), dtype=np.int32)
+    dims = batch.obs_dims.copy()
+    for sc in range(S):
+        for j in range(n):
+            if rng.uniform() > frac:
+                continue
+            k = int(rng.integers(3, max_vertices + 1))
+            ring = random_convex_ring(rng, k, 0.5 * dims[sc, j, 0], 0.5 * dims[sc, j, 1])
+            lo, hi = ring.min(axis=0), ring.max(axis=0)
+            ring = ring - 0.5 * (lo + hi)
+            poly[sc, j, :k] = ring
+            nvert[sc, j] = k
+            dims[sc, j] = 2.0 * np.abs(ring).max(axis=0)
+    kw = {k: getattr(batch, k) for k in ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+                                          "obs_pose", "final_time_step", "veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride", "samp_min", "samp_max",
+                                          "samp_res", "curvature_limits")}
+    return ProblemBatch(**kw, obs_dims=dims, obs_poly=poly, obs_nvert=nvert, meta=dict(batch.meta, shapes=seed))

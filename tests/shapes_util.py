@@ -62,35 +62,4 @@ def g12_batch(g, name, kind="FOP", boxes=False):
     return ProblemBatch(**kw, obs_pose=pose, obs_dims=np.stack([t.dims for t in tabs]), obs_poly=poly, obs_nvert=nvert)
 
 
-def random_convex_ring(rng, n, rx, ry):
-    """n vertices on an ellipse (rx, ry) at sorted random angles: a convex counter-clockwise ring around the origin."""
-    while True:
-        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
-        if np.max(np.diff(np.concatenate([ang, [ang[0] + 2 * np.pi]]))) < np.pi - 0.2:
-            break
-    return np.stack([rx * np.cos(ang), ry * np.sin(ang)], axis=1)
-
-
-def with_random_shapes(batch, seed, frac=0.6, max_vertices=12):
-    """A synth batch with a fraction of its rectangle columns turned into random convex polygons that fit the rectangle's box
-    (centred on their own bounding box, as the ABI wants: the pose is the rotation centre)."""
-    rng = np.random.default_rng(seed)
-    S, n = batch.S, batch.n_obs
-    poly = np.zeros((S, n, max_vertices, 2))
-    nvert = np.zeros((S, n), dtype=np.int32)
-    dims = batch.obs_dims.copy()
-    for sc in range(S):
-        for j in range(n):
-            if rng.uniform() > frac:
-                continue
-            k = int(rng.integers(3, max_vertices + 1))
-            ring = random_convex_ring(rng, k, 0.5 * dims[sc, j, 0], 0.5 * dims[sc, j, 1])
-            lo, hi = ring.min(axis=0), ring.max(axis=0)
-            ring = ring - 0.5 * (lo + hi)
-            poly[sc, j, :k] = ring
-            nvert[sc, j] = k
-            dims[sc, j] = 2.0 * np.abs(ring).max(axis=0)
-    kw = {k: getattr(batch, k) for k in ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
-                                          "obs_pose", "final_time_step", "veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride", "samp_min", "samp_max",
-                                          "samp_res", "curvature_limits")}
-    return ProblemBatch(**kw, obs_dims=dims, obs_poly=poly, obs_nvert=nvert, meta=dict(batch.meta))
+from fiss_plus_planner_amd.synth import random_convex_ring, with_random_shapes  # noqa: E402,F401  (the generator lives with the other synthetic inputs)
