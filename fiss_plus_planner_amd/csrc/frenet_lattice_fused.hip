@@ -126,7 +126,7 @@ struct SplitTab {
 
 // LDS carve-up (all offsets in bytes, 16-byte aligned)
 struct Layout {
-    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, nslice, best, konst, total;
+    int knots, coef, lut, dim, pose, frames, lat, dmax, ddmax, wfat, grp, iqueue, pows, samples, lon_sum, lat_sum, lon_meta, qlon, qlat, box, coll, queue, cnt, nslice, best, konst, nvert, poly, total;
 };
 
 __host__ __device__ inline int align16(int v) { return (v + 15) & ~15; }
@@ -142,7 +142,16 @@ constexpr bool kWalk = false;
 constexpr bool kWalk = true;
 #endif
 // gs = time-horizon slices the collision stages work on per barrier interval (1: one at a time; the per-slice tables are gs deep)
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs, int nwaves)
+// Polygon columns (POLY instances): the vertex counts always sit in LDS, the rings when they are small (kPolyLdsMax: a few KB keep the
+// three-workgroups-per-CU instance inside its 52 KB; 9.6 KB of 12-gons pushed config-3-sized scenes to two per CU: 208 -> 234 us) - a
+// narrow-phase lane reads another obstacle than its neighbour, and from global memory a ring costs it two dependent L2 round trips
+// (count, then vertices) per round.  Measured on config-3 sizes, half of the columns rings (same box): rectangle-only scene on its
+// shaped instance 138.7 us; the run-time-shape POLY instance with no polygon at all 162.5; 4-vertex rings that ARE their rectangles
+// 177.6 (185.9 with counts and rings in global memory).
+constexpr int kPolyLdsMax = 4 * 1024;
+__host__ __device__ inline int poly_lds_verts(int n_obs, int poly_stride) { return poly_stride > 0 && n_obs * poly_stride * 16 <= kPolyLdsMax ? n_obs * poly_stride : 0; }
+
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs, int nwaves, int poly_stride = 0)
 {
     Layout L;
     int o = 0;
@@ -181,6 +190,8 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * 16);  // (up to 16 wavefronts)
     L.konst = o;    o = align16(o + 64);  // per-ego constants the collision stages re-read (instead of registers held through the kernel)
+    L.nvert = o;    o = align16(o + (poly_stride > 0 ? 4 * n_obs : 0));                              // polygon columns: vertices per obstacle
+    L.poly = o;     o = align16(o + 16 * poly_lds_verts(n_obs, poly_stride));                        // ... and the rings, when they fit
     // the spline tables last: theirs is the one size no instance of the kernel knows at compile time, so every other offset folds
     L.knots = o;    o = align16(o + 8 * nx_max);
     L.coef = o;     o = align16(o + 64 * nx_max);
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const int n_obs_tab = kShape ? NOBS : bt.n_obs;  // obstacles per scene of the table
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs, kWaves);
+    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs, kWaves, POLY ? bt.poly_stride : 0);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
@@ -348,9 +359,12 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     struct DimTab {
         double2* hlw;
         double* rad;
+        double* rin;  // polygon columns: radius of the disk about the rotation centre inside the ring (poly_inner_radius); else 0
         __device__ __forceinline__ ObsDim get(int j) const { const double2 a = hlw[j]; return ObsDim{a.x, a.y, rad[j], 0.0}; }
     };
-    const DimTab s_dim{(double2*)(smem + L.dim), (double*)(smem + L.dim) + 2 * n_obs_tab};
+    const DimTab s_dim{(double2*)(smem + L.dim), (double*)(smem + L.dim) + 2 * n_obs_tab, (double*)(smem + L.dim) + 3 * n_obs_tab};
+    // polygon rings of the ego's scene: the LDS copy when it exists (indexed by obstacle), else the global table (indexed by column)
+    const bool rings_in_lds = POLY && poly_lds_verts(n_obs_tab, ka.b.poly_stride) > 0;
     // poses of the (row, obstacle) items that survive the group test, in the order of the item list: the table itself is read from
     // global memory exactly once (registers -> group test), only the ~7 % the slices can touch are kept
     const SplitTab<ObsPose> s_spose{(double2*)(smem + L.pose), (double2*)(smem + L.pose) + kItemCap};
@@ -402,6 +416,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const int skip_flag = bt.skip ? bt.skip[b] : 0;
     const int f = in_frame[b];
     const int sc = in_scene[b];
+    const double* ring_base = rings_in_lds ? (const double*)(smem + L.poly) : ka.b.obs_poly;
+    const size_t ring_col0 = rings_in_lds ? (size_t)0 : (size_t)(sc >= 0 ? sc : 0) * (size_t)ka.b.n_obs;
     const int t_now = in_tnow[b];
     const double target_speed = in_ts[b];
     const double* eg = in_ego + (size_t)b * 6;
@@ -478,10 +494,21 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         for (int i = tid; i < 8 * NX; i += kThreads) s_coef[i] = gc[i];  // [8][NX], same layout
         if (n_obs > 0) {
             const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
+            if constexpr (POLY) {  // the scene's rings, when they fit (same layout as in global memory: [obstacle][poly_stride] vertex pairs)
+                const int nv2 = poly_lds_verts(n_obs_tab, bt.poly_stride);
+                const double2* gr = (const double2*)bt.obs_poly + (size_t)sc * n_obs * bt.poly_stride;
+                for (int i = tid; i < nv2; i += kThreads) ((double2*)(smem + L.poly))[i] = gr[i];
+            }
             for (int j = tid; j < n_obs; j += kThreads) {
                 const double hl = 0.5 * gd[2 * j], hw = 0.5 * gd[2 * j + 1];
                 s_dim.hlw[j] = make_double2(hl, hw);
                 s_dim.rad[j] = sqrt(fma(hl, hl, hw * hw));
+                if constexpr (POLY) {
+                    const size_t col = (size_t)sc * n_obs + j;
+                    const int nvx = bt.obs_nvert[col];
+                    s_dim.rin[j] = nvx > 0 ? poly_inner_radius(bt.obs_poly + col * 2 * (size_t)bt.poly_stride, nvx) : 0.0;
+                    ((int32_t*)(smem + L.nvert))[j] = nvx;
+                }
             }
         }
     }
@@ -1065,8 +1092,13 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                     } else {
                                         const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
                                         const double dx = op.x - ego.x, dy = op.y - ego.y;
-                                        if constexpr (POLY) hit = fma(dx, dx, dy * dy) <= R * R && shape_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, bt.obs_nvert, bt.obs_poly, bt.poly_stride, (size_t)sc * n_obs + j);
-                                        else hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                        hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                        if constexpr (POLY) {
+                                            if (hit) {  // a polygon column: its box was a necessary condition, the ring decides
+                                                const int nvx = ((const int32_t*)(smem + L.nvert))[j];
+                                                if (nvx > 0) hit = ring_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, ring_base + (ring_col0 + j) * 2 * (size_t)bt.poly_stride, nvx, s_dim.rin[j]);
+                                            }
+                                        }
                                     }
                                     if (hit) FP_COUNT(5, 1);
                                 }
@@ -1294,8 +1326,13 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                             } else {
                                 const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
                                 const double dx = op.x - ego.x, dy = op.y - ego.y;
-                                if constexpr (POLY) hit = fma(dx, dx, dy * dy) <= R * R && shape_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, bt.obs_nvert, bt.obs_poly, bt.poly_stride, (size_t)sc * n_obs + j);
-                                        else hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                        if constexpr (POLY) {
+                                            if (hit) {  // a polygon column: its box was a necessary condition, the ring decides
+                                                const int nvx = ((const int32_t*)(smem + L.nvert))[j];
+                                                if (nvx > 0) hit = ring_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, ring_base + (ring_col0 + j) * 2 * (size_t)bt.poly_stride, nvx, s_dim.rin[j]);
+                                            }
+                                        }
                             }
                             if (hit) { s_coll[cand] = 1; FP_COUNT(5, 1); FP_COUNT(8 + (k >> 3), 1); }
                         }
@@ -1493,7 +1530,7 @@ int lattice_group_fit(const fp_params& p, const fp_batch& b)
     if (!fused_shape(p, b, &rows, &hp)) return 0;
     int gs = 0;
     for (int g = 1; g <= p.nt; ++g) {
-        if (g * p.nv > 256 || make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), g, FP_GROUP_THREADS / kWave).total > kLdsLimit) break;
+        if (g * p.nv > 256 || make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), g, FP_GROUP_THREADS / kWave, b.obs_nvert ? b.poly_stride : 0).total > kLdsLimit) break;
         gs = g;
     }
     return gs;
@@ -1519,7 +1556,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         const int fit = lattice_group_fit(p, b);
         gs = fit < 1 ? 1 : (gs > fit ? fit : gs);
     }
-    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1, kThreads / kWave);
+    const int pstride = b.obs_nvert && b.n_obs > 0 ? b.poly_stride : 0;  // (polygon columns: their counts - and rings, when they fit - live in LDS)
+    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1, kThreads / kWave, pstride);
     // the series of a three-per-CU launch: by epilogue workgroups appended to the grid (ka.epi_flag + ka.idx_shadow from the caller), if
     // there are fewer of them than resident slots (see the kernel); else the caller launches winner_traj_kernel behind this launch
     constexpr int kEpiPairs = kThreads / (2 * kWave);
@@ -1539,7 +1577,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     const bool epilogue = three && can_epi;
     KernelArgs kx = ka;  // (epilogue workgroups offered but not taken: the caller's winner_traj_kernel writes the series)
     if (ka.epi_flag && !epilogue) { kx.r.best_traj = nullptr; kx.epi_flag = nullptr; }
-    Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave);
+    Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave, pstride);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (epilogue && L.total < kEpiLds) L.total = kEpiLds;  // (every workgroup of a launch gets the same dynamic LDS)
     if (nsplit > p.nt) nsplit = p.nt;

@@ -216,9 +216,10 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
  * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
  * table; scenes whose table does not fit are checked straight from the scene table.  Identical results either way.
- * "lattice_winner": who writes fp_plan_dense's best_traj: 0 = auto (the lattice kernel itself while one round of workgroups
- * holds the batch, winner_traj_kernel right behind it for bigger batches), 1 = always the lattice kernel, 2 = always its own
- * launch.  Identical results.
+ * "lattice_winner": who writes fp_plan_dense's best_traj: 0 = auto (the lattice workgroups themselves while one round of them
+ * holds the batch; for bigger batches epilogue workgroups appended to the lattice launch, which become resident in the slots the
+ * draining launch leaves empty and wait for their egos' argmins - one launch per call), 1 = always the lattice workgroups, 2 = always
+ * winner_traj_kernel behind the lattice launch.  Identical results.
  * "validate": 1 = FP_MEM_DEVICE calls first run a one-lane-per-ego range check of frame_of / scene_of / t_now / nx / t_samples on the
  * device and return FP_EINVAL / FP_ELIMIT (with the offending index in fp_last_error) instead of faulting the GPU; the call then
  * WAITS for the stream (one small kernel + an 8-byte copy).  0 (default) = no check, nothing waits.

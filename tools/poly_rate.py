@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Step time of the dense call on polygon scenes (config-3 sizes, half of the obstacle columns random convex polygons) next to the
+same scenes with plain rectangles: python tools/poly_rate.py [max_vertices]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from fiss_plus_planner_amd import synth  # noqa: E402
+from fiss_plus_planner_amd.device_batch import DeviceBatch  # noqa: E402
+from fiss_plus_planner_amd.engine import FrenetEngine  # noqa: E402
+
+mv = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+base = synth.make_config(3)
+eng = FrenetEngine(0)
+dev = torch.device("cuda", 0)
+def rect_rings(b, frac=0.5):
+    """half of the columns as 4-vertex rings that ARE their rectangles: the same collisions, the polygon code path"""
+    from fiss_plus_planner_amd.batch import ProblemBatch
+    rng = np.random.default_rng(1)
+    S, n = b.S, b.n_obs
+    hl, hw = 0.5 * b.obs_dims[..., 0], 0.5 * b.obs_dims[..., 1]
+    poly = np.stack([np.stack([-hl, -hw], -1), np.stack([hl, -hw], -1), np.stack([hl, hw], -1), np.stack([-hl, hw], -1)], axis=2)
+    nvert = np.where(rng.uniform(size=(S, n)) < frac, 4, 0).astype(np.int32)
+    kw = {k: getattr(b, k) for k in ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+                                      "obs_pose", "obs_dims", "final_time_step", "veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride")}
+    return ProblemBatch(**kw, obs_poly=poly, obs_nvert=nvert)
+
+
+norect = rect_rings(base)
+norect.obs_nvert = np.zeros_like(norect.obs_nvert)  # (set behind the constructor's back: the POLY instance with no polygon column)
+for name, b in (("rectangles", base), ("POLY instance, no polygon", norect), ("rectangles as 4-vertex rings", rect_rings(base)), (f"polygons <= {mv} vertices", synth.with_random_shapes(base, 4242, frac=0.5, max_vertices=mv))):
+    db = DeviceBatch(b, 0)
+    B = b.B
+    bi = torch.empty(B, dtype=torch.int32, device=dev); bc = torch.empty(B, dtype=torch.float64, device=dev)
+    bf = torch.zeros(B, dtype=torch.int32, device=dev); bt = torch.empty((B, 16, 112), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    run = lambda: eng.plan_dense_device(db.params, db.fb, bi.data_ptr(), bc.data_ptr(), stream=st.cuda_stream, best_flags=bf.data_ptr(),
+                                        best_traj=bt.data_ptr(), traj_stride=112, traj_sparse=True)
+    for _ in range(20):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:28s} {e0.elapsed_time(e1) * 10:7.1f} us per step   winners {float((bi >= 0).float().mean()):.2f}")
