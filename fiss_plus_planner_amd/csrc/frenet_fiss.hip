@@ -505,6 +505,33 @@ __device__ __forceinline__ double analytic_cost(const fp_params& p, const double
     return combine_cost(p, N, ls, ds);
 }
 
+// The same cost with the two halves of the dependent chain in two lanes: lane L (role 0) solves the longitudinal boundary-value problem
+// and sums its three cost terms, lane L + 8 (role 1) does the lateral ones (both need the power sums of the horizon: each computes
+// them), then lane L fetches the lateral sums and recombines.  Same arithmetic per term, so the value is analytic_cost's bit for bit;
+// the chain of one evaluation is ~45 % shorter (the refinement rounds are R + 1 evaluations one after the other on a lone wavefront).
+// Valid in role-0 lanes; x must be the same in lanes L and L + 8.
+__device__ __forceinline__ double analytic_cost_two_lanes(const fp_params& p, const double* eg, double target_speed, const double* x, int role)
+{
+    const double T = x[2];
+    const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
+    const bool ok = N > 0 && N <= FP_MAX_POINTS;
+    double S[11], part[3] = {0.0, 0.0, 0.0};
+    if (ok) {
+        power_sums_closed(N, p.tick_t, S);
+        if (role == 0) {
+            const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], x[1], 0.0, T);
+            lon_cost_sums(lon, target_speed, S, part);
+        } else {
+            const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
+            lat_cost_sums(lat, S, part);
+        }
+    }
+    double ds[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) ds[m] = __shfl_down(part[m], 8, kWave);
+    return ok ? combine_cost(p, N, part, ds) : __builtin_nan("");
+}
+
 // Optional curvature checks (frenet_optimal_planner.py:145-150) of ONE trajectory whose M Cartesian points sit in xy[] (LDS), by
 // the whole wavefront: lane l holds elements l and l + 64 of every chain (M <= 128).  Same difference chains as CurvTrack /
 // winner_series: yaw_k = atan2 of segment k (the last point repeats the previous heading, :129), c = diff(yaw) / ds,
@@ -907,16 +934,17 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
         double my_x[3] = {nan, nan, nan}, my_cost = nan;  // lane c = refinement trajectory c (generation order)
         int ncand = 0;
         for (int r = 0; r < R; ++r) {
-            const int dim = lane >> 1;
+            // lanes 0..5: the six probes, lane 6: x itself (role 0: longitudinal half + recombination); lanes 8..14: their lateral halves
+            const int pk = lane & 7, dim = pk >> 1;
             double xp[3] = {x[0], x[1], x[2]};
-            if (lane < 6) {
-                xp[dim] += (lane & 1) ? res[dim] : -res[dim];
+            if (pk < 6) {
+                xp[dim] += (pk & 1) ? res[dim] : -res[dim];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) xp[m] = fmin(fmax(xp[m], lo[m]), hi[m]);  // np.clip
             }
             const bool bad = lane < 6 && (!(xp[0] == xp[0]) || !(xp[1] == xp[1]) || !(xp[2] == xp[2]));
             if (__ballot(bad)) break;
-            const double cp = analytic_cost(p, eg, target_speed, xp, L.S);  // lanes >= 6: the cost of x itself
+            const double cp = analytic_cost_two_lanes(p, eg, target_speed, xp, (lane >> 3) & 1);  // valid in lanes 0..6 (6: the cost of x itself)
             {
                 const double cx0 = __shfl(cp, 6, kWave);
                 if (!have_coarse) { coarse_cost0 = cx0; have_coarse = true; }
