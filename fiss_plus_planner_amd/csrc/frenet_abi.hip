@@ -745,6 +745,14 @@ __global__ void validate_batch_kernel(fp_params p, fp_batch b, int* err)
         const double n = b.t_samples[i] / p.tick_t;
         if (!(n > 0) || n > FP_MAX_POINTS) code = 5;
     }
+    // polygon columns: a vertex count outside {0} u [3, poly_stride] would walk off the ring table
+    if (!code && b.obs_nvert && b.S > 0 && b.n_obs > 0) {
+        const long cols = (long)b.S * b.n_obs;
+        for (long c = i; c < cols && !code; c += (long)gridDim.x * blockDim.x) {
+            const int n = b.obs_nvert[c];
+            if (n != 0 && (n < 3 || n > b.poly_stride)) { code = 6; if (atomicCAS(&err[0], 0, code) == 0) err[1] = (int)c; return; }
+        }
+    }
     if (code && atomicCAS(&err[0], 0, code) == 0) err[1] = i;
 }
 
@@ -768,6 +776,7 @@ int device_validate(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStrea
         case 2: return fail(FP_EINVAL, "scene_of[%d] out of range (device batch, S=%d)", at, b->S);
         case 3: return fail(FP_EINVAL, "t_now[%d] is negative (device batch)", at);
         case 4: return fail(FP_EINVAL, "nx[%d] out of range (device batch, NX=%d)", at, b->NX);
+        case 6: return fail(FP_EINVAL, "obs_nvert[%d] outside {0} and 3..poly_stride=%d (device batch)", at, b->poly_stride);
         default: return fail(FP_ELIMIT, "t_samples[%d] needs more than FP_MAX_POINTS points (device batch)", at);
     }
 }

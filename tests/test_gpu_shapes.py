@@ -190,6 +190,41 @@ def test_host_entry_validates_polygon_columns(engine):
         engine.plan_dense(two)
 
 
+def test_device_entry_validates_vertex_counts_on_request(engine):
+    """FP_MEM_DEVICE calls cannot look at the arrays; with the "validate" option a check kernel does (a count beyond poly_stride would
+    walk off the ring table)."""
+    from fiss_plus_planner_amd.device_batch import DeviceBatch
+
+    b = with_random_shapes(synth.make_batch(4, 5, 5, 5, 10, 60, True, 66), 66)
+    bad = b.obs_nvert.copy()
+    bad[1, 3] = b.obs_poly.shape[2] + 1
+    b.obs_nvert = bad
+    db = DeviceBatch(b, 0)
+    import torch
+    bi = torch.empty(4, dtype=torch.int32, device="cuda:0"); bc = torch.empty(4, dtype=torch.float64, device="cuda:0")
+    engine.set_option("validate", 1)
+    try:
+        with pytest.raises(_abi.FrenetGpuError, match="obs_nvert"):
+            engine.plan_dense_device(db.params, db.fb, bi.data_ptr(), bc.data_ptr())
+    finally:
+        engine.set_option("validate", 0)
+
+
+def test_closed_loop_on_polygon_scenes_one_launch_equals_two(engine):
+    """fp_plan_step (plan + hand-over in one launch, the run-time-shape POLY instances) against fp_plan_dense + fp_advance, cycle for
+    cycle, on scenes whose obstacles are half polygons."""
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+
+    goal = np.full((300, 2), 1e9)
+    mk = lambda: with_random_shapes(synth.make_batch(300, 5, 5, 5, 10, 100, True, 67), 67)
+    one = ClosedLoopRunner(engine, DeviceBatch(mk(), 0), goal, "FOP", fused=True).run(12)
+    two = ClosedLoopRunner(engine, DeviceBatch(mk(), 0), goal, "FOP", fused=False).run(12)
+    for k in ("done", "cycles", "t_now"):
+        np.testing.assert_array_equal(getattr(one, k), getattr(two, k), err_msg=k)
+    assert np.array_equal(one.ego, two.ego) and np.array_equal(one.cart, two.cart, equal_nan=True)
+    assert one.cycles.sum() > 300
+
+
 def test_audit_contact_bit_on_a_polygon_within_ulps_of_touching(engine):
     tri = np.array([(-2.0, -2.0), (2.0, -2.0), (0.0, 2.0)])
     ego = (4.0, 2.0, 0.0, 0.0, 0.0)
