@@ -233,6 +233,12 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
 // an ego costs 4 intervals instead of 4 nt and needs no split over workgroups (no ticket, no merge).
 // NTH: threads per workgroup, 512 or - the grouped latency instances, one workgroup per CU - 1024 (twice the wavefronts per pass).
 // the kernel's parameters as one struct: where InlineIn::bytes sits in the argument segment
+// LDS of an epilogue workgroup (kThreads / 128 trajectories): [4][FP_MAX_POINTS] doubles of difference-chain scratch per trajectory,
+// {first point off the spline} x 2, the argmin and the "had to wait" flag per trajectory; then, for reference lines of at most
+// kEpiSplineNX knots, room for one spline copy per trajectory
+constexpr int kEpiPairsC = 512 / (2 * kWave);
+constexpr int kEpiLdsBytes = kEpiPairsC * 4 * FP_MAX_POINTS * 8 + kEpiPairsC * 4 * 4 + 16;
+constexpr int kEpiSplineNX = 96;
 struct LatticeKernarg {
     KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from, epi_from; InlineIn inl;
 };
@@ -268,29 +274,43 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             const int eslot = ((int)blockIdx.x - epi_from) * kPairs + pair;
             const bool have = eslot < ka.b.B;
             const int eb = have ? (perm ? perm[eslot] : eslot) : 0;
+            const fp_params& pp = ka.p;
+            const fp_batch& bb = ka.b;
+            const int ef = bb.frame_of[eb];
+            const double* gk = bb.knots + (size_t)ef * bb.NX;
+            const double* gc = bb.coef + (size_t)ef * 8 * bb.NX;
+            // A pair that finds its ego's argmin not published yet is one of the launch's last: the launch ends when IT is done.  It spends
+            // the wait copying the ego's spline to LDS (9 NX doubles, when four copies fit), so that the segment searches and coefficient
+            // reads of the series - three to four dependent L2 round trips after the flag - become LDS reads.  Pairs whose argmin is
+            // already there (the many that run inside the drain) read the few segments they touch from global memory as before.
+            int* s_wait = s_idx + kPairs;
+            double* s_spl = (double*)(esm + kEpiLdsBytes) + (size_t)pair * 9 * bb.NX;
+            const bool can_copy = bb.NX <= kEpiSplineNX;
+            if (have && i == 0) s_wait[pair] = can_copy && __hip_atomic_load(&ka.epi_flag[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            __syncthreads();
+            const bool in_lds = have && s_wait[pair] != 0;
+            if (in_lds)
+                for (int k = i; k < 9 * bb.NX; k += 2 * kWave) s_spl[k] = k < bb.NX ? gk[k] : gc[k - bb.NX];
             if (have && i == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(&ka.epi_flag[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (++spins > (1 << 23)) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 25)) __builtin_trap();
                 }
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the index is read after the flag
                 s_idx[pair] = __hip_atomic_load(&ka.idx_shadow[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&ka.epi_flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
             }
             __syncthreads();
-            const fp_params& pp = ka.p;
-            const fp_batch& bb = ka.b;
             const int win = have ? s_idx[pair] : -1;
             double d_end = __builtin_nan(""), v_end = d_end, T_end = d_end;
             if (win >= 0) {
                 const int iv = win % pp.nv, it = (win / pp.nv) % pp.nt, id = win / (pp.nv * pp.nt);
                 d_end = bb.d_samples[id]; v_end = bb.v_samples[(size_t)eb * pp.nv + iv]; T_end = bb.t_samples[it];
             }
-            const int ef = bb.frame_of[eb];
             // (a pair beyond the batch still runs the barriers; it writes nothing)
-            winner_series_pair(ka, eb, eb, win >= 0, d_end, v_end, T_end, i, SplineLds{bb.knots + (size_t)ef * bb.NX, bb.coef + (size_t)ef * 8 * bb.NX, bb.nx[ef], bb.NX},
-                               scratch + pair * 4 * FP_MAX_POINTS, s_m + 2 * pair, have);
+            const SplineLds sp = in_lds ? SplineLds{s_spl, s_spl + bb.NX, bb.nx[ef], bb.NX} : SplineLds{gk, gc, bb.nx[ef], bb.NX};
+            winner_series_pair(ka, eb, eb, win >= 0, d_end, v_end, T_end, i, sp, scratch + pair * 4 * FP_MAX_POINTS, s_m + 2 * pair, have);
             return;
         }
     }
@@ -1560,8 +1580,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1, kThreads / kWave, pstride);
     // the series of a three-per-CU launch: by epilogue workgroups appended to the grid (ka.epi_flag + ka.idx_shadow from the caller), if
     // there are fewer of them than resident slots (see the kernel); else the caller launches winner_traj_kernel behind this launch
-    constexpr int kEpiPairs = kThreads / (2 * kWave);
-    constexpr int kEpiLds = kEpiPairs * 4 * FP_MAX_POINTS * 8 + kEpiPairs * 3 * 4 + 16;
+    constexpr int kEpiPairs = kEpiPairsC;
+    const int kEpiLds = kEpiLdsBytes + (b.NX <= kEpiSplineNX ? kEpiPairs * 9 * b.NX * 8 : 0);
 #if defined(FP_PHASE_STAMPS) || defined(FP_COUNTERS)  // (the stamps travel in the series block: the three-workgroup variant leaves the series themselves unwritten)
     const bool can_epi = false;
     bool three = gs == 1 && nsplit == 1 && b.B > 512 && L6.total <= 52 * 1024;
