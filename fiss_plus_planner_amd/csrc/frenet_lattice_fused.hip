@@ -1464,7 +1464,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     }
     if (tid == 0) {
         const Best r = s_best[0];
-        ka.r.best_idx[b] = r.idx;
+        // (the hand-over first: its s_waitcnt would otherwise also wait for the stores below, and best_idx / best_cost may be
+        // device-mapped HOST memory - a link round trip in front of every flag)
         if constexpr (OCC > 4) {
             if (ka.epi_flag) {  // hand the ego to the appended epilogue workgroups: index first, acknowledged by L2, then the flag
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -1476,6 +1477,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
         } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
+        ka.r.best_idx[b] = r.idx;
         ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
         if (ka.r.stats) {
             int32_t* st = ka.r.stats + (size_t)b * 4;
