@@ -593,6 +593,18 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # ---- device wake-up, outside the contract's W + K steps and reported in the line (`prewarm`): a process that has just started
+    # finds the GPU at idle clocks, and W = 5 steps are 0.8 ms of work - the K steps would be timed on the clock ramp (measured on
+    # MI355X with `--steps 20`: 0.160-0.164 ms per step with --warmup 5 against 0.150-0.155 with --warmup 300, same box, same
+    # process otherwise).  A quarter of a second of the same steps, untimed, brings the clocks up; then the W warm-up steps, then
+    # exactly K timed ones.  BENCH_PREWARM_S=0 turns it off.
+    prewarm_s = float(os.environ.get("BENCH_PREWARM_S", "0.25"))
+    prewarm_steps, t_pre = 0, time.perf_counter()
+    while time.perf_counter() - t_pre < prewarm_s:
+        for _ in range(32):
+            wls[prewarm_steps % n_rot].step(); wls[prewarm_steps % n_rot].fetch()
+            prewarm_steps += 1
+        torch.cuda.synchronize(dev)
     # ---- timed region (the contract: W warm-up steps, exactly K timed steps between barrier + synchronize)
     elapsed, kern_list = timed_run(torch, wls, args.steps, args.warmup, stream, barrier)
     enqueue_ms = timed_run.enqueue_s / args.steps * 1e3
@@ -892,6 +904,8 @@ def main():
                                      "the kernel is VALU-issue bound, not HBM bound: `binding` / `valu_fp64` carry the executed FP64 work of the PMC pass "
                                      "of this build (profiles/r04_*), `valu_issue` the instruction issue rate", fp64_exec),
             "host_enqueue_ms_per_step": enqueue_ms,
+            "prewarm": {"steps": prewarm_steps, "seconds": prewarm_s, "what": "untimed steps of the same workload before the W warm-up steps: the GPU leaves its "
+                        "idle clocks (a fresh process, W = 5: 0.160-0.164 ms per step timed on the ramp against 0.150-0.155); BENCH_PREWARM_S=0 disables it"},
             "kernel_ms_stats": {"mean": kern_ms, "min": float(np.min(kern_list)), "median": float(np.median(kern_list)), "max": float(np.max(kern_list)),
                                 "launches_timed": len(kern_list)},
             "egos_with_a_feasible_candidate": float(np.mean([(w.h_idx.numpy() >= 0).mean() for w in wls])) if not fiss else None,
