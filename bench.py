@@ -217,6 +217,18 @@ def timed_run(torch, workloads, steps, warmup, stream, barrier, ev_every=None):
     return elapsed, [a.elapsed_time(b) for a, b in ev]
 
 
+def wake(torch, dev, fn, seconds):
+    """Device wake-up before a timed leg (see `prewarm` in main): the CPU-side parity checks between the legs leave the GPU idle for
+    seconds, and a leg's own few warm-up steps are too short for its clocks to come back.  Runs fn() untimed for `seconds`."""
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(16):
+            fn()
+            n += 1
+        torch.cuda.synchronize(dev)
+    return n
+
+
 def roofline_obj(bytes_launch, kern_ms, kernel, traffic=None, note=None, fp64=None):
     """The contract's roofline object for the HBM bound (north_star asks for HBM GB/s) and, when the PMC pass of this build is at hand,
     the bound that actually binds: executed FP64 VALU work against the vector FP64 peak.  `binding` names which of the two is closer
@@ -444,7 +456,7 @@ def cpu_baseline_leg(batch, h_idx, h_cost, seconds, max_threads):
     return out
 
 
-def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads, eng2=None, stream2=None):
+def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads, eng2=None, stream2=None, wake_s=0.0):
     """north_star's workload is "many scenarios x many cycles": B egos stepped `cycles` plan cycles entirely on the device
     ([plan -> advance] per cycle, planners/benchmark/planning.py:120-162; no host round trip).  Parity: the state the loop left
     behind is planned once more and compared with the oracle planning the same states."""
@@ -458,11 +470,20 @@ def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads, eng2=None, stre
         batch = synth.make_config(cfg, B=B, layout=layout)
         goal = np.full((B, 2), 1e9)  # never reached: an ego runs until the map ends or no candidate survives
         run = ClosedLoopRunner(eng, DeviceBatch(batch, dev.index), goal, planner)
-        run.run(2)
-        # restart from the initial states for the timed loop
-        run.db.t["ego"].copy_(torch.from_numpy(batch.ego)); run.db.t["t_now"].zero_(); run.done.zero_(); run.cycles.zero_()
-        if planner != "FOP":
-            run.prev.fill_(-1)
+        ego0 = torch.from_numpy(batch.ego).to(dev)
+
+        def restart():  # back to the initial states
+            run.db.t["ego"].copy_(ego0); run.db.t["t_now"].zero_(); run.done.zero_(); run.cycles.zero_()
+            if planner != "FOP":
+                run.prev.fill_(-1)
+
+        # device wake-up (see `prewarm`): the whole loop, untimed, until the clocks are up; then the timed loop from the initial states
+        t_w = time.perf_counter()
+        while True:
+            run.run(cycles - 1 if wake_s > 0 else 2)
+            restart()
+            if time.perf_counter() - t_w >= wake_s:
+                break
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         res = run.run(cycles - 1)
@@ -513,14 +534,22 @@ def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads, eng2=None, stre
                     rn = ClosedLoopRunner(e_, DeviceBatch(sb, dev.index), goal[lo:hi], planner)
                 halves.append((rn, st_, sb))
             torch.cuda.synchronize(dev)
-            for rn, st_, sb in halves:  # warm-up, then back to the initial states
-                rn.step(st_.cuda_stream); rn.step(st_.cuda_stream)
-            torch.cuda.synchronize(dev)
-            for rn, st_, sb in halves:
-                with torch.cuda.stream(st_):
-                    rn.db.t["ego"].copy_(torch.from_numpy(sb.ego)); rn.db.t["t_now"].zero_(); rn.done.zero_(); rn.cycles.zero_()
-                    if planner != "FOP":
-                        rn.prev.fill_(-1)
+            def restart_halves():
+                for rn, st_, sb in halves:
+                    with torch.cuda.stream(st_):
+                        rn.db.t["ego"].copy_(torch.from_numpy(sb.ego)); rn.db.t["t_now"].zero_(); rn.done.zero_(); rn.cycles.zero_()
+                        if planner != "FOP":
+                            rn.prev.fill_(-1)
+
+            t_w = time.perf_counter()
+            while True:  # warm-up (and device wake-up: the parity check above left the GPU idle), then back to the initial states
+                for _ in range(24):
+                    for rn, st_, sb in halves:
+                        rn.step(st_.cuda_stream)
+                torch.cuda.synchronize(dev)
+                restart_halves()
+                if time.perf_counter() - t_w >= wake_s:
+                    break
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(cycles - 1):
@@ -678,6 +707,8 @@ def main():
         steps_x, warm_x = min(args.steps, 50), min(args.warmup, 5)
 
         def measure(ws, label_kernel, ev_every=None):
+            if prewarm_s > 0:
+                wake(torch, dev, lambda: (ws[0].step(), ws[0].fetch()), 0.5 * prewarm_s)
             el, kl = timed_run(torch, ws, steps_x, warm_x, stream, barrier, ev_every)
             k_ms = float(np.mean(kl))
             cand = sum(w.candidates for w in ws) / len(ws)
@@ -726,6 +757,14 @@ def main():
         from fiss_plus_planner_amd.sharded import ShardedEngine
         with ShardedEngine(devices=[local_rank]) as seng:
             sdbs = [seng.upload(w.batch, winner=True) for w in wls]
+            if prewarm_s > 0:  # device wake-up (the engine has its own ctx: its launch order is learnt here too, like the headline's in `prewarm`)
+                t_w, kw = time.perf_counter(), 0
+                while time.perf_counter() - t_w < prewarm_s:
+                    for _ in range(32):
+                        seng.plan_dense(sdbs[kw % len(sdbs)], winner=True, sync=False)
+                        kw += 1
+                    for sd in sdbs:
+                        sd.synchronize()
             for k in range(warm_x):
                 seng.plan_dense(sdbs[k % len(sdbs)], winner=True, sync=False)
             for sd in sdbs:
@@ -813,6 +852,8 @@ def main():
         stream2 = torch.cuda.Stream(dev)
 
         def measure2(ws):
+            if prewarm_s > 0:
+                wake(torch, dev, lambda: [(w.step(), w.fetch()) for w in ws[:2]], 0.5 * prewarm_s)
             for k in range(warm_x):
                 ws[k % len(ws)].step(); ws[k % len(ws)].fetch()
             barrier()
@@ -847,7 +888,7 @@ def main():
         del ws2, w4a, w4b
         # (e) many scenarios x many cycles on the device, and the PCIe-inclusive host-buffer entry
         if args.cpu_seconds > 0:
-            extras["closed_loop"] = closed_loop_leg(torch, eng, dev, B, args.layout, 50, gate_threads, eng2, stream2)
+            extras["closed_loop"] = closed_loop_leg(torch, eng, dev, B, args.layout, 50, gate_threads, eng2, stream2, wake_s=0.5 * prewarm_s)
         del eng2
         t_host = []
         for _ in range(4):
