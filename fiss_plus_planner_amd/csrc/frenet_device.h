@@ -296,20 +296,6 @@ __device__ __forceinline__ bool obb_overlap(const Obb& a, const Obb& b)
     return true;
 }
 
-// The same verdict without early exits: in the lattice kernel's narrow phase two thirds of the lanes of a round collide (every axis
-// is evaluated for them anyway), so the four exits only cost exec-mask bookkeeping and branches on the wavefront's dependent chain.
-__device__ __forceinline__ bool obb_overlap_flat(const Obb& a, const Obb& b)
-{
-    const double dx = b.x - a.x, dy = b.y - a.y;
-    const double C = fabs(fma(a.c, b.c, a.s * b.s));
-    const double S = fabs(fma(a.s, b.c, -a.c * b.s));
-    const bool s0 = fabs(fma(dx, a.c, dy * a.s)) > a.hl + fma(b.hl, C, b.hw * S);
-    const bool s1 = fabs(fma(dy, a.c, -dx * a.s)) > a.hw + fma(b.hl, S, b.hw * C);
-    const bool s2 = fabs(fma(dx, b.c, dy * b.s)) > b.hl + fma(a.hl, C, a.hw * S);
-    const bool s3 = fabs(fma(dy, b.c, -dx * b.s)) > b.hw + fma(a.hl, S, a.hw * C);
-    return !((int)s0 | (int)s1 | (int)s2 | (int)s3);
-}
-
 // The same four axes as a signed distance: max over the axes of (centre distance along the axis - the two boxes' reach along it).
 // <= 0: the boxes overlap (obb_overlap is `obb_gap <= 0` with early exits); > 0: separated by at least that much along the best
 // axis (a lower bound of the true distance).  The audit pass (audit_kernel) calls a decision "thin" when |gap| is below its tolerance.

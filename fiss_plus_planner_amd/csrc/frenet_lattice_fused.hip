@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                     } else {
                                         const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
                                         const double dx = op.x - ego.x, dy = op.y - ego.y;
-                                        hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap_flat(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                        hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
                                         if constexpr (POLY) {
                                             if (hit) {  // a polygon column: its box was a necessary condition, the ring decides
                                                 const int nvx = ((const int32_t*)(smem + L.nvert))[j];
