@@ -111,6 +111,7 @@ def series_bytes(best_flags: np.ndarray, lines: bool = False) -> float:
 
 class Workload:
     """One problem batch resident in HBM + its output buffers + the step that plans it."""
+    kPrevRing = 64
 
     def __init__(self, torch, eng, batch, dev, stream, fiss=False, tables=False):
         from fiss_plus_planner_amd import _abi
@@ -146,7 +147,12 @@ class Workload:
             self.best_cost, self.best_idx = self.h_cost, self.h_idx
         if fiss:
             self.f_t = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in ("samp_min", "samp_max", "samp_res")}
-            self.prev = torch.full((B, 3), -1, dtype=torch.int32, device=dev)
+            # prev_best_idx is in/out (the search's history heuristic); every step must plan the same cycle, so every step gets a fresh
+            # all -1 array out of a ring that is refilled by ONE fill per kPrevRing steps (a fill per step was a 4.6 us kernel + a
+            # launch gap inside every timed step - an artefact of replaying one cycle, not a part of the pipeline)
+            self.prev_ring = torch.full((self.kPrevRing, B, 3), -1, dtype=torch.int32, device=dev)
+            self.prev_k = 0
+            self.prev = self.prev_ring[0]
             self.ijk = torch.empty((B, 3), dtype=torch.int32, device=dev)
             self.end_state = torch.empty((B, 3), dtype=torch.float64, device=dev)
             self.opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS, 3, 10.0, 0.5)
@@ -164,8 +170,13 @@ class Workload:
 
     def step(self):
         if self.fiss:
-            with self.torch.cuda.stream(self.stream):
-                self.prev.fill_(-1)  # every step plans the same cycle: no history carried over
+            if self.prev_k == self.kPrevRing:
+                with self.torch.cuda.stream(self.stream):
+                    self.prev_ring.fill_(-1)  # (all of the ring's arrays have been used: the kernels before this fill are done with them in stream order)
+                self.prev_k = 0
+            self.prev = self.prev_ring[self.prev_k]
+            self.io.prev_best_idx = self.prev.data_ptr()
+            self.prev_k += 1
             self.eng.plan_fiss_device(self.params, self.fb, self.opts, self.io, stream=self.stream.cuda_stream)
         else:
             # one launch: lattice + argmin + the winner's series (what plan() returns) written by the workgroup that found it
@@ -807,17 +818,21 @@ def main():
         # (c) BASELINE configs[3]: the FISS+ pipeline on 2048 egos; per-stage times from runs that stop after stage 1 / 2
         b4 = synth.make_config(4, B=B, layout=args.layout)
         w4 = Workload(torch, eng, b4, dev, stream, fiss=True)
-        o4 = measure([w4], "lattice_fused + fissplus_search + fiss_refine (whole FISS+ pipeline, 3 kernels)")
+        o4 = measure([w4], "lattice_fused (+ the FISS+ search in workgroups appended to its grid) + fiss_refine: the whole FISS+ pipeline in 2 launches")
+        # stage times: the pipeline with the search in its OWN launch (fiss_fused = 0), stopped after stage 1 / 2 / 3; the leg's number
+        # above is the default pipeline, whose search runs in workgroups appended to the lattice launch
         stage_ms = {}
-        for st_n in (1, 2):
+        eng.set_option("fiss_fused", 0)
+        for st_n in (1, 2, 3):
             eng.set_option("fiss_stages", st_n)
             _, kl = timed_run(torch, [w4], 20, 3, stream, barrier, ev_every=1)
             stage_ms[st_n] = float(np.mean(kl))
-        eng.set_option("fiss_stages", 3)
+        eng.set_option("fiss_fused", 1)
         w4.step(); torch.cuda.synchronize(dev)  # leave complete outputs behind
         k4 = o4["roofline"]["kernel_ms"]
-        o4["stage_ms"] = {"lattice_fused_kernel (dense tables)": stage_ms[1], "fissplus_search_kernel": stage_ms[2] - stage_ms[1],
-                          "fiss_refine_kernel (3 rounds + validation + winner series)": k4 - stage_ms[2]}
+        o4["stage_ms"] = {"lattice_fused_kernel (dense tables)": stage_ms[1], "fissplus_search_kernel (own launch)": stage_ms[2] - stage_ms[1],
+                          "fiss_refine_kernel (3 rounds + validation + winner series)": stage_ms[3] - stage_ms[2],
+                          "three launches": stage_ms[3], "search appended to the lattice launch (default): two launches": k4}
         o4["workload"] = f"BASELINE.json configs[3]: FISS+ (search walk + 3 refinement rounds) over {b4.B} egos x 9x9x7, 50 dynamic obstacles; counts C + 21 trajectories per ego"
         if args.cpu_seconds > 0:
             o4["parity"] = fiss_parity("config4", w4, np.arange(0, B, max(1, B // 128)))

@@ -131,6 +131,7 @@ struct fp_ctx {
     DeviceBuf validate_buf;        // two ints on the device: first failing check, index
     int* validate_host = nullptr;  // ... and their pinned mirror
     int lattice_winner = 0;        // fp_ctx_set_option("lattice_winner"): 0 auto, 1 inside the lattice kernel, 2 its own launch
+    int fiss_fused = 1;            // fp_ctx_set_option("fiss_fused"): 1 = the FISS+ search of a multi-round batch runs in workgroups appended to the lattice launch; 0 = always its own launch
     int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
     // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
     // leaves its ego's duration in dur_dev; now and then the host fetches them (async copy + event, never a wait), sorts the egos
@@ -891,6 +892,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->lattice_winner = value;
         return FP_OK;
     }
+    if (strcmp(name, "fiss_fused") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "fiss_fused must be 0 or 1");
+        ctx->fiss_fused = value;
+        return FP_OK;
+    }
     if (strcmp(name, "fiss_stages") == 0) {
         if (value < 1 || value > 3) return fail(FP_EINVAL, "fiss_stages must be 1 (lattice only), 2 (+ search) or 3 (all)");
         ctx->fiss_stages = value;
@@ -944,7 +950,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
         {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
-        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"lattice_launches", ctx->lattice_launches},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
         if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
@@ -1216,17 +1222,24 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group, &tail));
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
+    bool search_done = false;
     if (inl.on) {
         fp::KernelArgs kl = fa.ka;
         kl.b = lat_b;
         LAUNCH_TRY(fp::launch_lattice(kl, stream, 2, parts, nsplit, nullptr, perm, dur, group, &inl, tail), "lattice kernel");
     } else {
-        LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group, nullptr, tail), "lattice kernel");
+        // the FISS+ search as workgroups appended to the lattice launch (launch_lattice_fused takes the offer for three-per-CU launches;
+        // "fiss_fused" 0, the stage-timing diagnostic and every other shape: the search kernel follows in its own launch)
+        fp::FissTail ft;
+        ft.opts = fa.opts; ft.io = fa.io; ft.walk_jump = ctx->fiss_jump;
+        ft.flag = (ctx->fiss_fused && ctx->fiss_stages >= 3 && opts->kind == FP_FISS_PLUS) ? epi_flags_for(ctx, B, stream) : nullptr;
+        LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group, nullptr, tail, ft.flag ? &ft : nullptr, &search_done),
+                   "lattice kernel");
     }
     FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     fa.walk_jump = ctx->fiss_jump;
-    LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
+    if (!search_done) LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
     if (R > 0 && ctx->fiss_stages >= 3) {
         // three refinement workgroups per CU are resident at once (fiss_refine_kernel: 168 VGPRs, ~52 KB LDS)
         const int* rperm; int* rdur;

@@ -86,6 +86,17 @@ struct FissArgs {
     int walk_jump = 1;         // FISS+ walk: skip the iterations below the first feasible sample's minimax level (frenet_fissplus.hip)
 };
 
+// The FISS+ search as workgroups appended to the fused lattice launch (lattice_fused_kernel's FISS instances): what the search needs
+// beside the lattice's KernelArgs.  flag: [B] ints, zero between launches - an ego's lattice workgroup sets its flag when the ego's
+// rows of the dense tables are written (agent-scope stores), the ego's search workgroup waits for it and clears it.
+struct FissTail {
+    fp_fiss_opts opts;
+    fp_fiss_io io;
+    int NB = 0;          // buckets of the ranking (fsp::fissplus_search_ego)
+    int walk_jump = 1;
+    int32_t* flag = nullptr;
+};
+
 // One wavefront per ego: coarse FISS / FISS+ search over the dense tables.
 hipError_t launch_fiss_search(const FissArgs& fa, hipStream_t stream);
 // The FISS+ walk in rank space (frenet_fissplus.hip); launch_fiss_search dispatches to it for FP_FISS_PLUS.
@@ -108,9 +119,11 @@ constexpr size_t kTicketBytes = 64 * 1024;
 // launch has more egos than stay resident); 0: off.
 // *step_done (optional, ka.has_loop set): the launched instance hands the egos over to their next states itself (fp_plan_step); false:
 // the caller launches advance_kernel behind it.
+// ft / search_done (optional): the FISS+ search of every ego in workgroups appended to the launch (three-per-CU launches of lattices up
+// to 1024 samples whose tables ka.r.cost_tbl / flag_tbl are written); *search_done = false: the caller launches the search kernel.
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done = nullptr,
                                 const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0,
-                                bool* step_done = nullptr);
+                                bool* step_done = nullptr, const FissTail* ft = nullptr, bool* search_done = nullptr);
 int lattice_group_fit(const fp_params& p, const fp_batch& b);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Curvature flags of every lattice candidate -> out [B][C] (one workgroup per ego, one lane per candidate, spline in LDS).
@@ -118,7 +131,8 @@ hipError_t launch_curvature_flags(const KernelArgs& ka, uint8_t* out, hipStream_
 // Dispatcher used by the ABI.  which: 0 = auto (fused, else per-candidate), 1 = per-candidate, 2 = fused only.
 // inl (optional, see InlineIn): only with which == 2 semantics guaranteed by the caller (the problem fits the fused kernel).
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done = nullptr,
-                          const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0);
+                          const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0,
+                          const FissTail* ft = nullptr, bool* search_done = nullptr);
 // Winner epilogue: recompute the full series of trajectory best_idx[b] for every ego (one lane per time point).
 // end_states = nullptr: series of lattice candidate ka.r.best_idx[b]; else [B][3] explicit (d, v, T) end states (NaN = none).
 hipError_t launch_winner_traj(const KernelArgs& ka, const double* end_states, hipStream_t stream);

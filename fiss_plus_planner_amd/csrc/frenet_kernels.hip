@@ -809,14 +809,16 @@ hipError_t launch_fopplus_count(int B, int C, const double* cost_tbl, const uint
 }
 
 hipError_t launch_lattice(const KernelArgs& ka, hipStream_t stream, int which, void* part_scratch, int nsplit, bool* winner_done, const int* perm,
-                          int* dur, int group, const InlineIn* inl, int tail)
+                          int* dur, int group, const InlineIn* inl, int tail, const FissTail* ft, bool* search_done)
 {
     if (winner_done) *winner_done = false;
+    if (search_done) *search_done = false;
     if (which == 1) return inl && inl->on ? hipErrorInvalidValue : launch_lattice_percand(ka, stream);
-    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur, group, inl, tail);
+    hipError_t e = launch_lattice_fused(ka, stream, part_scratch, nsplit, winner_done, perm, dur, group, inl, tail, nullptr, ft, search_done);
     if (e == hipErrorInvalidValue && which != 2 && !(inl && inl->on)) {
         (void)hipGetLastError();
         if (winner_done) *winner_done = false;
+        if (search_done) *search_done = false;
         return launch_lattice_percand(ka, stream);
     }
     return e;

@@ -38,6 +38,7 @@
 #include "frenet_kernels.h"
 #include "frenet_winner.h"
 #include "frenet_advance.h"
+#include "frenet_fissplus.h"
 
 namespace fp {
 
@@ -240,17 +241,48 @@ constexpr int kEpiPairsC = 512 / (2 * kWave);
 constexpr int kEpiLdsBytes = kEpiPairsC * 4 * FP_MAX_POINTS * 8 + kEpiPairsC * 4 * 4 + 16;
 constexpr int kEpiSplineNX = 96;
 struct LatticeKernarg {
-    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from, epi_from; InlineIn inl;
+    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from, epi_from; FissTail ft; InlineIn inl;
 };
 constexpr size_t kInlineOffset = offsetof(LatticeKernarg, inl) + offsetof(InlineIn, bytes);
 
 // POLY: the scene may hold convex-polygon obstacle columns (fp_batch.obs_nvert != NULL).  Only the run-time-shape instances exist with
 // POLY = true: the polygon branch in the narrow phase costs the rectangle-only instances 26 more spilled SGPRs and 2 % of the headline
 // step (same-box A/B), and scenes with polygons are not what the shaped instances were made for.
-template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH, bool POLY = false>
+// FISS: the launch carries one appended workgroup per ego that runs the FISS+ search (frenet_fissplus.h) on the ego's dense tables as
+// soon as the ego's lattice workgroup has written them - inside the launch's drain instead of in a launch of its own (a launch that is
+// one round of 4-wavefront workgroups as long as its slowest ego, behind a kernel boundary).  The tables travel between workgroups of
+// ONE launch, possibly on different XCDs whose L2s are not coherent with each other: they are written with agent-scope stores and read
+// with agent-scope loads; the flag follows the stores of ALL threads of the writing workgroup (s_waitcnt + barrier).
+template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH, bool POLY = false, bool FISS = false>
 __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit_arg, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur, int gs_arg, int tail_from, int epi_from, InlineIn inl)
+                                                                   int* dur, int gs_arg, int tail_from, int epi_from, FissTail ft, InlineIn inl)
 {
+    if constexpr (FISS) {
+        if (epi_from >= 0 && (int)blockIdx.x >= epi_from) {  // ---- appended search workgroup: one ego, in launch order
+            extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+            const int eslot = (int)blockIdx.x - epi_from;
+            const int eb = perm ? perm[eslot] : eslot;
+            if (threadIdx.x == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(&ft.flag[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 25)) __builtin_trap();
+                }
+                __hip_atomic_store(&ft.flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+            __syncthreads();
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the tables are read after the flag
+            FissArgs fa;
+            fa.ka = ka;
+            fa.opts = ft.opts;
+            fa.io = ft.io;
+            fa.cost_tbl = ka.r.cost_tbl;
+            fa.flag_tbl = ka.r.flag_tbl;
+            fa.walk_jump = ft.walk_jump;
+            fsp::fissplus_search_ego<NTH / kWave, 1, 1024, true>(fa, ft.NB, eb, fsm);
+            return;
+        }
+    }
     // ---------------------------------------------------------------- appended epilogue workgroups (blockIdx >= epi_from)
     // The three-workgroups-per-CU instances cannot write the winner's series themselves (the slot time of a one-wavefront dependent
     // chain, and 125 registers), and a winner_traj_kernel behind the launch costs ~9.5 us of a ~155 us step in which the last ~25 us
@@ -460,6 +492,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 }
             }
             if (tid == 0 && ka.idx_shadow) ka.idx_shadow[b] = -1;
+            if constexpr (FISS) {
+                if (tid == 0 && ft.flag) __hip_atomic_store(&ft.flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (its search workgroup writes the "none" outputs)
+            }
             if (ka.r.best_traj) {  // NaN series, flag word 0 (returns before it touches the spline or the scratch)
                 const double nan = __builtin_nan("");
                 if (wave == 0) winner_series_wave(ka, b, b, false, nan, nan, nan, lane, SplineLds{nullptr, nullptr, 0, 0});
@@ -1405,9 +1440,19 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             cost = __builtin_nan("");        // exactly what the lane-per-candidate kernel reports (traj_eval)
             word = flags = FP_FLAG_SPEED | FP_FLAG_ACCEL | FP_FLAG_COLLISION;
         }
-        if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = cost;
-        if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = word;
+        if constexpr (FISS) {  // (read by the ego's search workgroup in THIS launch: agent-scope stores, see the template's comment)
+            __hip_atomic_store((unsigned long long*)&ka.r.cost_tbl[(size_t)b * C + c], (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ka.r.flag_tbl[(size_t)b * C + c], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = cost;
+            if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = word;
+        }
         if (!(flags & FP_FLAG_INFEASIBLE) && cost == cost) mine = best_merge(mine, Best{cost, c});
+    }
+    if constexpr (FISS) {  // every thread's table stores are acknowledged before the barrier below - and so before the ticket / the flag
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
     }
     // [/section ASM]
     mine = wave_best(mine);
@@ -1477,6 +1522,13 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
         } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
+        if constexpr (FISS) {
+            if (ft.flag) {  // the ego's rows of the tables are complete (both halves of a tail-split ego: the ticket came after theirs)
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __hip_atomic_store(&ft.flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            }
+        }
         ka.r.best_idx[b] = r.idx;
         ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
         if (ka.r.stats) {
@@ -1559,9 +1611,10 @@ int lattice_group_fit(const fp_params& p, const fp_batch& b)
 }
 
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
-                                int group, const InlineIn* inl, int tail, bool* step_done)
+                                int group, const InlineIn* inl, int tail, bool* step_done, const FissTail* ft, bool* search_done)
 {
     if (step_done) *step_done = false;
+    if (search_done) *search_done = false;
     static const InlineIn kNoInline{};
     const InlineIn& in = inl ? *inl : kNoInline;
     if (winner_done) *winner_done = false;
@@ -1597,11 +1650,20 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     three = false;
 #endif
     const bool epilogue = three && can_epi;
+    // the FISS+ search in appended workgroups: three-per-CU launches that write their tables, lattices the 1024-sample search instance holds
+    const int C_all = p.nd * p.nv * p.nt;
+    const bool search = three && ft && ft->flag && ka.r.cost_tbl && ka.r.flag_tbl && !ka.r.best_traj && !ka.has_loop && C_all > 4 * kWave && C_all <= 1024 &&
+                        ft->opts.kind == FP_FISS_PLUS && !(b.obs_nvert && b.n_obs > 0);
+    static const FissTail kNoFiss{};
+    FissTail fx = search ? *ft : kNoFiss;
+    if (search) fx.NB = 512;  // (a multiple of 64 x the 8 wavefronts of the appended workgroups)
+    const int search_lds = search ? fsp::fissplus_lds_bytes(C_all, fx.NB) : 0;
     KernelArgs kx = ka;  // (epilogue workgroups offered but not taken: the caller's winner_traj_kernel writes the series)
     if (ka.epi_flag && !epilogue) { kx.r.best_traj = nullptr; kx.epi_flag = nullptr; }
     Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave, pstride);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (epilogue && L.total < kEpiLds) L.total = kEpiLds;  // (every workgroup of a launch gets the same dynamic LDS)
+    if (search && L.total < search_lds) L.total = search_lds;
     if (nsplit > p.nt) nsplit = p.nt;
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
     int* part_count = (int*)part_scratch;
@@ -1622,8 +1684,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     }
 #endif
     const unsigned lattice_grid = tail_from >= 0 ? (unsigned)(2 * b.B - tail_from) : (unsigned)(b.B * nsplit);
-    const int epi_from = epilogue ? (int)lattice_grid : -1;
-    const unsigned grid = lattice_grid + (epilogue ? (unsigned)((b.B + kEpiPairs - 1) / kEpiPairs) : 0u);
+    const int epi_from = epilogue || search ? (int)lattice_grid : -1;
+    const unsigned grid = lattice_grid + (epilogue ? (unsigned)((b.B + kEpiPairs - 1) / kEpiPairs) : 0u) + (search ? (unsigned)b.B : 0u);
     hipError_t e;
     if (p.curvature_mask) {  // optional curvature checks: their own launch, ORed into the flag words by the assembly stage
         if (!ka.curv_tbl) return hipErrorInvalidValue;
@@ -1634,7 +1696,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     auto go = [&](auto kernel, int* configured, int threads = kThreads) -> hipError_t {
         hipError_t err = ensure_dynamic_lds((const void*)kernel, L.total, configured);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, stream, kx, rows, hp, nsplit, part_best, part_count, perm, dur, gs, tail_from, epi_from, in);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, stream, kx, rows, hp, nsplit, part_best, part_count, perm, dur, gs, tail_from, epi_from, fx, in);
         return hipGetLastError();
     };
     FP_LDS_SLOTS(cfg_generic);
@@ -1646,6 +1708,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_generic_g);
     FP_LDS_SLOTS(cfg_997_g);
     FP_LDS_SLOTS(cfg_555_g);
+    FP_LDS_SLOTS(cfg_9976f);
+    FP_LDS_SLOTS(cfg_generic6f);
     FP_LDS_SLOTS(cfg_poly);
     FP_LDS_SLOTS(cfg_poly6);
     FP_LDS_SLOTS(cfg_poly_g);
@@ -1663,6 +1727,9 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 4, 0, FP_GROUP_THREADS>, cfg_997_g, FP_GROUP_THREADS);
         else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4, 0, FP_GROUP_THREADS>, cfg_555_g, FP_GROUP_THREADS);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS>, cfg_generic_g, FP_GROUP_THREADS);
+    } else if (search) {
+        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, false, true>, cfg_9976f);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, false, true>, cfg_generic6f);
     } else if (three) {
         if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512>, cfg_9976);
         else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 6, 1, 512>, cfg_5556);
@@ -1676,6 +1743,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     if (e != hipSuccess) return e;
     if (winner_done) *winner_done = kx.r.best_traj != nullptr && (!three || epilogue);
     if (step_done) *step_done = ka.has_loop != 0 && !three;  // (ka.has_loop: the two-per-CU instances hand the egos over themselves)
+    if (search_done) *search_done = search;
     return hipSuccess;
 }
 

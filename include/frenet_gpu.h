@@ -233,6 +233,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * all (fp_plan_fiss: the lattice kernel leaves them in device memory for the kernels behind it).
  * zero_copy_in: the kernels read inputs from the pinned host block over the link (1: the per-ego arrays of a tagged call, 2:
  * everything) - measured slower than the copy kernel, kept for experiments.  Identical results in every combination.
+ * "fiss_fused": 1 (default) = a FISS+ call of more egos than stay resident runs its search walk in workgroups APPENDED to the lattice
+ * launch (one per ego; they become resident in the slots the draining launch leaves empty, wait for their ego's dense tables and walk
+ * them - two launches per call instead of three); 0 = the search kernel always follows in its own launch.  Identical results.
  * "fiss_stages": timing diagnostic of fp_plan_fiss, 3 (default) = the whole pipeline, 2 = stop after the search walk (no
  * refinement), 1 = stop after the dense lattice pass; with 1 or 2 the outputs of the skipped stages are NOT produced. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);

@@ -70,8 +70,11 @@ def test_bench_single_gpu_line_has_every_configuration():
     c5 = line["config5_single_gpu"]
     assert c5["value"] > 0 and c5["parity"]["index_exact"] and "16384" in c5["workload"]
     assert line["config4"]["parity"]["stats_exact"] and line["config4"]["parity"]["checked_egos"] >= 64
-    assert set(line["config4"]["stage_ms"]) == {"lattice_fused_kernel (dense tables)", "fissplus_search_kernel",
-                                                "fiss_refine_kernel (3 rounds + validation + winner series)"}
+    st = line["config4"]["stage_ms"]
+    assert set(st) == {"lattice_fused_kernel (dense tables)", "fissplus_search_kernel (own launch)", "fiss_refine_kernel (3 rounds + validation + winner series)",
+                       "three launches", "search appended to the lattice launch (default): two launches"}
+    assert all(v > 0 for v in st.values())
+    assert line["polygon_scenes"]["parity"]["index_exact"] and line["two_streams"]["config2"]["parity"]["index_exact"] and line["prewarm"]["steps"] > 0
     for planner in ("FOP", "FISS+"):
         cl = line["closed_loop"][planner]
         assert cl["value"] > 0 and cl["ego_plans"] >= 2048 and cl["parity"]["max_abs_cost_err"] <= 1e-6
