@@ -98,3 +98,44 @@ def test_random_polygon_scenes_keep_rectangles_verdicts_where_nothing_changed(or
         c0 = (p0.dense_tables()[1] & 4) != 0
         c1 = (p1.dense_tables()[1] & 4) != 0
         assert not (c1 & ~c0).any()
+
+
+def test_random_non_convex_shapes_against_the_stand_in_geometry(oracle):
+    """The whole chain on random simple (star-shaped) polygons at random poses: obstacles.shape_columns (bounding-box centre, convex
+    pieces) + the oracle's ring predicate per piece, OR-ed, against construct_polygon + Polygon.intersects on the UNDIVIDED ring in the
+    goldens' stand-in geometry (translate, rotate about the bounding-box centre, exact general intersection)."""
+    import os
+    import sys
+    from types import SimpleNamespace
+
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import refshim
+    from fiss_plus_planner_amd.obstacles import shape_columns
+
+    rng = np.random.default_rng(12)
+    veh = refshim.Polygon([(-2.0, -1.0), (2.0, -1.0), (2.0, 1.0), (-2.0, 1.0)])
+    n_hit = n_nonconvex = 0
+    for case in range(250):
+        n = int(rng.integers(5, 12))
+        while True:
+            ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+            if np.max(np.diff(np.concatenate([ang, [ang[0] + 2 * np.pi]]))) < np.pi - 0.05:
+                break
+        r = rng.uniform(0.6, 3.0, n)
+        ring = np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1) + rng.uniform(-2, 2, 2)   # (off-centre on purpose)
+        shape = refshim.Polygon(ring)
+        n_nonconvex += not shape.convex
+        cols = shape_columns(SimpleNamespace(shapely_object=shape))
+        for _ in range(4):
+            ex, ey, eyaw = rng.uniform(-6, 6), rng.uniform(-6, 6), rng.uniform(-np.pi, np.pi)
+            ox, oy, oyaw = rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-np.pi, np.pi)
+            ego_poly = refshim.affinity.rotate(refshim.affinity.translate(veh, ex, ey), eyaw, use_radians=True)
+            obs_poly = refshim.affinity.rotate(refshim.affinity.translate(shape, ox, oy), oyaw, use_radians=True)
+            want = ego_poly.intersects_general_exact(obs_poly)
+            got = any(oracle.box_ring_intersect((4.0, 2.0, ex, ey, eyaw), c[4], (ox + c[2], oy + c[3], oyaw)) for c in cols)
+            if got != want:  # only a pair within rounding of contact may differ: decide it by the exact piecewise predicate
+                got = any(oracle.box_ring_intersect((4.0, 2.0, ex, ey, eyaw), c[4], (ox + c[2], oy + c[3], oyaw), exact=True) for c in cols)
+            assert got == want, (case, ring.tolist(), (ex, ey, eyaw), (ox, oy, oyaw))
+            n_hit += want
+    assert n_nonconvex > 100 and 100 < n_hit < 900
