@@ -639,6 +639,11 @@ def main():
     # process otherwise).  A quarter of a second of the same steps, untimed, brings the clocks up; then the W warm-up steps, then
     # exactly K timed ones.  BENCH_PREWARM_S=0 turns it off.
     prewarm_s = float(os.environ.get("BENCH_PREWARM_S", "0.25"))
+    cold = None
+    if prewarm_s > 0:  # the same W + K steps WITHOUT the wake-up first, reported beside the headline (`cold_start`)
+        el_c, _ = timed_run(torch, wls, args.steps, args.warmup, stream, barrier)
+        cold = {"ms_per_step": el_c / args.steps * 1e3, "value": float(np.mean([w.candidates for w in wls])) * args.steps / el_c * world,
+                "what": "the W warm-up + K timed steps of this invocation run first, in the fresh process, before any wake-up: the GPU is on its clock ramp (rank 0's time)"}
     prewarm_steps, t_pre = 0, time.perf_counter()
     while time.perf_counter() - t_pre < prewarm_s:
         for _ in range(32):
@@ -960,6 +965,7 @@ def main():
                                      "the kernel is VALU-issue bound, not HBM bound: `binding` / `valu_fp64` carry the executed FP64 work of the PMC pass "
                                      "of this build (profiles/r04_*), `valu_issue` the instruction issue rate", fp64_exec),
             "host_enqueue_ms_per_step": enqueue_ms,
+            "cold_start": cold,
             "prewarm": {"steps": prewarm_steps, "seconds": prewarm_s, "what": "untimed steps of the same workload before the W warm-up steps: the GPU leaves its "
                         "idle clocks (a fresh process, W = 5: 0.160-0.164 ms per step timed on the ramp against 0.150-0.155); BENCH_PREWARM_S=0 disables it"},
             "kernel_ms_stats": {"mean": kern_ms, "min": float(np.min(kern_list)), "median": float(np.median(kern_list)), "max": float(np.max(kern_list)),

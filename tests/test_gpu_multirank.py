@@ -74,7 +74,7 @@ def test_bench_single_gpu_line_has_every_configuration():
     assert set(st) == {"lattice_fused_kernel (dense tables)", "fissplus_search_kernel (own launch)", "fiss_refine_kernel (3 rounds + validation + winner series)",
                        "three launches", "search appended to the lattice launch (default): two launches"}
     assert all(v > 0 for v in st.values())
-    assert line["polygon_scenes"]["parity"]["index_exact"] and line["two_streams"]["config2"]["parity"]["index_exact"] and line["prewarm"]["steps"] > 0
+    assert line["cold_start"]["ms_per_step"] > 0 and line["polygon_scenes"]["parity"]["index_exact"] and line["two_streams"]["config2"]["parity"]["index_exact"] and line["prewarm"]["steps"] > 0
     for planner in ("FOP", "FISS+"):
         cl = line["closed_loop"][planner]
         assert cl["value"] > 0 and cl["ego_plans"] >= 2048 and cl["parity"]["max_abs_cost_err"] <= 1e-6
