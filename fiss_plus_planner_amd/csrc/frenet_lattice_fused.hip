@@ -262,6 +262,10 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
             const int eslot = (int)blockIdx.x - epi_from;
             const int eb = perm ? perm[eslot] : eslot;
+#if defined(FP_TL)  // timeline diagnostic (tools/fused_timeline.py, -DFP_TL): the FISS+ outputs carry clock ticks instead of results
+            const long long tl0 = wall_clock64();
+            long long tl1 = 0;
+#endif
             if (threadIdx.x == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(&ft.flag[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -269,6 +273,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                     if (++spins > (1 << 25)) __builtin_trap();
                 }
                 __hip_atomic_store(&ft.flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+#if defined(FP_TL)
+                tl1 = wall_clock64();
+#endif
             }
             __syncthreads();
             __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the tables are read after the flag
@@ -280,6 +287,18 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             fa.flag_tbl = ka.r.flag_tbl;
             fa.walk_jump = ft.walk_jump;
             fsp::fissplus_search_ego<NTH / kWave, 1, 1024, true>(fa, ft.NB, eb, fsm);
+#if defined(FP_TL)
+            if (threadIdx.x == 0) {  // (the lattice workgroup left its start / end in the dense call's best_idx / best_cost)
+                const long long tl2 = wall_clock64();
+                const double lat_end = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&ka.r.best_cost[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const int lat_start = __hip_atomic_load(&ka.r.best_idx[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_waitcnt(0);
+                double* es = ft.io.end_state + (size_t)eb * 3;
+                es[0] = (double)(tl0 & 0xFFFFFFFFFFll); es[1] = (double)(tl1 & 0xFFFFFFFFFFll); es[2] = (double)(tl2 & 0xFFFFFFFFFFll);
+                ft.io.best_cost[eb] = lat_end;
+                ft.io.refined[eb] = lat_start;
+            }
+#endif
             return;
         }
     }
@@ -363,6 +382,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const int hp_max = kShape ? (ROWS > 0 ? (ROWS * STRIDE + 1 > FP_MAX_POINTS ? FP_MAX_POINTS : ROWS * STRIDE + 1) : 0) : hp_max_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #if defined(FP_PHASE_STAMPS)
+    const long long t_begin = wall_clock64();
+#elif defined(FP_TL)
     const long long t_begin = wall_clock64();
 #else
     const long long t_begin = dur ? wall_clock64() : 0;
@@ -1522,6 +1543,11 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
         } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
+#if defined(FP_TL)
+        __hip_atomic_store((unsigned long long*)&ka.r.best_cost[b], (unsigned long long)__double_as_longlong((double)(wall_clock64() & 0xFFFFFFFFFFll)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ka.r.best_idx[b], (int)(t_begin & 0x7FFFFFFFll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
         if constexpr (FISS) {
             if (ft.flag) {  // the ego's rows of the tables are complete (both halves of a tail-split ego: the ticket came after theirs)
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -1529,8 +1555,10 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
         }
+#if !defined(FP_TL)
         ka.r.best_idx[b] = r.idx;
         ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
+#endif
         if (ka.r.stats) {
             int32_t* st = ka.r.stats + (size_t)b * 4;
             st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
