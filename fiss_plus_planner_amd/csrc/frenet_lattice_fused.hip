@@ -1740,6 +1740,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_generic6f);
     FP_LDS_SLOTS(cfg_poly);
     FP_LDS_SLOTS(cfg_poly6);
+    FP_LDS_SLOTS(cfg_poly9976);
     FP_LDS_SLOTS(cfg_poly_g);
     auto is = [&](int nd, int nv, int nt, int stride, int n_obs, int r) {
         return p.nd == nd && p.nv == nv && p.nt == nt && p.check_stride == stride && b.n_obs == n_obs && rows == r;
@@ -1749,6 +1750,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
 #else
     if (b.obs_nvert && b.n_obs > 0) {  // convex-polygon columns: the run-time-shape instances with the polygon narrow phase
         if (gs > 1) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS, true>, cfg_poly_g, FP_GROUP_THREADS);
+        else if (three && is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, true>, cfg_poly9976);
         else if (three) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, true>, cfg_poly6);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 1, 512, true>, cfg_poly);
     } else if (gs > 1) {

@@ -96,10 +96,12 @@ def test_random_convex_polygons_vs_oracle(oracle, any_kernel, cfg):
         assert ((flags_rect & 4) != 0).sum() > ((flags & 4) != 0).sum()
 
 
-def test_random_polygons_at_config3_size_both_kernels_and_the_fiss_pipeline(oracle, engine):
-    """Three-workgroups-per-CU instance (B > 512) + tail split + feedback order on polygon scenes: identical to the lane-per-candidate
-    kernel on every ego, to the oracle on a sample; FISS+ (search + refinement kernel) against the oracle on a sample."""
-    base = synth.make_config(3, B=640)
+@pytest.mark.parametrize("n_obs", [50, 48])
+def test_random_polygons_at_config3_size_both_kernels_and_the_fiss_pipeline(oracle, engine, n_obs):
+    """Three-workgroups-per-CU instances (B > 512; 50 obstacles: the instance compiled for BASELINE's config-3 shape, 48: the
+    run-time-shape one) + tail split + feedback order on polygon scenes: identical to the lane-per-candidate kernel on every ego, to the
+    oracle on a sample; FISS+ (search + refinement kernel) against the oracle on a sample."""
+    base = synth.make_config(3, B=640) if n_obs == 50 else synth.make_batch(640, 9, 9, 7, n_obs, 50, True, synth.CONFIG_SEEDS[3], "FOP")
     b = with_random_shapes(base, 99, frac=0.5)
     fused = engine.plan_dense(b, tables=True)
     engine.set_option("lattice_kernel", 1)
