@@ -319,8 +319,60 @@ def parity_fail(leg, what):
     raise SystemExit(f"PARITY FAILURE ({leg}): {what}")
 
 
-def fop_parity(leg, batch, egos, g_idx, g_cost, threads):
-    """FOP outputs of `egos` against the oracle: selected index exact, cost <= 1e-6.  -> the leg's `parity` object."""
+def series_parity(leg, wl, egos, max_egos=64):
+    """The winners' series the step left in HBM (best_flags / best_traj of `wl`, compact layout) against the oracle's restatement of
+    calc_frenet_paths + calc_global_paths (frenet_optimal_planner.py:69-138) for up to max_egos of `egos` that have a winner: the flag
+    word's N / M exact, rows 0-10 (t, s .. s_ddd, d .. d_ddd, x, y) within 1e-8, rows 11-15 (yaw, ds, c, c_d, c_dd: difference chains
+    of x / y) within the bound derived from a few-ulp position error.  -> {"series_checked": n, ...} merged into the leg's `parity`."""
+    from oracle import oracle as O
+
+    batch = wl.batch
+    idx = wl.h_idx.numpy() if wl.zero_copy else wl.best_idx.cpu().numpy()
+    egos = [int(e) for e in np.asarray(egos) if idx[e] >= 0][:max_egos]
+    if not egos:
+        return {"series_checked": 0}
+    sel = wl.torch.as_tensor(egos, device=wl.dev)
+    fl = wl.best_flags[sel].cpu().numpy().view(np.uint32)
+    tr = wl.best_traj[sel].cpu().numpy()
+    err_pos = err_chain = 0.0
+    for k, (e, pr) in enumerate(zip(egos, O.problems_from_batch(batch, egos))):
+        bi = int(idx[e])
+        iv, it, i_d = bi % batch.nv, (bi // batch.nv) % batch.nt, bi // (batch.nv * batch.nt)
+        t = pr.eval_traj(batch.d_samples[i_d], batch.v_samples[e, iv], batch.t_samples[it], dump=True, stride=wl.traj_stride)
+        N, M = int((fl[k] >> 8) & 0xFFF), int(fl[k] >> 20)
+        if (N, M) != (t.N, t.M):
+            parity_fail(leg, f"series of ego {e}: N / M = {(N, M)}, oracle {(t.N, t.M)}")
+        want, got = t.arrays, tr[k]
+        m = ~np.isnan(want)  # (compact layout: only the elements that exist are written; the rest of the block is the caller's bytes)
+        if np.isnan(got[m]).any():
+            parity_fail(leg, f"series of ego {e}: an element the oracle has is NaN")
+        d = np.abs(np.where(m, got - want, 0.0))
+        err_pos = max(err_pos, float(d[:11].max()))
+        if not d[:11].max() <= 1e-8:
+            parity_fail(leg, f"series of ego {e}: rows 0-10 differ by {d[:11].max():.3e}")
+        # rows 11-15: 2 * (position error) / ds through the chain, as tests/conftest.py:series_tol derives it
+        ds = want[12]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t_yaw = np.where(ds > 0, 2 * 4e-13 / ds, np.inf)
+            if M >= 2:
+                t_yaw[M - 1] = t_yaw[M - 2]
+            nxt = lambda a: np.append(a[1:], np.inf)  # noqa: E731
+            t_c = (t_yaw + nxt(t_yaw)) / ds + np.abs(want[13]) * 2 * 4e-13 / ds
+            t_cd = (t_c + nxt(t_c)) / batch.tick_t
+            t_cdd = (t_cd + nxt(t_cd)) / batch.tick_t
+        for row, tl in ((11, t_yaw), (12, np.full(ds.shape, 8e-13)), (13, t_c), (14, t_cd), (15, t_cdd)):
+            tol = np.maximum(1e-9, np.nan_to_num(tl, nan=np.inf, posinf=np.inf)) * 4 + 1e-9
+            if (m[row] & ~(d[row] <= tol)).any():
+                parity_fail(leg, f"series of ego {e}: row {row} differs by {d[row][m[row]].max():.3e}")
+            fin = m[row] & np.isfinite(tol)
+            err_chain = max(err_chain, float(d[row][fin].max()) if fin.any() else 0.0)
+    return {"series_checked": len(egos), "series_NM_exact": True, "series_rows_0_10_max_abs_err": err_pos, "series_rows_0_10_tolerance": 1e-8,
+            "series_rows_11_15_max_abs_err": err_chain, "series_oracle": "oracle/libfrenet_oracle.so orc_eval_traj (dump)"}
+
+
+def fop_parity(leg, batch, egos, g_idx, g_cost, threads, wl=None):
+    """FOP outputs of `egos` against the oracle: selected index exact, cost <= 1e-6; with `wl` (the workload whose last step wrote the
+    outputs) also the winners' flag words and series (series_parity).  -> the leg's `parity` object."""
     from oracle import oracle as O
 
     egos = np.asarray(egos)
@@ -331,8 +383,11 @@ def fop_parity(leg, batch, egos, g_idx, g_cost, threads):
     err = float(np.abs(g_cost[egos][ok] - o_cost[ok]).max()) if ok.any() else 0.0
     if not err <= COST_TOL:
         parity_fail(leg, f"best cost differs by {err:.3e}")
-    return {"checked_egos": int(len(egos)), "index_exact": True, "max_abs_cost_err": err, "cost_tolerance": COST_TOL,
-            "egos_with_a_winner": int(ok.sum()), "oracle": "oracle/libfrenet_oracle.so orc_fop_plan"}
+    par = {"checked_egos": int(len(egos)), "index_exact": True, "max_abs_cost_err": err, "cost_tolerance": COST_TOL,
+           "egos_with_a_winner": int(ok.sum()), "oracle": "oracle/libfrenet_oracle.so orc_fop_plan"}
+    if wl is not None:
+        par.update(series_parity(leg, wl, egos))
+    return par
 
 
 def tables_parity(leg, batch, egos, g_cost_tbl, g_flag_tbl, g_stats):
@@ -675,8 +730,9 @@ def main():
         else:
             cpu = cpu_baseline_leg(batch, main_wl.h_idx.numpy(), main_wl.h_cost.numpy(), args.cpu_seconds, threads_all)
             parity_main = {"batches": [dict(cpu["cpu_baseline"]["parity"], note="the cpu_baseline sample")] +
-                                      [fop_parity(f"main batch {k}", w.batch, np.arange(0, B, max(1, B // 64)), w.h_idx.numpy(), w.h_cost.numpy(), gate_threads)
+                                      [fop_parity(f"main batch {k}", w.batch, np.arange(0, B, max(1, B // 64)), w.h_idx.numpy(), w.h_cost.numpy(), gate_threads, wl=w)
                                        for k, w in enumerate(wls) if k > 0]}
+            parity_main["batches"][0].update(series_parity("main batch 0", main_wl, np.arange(0, B, max(1, B // 160)), 96))
 
     # ---- plan-cycle latency (rank 0, N=1): BASELINE configs[0] - single ego, FOP 5x5x5, DEU_Flensburg-1_1_T-1 closed loop,
     # timed around plan() exactly where the reference times it (planners/benchmark/planning.py:124-128).  Inputs are the
@@ -734,7 +790,7 @@ def main():
 
         def gate(leg, w, n):
             w.step(); w.fetch(); torch.cuda.synchronize(dev)
-            return fop_parity(leg, w.batch, np.arange(0, w.batch.B, max(1, w.batch.B // n)), w.h_idx.numpy(), w.h_cost.numpy(), gate_threads)
+            return fop_parity(leg, w.batch, np.arange(0, w.batch.B, max(1, w.batch.B // n)), w.h_idx.numpy(), w.h_cost.numpy(), gate_threads, wl=w)
 
         if args.cpu_seconds <= 0:
             gate = lambda leg, w, n: None  # noqa: E731  (--cpu-seconds 0: profiling runs, no oracle in the process)
@@ -919,6 +975,21 @@ def main():
         extras["host_buffers"] = {"value": B * C / float(np.median(t_host[1:])), "unit": "candidates/s", "ms_per_call": float(np.median(t_host[1:])) * 1e3,
                                   "what": "fp_plan_dense with FP_MEM_HOST: pageable numpy inputs -> pack -> H2D -> kernels -> D2H (PCIe-inclusive; never the headline value)",
                                   "parity": par_h}
+        # the same entry with fp_batch.tables_tag set (what the drop-in planners do): the frame / scene tables stay on the device after the
+        # first call, only the per-ego arrays travel
+        batch.tables_tag = 777001
+        t_tag = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            ht = eng.plan_dense(batch, tables=False)
+            t_tag.append(time.perf_counter() - t0)
+        batch.tables_tag = 0
+        par_t = fop_parity("host_buffers_tagged", batch, np.arange(0, B, max(1, B // 64)), ht.best_idx, ht.best_cost, gate_threads) if args.cpu_seconds > 0 else None
+        extras["host_buffers_tagged"] = {"value": B * C / float(np.median(t_tag[1:])), "unit": "candidates/s", "ms_per_call": float(np.median(t_tag[1:])) * 1e3,
+                                         "first_call_ms": t_tag[0] * 1e3,
+                                         "what": "fp_plan_dense with FP_MEM_HOST and fp_batch.tables_tag set, no tables asked for: the frame / scene tables are uploaded by the first "
+                                                 "call and stay on the device; later calls move the per-ego arrays in and index / cost / Stats out (PCIe-inclusive; never the headline value)",
+                                         "parity": par_t}
 
     if rank == 0:
         value = world * np.mean([w.candidates for w in wls]) * args.steps / elapsed
@@ -928,16 +999,20 @@ def main():
         # executed VALU work of the dominant kernel from the committed PMC pass (a property of kernel + input, not of the run);
         # the rates use this run's kernel time
         valu_issue = fp64_exec = None
-        pmc = load_profile_json(f"r04_config3_{args.layout}_pmc_summary.json")  # (collected on THIS build: profiles/README.md)
+        # (the newest committed PMC pass; profiles/README.md says which commit it was collected on - the file's kernel name is carried in the line)
+        pmc_file = next((f for f in (f"r05_config3_{args.layout}_pmc_summary.json", f"r04_config3_{args.layout}_pmc_summary.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+        pmc = load_profile_json(pmc_file) if pmc_file else None
+        pmc_kernel = None
         if pmc and not fiss and config == 3 and B == 2048:
             try:
-                k = next(v for kk, v in pmc.items() if "lattice_fused" in kk)
+                pmc_kernel, k = next((kk, v) for kk, v in pmc.items() if "lattice_fused" in kk)
                 insts = k["SQ_INSTS_VALU"]
                 peak = 256 * 4 * 2.4e9 / 4.0
                 valu_issue = {"wave_instructions_per_launch": insts, "rate": insts / (kern_ms * 1e-3), "peak": peak,
                               "unit": "wave-instructions/s", "frac": insts / (kern_ms * 1e-3) / peak,
-                              "source": "SQ_INSTS_VALU from profiles/r04_config3_*_pmc_summary.json (rocprofv3 --pmc, this build), this run's kernel time; "
-                                        "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
+                              "source": f"SQ_INSTS_VALU from profiles/{pmc_file} (rocprofv3 --pmc; kernel instance and commit in profiles/README.md), this run's kernel time; "
+                                        "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction", "pmc_kernel": pmc_kernel}
                 flops = 64.0 * (2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_TRANS_F64"])
                 fp64_exec = {"executed_flops_per_launch": flops, "achieved": flops / (kern_ms * 1e-3) / 1e12, "rate": flops / (kern_ms * 1e-3) / 1e12,
                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
@@ -962,9 +1037,11 @@ def main():
                        "input_digest": batch.digest()[:16], "input_digests": [w.batch.digest()[:16] for w in wls]},
             "parity": parity_main,
             "roofline": roofline_obj(bytes_launch, kern_ms, kname, traffic,
-                                     "the kernel is VALU-issue bound, not HBM bound: `binding` / `valu_fp64` carry the executed FP64 work of the PMC pass "
-                                     "of this build (profiles/r04_*), `valu_issue` the instruction issue rate", fp64_exec),
+                                     "the kernel is VALU-issue bound, not HBM bound: `binding` / `valu_fp64` carry the executed FP64 work of the committed PMC pass "
+                                     f"(profiles/{pmc_file}), `valu_issue` the instruction issue rate", fp64_exec),
             "host_enqueue_ms_per_step": enqueue_ms,
+            # the SAME W + K steps timed first, in the fresh process, before the wake-up (the literal contract; `prewarm` below says what `value` adds)
+            "value_cold": cold["value"] if cold else None, "ms_per_step_cold": cold["ms_per_step"] if cold else None,
             "cold_start": cold,
             "prewarm": {"steps": prewarm_steps, "seconds": prewarm_s, "what": "untimed steps of the same workload before the W warm-up steps: the GPU leaves its "
                         "idle clocks (a fresh process, W = 5: 0.160-0.164 ms per step timed on the ramp against 0.150-0.155); BENCH_PREWARM_S=0 disables it"},

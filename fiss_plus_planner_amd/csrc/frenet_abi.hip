@@ -142,6 +142,13 @@ struct fp_ctx {
     DeviceBuf idx_shadow;          // [B] device copy of best_idx for the winner kernel of a dense call (KernelArgs::idx_shadow)
     DeviceBuf epi_flags;           // [B] hand-over flags of the epilogue workgroups appended to a multi-round lattice launch (KernelArgs::epi_flag); zero between launches
     DeviceBuf curv_buf;            // [B][C] curvature flag bytes of the lattice (fp_params.curvature_mask), written ahead of the fused kernel
+    // Workgroups appended to a lattice launch (winner-series epilogue, FISS+ search) wait for flags that other workgroups of the SAME
+    // launch set; that they cannot starve rests on the workgroup distributors starting workgroups in index order - observed on gfx942 /
+    // gfx950, documented nowhere.  appended_ok: the device is one of those architectures and no hand-over of this ctx ever timed out.
+    // hand_err: one int of device-mapped, coherent host memory; a wait that runs out leaves a code there instead of trapping
+    // (KernelArgs::err_word), and the next call on the ctx reports it, resets the flags and stops offering appended workgroups.
+    bool appended_ok = false;
+    int32_t* hand_err = nullptr;
 };
 
 namespace {
@@ -382,6 +389,17 @@ int check_batch_host(const fp_params* p, const fp_batch* b)
                 area2 += a[0] * q[1] - a[1] * q[0];
             }
             if (!(area2 > 0.0)) return fail(FP_EINVAL, "obs_poly column %ld is not counter-clockwise (twice its signed area = %g)", c, area2);
+            // convex: the narrow phase treats the ring as the intersection of its edge half-planes - a reflex vertex would silently shrink
+            // the obstacle to its kernel (missed collisions).  Every turn must be to the left; collinear vertices pass (the tolerance
+            // covers the rounding of a cross product of coordinates ~ mx, my).
+            const double turn_tol = 64.0 * 2.220446049250313e-16 * (mx + my) * (mx + my);
+            for (int i = 0; i < n; ++i) {
+                const double* a = v + 2 * i;
+                const double* q = v + 2 * ((i + 1) % n);
+                const double* r = v + 2 * ((i + 2) % n);
+                const double cr = (q[0] - a[0]) * (r[1] - q[1]) - (q[1] - a[1]) * (r[0] - q[0]);
+                if (!(cr >= -turn_tol)) return fail(FP_EINVAL, "obs_poly column %ld is not convex (right turn at vertex %d, cross product %g): cut it into convex pieces (obstacles.shape_columns)", c, (i + 1) % n, cr);
+            }
             if (!(b->obs_dims[2 * c] >= 2.0 * mx) || !(b->obs_dims[2 * c + 1] >= 2.0 * my))
                 return fail(FP_EINVAL, "obs_dims of polygon column %ld (%g x %g) does not contain its vertices (needs %g x %g)", c, b->obs_dims[2 * c], b->obs_dims[2 * c + 1], 2.0 * mx, 2.0 * my);
         }
@@ -678,12 +696,28 @@ int32_t* epi_flags_for(fp_ctx* ctx, size_t B, hipStream_t stream)
 // otherwise it reports winner_done = false and winner_traj_kernel follows).
 void offer_epilogue(fp_ctx* ctx, const fp::KernelArgs& ka, fp::KernelArgs* kl, size_t B, hipStream_t stream)
 {
-    if (ctx->lattice_winner != 0 || !ka.r.best_traj || !ka.idx_shadow) return;
+    if (ctx->lattice_winner != 0 || !ctx->appended_ok || !ka.r.best_traj || !ka.idx_shadow) return;
     int32_t* flags = epi_flags_for(ctx, B, stream);
     if (!flags) return;
     kl->r.best_traj = ka.r.best_traj;
     kl->epi_flag = flags;
 }
+
+// A hand-over of an earlier launch on this ctx timed out (fp_ctx::hand_err): the flags are reset in stream order, appended workgroups
+// are not offered again on this ctx (winner_traj_kernel / the search kernel take over), and the caller learns that the outputs of that
+// earlier call were incomplete.  FP_OK when nothing happened.
+bool handover_failed(const fp_ctx* ctx) { return ctx->hand_err && *(volatile int32_t*)ctx->hand_err != 0; }
+int handover_recover(fp_ctx* ctx, hipStream_t stream)
+{
+    const int code = *(volatile int32_t*)ctx->hand_err;
+    ctx->appended_ok = false;
+    *(volatile int32_t*)ctx->hand_err = 0;
+    if (ctx->epi_flags.base) HIP_TRY(hipMemsetAsync(ctx->epi_flags.base, 0, ctx->epi_flags.cap, stream));
+    return fail(FP_EHIP, "a %s workgroup appended to an earlier lattice launch on this ctx waited 2 s for its ego's results and gave up: that call's "
+                         "%s incomplete; the ctx now runs them in their own launches (call again)",
+                code == 2 ? "FISS+ search" : "winner-series", code == 2 ? "FISS+ outputs are" : "series are");
+}
+int handover_check(fp_ctx* ctx, hipStream_t stream) { return handover_failed(ctx) ? handover_recover(ctx, stream) : FP_OK; }
 
 // Optional curvature checks: the fused lattice kernel reads them from a [B][C] byte table that launch_lattice fills first.
 int lattice_curv_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, const uint8_t** out)
@@ -746,12 +780,40 @@ __global__ void validate_batch_kernel(fp_params p, fp_batch b, int* err)
         const double n = b.t_samples[i] / p.tick_t;
         if (!(n > 0) || n > FP_MAX_POINTS) code = 5;
     }
-    // polygon columns: a vertex count outside {0} u [3, poly_stride] would walk off the ring table
+    // polygon columns, one lane per column: a vertex count outside {0} u [3, poly_stride] would walk off the ring table; a ring that is
+    // not counter-clockwise and convex, or that reaches outside the box of obs_dims, would be tested as a smaller shape than it is
+    // (check_batch_host's checks, same tolerances)
     if (!code && b.obs_nvert && b.S > 0 && b.n_obs > 0) {
         const long cols = (long)b.S * b.n_obs;
         for (long c = i; c < cols && !code; c += (long)gridDim.x * blockDim.x) {
             const int n = b.obs_nvert[c];
-            if (n != 0 && (n < 3 || n > b.poly_stride)) { code = 6; if (atomicCAS(&err[0], 0, code) == 0) err[1] = (int)c; return; }
+            if (n == 0) continue;
+            if (n < 3 || n > b.poly_stride) code = 6;
+            else {
+                const double* v = b.obs_poly + (size_t)c * 2 * b.poly_stride;
+                double mx = 0.0, my = 0.0, area2 = 0.0;
+                bool nan = false;
+                for (int k = 0; k < n; ++k) {
+                    const double* a = v + 2 * k;
+                    const double* q = v + 2 * ((k + 1) % n);
+                    nan = nan || !(a[0] == a[0]) || !(a[1] == a[1]);
+                    mx = fmax(mx, fabs(a[0])); my = fmax(my, fabs(a[1]));
+                    area2 += a[0] * q[1] - a[1] * q[0];
+                }
+                const double turn_tol = 64.0 * 2.220446049250313e-16 * (mx + my) * (mx + my);
+                bool convex = true;
+                for (int k = 0; k < n; ++k) {
+                    const double* a = v + 2 * k;
+                    const double* q = v + 2 * ((k + 1) % n);
+                    const double* r = v + 2 * ((k + 2) % n);
+                    convex = convex && ((q[0] - a[0]) * (r[1] - q[1]) - (q[1] - a[1]) * (r[0] - q[0]) >= -turn_tol);
+                }
+                if (nan) code = 7;
+                else if (!(area2 > 0.0)) code = 8;
+                else if (!convex) code = 9;
+                else if (!(b.obs_dims[2 * c] >= 2.0 * mx) || !(b.obs_dims[2 * c + 1] >= 2.0 * my)) code = 10;
+            }
+            if (code) { if (atomicCAS(&err[0], 0, code) == 0) err[1] = (int)c; return; }
         }
     }
     if (code && atomicCAS(&err[0], 0, code) == 0) err[1] = i;
@@ -766,6 +828,11 @@ int device_validate(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStrea
     HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(int), stream));
     int n = b->B > b->F ? b->B : b->F;
     if (p->nt > n) n = p->nt;
+    if (b->obs_nvert && b->S > 0 && b->n_obs > 0) {  // (polygon columns: a lane per column, grid-stride beyond 64 K lanes)
+        const long cols = (long)b->S * b->n_obs;
+        const int want = (int)(cols < 65536 ? cols : 65536);
+        if (want > n) n = want;
+    }
     hipLaunchKernelGGL(validate_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *p, *b, d_err);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->validate_host, d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -778,6 +845,10 @@ int device_validate(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStrea
         case 3: return fail(FP_EINVAL, "t_now[%d] is negative (device batch)", at);
         case 4: return fail(FP_EINVAL, "nx[%d] out of range (device batch, NX=%d)", at, b->NX);
         case 6: return fail(FP_EINVAL, "obs_nvert[%d] outside {0} and 3..poly_stride=%d (device batch)", at, b->poly_stride);
+        case 7: return fail(FP_EINVAL, "obs_poly column %d has a NaN vertex (device batch)", at);
+        case 8: return fail(FP_EINVAL, "obs_poly column %d is not counter-clockwise (device batch)", at);
+        case 9: return fail(FP_EINVAL, "obs_poly column %d is not convex (device batch): cut it into convex pieces (obstacles.shape_columns)", at);
+        case 10: return fail(FP_EINVAL, "obs_dims of polygon column %d does not contain its vertices (device batch)", at);
         default: return fail(FP_ELIMIT, "t_samples[%d] needs more than FP_MAX_POINTS points (device batch)", at);
     }
 }
@@ -836,13 +907,21 @@ int fp_ctx_create(int device, fp_ctx** out)
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->pinned, kSmallRegion, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->hand_err, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) memset(ctx->hand_err, 0, 64);
     if (e != hipSuccess) {
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        if (ctx->hand_err) (void)hipHostFree(ctx->hand_err);
         delete ctx;
         return fail(FP_EHIP, "ctx resources: %s", hipGetErrorString(e));
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->resident_groups = 2 * prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        if (prop.multiProcessorCount > 0) ctx->resident_groups = 2 * prop.multiProcessorCount;
+        // (in-order workgroup dispatch per XCD was verified on these two; anything else gets the series / the search in their own launches)
+        ctx->appended_ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0 || strncmp(prop.gcnArchName, "gfx942", 6) == 0;
+    }
     *out = ctx;
     return FP_OK;
 }
@@ -863,6 +942,7 @@ int fp_ctx_destroy(fp_ctx* ctx)
     ctx->order_lattice.release();
     ctx->order_refine.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->hand_err) (void)hipHostFree(ctx->hand_err);
     if (ctx->validate_host) (void)hipHostFree(ctx->validate_host);
     delete ctx;
     return FP_OK;
@@ -895,6 +975,16 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
     if (strcmp(name, "fiss_fused") == 0) {
         if (value < 0 || value > 1) return fail(FP_EINVAL, "fiss_fused must be 0 or 1");
         ctx->fiss_fused = value;
+        return FP_OK;
+    }
+    if (strcmp(name, "appended_workgroups") == 0) {  // 0: never offer appended workgroups on this ctx (what a timed-out hand-over sets)
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "appended_workgroups must be 0 or 1");
+        ctx->appended_ok = value != 0;
+        return FP_OK;
+    }
+    if (strcmp(name, "handover_inject") == 0) {  // test hook: what a timed-out hand-over leaves in the ctx's error word (1 series, 2 search)
+        if (value < 1 || value > 2 || !ctx->hand_err) return fail(FP_EINVAL, "handover_inject must be 1 or 2");
+        *(volatile int32_t*)ctx->hand_err = value;
         return FP_OK;
     }
     if (strcmp(name, "fiss_stages") == 0) {
@@ -950,7 +1040,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
         {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
-        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"lattice_launches", ctx->lattice_launches},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
         if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
@@ -965,11 +1055,13 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     if (result->audit && result->fopplus) return fail(FP_EINVAL, "result.audit settles FrenetOptimalPlanner's argmin: not together with result.fopplus");
     if (batch->B == 0) return FP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    FP_TRY(handover_check(ctx, mem == FP_MEM_DEVICE ? (hipStream_t)stream : ctx->stream));
     const size_t C = (size_t)params->nd * params->nv * params->nt, B = (size_t)batch->B;
     int stride;
     FP_TRY(traj_stride_of(result->traj_stride, &stride));
     fp::KernelArgs ka;
     ka.p = *params;
+    ka.err_word = ctx->hand_err;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
@@ -1048,7 +1140,12 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     if (d_fopplus)
         LAUNCH_TRY(fp::launch_fopplus_count((int)B, (int)C, ka.r.cost_tbl, ka.r.flag_tbl, ka.r.best_idx, ka.r.best_cost, d_fopplus, ka.r.stats, ka.b.skip, ctx->stream),
                    "FOP+ count kernel");
-    return hs.fetch_out();
+    FP_TRY(hs.fetch_out());
+    if (handover_failed(ctx)) {  // (the call has synchronised: a timed-out hand-over of ITS launch is known now - run it again without appended workgroups)
+        (void)handover_recover(ctx, ctx->stream);
+        return fp_plan_dense(ctx, params, batch, result, mem, stream);
+    }
+    return FP_OK;
 }
 
 int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, uint32_t* best_flags,
@@ -1145,6 +1242,10 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     const size_t B = (size_t)batch->B, C = (size_t)params->nd * params->nv * params->nt;
     const int R = opts->kind == FP_FISS_PLUS ? opts->max_refine_iters : 0;
     hipStream_t stream = mem == FP_MEM_DEVICE ? (hipStream_t)stream_v : ctx->stream;
+    FP_TRY(handover_check(ctx, stream));
+    // (host entry: prev_best_idx is in / out - should the appended search of this call time out, the call is repeated from the caller's values)
+    std::vector<int32_t> prev_in;
+    if (mem == FP_MEM_HOST && ctx->appended_ok && ctx->fiss_fused && B > (size_t)ctx->resident_groups) prev_in.assign(io->prev_best_idx, io->prev_best_idx + B * 3);
 
     // dense tables + per-ego dense results live in the scratch buffer in both modes
     const size_t scratch_need = align_up(sizeof(double) * B * C) + align_up(sizeof(uint32_t) * B * C) + align_up(sizeof(int32_t) * B) +
@@ -1154,6 +1255,7 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     char* sp = ctx->scratch.base;
     fp::FissArgs fa;
     fa.ka.p = *params;
+    fa.ka.err_word = ctx->hand_err;
     fa.opts = *opts;
     fa.opts.max_refine_iters = R;
     fa.ka.r = no_result();
@@ -1232,7 +1334,7 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         // "fiss_fused" 0, the stage-timing diagnostic and every other shape: the search kernel follows in its own launch)
         fp::FissTail ft;
         ft.opts = fa.opts; ft.io = fa.io; ft.walk_jump = ctx->fiss_jump;
-        ft.flag = (ctx->fiss_fused && ctx->fiss_stages >= 3 && opts->kind == FP_FISS_PLUS) ? epi_flags_for(ctx, B, stream) : nullptr;
+        ft.flag = (ctx->fiss_fused && ctx->appended_ok && ctx->fiss_stages >= 3 && opts->kind == FP_FISS_PLUS) ? epi_flags_for(ctx, B, stream) : nullptr;
         LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group, nullptr, tail, ft.flag ? &ft : nullptr, &search_done),
                    "lattice kernel");
     }
@@ -1255,7 +1357,14 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         kw.r.traj_sparse = fa.io.traj_sparse;
         LAUNCH_TRY(fp::launch_winner_traj(kw, fa.io.end_state, stream), "winner epilogue");
     }
-    return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;
+    if (mem != FP_MEM_HOST) return FP_OK;
+    FP_TRY(hs.fetch_out());
+    if (handover_failed(ctx)) {  // (see fp_plan_dense)
+        (void)handover_recover(ctx, ctx->stream);
+        if (!prev_in.empty()) memcpy(io->prev_best_idx, prev_in.data(), prev_in.size() * sizeof(int32_t));
+        return fp_plan_fiss(ctx, params, batch, opts, io, mem, stream_v);
+    }
+    return FP_OK;
 }
 
 int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, const double* end_state,
@@ -1323,9 +1432,11 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         return fp_advance(ctx, params, batch, result->best_idx, nullptr, io, mem, stream);
     }
     HIP_TRY(hipSetDevice(ctx->device));
+    FP_TRY(handover_check(ctx, (hipStream_t)stream));
     const size_t B = (size_t)batch->B;
     fp::KernelArgs ka;
     ka.p = *params;
+    ka.err_word = ctx->hand_err;
     ka.b = *batch;
     ka.b.skip = io->done;
     if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;

@@ -56,6 +56,9 @@ struct KernelArgs {
     // The workgroup that publishes an ego's argmin sets its flag; the appended workgroups - dispatched last, i.e. into the slots the
     // draining launch leaves empty - wait for it, write the winner's series (r.best_traj) and clear it.  Needs idx_shadow.
     int32_t* epi_flag = nullptr;
+    // The ctx's hand-over error word (device-mapped pinned host memory, or nullptr): an appended workgroup whose wait for its ego's flag
+    // runs out leaves a code here instead of trapping (1: winner-series epilogue, 2: FISS+ search); the host reads it at the next call.
+    int32_t* err_word = nullptr;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

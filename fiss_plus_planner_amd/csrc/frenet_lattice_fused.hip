@@ -88,6 +88,26 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Hand-over wait of the workgroups appended to a launch (winner-series epilogue, FISS+ search): spin on the ego's flag - set by the
+// lattice workgroup that published the ego's results - for at most kHandoverTimeout ticks of the 100 MHz wall clock.  A wait that
+// runs out (only possible if the workgroup distributors did NOT start this XCD's lattice workgroups before this one, see the kernel)
+// does not trap - a trap aborts the queue and with it the ctx: it leaves `code` in the ctx's error word (device-mapped host memory,
+// system scope: the host sees it without a synchronisation) and the workgroup returns without output; the slot falls free, the
+// launch completes, and the next call on the ctx reports the failure, resets the flags and stops using appended workgroups.
+constexpr long long kHandoverTimeout = 200000000ll;  // 2 s
+__device__ __forceinline__ bool handover_wait(const int32_t* flag, int32_t* err_word, int code)
+{
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > kHandoverTimeout) {
+            if (err_word) __hip_atomic_store(err_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+    }
+    return true;
+}
+
 #if defined(FP_ABL_NO_SLICE_SYNC)  // timing ablation: the slice loop without its barriers (results are wrong)
 #define SLICE_SYNC() do { } while (0)
 #else
@@ -266,18 +286,17 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             const long long tl0 = wall_clock64();
             long long tl1 = 0;
 #endif
+            __shared__ int s_handed;
             if (threadIdx.x == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(&ft.flag[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1 << 25)) __builtin_trap();
-                }
-                __hip_atomic_store(&ft.flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                const bool ok = handover_wait(&ft.flag[eb], ka.err_word, 2);
+                if (ok) __hip_atomic_store(&ft.flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                s_handed = ok;
 #if defined(FP_TL)
                 tl1 = wall_clock64();
 #endif
             }
             __syncthreads();
+            if (!s_handed) return;  // (timed out: reported through the ctx's error word, see handover_wait)
             __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the tables are read after the flag
             FissArgs fa;
             fa.ka = ka;
@@ -312,8 +331,10 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // and writes the four series, two wavefronts per trajectory (winner_series_pair: one point per lane, 80 registers).
     // No deadlock: an epilogue workgroup only ever waits for lattice workgroups, and a workgroup distributor (one per XCD, each
     // taking every eighth workgroup) starts its workgroups in index order: when an epilogue workgroup holds a slot, every lattice
-    // workgroup of the same XCD has been started, and those of the other XCDs do not depend on this XCD's slots.  Should that
-    // ever not hold the wait gives up after ~2 s and traps (a failed call instead of a hung device).
+    // workgroup of the same XCD has been started, and those of the other XCDs do not depend on this XCD's slots.  That order is
+    // observed, not documented: the host offers appended workgroups only on the architectures it was verified on (gfx942 / gfx950,
+    // fp_ctx_create), and should it ever not hold the wait gives up after 2 s WITHOUT a trap (handover_wait): the slot falls free,
+    // the launch completes, and the next call on the ctx reports the failed hand-over and falls back to winner_traj_kernel.
     if constexpr (OCC > 4) {
         if (epi_from >= 0 && (int)blockIdx.x >= epi_from) {
             extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
@@ -343,17 +364,17 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             if (in_lds)
                 for (int k = i; k < 9 * bb.NX; k += 2 * kWave) s_spl[k] = k < bb.NX ? gk[k] : gc[k - bb.NX];
             if (have && i == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(&ka.epi_flag[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1 << 25)) __builtin_trap();
+                if (handover_wait(&ka.epi_flag[eb], ka.err_word, 1)) {
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the index is read after the flag
+                    s_idx[pair] = __hip_atomic_load(&ka.idx_shadow[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ka.epi_flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                } else {
+                    s_idx[pair] = -2;  // timed out: nothing is written for this ego (reported through the ctx's error word)
                 }
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the index is read after the flag
-                s_idx[pair] = __hip_atomic_load(&ka.idx_shadow[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ka.epi_flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
             }
             __syncthreads();
             const int win = have ? s_idx[pair] : -1;
+            const bool handed = have && win != -2;
             double d_end = __builtin_nan(""), v_end = d_end, T_end = d_end;
             if (win >= 0) {
                 const int iv = win % pp.nv, it = (win / pp.nv) % pp.nt, id = win / (pp.nv * pp.nt);
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             }
             // (a pair beyond the batch still runs the barriers; it writes nothing)
             const SplineLds sp = in_lds ? SplineLds{s_spl, s_spl + bb.NX, bb.nx[ef], bb.NX} : SplineLds{gk, gc, bb.nx[ef], bb.NX};
-            winner_series_pair(ka, eb, eb, win >= 0, d_end, v_end, T_end, i, sp, scratch + pair * 4 * FP_MAX_POINTS, s_m + 2 * pair, have);
+            winner_series_pair(ka, eb, eb, win >= 0, d_end, v_end, T_end, i, sp, scratch + pair * 4 * FP_MAX_POINTS, s_m + 2 * pair, handed);
             return;
         }
     }

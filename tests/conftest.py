@@ -85,3 +85,47 @@ def assert_series_close(got: np.ndarray, want: np.ndarray, dt: float = 0.1, what
     bad = m & ~(np.abs(np.where(m, got - want, 0.0)) <= tol)
     assert not bad.any(), f"{what}: rows {sorted(set(np.nonzero(bad)[0].tolist()))} first {np.argwhere(bad)[:4].tolist()} " \
                           f"err {np.abs(got - want)[bad][:4]} tol {tol[bad][:4]}"
+
+
+class SecondStream:
+    """A second fp_ctx + HIP stream that keeps the device busy with multi-round dense launches of ANOTHER batch from its own host thread
+    while the test's engine runs (ctypes drops the GIL inside the C calls, so the two streams' launches interleave on the device)."""
+
+    def __init__(self, batch, fiss=False):
+        import threading
+
+        from fiss_plus_planner_amd.engine import FrenetEngine
+
+        self.eng, self.batch, self.fiss = FrenetEngine(0), batch, fiss
+        batch.tables_tag = 9900  # (its tables stay on the device: the calls are launches, not uploads)
+        self.stop, self.calls, self.err = threading.Event(), 0, None
+        self.ref = self._call()
+        self.th = threading.Thread(target=self._loop, daemon=True)
+
+    def _call(self):
+        if self.fiss:
+            return self.eng.plan_fiss(self.batch, "FISS+")
+        return self.eng.plan_dense(self.batch, tables=False, winner=True, traj_stride=112, traj_sparse=True)
+
+    def _loop(self):
+        try:
+            while not self.stop.is_set():
+                out = self._call()
+                self.calls += 1
+                if self.fiss:  # (the hammer's own hand-overs are checked too: it runs the same appended workgroups)
+                    assert np.array_equal(out.best_ijk, self.ref.best_ijk) and np.array_equal(out.stats, self.ref.stats)
+                else:
+                    assert np.array_equal(out.best_idx, self.ref.best_idx) and np.array_equal(out.best_traj, self.ref.best_traj, equal_nan=True)
+        except BaseException as ex:  # noqa: BLE001  (reported by the test thread)
+            self.err = ex
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.th.join(timeout=120)
+        self.eng.close()
+        if self.err is not None and exc[0] is None:
+            raise self.err

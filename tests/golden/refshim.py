@@ -1,9 +1,12 @@
 """Import shim for generating golden vectors from the Python reference.
 
-RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).  It is never imported
-by the product, by `-m gpu` tests, by smoke() or by bench.py: the GPU box has no
-/root/reference.  The vectors it helps to produce are committed as .npz files
-next to this script.
+Two halves.  `load_reference()` imports the reference from /root/reference and RUNS ONLY IN THE BUILD CONTAINER (the GPU box has no
+/root/reference): it is called by gen_golden.py / audit_goldens.py alone, never by the product, by smoke() or by bench.py, and no
+`-m gpu` test calls it.  The stand-ins for the third-party packages the reference imports but this image lacks (the `shapely`
+Polygon / affinity restatement with its exact rational `intersects`, the commonroad stubs) are the builder's own code, import nothing
+from the reference, and ARE imported by tests - tests/shapes_util.py (used by tests/test_gpu_shapes.py) and tests/test_gpu_planners.py
+build obstacle OBJECTS with `shapely_object` polygons from them, tests/test_collision_exact.py uses the exact predicate as ground
+truth.  The vectors the first half helps to produce are committed as .npz files next to this script.
 
 What it does
 ------------

@@ -74,3 +74,27 @@ def test_fused_search_other_lattice_shape_and_skipped_egos(engine):
     for k in ("done", "cycles", "t_now"):
         np.testing.assert_array_equal(getattr(out, k), getattr(ref, k), err_msg=k)
     assert np.array_equal(out.ego, ref.ego) and (ref.done != 0).any()
+
+
+def test_fused_search_beside_a_second_stream(oracle, engine):
+    """The appended search workgroups while a second ctx / stream runs its own fused FISS+ launches (and their hand-overs) beside them:
+    60 repeated 2048-ego calls, every output equal to the three-launch pipeline's; a sample against the oracle."""
+    from conftest import SecondStream
+
+    B = 2048
+    batch = synth.make_config(4, B=B)
+    batch.tables_tag = 9200
+    ref = _run(engine, batch, 0, None)
+    egos = list(range(0, B, 64))
+    for e, p in zip(egos, oracle.problems_from_batch(batch, egos)):
+        r = p.fissplus_plan()
+        np.testing.assert_array_equal(ref.stats[e], r.stats, err_msg=f"ego {e}")
+        assert np.isnan(ref.best_cost[e]) == np.isnan(r.best_cost)
+        if not np.isnan(r.best_cost):
+            assert abs(ref.best_cost[e] - r.best_cost) < 1e-6
+    for rep in range(20):
+        _same(_run(engine, batch, 1, None), ref, f"alone, repetition {rep}")
+    with SecondStream(synth.make_config(4, B=1300, ego_offset=40000), fiss=True) as h:
+        for rep in range(40):
+            _same(_run(engine, batch, 1, None), ref, f"beside a second stream, repetition {rep}")
+    assert h.calls >= 2

@@ -190,6 +190,13 @@ def test_host_entry_validates_polygon_columns(engine):
     two.obs_nvert = np.array([[2]], dtype=np.int32)
     with pytest.raises(_abi.FrenetGpuError, match="obs_nvert"):
         engine.plan_dense(two)
+    # a reflex vertex: the half-plane test would shrink the arrow head to its kernel (missed collisions) - rejected, not shrunk
+    arrow = np.array([(-2.0, -2.0), (0.0, -1.0), (2.0, -2.0), (0.0, 2.0)])
+    with pytest.raises(_abi.FrenetGpuError, match="not convex"):
+        engine.plan_dense(_one_pose_polygon_scene((4.0, 2.0, 0.0, 0.0, 0.0), arrow, (9.0, 0.0, 0.0)))
+    # collinear vertices (a rectangle with a vertex in the middle of an edge) are convex
+    flat = np.array([(-2.0, -1.0), (0.0, -1.0), (2.0, -1.0), (2.0, 1.0), (-2.0, 1.0)])
+    engine.plan_dense(_one_pose_polygon_scene((4.0, 2.0, 0.0, 0.0, 0.0), flat, (9.0, 0.0, 0.0)))
 
 
 def test_device_entry_validates_vertex_counts_on_request(engine):
@@ -207,6 +214,39 @@ def test_device_entry_validates_vertex_counts_on_request(engine):
     engine.set_option("validate", 1)
     try:
         with pytest.raises(_abi.FrenetGpuError, match="obs_nvert"):
+            engine.plan_dense_device(db.params, db.fb, bi.data_ptr(), bc.data_ptr())
+    finally:
+        engine.set_option("validate", 0)
+
+
+@pytest.mark.parametrize("what,match", [("clockwise", "counter-clockwise"), ("reflex", "not convex"), ("box", "does not contain"), ("nan", "NaN")])
+def test_device_entry_validates_rings_on_request(engine, what, match):
+    """The "validate" option also runs check_batch_host's ring checks on device-resident columns (one lane per column): orientation,
+    convexity, the box of obs_dims - a bad ring would be tested as a smaller shape than it is (include/frenet_gpu.h)."""
+    import torch
+
+    from fiss_plus_planner_amd.device_batch import DeviceBatch
+
+    b = with_random_shapes(synth.make_batch(4, 5, 5, 5, 10, 60, True, 68), 68)
+    s, j = [(s, j) for s in range(b.obs_nvert.shape[0]) for j in range(b.obs_nvert.shape[1]) if b.obs_nvert[s, j] >= 4][-1]
+    n = int(b.obs_nvert[s, j])
+    poly, dims = b.obs_poly.copy(), b.obs_dims.copy()
+    if what == "clockwise":
+        poly[s, j, :n] = poly[s, j, :n][::-1]
+    elif what == "reflex":
+        poly[s, j, 1] = 0.25 * (poly[s, j, 0] + poly[s, j, 2]) + 0.5 * poly[s, j, (n // 2 + 1) % n]  # pulled inside the ring
+    elif what == "box":
+        dims[s, j] *= 0.5
+    else:
+        poly[s, j, 0, 1] = np.nan
+    b.obs_poly, b.obs_dims = poly, dims
+    db = DeviceBatch(b, 0)
+    bi = torch.empty(4, dtype=torch.int32, device="cuda:0"); bc = torch.empty(4, dtype=torch.float64, device="cuda:0")
+    engine.plan_dense_device(db.params, db.fb, bi.data_ptr(), bc.data_ptr())  # unvalidated: runs (the result for that ring is undefined)
+    torch.cuda.synchronize()
+    engine.set_option("validate", 1)
+    try:
+        with pytest.raises(_abi.FrenetGpuError, match=match):
             engine.plan_dense_device(db.params, db.fb, bi.data_ptr(), bc.data_ptr())
     finally:
         engine.set_option("validate", 0)
