@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 12
+FP_ABI_VERSION = 13
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND, FP_MAX_POLY_VERTS = 128, 512, 4096, 128
@@ -27,7 +27,8 @@ _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option", "fp_ctx_get_option",
-                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_plan_step", "fp_frames_build", "fp_from_state", "fp_materialize_all")
+                    "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_plan_step", "fp_frames_build", "fp_from_state", "fp_materialize_all",
+                    "fp_group_create", "fp_group_destroy", "fp_group_submit", "fp_group_wait")
 
 
 class FpParams(C.Structure):
@@ -75,6 +76,17 @@ class FpLoopIo(C.Structure):
 RUNNING, DONE_GOAL, DONE_END_OF_LINE, DONE_NO_SOLUTION, DONE_GOAL_REGION = 0, 1, 2, 3, 4
 
 
+class FpCopy(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+class FpShardCall(C.Structure):
+    """One shard's call of an fp_group round (include/frenet_gpu.h: which entry point runs follows from the pointers that are set)."""
+    _fields_ = [("params", C.POINTER(FpParams)), ("batch", C.POINTER(FpBatch)), ("result", C.POINTER(FpResult)), ("loop", C.POINTER(FpLoopIo)),
+                ("fiss_opts", C.POINTER(FpFissOpts)), ("fiss_io", C.POINTER(FpFissIo)), ("stream", C.c_void_p),
+                ("copies", C.POINTER(FpCopy)), ("n_copies", C.c_int32), ("reserved0", C.c_int32)]
+
+
 class FrenetGpuError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libfrenetgpu error {code}: {msg}")
@@ -120,6 +132,10 @@ def load() -> C.CDLL:
     L.fp_frames_build.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fp_from_state.argtypes = [C.c_void_p, C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fp_materialize_all.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
+    L.fp_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
+    L.fp_group_destroy.argtypes = [C.c_void_p]
+    L.fp_group_submit.argtypes = [C.c_void_p, C.POINTER(FpShardCall)]
+    L.fp_group_wait.argtypes = [C.c_void_p]
     if L.fp_abi_version() != FP_ABI_VERSION:
         raise ImportError(f"libfrenetgpu ABI {L.fp_abi_version()} != binding {FP_ABI_VERSION}: rebuild")
     _lib = L

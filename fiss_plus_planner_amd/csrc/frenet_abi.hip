@@ -16,6 +16,10 @@
 #include <new>
 #include <string>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "frenet_kernels.h"
@@ -1577,6 +1581,189 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
     if (traj_sparse && d_traj) HIP_TRY(hipMemcpyAsync(d_traj, traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     LAUNCH_TRY(fp::launch_eval_trajs(ka, K, d_end, d_cost, d_flags, d_traj, stride, traj_sparse, ctx->stream), "eval kernel");
     return hs.fetch_out();
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------- fp_group
+// One persistent host thread per ctx, fed through a one-deep mailbox (include/frenet_gpu.h).  posted / done are sequence numbers:
+// the submitter copies a call into the worker's slot and increments `posted`; the worker runs it and sets `done` = the number it
+// ran.  A worker spins on `posted` for kSpinRounds pause instructions after its last call (~50 us: the next step of a running loop
+// arrives well inside that), then sleeps on a condition variable; the submitter notifies only when it finds the worker asleep.
+namespace {
+
+inline void cpu_pause()
+{
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+    __builtin_ia32_pause();
+#endif
+}
+
+constexpr int kSpinRounds = 4000;
+constexpr int kMaxCopies = 8;
+
+struct GroupWorker {
+    fp_ctx* ctx = nullptr;
+    std::thread th;
+    // the mailbox (written by the submitter while done == posted, read by the worker after it saw posted move)
+    int kind = 0;  // 1 dense, 2 step, 3 fiss, 4 fiss + advance
+    fp_params params;
+    fp_batch batch;
+    fp_result result;
+    fp_loop_io loop;
+    fp_fiss_opts fopts;
+    fp_fiss_io fio;
+    void* stream = nullptr;
+    fp_copy copies[kMaxCopies];
+    int n_copies = 0;
+    std::atomic<unsigned long long> posted{0}, done{0};
+    std::atomic<bool> asleep{false}, stop{false};
+    std::mutex m;
+    std::condition_variable cv;
+    int rc = FP_OK;        // of the last call (read by fp_group_wait after done == posted)
+    std::string err;
+};
+
+void group_worker_main(GroupWorker* w)
+{
+    (void)hipSetDevice(w->ctx->device);
+    unsigned long long seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (w->posted.load(std::memory_order_acquire) == seen && !w->stop.load(std::memory_order_relaxed)) {
+            if (++spins < kSpinRounds) { cpu_pause(); continue; }
+            std::unique_lock<std::mutex> lk(w->m);
+            w->asleep.store(true, std::memory_order_seq_cst);
+            w->cv.wait(lk, [&] { return w->posted.load(std::memory_order_seq_cst) != seen || w->stop.load(std::memory_order_seq_cst); });
+            w->asleep.store(false, std::memory_order_seq_cst);
+            spins = 0;
+        }
+        if (w->stop.load(std::memory_order_relaxed) && w->posted.load(std::memory_order_acquire) == seen) return;
+        seen = w->posted.load(std::memory_order_acquire);
+        int rc = FP_OK;
+        switch (w->kind) {
+            case 1: rc = fp_plan_dense(w->ctx, &w->params, &w->batch, &w->result, FP_MEM_DEVICE, w->stream); break;
+            case 2: rc = fp_plan_step(w->ctx, &w->params, &w->batch, &w->result, &w->loop, FP_MEM_DEVICE, w->stream); break;
+            case 3: rc = fp_plan_fiss(w->ctx, &w->params, &w->batch, &w->fopts, &w->fio, FP_MEM_DEVICE, w->stream); break;
+            case 4:
+                rc = fp_plan_fiss(w->ctx, &w->params, &w->batch, &w->fopts, &w->fio, FP_MEM_DEVICE, w->stream);
+                if (rc == FP_OK) rc = fp_advance(w->ctx, &w->params, &w->batch, nullptr, w->fio.end_state, &w->loop, FP_MEM_DEVICE, w->stream);
+                break;
+            default: break;
+        }
+        for (int i = 0; rc == FP_OK && i < w->n_copies; ++i) {
+            const hipError_t e = hipMemcpyAsync(w->copies[i].dst, w->copies[i].src, w->copies[i].bytes, hipMemcpyDefault, (hipStream_t)w->stream);
+            if (e != hipSuccess) rc = fail(FP_EHIP, "fp_group copy %d failed: %s", i, hipGetErrorString(e));
+        }
+        w->rc = rc;
+        if (rc != FP_OK) w->err = g_last_error;  // (thread-local: the worker's own)
+        w->done.store(seen, std::memory_order_release);
+    }
+}
+
+void group_wait_worker(GroupWorker& w)
+{
+    const unsigned long long want = w.posted.load(std::memory_order_relaxed);
+    while (w.done.load(std::memory_order_acquire) != want) cpu_pause();
+}
+
+}  // namespace
+
+struct fp_group {
+    std::vector<GroupWorker*> workers;
+};
+
+extern "C" {
+
+int fp_group_create(fp_ctx* const* ctxs, int32_t n, fp_group** out)
+{
+    if (!out) return fail(FP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!ctxs || n < 1 || n > 1024) return fail(FP_EINVAL, "fp_group_create: need 1..1024 contexts");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(FP_EINVAL, "fp_group_create: ctxs[%d] is NULL", i);
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(FP_EINVAL, "fp_group_create: ctxs[%d] and ctxs[%d] are the same ctx (one worker per ctx)", j, i);
+    }
+    fp_group* g = new (std::nothrow) fp_group();
+    if (!g) return fail(FP_ENOMEM, "out of host memory");
+    for (int i = 0; i < n; ++i) {
+        GroupWorker* w = new (std::nothrow) GroupWorker();
+        if (!w) { fp_group_destroy(g); return fail(FP_ENOMEM, "out of host memory"); }
+        w->ctx = ctxs[i];
+        g->workers.push_back(w);
+        w->th = std::thread(group_worker_main, w);
+    }
+    *out = g;
+    return FP_OK;
+}
+
+int fp_group_destroy(fp_group* g)
+{
+    if (!g) return FP_OK;
+    for (GroupWorker* w : g->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->stop.store(true, std::memory_order_seq_cst);
+        }
+        w->cv.notify_one();
+        if (w->th.joinable()) w->th.join();
+        delete w;
+    }
+    delete g;
+    return FP_OK;
+}
+
+int fp_group_submit(fp_group* g, const fp_shard_call* calls)
+{
+    if (!g || !calls) return fail(FP_EINVAL, "group/calls is NULL");
+    const int n = (int)g->workers.size();
+    for (int i = 0; i < n; ++i) {  // validate the whole round before any of it is posted
+        const fp_shard_call& c = calls[i];
+        if (!c.params) continue;
+        if (!c.batch) return fail(FP_EINVAL, "fp_group_submit: calls[%d].batch is NULL", i);
+        if (!c.result && !(c.fiss_opts && c.fiss_io)) return fail(FP_EINVAL, "fp_group_submit: calls[%d] needs result or fiss_opts + fiss_io", i);
+        if (c.result && (c.fiss_opts || c.fiss_io)) return fail(FP_EINVAL, "fp_group_submit: calls[%d] sets both result and the FISS structs", i);
+        if (c.n_copies < 0 || c.n_copies > kMaxCopies || (c.n_copies > 0 && !c.copies)) return fail(FP_EINVAL, "fp_group_submit: calls[%d].n_copies must be 0..%d", i, kMaxCopies);
+    }
+    for (int i = 0; i < n; ++i) {
+        const fp_shard_call& c = calls[i];
+        if (!c.params) continue;
+        GroupWorker& w = *g->workers[i];
+        group_wait_worker(w);  // the mailbox is one deep
+        if (w.rc != FP_OK) continue;  // (a failed call stays visible until fp_group_wait reports it)
+        w.params = *c.params;
+        w.batch = *c.batch;
+        if (c.result) w.result = *c.result;
+        if (c.loop) w.loop = *c.loop;
+        if (c.fiss_opts) { w.fopts = *c.fiss_opts; w.fio = *c.fiss_io; }
+        w.kind = c.result ? (c.loop ? 2 : 1) : (c.loop ? 4 : 3);
+        w.stream = c.stream;
+        w.n_copies = c.n_copies;
+        for (int k = 0; k < c.n_copies; ++k) w.copies[k] = c.copies[k];
+        w.posted.fetch_add(1, std::memory_order_seq_cst);
+        if (w.asleep.load(std::memory_order_seq_cst)) {
+            std::lock_guard<std::mutex> lk(w.m);
+            w.cv.notify_one();
+        }
+    }
+    return FP_OK;
+}
+
+int fp_group_wait(fp_group* g)
+{
+    if (!g) return fail(FP_EINVAL, "group is NULL");
+    int rc = FP_OK;
+    for (size_t i = 0; i < g->workers.size(); ++i) {
+        GroupWorker& w = *g->workers[i];
+        group_wait_worker(w);
+        if (w.rc != FP_OK) {
+            if (rc == FP_OK) rc = fail(w.rc, "shard %zu: %s", i, w.err.c_str());
+            w.rc = FP_OK;
+            w.err.clear();
+        }
+    }
+    return rc;
 }
 
 }  // extern "C"

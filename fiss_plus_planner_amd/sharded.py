@@ -15,6 +15,7 @@ lets one device's H2D staging overlap another shard's kernels).
 """
 from __future__ import annotations
 
+import ctypes as C
 import logging
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -32,6 +33,32 @@ _log = logging.getLogger(__name__)
 def _rows(ns: SimpleNamespace, lo: int, hi: int) -> SimpleNamespace:
     """The same output object restricted to egos [lo, hi): contiguous views, written in place by the shard's call."""
     return SimpleNamespace(**{k: (v[lo:hi] if isinstance(v, np.ndarray) else v) for k, v in vars(ns).items()})
+
+
+class _Group:
+    """fp_group over the shards' contexts (include/frenet_gpu.h): one PERSISTENT worker thread per ctx inside the library, fed through
+    a mailbox.  A resident plan step of W shards is ONE ctypes call that posts W prebuilt argument blocks (`submit`) - the enqueues
+    then run side by side on the workers' threads, without the GIL, a thread-pool hop or per-call argument marshalling (the
+    ThreadPoolExecutor path of round 4 cost a Python submit + a future per shard and step: host-bound long before 8 x 0.146 ms steps).
+    `wait` returns when every worker has enqueued its call, with the first error."""
+
+    def __init__(self, engines):
+        self._lib = _abi.load()
+        self.n = len(engines)
+        ctxs = (C.c_void_p * self.n)(*[e._ctx for e in engines])
+        self._h = C.c_void_p()
+        _abi.check(self._lib.fp_group_create(ctxs, self.n, C.byref(self._h)))
+
+    def submit(self, calls):
+        _abi.check(self._lib.fp_group_submit(self._h, calls))
+
+    def wait(self):
+        _abi.check(self._lib.fp_group_wait(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.fp_group_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class ShardedDeviceBatch:
@@ -90,15 +117,37 @@ class ShardedDeviceBatch:
             self.shards.append(sh)
 
     # -- plumbing
-    def _home(self, sh, names):
-        """Results of one shard -> the pinned rows (only when they were not written there directly)."""
-        for k in names:
-            if not self.zero_copy or k == "prev_best_idx":
-                self._pinned[k][sh.lo:sh.hi].copy_(sh.res[k], non_blocking=True)
-
     def synchronize(self):
+        """Every shard's stream has run dry (the calls posted to the engine's workers have been enqueued first)."""
+        self.eng.group_wait()
         for sh in self.shards:
             sh.stream.synchronize()
+
+    def round_calls(self, key, build):
+        """The fp_shard_call array of one kind of resident call on this batch, built once (`build(shard)` -> (FpShardCall fields,
+        objects to keep alive)) and re-posted every step; slots of shards without egos stay empty (params = NULL)."""
+        cache = self.__dict__.setdefault("_rounds", {})
+        if key not in cache:
+            calls = (_abi.FpShardCall * self.eng.world)()
+            keep = []
+            for sh in self.shards:
+                fields, alive = build(sh)
+                c = calls[sh.rank]
+                c.params, c.batch, c.stream = C.pointer(sh.db.params), C.pointer(sh.db.fb), sh.stream.cuda_stream
+                for k, v in fields.items():
+                    setattr(c, k, v)
+                keep.append(alive)
+            cache[key] = (calls, keep)
+        return cache[key][0]
+
+    def home_copies(self, sh, names):
+        """fp_copy list that brings a shard's per-ego results to the pinned rows (nothing when they are written there directly)."""
+        todo = [k for k in names if not self.zero_copy or k == "prev_best_idx"]
+        arr = (_abi.FpCopy * max(1, len(todo)))()
+        for i, k in enumerate(todo):
+            dst = self._pinned[k][sh.lo:sh.hi]
+            arr[i].dst, arr[i].src, arr[i].bytes = dst.data_ptr(), sh.res[k].data_ptr(), dst.numel() * dst.element_size()
+        return arr, len(todo)
 
     def reset_state(self, batch: ProblemBatch):
         """Upload the start states / time steps of `batch` again (a closed loop advances the resident ones in place)."""
@@ -137,7 +186,8 @@ class ShardedEngine:
             _log.info("ShardedEngine(shards_per_device=%d): set GPU_MAX_HW_QUEUES=8 (takes effect only if the HIP runtime has not started)",
                       int(shards_per_device))
         self.engines = [engine_factory(d) for d in self.devices]
-        self._pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="frenet-shard")
+        self._pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="frenet-shard")  # host-staged calls (the *_host methods)
+        self._group = None   # resident calls: the library's own worker threads (created on first use; real engines only)
 
     world = property(lambda self: len(self.engines))
 
@@ -150,10 +200,22 @@ class ShardedEngine:
             streams[r] = torch.cuda.Stream(torch.device("cuda", self.devices[r]))
         return streams[r]
 
+    def group(self) -> _Group:
+        if self._group is None:
+            self._group = _Group(self.engines)
+        return self._group
+
+    def group_wait(self):
+        if self._group is not None:
+            self._group.wait()
+
     def close(self):
         pool, self._pool = getattr(self, "_pool", None), None
         if pool is not None:
             pool.shutdown(wait=True)
+        grp, self._group = getattr(self, "_group", None), None
+        if grp is not None:
+            grp.close()
         for e in getattr(self, "engines", []):
             e.close()
         self.engines = []
@@ -250,14 +312,11 @@ class ShardedEngine:
         """Cut `batch` into the engine's shards and make every shard resident on its device (see ShardedDeviceBatch)."""
         return ShardedDeviceBatch(self, batch, tables, winner, fiss_rounds_max, traj_stride)
 
-    def _each(self, sdb: ShardedDeviceBatch, call, sync: bool):
-        """call(shard) for every shard.  One shard: in the caller's thread (a thread hop costs more than the enqueue); several: one
-        host thread each, so the enqueues of different devices do not queue up behind each other."""
-        if len(sdb.shards) == 1:
-            call(sdb.shards[0])
-        else:
-            for f in [self._pool.submit(call, sh) for sh in sdb.shards]:
-                f.result()
+    def _round(self, sdb: ShardedDeviceBatch, calls, sync: bool):
+        """One resident call on every shard: a single ctypes call posts the prebuilt argument blocks to the library's per-ctx worker
+        threads (fp_group_submit), which enqueue side by side.  sync=False returns at once - the next round may be posted while the
+        workers are still enqueuing this one; sdb.synchronize() waits for the workers first."""
+        self.group().submit(calls)
         if sync:
             sdb.synchronize()
 
@@ -268,19 +327,18 @@ class ShardedEngine:
         buffers (upload(..., tables=True / winner=True))."""
         if (tables and not sdb.tables) or (winner and not sdb.winner):
             raise ValueError("upload(batch, tables=..., winner=...) did not reserve the buffers this call asks for")
-        torch = sdb.torch
 
-        def call(sh):
+        def build(sh):
             r = sh.res
-            with torch.cuda.device(sh.db.dev):
-                sh.engine.plan_dense_device(sh.db.params, sh.db.fb, r["best_idx"].data_ptr(), r["best_cost"].data_ptr(), r["stats"].data_ptr(),
-                                            sh.cost_tbl.data_ptr() if tables else 0, sh.flag_tbl.data_ptr() if tables else 0,
-                                            stream=sh.stream.cuda_stream, best_flags=r["best_flags"].data_ptr() if winner else 0,
-                                            best_traj=sh.best_traj.data_ptr() if winner else 0, traj_stride=sdb.traj_stride, traj_sparse=True)
-                with torch.cuda.stream(sh.stream):
-                    sdb._home(sh, ("best_idx", "best_cost", "stats") + (("best_flags",) if winner else ()))
+            res = _abi.FpResult()
+            res.best_idx, res.best_cost, res.stats = r["best_idx"].data_ptr(), r["best_cost"].data_ptr(), r["stats"].data_ptr()
+            res.cost_tbl, res.flag_tbl = (sh.cost_tbl.data_ptr(), sh.flag_tbl.data_ptr()) if tables else (None, None)
+            res.best_flags, res.best_traj = (r["best_flags"].data_ptr(), sh.best_traj.data_ptr()) if winner else (None, None)
+            res.traj_stride, res.traj_sparse = sdb.traj_stride, 1
+            copies, n = sdb.home_copies(sh, ("best_idx", "best_cost", "stats") + (("best_flags",) if winner else ()))
+            return dict(result=C.pointer(res), copies=copies, n_copies=n), (res, copies)
 
-        self._each(sdb, call, sync)
+        self._round(sdb, sdb.round_calls(("dense", bool(tables), bool(winner)), build), sync)
         return sdb.host
 
     def _plan_fiss_resident(self, sdb: ShardedDeviceBatch, kind="FISS+", prev_best_idx=None, w_heuristic: float = 10.0, max_refine_iters: int = 3,
@@ -293,30 +351,33 @@ class ShardedEngine:
         torch = sdb.torch
         R = fiss_rounds(kind, max_refine_iters)
         plus = kind in ("FISS+", _abi.FP_FISS_PLUS)
-        prev = None if prev_best_idx is None else np.ascontiguousarray(prev_best_idx, dtype=np.int32).reshape(sdb.B, 3)
-
-        def call(sh):
-            r = sh.res
-            with torch.cuda.device(sh.db.dev), torch.cuda.stream(sh.stream):
-                if prev is not None:
+        if prev_best_idx is not None:
+            prev = np.ascontiguousarray(prev_best_idx, dtype=np.int32).reshape(sdb.B, 3)
+            self.group_wait()  # (the copies below go to the shards' streams from this thread: behind whatever the workers still enqueue)
+            for sh in sdb.shards:
+                with torch.cuda.device(sh.db.dev), torch.cuda.stream(sh.stream):
                     sh.prev.copy_(torch.from_numpy(prev[sh.lo:sh.hi]), non_blocking=False)
-                opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
-                io = _abi.FpFissIo()
-                io.samp_min, io.samp_max, io.samp_res = (sh.db.t[k].data_ptr() for k in ("samp_min", "samp_max", "samp_res"))
-                io.prev_best_idx, io.best_ijk, io.best_cost = sh.prev.data_ptr(), r["best_ijk"].data_ptr(), r["best_cost"].data_ptr()
-                io.end_state, io.refined, io.stats, io.trace = r["end_state"].data_ptr(), r["refined"].data_ptr(), r["stats"].data_ptr(), None
-                io.best_flags = r["best_flags"].data_ptr() if winner else None
-                io.best_traj = sh.best_traj.data_ptr() if winner else None
-                io.traj_stride, io.traj_sparse = sdb.traj_stride, 1
-                sh.engine.plan_fiss_device(sh.db.params, sh.db.fb, opts, io, stream=sh.stream.cuda_stream)
-                sdb._home(sh, ("best_ijk", "best_cost", "end_state", "refined", "stats", "prev_best_idx") + (("best_flags",) if winner else ()))
 
-        self._each(sdb, call, sync)
+        def build(sh):
+            r = sh.res
+            opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS if plus else _abi.FP_FISS, R, w_heuristic, decaying_factor)
+            io = _abi.FpFissIo()
+            io.samp_min, io.samp_max, io.samp_res = (sh.db.t[k].data_ptr() for k in ("samp_min", "samp_max", "samp_res"))
+            io.prev_best_idx, io.best_ijk, io.best_cost = sh.prev.data_ptr(), r["best_ijk"].data_ptr(), r["best_cost"].data_ptr()
+            io.end_state, io.refined, io.stats, io.trace = r["end_state"].data_ptr(), r["refined"].data_ptr(), r["stats"].data_ptr(), None
+            io.best_flags = r["best_flags"].data_ptr() if winner else None
+            io.best_traj = sh.best_traj.data_ptr() if winner else None
+            io.traj_stride, io.traj_sparse = sdb.traj_stride, 1
+            copies, n = sdb.home_copies(sh, ("best_ijk", "best_cost", "end_state", "refined", "stats", "prev_best_idx") + (("best_flags",) if winner else ()))
+            return dict(fiss_opts=C.pointer(opts), fiss_io=C.pointer(io), copies=copies, n_copies=n), (opts, io, copies)
+
+        self._round(sdb, sdb.round_calls(("fiss", plus, R, float(w_heuristic), float(decaying_factor), bool(winner)), build), sync)
         return sdb.host
 
     def _closed_loop_resident(self, sdb: ShardedDeviceBatch, goal_xy: np.ndarray, planner: str = "FOP", max_cycles: int = 100):
         """The device-resident closed loop (planning.py:120-162) on shards that are ALREADY resident: no upload, the resident start
-        states are advanced in place (sdb.reset_state(batch) rewinds them)."""
+        states are advanced in place (sdb.reset_state(batch) rewinds them).  One fp_group round per cycle: fp_plan_step for FOP,
+        fp_plan_fiss + fp_advance for FISS / FISS+ - the host thread posts max_cycles rounds, the workers enqueue them."""
         from .device_batch import ClosedLoopRunner
 
         torch = sdb.torch
@@ -324,14 +385,31 @@ class ShardedEngine:
         B = sdb.B
         out = SimpleNamespace(done=np.empty(B, dtype=np.int32), cycles=np.empty(B, dtype=np.int32), ego=np.empty((B, 6)),
                               t_now=np.empty(B, dtype=np.int32), cart=np.empty((B, 3)))
-
-        def call(sh):
+        self.group_wait()
+        runners = {}
+        for sh in sdb.shards:
             with torch.cuda.device(sh.db.dev), torch.cuda.stream(sh.stream):
                 sh.db.fb.skip = None
-                res = ClosedLoopRunner(sh.engine, sh.db, goal[sh.lo:sh.hi], planner).run(max_cycles)
-                sh.db.fb.skip = None  # (the runner's `done` array dies with it)
-            for k in ("done", "cycles", "ego", "t_now", "cart"):
-                getattr(out, k)[sh.lo:sh.hi] = getattr(res, k)
-
-        self._each(sdb, call, True)
+                runners[sh.rank] = ClosedLoopRunner(sh.engine, sh.db, goal[sh.lo:sh.hi], planner)  # (sets fb.skip = its `done` array)
+        calls = (_abi.FpShardCall * self.world)()
+        keep = []
+        for sh in sdb.shards:
+            run, c = runners[sh.rank], calls[sh.rank]
+            c.params, c.batch, c.stream, c.loop = C.pointer(sh.db.params), C.pointer(sh.db.fb), sh.stream.cuda_stream, C.pointer(run.io)
+            if planner == "FOP":
+                res = _abi.FpResult()
+                res.best_idx, res.best_cost, res.stats = run.best_idx.data_ptr(), run.best_cost.data_ptr(), run.stats.data_ptr()
+                c.result = C.pointer(res)
+                keep.append(res)
+            else:
+                c.fiss_opts, c.fiss_io = C.pointer(run.fopts), C.pointer(run.fio)
+        grp = self.group()
+        for _ in range(max_cycles):
+            grp.submit(calls)
+        sdb.synchronize()
+        for sh in sdb.shards:
+            run = runners[sh.rank]
+            sh.db.fb.skip = None  # (the runner's `done` array dies with it)
+            for k, v in (("done", run.done), ("cycles", run.cycles), ("ego", sh.db.t["ego"]), ("t_now", sh.db.t["t_now"]), ("cart", run.cart)):
+                getattr(out, k)[sh.lo:sh.hi] = v.cpu().numpy()
         return out

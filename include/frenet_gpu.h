@@ -31,13 +31,14 @@
 #ifndef FRENET_GPU_H
 #define FRENET_GPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 12
+#define FP_ABI_VERSION 13
 
 /* error codes */
 #define FP_OK 0
@@ -387,6 +388,49 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
  * for the series, takes the two-launch path (same results).  Identical to fp_plan_dense + fp_advance in every output. */
 int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, const fp_loop_io* io, int mem,
                  void* stream);
+
+/* ---- several devices from one host thread ----------------------------------------------------------------------
+ * The path shards over independent egos, one shard per GPU, no collective (planning.py:120-162 plans its scenarios one after the
+ * other; nothing is exchanged).  An 8-GPU node running 0.15 ms plan steps - or 0.07 ms closed-loop cycles - per device needs
+ * 50 000-120 000 enqueued calls per second: more than one host thread issues when every call crosses an FFI.  A group owns one
+ * PERSISTENT worker thread per ctx (a mailbox per worker: it spins for a few tens of microseconds after its last call, then sleeps on
+ * a condition variable); fp_group_submit posts one call per ctx and returns, fp_group_wait returns when every worker has ENQUEUED its
+ * call (not when the GPUs are done: synchronise the streams for that) with the first error.  FP_MEM_DEVICE calls only; the structs a
+ * call points to are copied at submit time.  One submitter at a time per group; a ctx of a group must not be used from other
+ * threads while the group has work in flight. */
+typedef struct fp_group fp_group;
+
+typedef struct {
+    void* dst;        /* host (pinned) or device address */
+    const void* src;  /* device address */
+    size_t bytes;
+} fp_copy;            /* hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault) on the call's stream, behind its kernels */
+
+/* One shard's call.  Which entry point runs follows from the pointers that are set:
+ *   result                        fp_plan_dense(ctx, params, batch, result, FP_MEM_DEVICE, stream)
+ *   result + loop                 fp_plan_step (..., result, loop, ...)
+ *   fiss_opts + fiss_io           fp_plan_fiss (..., fiss_opts, fiss_io, ...)
+ *   fiss_opts + fiss_io + loop    fp_plan_fiss, then fp_advance(..., NULL, fiss_io->end_state, loop, ...)
+ * params == NULL: nothing for this ctx in this round. */
+typedef struct {
+    const fp_params* params;
+    const fp_batch* batch;
+    const fp_result* result;
+    const fp_loop_io* loop;
+    const fp_fiss_opts* fiss_opts;
+    const fp_fiss_io* fiss_io;
+    void* stream;
+    const fp_copy* copies;   /* NULL or [n_copies] (at most 8) */
+    int32_t n_copies;
+    int32_t reserved0;
+} fp_shard_call;
+
+int fp_group_create(fp_ctx* const* ctxs, int32_t n, fp_group** out);
+int fp_group_destroy(fp_group* group);
+/* calls [n], calls[i] runs on ctxs[i].  A worker that is still busy with the previous round is waited for first. */
+int fp_group_submit(fp_group* group, const fp_shard_call* calls);
+/* FP_OK, or the first failing worker's code (fp_last_error() then carries its message, prefixed with the shard index). */
+int fp_group_wait(fp_group* group);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ def test_struct_layouts_match_header(tmp_path):
     """Every struct of include/frenet_gpu.h against its ctypes mirror: size and the offset of every field, as gcc lays them out
     (a C program built from the header prints them)."""
     pairs = {"fp_params": _abi.FpParams, "fp_batch": _abi.FpBatch, "fp_result": _abi.FpResult, "fp_fiss_opts": _abi.FpFissOpts,
-             "fp_fiss_io": _abi.FpFissIo, "fp_loop_io": _abi.FpLoopIo}
+             "fp_fiss_io": _abi.FpFissIo, "fp_loop_io": _abi.FpLoopIo, "fp_copy": _abi.FpCopy, "fp_shard_call": _abi.FpShardCall}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "frenet_gpu.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -174,3 +174,45 @@ def test_resident_shards_config5_closed_loop(engine, sharded8, planner):
     sdb.reset_state(batch)
     if planner == "FOP":
         np.testing.assert_array_equal(sharded8.plan_dense(sdb).best_idx, engine.plan_dense(batch, tables=False).best_idx)
+
+
+def test_group_rounds_pipelined_and_empty_shards(engine):
+    """fp_group (the library's per-ctx worker threads behind the resident calls): 300 rounds posted back to back without waiting
+    (the mailbox is one deep: a round waits for the worker's previous call), fewer egos than shards (empty mail slots), results equal
+    to the single engine's."""
+    batch = synth.make_batch(5, 5, 5, 5, 10, 60, True, 17)
+    ref = engine.plan_dense(batch, tables=False)
+    with ShardedEngine(devices=[0], shards_per_device=8) as eng:
+        sdb = eng.upload(batch)
+        assert len(sdb.shards) == 5
+        for _ in range(300):
+            eng.plan_dense(sdb, sync=False)
+        sdb.synchronize()
+        np.testing.assert_array_equal(sdb.host.best_idx, ref.best_idx)
+        assert np.array_equal(sdb.host.best_cost, ref.best_cost, equal_nan=True)
+
+
+def test_group_reports_the_failing_shard():
+    """A worker's error comes back from fp_group_wait with the shard's index; the group keeps working afterwards."""
+    import ctypes as C
+
+    from fiss_plus_planner_amd import _abi
+
+    batch = synth.make_batch(8, 5, 5, 5, 10, 60, True, 18)
+    with ShardedEngine(devices=[0], shards_per_device=2) as eng:
+        sdb = eng.upload(batch)
+        good = eng.plan_dense(sdb).best_idx.copy()
+        calls = sdb.round_calls(("dense", False, False), None)  # (cached by the call above)
+        bad = (_abi.FpShardCall * 2)()
+        C.memmove(bad, calls, C.sizeof(bad))
+        p = _abi.FpParams.from_buffer_copy(sdb.shards[1].db.params)
+        p.nd = 0
+        bad[1].params = C.pointer(p)
+        eng.group().submit(bad)
+        with pytest.raises(_abi.FrenetGpuError, match="shard 1: lattice sizes"):
+            eng.group().wait()
+        np.testing.assert_array_equal(eng.plan_dense(sdb).best_idx, good)
+        with pytest.raises(_abi.FrenetGpuError, match="needs result"):
+            empty = (_abi.FpShardCall * 2)()
+            empty[0].params, empty[0].batch = calls[0].params, calls[0].batch
+            eng.group().submit(empty)
