@@ -210,7 +210,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.cnt = o;      o = align16(o + 32);  // list counters (monotone) + scan mask + ticket + two fp32 bounds
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
     L.best = o;     o = align16(o + 16 * 16);  // (up to 16 wavefronts)
-    L.konst = o;    o = align16(o + 64);  // per-ego constants the collision stages re-read (instead of registers held through the kernel)
+    L.konst = o;    o = align16(o + 96);  // per-ego constants the collision stages re-read (instead of registers held through the kernel)
     L.nvert = o;    o = align16(o + (poly_stride > 0 ? 4 * n_obs : 0));                              // polygon columns: vertices per obstacle
     L.poly = o;     o = align16(o + 16 * poly_lds_verts(n_obs, poly_stride));                        // ... and the rings, when they fit
     // the spline tables last: theirs is the one size no instance of the kernel knows at compile time, so every other offset folds
@@ -286,17 +286,15 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             const long long tl0 = wall_clock64();
             long long tl1 = 0;
 #endif
-            __shared__ int s_handed;
+            int timed_out = 0;
             if (threadIdx.x == 0) {
-                const bool ok = handover_wait(&ft.flag[eb], ka.err_word, 2);
-                if (ok) __hip_atomic_store(&ft.flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-                s_handed = ok;
+                timed_out = !handover_wait(&ft.flag[eb], ka.err_word, 2);
+                if (!timed_out) __hip_atomic_store(&ft.flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
 #if defined(FP_TL)
                 tl1 = wall_clock64();
 #endif
             }
-            __syncthreads();
-            if (!s_handed) return;  // (timed out: reported through the ctx's error word, see handover_wait)
+            if (__syncthreads_or(timed_out)) return;  // (timed out: reported through the ctx's error word, see handover_wait)
             __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the tables are read after the flag
             FissArgs fa;
             fa.ka = ka;
@@ -394,6 +392,13 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const int slot = in_tail ? tail_from + (((int)blockIdx.x - tail_from) >> 1) : (int)blockIdx.x / nsplit_arg;
     const int part_of_slot = in_tail ? (((int)blockIdx.x - tail_from) & 1) : (int)blockIdx.x - slot * nsplit_arg;
     constexpr bool kShape = ND > 0;  // (all six are set together)
+    // The run-time-shape three-per-CU instances have no register to spare (80 VGPRs, run-time sizes in place of immediates): from the
+    // prologue's second barrier on they re-read the ego's start state from LDS (s_k[5..10]) where it is used instead of holding twelve
+    // VGPRs through the kernel.  NOT an optimisation: this build of the compiler places VGPR spill stores in the exit block of a
+    // divergent loop BEFORE the exec mask is restored (exec = 0: nothing is stored, the reload returns whatever the scratch slot held -
+    // zeros in a launch's first round of workgroups, another workgroup's values later), so no instance may spill a VGPR at all
+    // (tools/resource_usage.py must show 0 in "VGPRs Spill" for every kernel; tests/test_abi_cpu.py checks it).
+    constexpr bool kEgoLds = ND == 0 && OCC > 4;
     constexpr bool kGroup = GS != 1;
     constexpr int kThreads = NTH, kWaves = NTH / kWave;  // (shadow the file-scope defaults)
     static_assert(GS == 0 || GS == 1, "GS: 1 or 0 (run-time group size)");
@@ -777,12 +782,19 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         }
     }
     if (tid == 0) { s_k[0] = knot0; s_k[1] = inv_bucket_w; s_k[2] = veh_hl; s_k[3] = veh_hw; s_k[4] = r_ego; }
+    if (kEgoLds && tid == 1) { s_k[5] = s0; s_k[6] = s_d0; s_k[7] = s_dd0; s_k[8] = d0; s_k[9] = d_d0; s_k[10] = d_dd0; }
     {   // power sums of every slice (they need nothing but the time samples): a few threads of the middle
         const int i = tid - kThreads / 2;
         if (i >= 0 && i < n_it) power_sums_closed(arange_len(s_ts[it_lo + i], tick), tick, s_pows + (it_lo + i) * 11);
     }
     __syncthreads();
     FP_STAMP(2);
+    auto eS0 = [&]() -> double { if constexpr (kEgoLds) return s_k[5]; else return s0; };
+    auto eSd0 = [&]() -> double { if constexpr (kEgoLds) return s_k[6]; else return s_d0; };
+    auto eSdd0 = [&]() -> double { if constexpr (kEgoLds) return s_k[7]; else return s_dd0; };
+    auto eD0 = [&]() -> double { if constexpr (kEgoLds) return s_k[8]; else return d0; };
+    auto eDd0 = [&]() -> double { if constexpr (kEgoLds) return s_k[9]; else return d_d0; };
+    auto eDdd0 = [&]() -> double { if constexpr (kEgoLds) return s_k[10]; else return d_dd0; };
     if (n_obs > 0 && pose_limit > 0) {
         // ---- arclength range of every checked pose row over the lon profiles of ALL slices of this workgroup: lane = (row, slice),
         // loop over the end-speed samples, then LDS atomic min / max on order-preserving fp32 bit patterns (relative to the first knot).
@@ -798,7 +810,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             bool bad = false;
             for (int iv = 0; iv < nv; ++iv) {
                 const double a3 = s_qlon[2 * (mul24(it, nv) + iv)], a4 = s_qlon[2 * (mul24(it, nv) + iv) + 1];
-                const double sv = fma(fma(fma(fma(a4, t, a3), t, s_dd0 * 0.5), t, s_d0), t, s0) - knot0;
+                const double sv = fma(fma(fma(fma(a4, t, a3), t, eSdd0() * 0.5), t, eSd0()), t, eS0()) - knot0;
                 bad = bad || !(sv == sv);
                 lo = fmin(lo, sv); hi = fmax(hi, sv);
             }
@@ -821,10 +833,10 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         for (int e = tid; e < nv * N; e += kThreads) {
             const int iv = div_small(e, inv_n), i = e - mul24(iv, N);
             const double a3 = s_qlon[2 * (mul24(it, nv) + iv)], a4 = s_qlon[2 * (mul24(it, nv) + iv) + 1];
-            const double a2 = s_dd0 * 0.5;
+            const double a2 = eSdd0() * 0.5;
             const double t = (double)i * tick;
-            const double s = fma(fma(fma(fma(a4, t, a3), t, a2), t, s_d0), t, s0);
-            const double s_d = fma(fma(fma(4.0 * a4, t, 3.0 * a3), t, 2.0 * a2), t, s_d0);
+            const double s = fma(fma(fma(fma(a4, t, a3), t, a2), t, eSd0()), t, eS0());
+            const double s_d = fma(fma(fma(4.0 * a4, t, 3.0 * a3), t, 2.0 * a2), t, eSd0());
             const double s_dd = fma(fma(12.0 * a4, t, 6.0 * a3), t, 2.0 * a2);
             const uint32_t bad = (s_d > p.max_speed ? FP_FLAG_SPEED : 0u) | (fabs(s_dd) > p.max_accel ? FP_FLAG_ACCEL : 0u);
             if (bad) atomicOr((unsigned int*)&s_lon_meta[mul24(it, nv) + iv].y, bad);
@@ -841,14 +853,14 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         const double* S = s_pows + it * 11;
         if (!live) {
         } else if (sub < nv) {
-            const Quartic q{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (mul24(it, nv) + sub)], s_qlon[2 * (mul24(it, nv) + sub) + 1]};
+            const Quartic q{eS0(), eSd0(), eSdd0() * 0.5, s_qlon[2 * (mul24(it, nv) + sub)], s_qlon[2 * (mul24(it, nv) + sub) + 1]};
             double lon[3];
             lon_cost_sums(q, target_speed, S, lon);
             double* o = s_lon_sum + 3 * (mul24(it, nv) + sub);
             o[0] = lon[0]; o[1] = lon[1]; o[2] = lon[2];
         } else {
             const int id = sub - nv;
-            const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, T);
+            const Quintic q = quintic_bvp(eD0(), eDd0(), eDdd0(), s_ds[id], 0.0, 0.0, T);
             double lat[3];
             lat_cost_sums(q, S, lat);
             double* o = s_lat_sum + 3 * (mul24(id, nt) + it);
@@ -862,7 +874,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if constexpr (kWalk) {  // every slice of this workgroup, [slice][lateral sample] (absolute slice index)
             for (int e = kThreads - 1 - tid; e < mul24(n_it, nd); e += kThreads) {
                 const int itl = div_small(e, inv_nd_g), id = e - mul24(itl, nd);
-                const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, s_ts[it_lo + itl]);
+                const Quintic q = quintic_bvp(eD0(), eDd0(), eDdd0(), s_ds[id], 0.0, 0.0, s_ts[it_lo + itl]);
                 double* o = s_qlat + 3 * (mul24(it_lo + itl, nd) + id);
                 o[0] = q.a3; o[1] = q.a4; o[2] = q.a5;
             }
@@ -872,7 +884,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if (idg < mul24(gs, nd)) {
             const int itl = kGroup ? div_small(idg, inv_nd_g) : 0, id = idg - mul24(itl, nd);
             if (it0 + itl < it_hi) {
-                const Quintic q = quintic_bvp(d0, d_d0, d_dd0, s_ds[id], 0.0, 0.0, s_ts[it0 + itl]);
+                const Quintic q = quintic_bvp(eD0(), eDd0(), eDdd0(), s_ds[id], 0.0, 0.0, s_ts[it0 + itl]);
                 s_qlat[3 * idg] = q.a3; s_qlat[3 * idg + 1] = q.a4; s_qlat[3 * idg + 2] = q.a5;
             }
         }
@@ -907,8 +919,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                 for (int side = 0; side < 2; ++side) {
                     const double* ql = s_qlat + 3 * (mul24(it, nd) + (side ? id_hi : id_lo));
                     const double a3 = ql[0], a4 = ql[1], a5 = ql[2];
-                    const double d = fma(fma(fma(fma(fma(a5, t, a4), t, a3), t, d_dd0 * 0.5), t, d_d0), t, d0);
-                    const double dn = fma(fma(fma(fma(fma(a5, tn, a4), tn, a3), tn, d_dd0 * 0.5), tn, d_d0), tn, d0);
+                    const double d = fma(fma(fma(fma(fma(a5, t, a4), t, a3), t, eDdd0() * 0.5), t, eDd0()), t, eD0());
+                    const double dn = fma(fma(fma(fma(fma(a5, tn, a4), tn, a3), tn, eDdd0() * 0.5), tn, eDd0()), tn, eD0());
                     // (a NaN offset poisons the bound: as an unsigned bit pattern NaN is the largest)
                     const float fd = float_above(fabs(d)), fdd = float_above(fabs(dn - d));
                     dm = __float_as_uint(fd) > __float_as_uint(dm) ? fd : dm;
@@ -1074,7 +1086,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // [section FRAMES]
                         for (int i = lane; i < npm; i += kWave) {
                             const double t = (double)i * tick;
-                            const double s = fma(fma(fma(fma(a4, t, a3), t, s_dd0 * 0.5), t, s_d0), t, s0);
+                            const double s = fma(fma(fma(fma(a4, t, a3), t, eSdd0() * 0.5), t, eSd0()), t, eS0());
                             const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
                             Frame fr;
                             spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
@@ -1171,8 +1183,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                     const double* ql = qlat + mul24(id_l, 3);
                                     const double b3 = ql[0], b4 = ql[1], b5 = ql[2];
                                     const double ta = (double)ka_ * tick, tb = (double)(ka_ + 1) * tick;
-                                    const double da = fma(fma(fma(fma(fma(b5, ta, b4), ta, b3), ta, d_dd0 * 0.5), ta, d_d0), ta, d0);
-                                    const double db = fma(fma(fma(fma(fma(b5, tb, b4), tb, b3), tb, d_dd0 * 0.5), tb, d_d0), tb, d0);
+                                    const double da = fma(fma(fma(fma(fma(b5, ta, b4), ta, b3), ta, eDdd0() * 0.5), ta, eDd0()), ta, eD0());
+                                    const double db = fma(fma(fma(fma(fma(b5, tb, b4), tb, b3), tb, eDdd0() * 0.5), tb, eDd0()), tb, eD0());
                                     double xa, ya, xb, yb;
                                     frenet_to_cartesian(f0.px, f0.py, f0.tx, f0.ty, da, xa, ya);
                                     frenet_to_cartesian(f1.px, f1.py, f1.tx, f1.ty, db, xb, yb);
@@ -1247,7 +1259,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                     const int q = div_small(e, inv_np), i = e - mul24(q, np);
                     const int M = s_lon_meta[q0 + q].x;
                     if (i < M) {  // the point is on the spline (M <= the slice's N)
-                        const Quartic ql{s0, s_d0, s_dd0 * 0.5, s_qlon[2 * (q0 + q)], s_qlon[2 * (q0 + q) + 1]};
+                        const Quartic ql{eS0(), eSd0(), eSdd0() * 0.5, s_qlon[2 * (q0 + q)], s_qlon[2 * (q0 + q) + 1]};
                         const double t = (double)i * tick;
                         const double s = fma(fma(fma(fma(ql.a4, t, ql.a3), t, ql.a2), t, ql.a1), t, ql.a0);
                         const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
@@ -1268,7 +1280,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         if (i >= np_i) continue;
                     }
                     const double* ql = s_qlat + mul24(idg, 3);
-                    const Quintic q{d0, d_d0, d_dd0 * 0.5, ql[0], ql[1], ql[2]};
+                    const Quintic q{eD0(), eDd0(), eDdd0() * 0.5, ql[0], ql[1], ql[2]};
                     const double t = (double)i * tick;
                     const double d = fma(fma(fma(fma(fma(q.a5, t, q.a4), t, q.a3), t, q.a2), t, q.a1), t, q.a0);
                     s_lat[mul24(idg, hp_max) + i] = d;

@@ -121,3 +121,17 @@ def test_integration_md_stub_matches_the_binding():
         assert [(f[0], C.sizeof(f[1])) for f in doc._fields_] == [(f[0], C.sizeof(f[1])) for f in ours._fields_], name
         assert C.sizeof(doc) == C.sizeof(ours)
     assert "best_traj.ctypes.data, None, None, 0, 0)" in txt  # the call site passes all eleven fields
+
+
+def test_no_kernel_spills_a_vgpr():
+    """Every gfx950 kernel must fit its register budget without spilling a VGPR to scratch: this compiler build places the spill store
+    of a value that lives across a divergent loop in the loop's exit block BEFORE the exec mask is restored (nothing is stored; the
+    reload returns the scratch slot's old content - found on the run-time-shape three-per-CU lattice instances, whose workgroups of a
+    launch's second round then planned with another ego's numbers).  tools/resource_usage.py's table, asserted."""
+    out = subprocess.check_output(["python", os.path.join(ROOT, "tools", "resource_usage.py")], text=True)
+    rows = [l for l in out.splitlines()[1:] if l.strip()]
+    assert len(rows) >= 30
+    for l in rows:
+        cols = l.split()
+        spill_v, scratch = int(cols[-5]), int(cols[-3])   # ... VGPRs Spill, SGPRs Spill, ScratchSize, Occupancy, LDS Size
+        assert spill_v == 0 and scratch == 0, l

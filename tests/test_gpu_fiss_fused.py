@@ -39,7 +39,10 @@ def test_fused_search_equals_its_own_launch(engine, B):
     prev = np.where(rng.uniform(size=(B, 1)) < 0.5, -1, np.column_stack([rng.integers(0, batch.nd, B), rng.integers(0, batch.nv, B), rng.integers(0, batch.nt, B)])).astype(np.int32)
     ref = _run(engine, batch, 0, prev)
     assert (~np.isnan(ref.best_cost)).any() and np.isnan(ref.best_cost).any() and ref.refined.any()
+    other = synth.make_config(4, B=B, ego_offset=50000)
     for rep in range(6):
+        if rep % 2 == 0:  # other egos' tables in the ctx's scratch: a search that read its rows too early would walk THOSE
+            _run(engine, other, rep // 2 % 2, None)
         _same(_run(engine, batch, 1, prev), ref, f"B={B} repetition {rep}")
 
 
@@ -61,6 +64,11 @@ def test_fused_search_other_lattice_shape_and_skipped_egos(engine):
     lattice workgroups leave at once and still have to release their search workgroups)."""
     b = synth.make_batch(600, 7, 7, 7, 20, 50, True, 81, kind="FISS+")
     _same(_run(engine, b, 1, None), _run(engine, b, 0, None), "7x7x7")
+    # several rounds of workgroups on the run-time-shape instances (round 5: a VGPR spill the compiler stored under an empty exec mask
+    # gave the second round's workgroups another workgroup's values - only on these instances, only beyond 768 egos)
+    for shape, B in (((7, 7, 7, 20, 50), 769), ((7, 7, 7, 20, 50), 2048), ((9, 9, 7, 50, 40), 1500), ((6, 9, 5, 12, 50), 1000)):
+        b = synth.make_batch(B, *shape, True, 82, kind="FISS+")
+        _same(_run(engine, b, 1, None), _run(engine, b, 0, None), f"{shape} B={B}")
     from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
 
     goal = np.full((600, 2), 1e9)
