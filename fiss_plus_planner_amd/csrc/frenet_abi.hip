@@ -1230,8 +1230,13 @@ int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* bat
     return hs.fetch_out();
 }
 
-int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, int mem,
-                 void* stream_v)
+}  // extern "C"
+
+namespace {
+
+// fp_plan_fiss, and - with `loop` (FP_MEM_DEVICE only) - fp_plan_fiss_step: the pipeline plus the egos' hand-over to their next states.
+int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, const fp_loop_io* loop,
+                   int mem, void* stream_v)
 {
     FP_TRY(common_checks(ctx, params, batch, mem, stream_v));
     if (!opts || !io) return fail(FP_EINVAL, "opts/io is NULL");
@@ -1281,6 +1286,7 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     fp_batch lat_b;     // the batch as the lattice kernel addresses it (byte offsets into inl.bytes when inl.on)
     if (mem == FP_MEM_DEVICE) {
         fa.ka.b = *batch;
+        if (loop) fa.ka.b.skip = loop->done;
         if (!(batch->S > 0 && batch->n_obs > 0)) fa.ka.b.n_obs = 0;
         fa.io = *io;
         if (!trace_doubles) fa.io.trace = nullptr;
@@ -1346,11 +1352,18 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     fa.walk_jump = ctx->fiss_jump;
     if (!search_done) LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
+    bool handed_over = false;
     if (R > 0 && ctx->fiss_stages >= 3) {
         // three refinement workgroups per CU are resident at once (fiss_refine_kernel: 168 VGPRs, ~52 KB LDS)
         const int* rperm; int* rdur;
         FP_TRY(launch_order_before(ctx, ctx->order_refine, ctx->resident_groups / 2 * 3, batch, 1, stream, &rperm, &rdur));
-        LAUNCH_TRY(fp::launch_fiss_refine(fa, stream, ctx->refine_table_kb, rperm, rdur), "refinement kernel");
+        fp::FissArgs fr = fa;
+        if (loop) {  // fp_plan_fiss_step: the refinement workgroup that settles an ego's trajectory hands the ego over itself
+            fr.ka.loop = *loop;
+            fr.ka.has_loop = 1;
+            handed_over = true;
+        }
+        LAUNCH_TRY(fp::launch_fiss_refine(fr, stream, ctx->refine_table_kb, rperm, rdur), "refinement kernel");
         FP_TRY(launch_order_after(ctx->order_refine, batch, rdur, stream));
     }
     if (fa.io.best_traj && R <= 0) {  // with refinement rounds the refinement kernel writes the series itself
@@ -1361,14 +1374,40 @@ int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         kw.r.traj_sparse = fa.io.traj_sparse;
         LAUNCH_TRY(fp::launch_winner_traj(kw, fa.io.end_state, stream), "winner epilogue");
     }
+    if (loop && !handed_over) LAUNCH_TRY(fp::launch_advance(fa.ka, nullptr, fa.io.end_state, *loop, stream), "advance kernel");  // (FISS, or no refinement rounds)
     if (mem != FP_MEM_HOST) return FP_OK;
     FP_TRY(hs.fetch_out());
     if (handover_failed(ctx)) {  // (see fp_plan_dense)
         (void)handover_recover(ctx, ctx->stream);
         if (!prev_in.empty()) memcpy(io->prev_best_idx, prev_in.data(), prev_in.size() * sizeof(int32_t));
-        return fp_plan_fiss(ctx, params, batch, opts, io, mem, stream_v);
+        return plan_fiss_impl(ctx, params, batch, opts, io, loop, mem, stream_v);
     }
     return FP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, int mem,
+                 void* stream_v)
+{
+    return plan_fiss_impl(ctx, params, batch, opts, io, nullptr, mem, stream_v);
+}
+
+int fp_plan_fiss_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io,
+                      const fp_loop_io* loop, int mem, void* stream)
+{
+    if (!loop || !loop->ego || !loop->t_now || !loop->done || !loop->cycles || !loop->goal_xy) return fail(FP_EINVAL, "fp_loop_io has a NULL mandatory array");
+    if (loop->goal_poly && (!loop->goal_nv || loop->goal_max_vertices < 3)) return fail(FP_EINVAL, "fp_loop_io.goal_poly needs goal_nv and goal_max_vertices >= 3");
+    if (mem != FP_MEM_DEVICE) {  // host buffers: the two staged calls (every array travels anyway)
+        if (!batch || !io) return fail(FP_EINVAL, "batch/io is NULL");
+        fp_batch bb = *batch;
+        bb.skip = loop->done;
+        FP_TRY(plan_fiss_impl(ctx, params, &bb, opts, io, nullptr, mem, stream));
+        return fp_advance(ctx, params, batch, nullptr, io->end_state, loop, mem, stream);
+    }
+    return plan_fiss_impl(ctx, params, batch, opts, io, loop, mem, stream);
 }
 
 int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const int32_t* best_idx, const double* end_state,
@@ -1645,10 +1684,7 @@ void group_worker_main(GroupWorker* w)
             case 1: rc = fp_plan_dense(w->ctx, &w->params, &w->batch, &w->result, FP_MEM_DEVICE, w->stream); break;
             case 2: rc = fp_plan_step(w->ctx, &w->params, &w->batch, &w->result, &w->loop, FP_MEM_DEVICE, w->stream); break;
             case 3: rc = fp_plan_fiss(w->ctx, &w->params, &w->batch, &w->fopts, &w->fio, FP_MEM_DEVICE, w->stream); break;
-            case 4:
-                rc = fp_plan_fiss(w->ctx, &w->params, &w->batch, &w->fopts, &w->fio, FP_MEM_DEVICE, w->stream);
-                if (rc == FP_OK) rc = fp_advance(w->ctx, &w->params, &w->batch, nullptr, w->fio.end_state, &w->loop, FP_MEM_DEVICE, w->stream);
-                break;
+            case 4: rc = fp_plan_fiss_step(w->ctx, &w->params, &w->batch, &w->fopts, &w->fio, &w->loop, FP_MEM_DEVICE, w->stream); break;
             default: break;
         }
         for (int i = 0; rc == FP_OK && i < w->n_copies; ++i) {

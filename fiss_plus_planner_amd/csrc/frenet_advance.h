@@ -37,6 +37,8 @@ __device__ __forceinline__ bool in_goal_interval(double v, double lo, double hi)
 
 // best >= 0: lattice candidate (flat FOP index); best < 0 with end_state == nullptr: no solution.  end_state (optional): explicit
 // (d, v, T) of the chosen trajectory (NaN = none), takes precedence.
+__device__ __forceinline__ void advance_ego_to(const KernelArgs& ka, int b, double d_end, double v_end, double T, const fp_loop_io& io);
+
 __device__ __forceinline__ void advance_ego(const KernelArgs& ka, int b, int best, const double* end_state, const fp_loop_io& io)
 {
     if (io.done[b] != FP_RUNNING) return;
@@ -50,6 +52,15 @@ __device__ __forceinline__ void advance_ego(const KernelArgs& ka, int b, int bes
         const int iv = best % p.nv, it = (best / p.nv) % p.nt, id = best / (p.nv * p.nt);
         d_end = bt.d_samples[id]; v_end = bt.v_samples[(size_t)b * p.nv + iv]; T = bt.t_samples[it];
     }
+    advance_ego_to(ka, b, d_end, v_end, T, io);
+}
+
+// The same with the chosen trajectory's end state (d, v, T) in registers (NaN = plan() returned None); the caller has checked nothing.
+__device__ __forceinline__ void advance_ego_to(const KernelArgs& ka, int b, double d_end, double v_end, double T, const fp_loop_io& io)
+{
+    if (io.done[b] != FP_RUNNING) return;
+    const fp_params& p = ka.p;
+    const fp_batch& bt = ka.b;
     if (!(T == T) || !(d_end == d_end) || !(v_end == v_end)) {  // plan() returned None (:131-133)
         io.done[b] = FP_DONE_NO_SOLUTION;
         return;
@@ -65,30 +76,30 @@ __device__ __forceinline__ void advance_ego(const KernelArgs& ka, int b, int bes
     // when point 2 is off the spline (the repeated last heading, :127-129).  Points are evaluated one at a time (few live registers:
     // this runs at the tail of the lattice kernel, whose register budget is the collision stages').
     const int N = arange_len(T, p.tick_t);
-    auto point = [&](int i, double& x, double& y, double* fr) -> bool {  // fr (optional) <- s, s_d, s_dd, d, d_d, d_dd
+    struct Fr { double s, s_d, s_dd, d, d_d, d_dd; };  // (by value: an array reached through a pointer parameter ends up in scratch memory)
+    auto point = [&](int i, double& x, double& y, Fr& fr) -> bool {
         const double t = (double)i * p.tick_t;
-        double sv[4], dv[4];
-        quartic_eval(lon, t, sv[0], sv[1], sv[2], sv[3]);
-        quintic_eval(lat, t, dv[0], dv[1], dv[2], dv[3]);
-        const int seg = (i < N) ? spline_segment(sp, sv[0], -1) : -1;
+        double s3, d3;
+        quartic_eval(lon, t, fr.s, fr.s_d, fr.s_dd, s3);
+        quintic_eval(lat, t, fr.d, fr.d_d, fr.d_dd, d3);
+        const int seg = (i < N) ? spline_segment(sp, fr.s, -1) : -1;
         if (seg < 0) return false;
         double px, py, tx, ty;
-        spline_frame(sp, seg, sv[0] - knots[seg], px, py, tx, ty);
-        frenet_to_cartesian(px, py, tx, ty, dv[0], x, y);
-        if (fr) { fr[0] = sv[0]; fr[1] = sv[1]; fr[2] = sv[2]; fr[3] = dv[0]; fr[4] = dv[1]; fr[5] = dv[2]; }
+        spline_frame(sp, seg, fr.s - knots[seg], px, py, tx, ty);
+        frenet_to_cartesian(px, py, tx, ty, fr.d, x, y);
         return true;
     };
-    double x0, y0, x1, y1, xn, yn, next[6];
+    double x0, y0, x1, y1, xn, yn;
+    Fr next, other;
     // (the first point off the spline truncates the series: point 1 exists only if point 0 does)
-    if (!point(0, x0, y0, nullptr) || !point(1, x1, y1, next)) {  // the reference indexes x[1] of a trajectory that left the spline at once: IndexError -> the run ends
+    if (!point(0, x0, y0, other) || !point(1, x1, y1, next)) {  // the reference indexes x[1] of a trajectory that left the spline at once: IndexError -> the run ends
         io.done[b] = FP_DONE_NO_SOLUTION;
         return;
     }
-    const bool fwd = point(2, xn, yn, nullptr);
+    const bool fwd = point(2, xn, yn, other);
     const double yaw = fwd ? atan2(yn - y1, xn - x1) : atan2(y1 - y0, x1 - x0);
-    const double xs1 = x1, ys1 = y1, s_d1 = next[1];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) eg[m] = next[m];
+    const double xs1 = x1, ys1 = y1, s_d1 = next.s_d;
+    eg[0] = next.s; eg[1] = next.s_d; eg[2] = next.s_dd; eg[3] = next.d; eg[4] = next.d_d; eg[5] = next.d_dd;
     const int cycle = io.t_now[b];  // state.time_step = i (:138)
     io.t_now[b] = cycle + 1;
     io.cycles[b] += 1;

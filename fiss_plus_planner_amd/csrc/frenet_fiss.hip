@@ -22,6 +22,7 @@
 #include "frenet_device.h"
 #include "frenet_kernels.h"
 #include "frenet_winner.h"
+#include "frenet_advance.h"
 
 namespace fp {
 
@@ -842,6 +843,14 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
             const double none = __builtin_nan("");
             if (wave == 0) winner_series_wave(kw, b, b, false, none, none, none, lane, SplineLds{nullptr, nullptr, 0, 0});
         }
+        // fp_plan_fiss_step: the hand-over of an ego without a trajectory (R > 0: with R == 0 this kernel is not launched) - "no solution"
+        if (ka.has_loop && tid == 0 && R > 0) {
+            int off = (int)offsetof(FissArgs, ka);
+            asm volatile("" : "+s"(off) : : "memory");
+            const KernelArgs& kl = *(const KernelArgs*)((const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+            const double none = __builtin_nan("");
+            advance_ego_to(kl, b, none, none, none, kl.loop);
+        }
         return;
     }
     const int f = bt.frame_of[b];
@@ -1108,19 +1117,33 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
 #if defined(FP_RABL) && FP_RABL == 2  // timing ablation: no series
     return;
 #endif
-    if (fa.io.best_traj && wave == 0) {
+    if ((fa.io.best_traj || ka.has_loop) && wave == 0) {
         double fx[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) fx[m] = winner >= 0 ? __shfl(my_x[m], winner, kWave) : coarse_x[m];
-        KernelArgs kw = ka;
-        kw.r.best_traj = fa.io.best_traj;
-        kw.r.best_flags = fa.io.best_flags;
-        kw.r.traj_stride = fa.io.traj_stride;
-        kw.r.traj_sparse = fa.io.traj_sparse;
-        FP_RSTAMP(10);
-        winner_series_wave(kw, b, b, true, fx[0], fx[1], fx[2], lane, SplineLds{L.knots, L.coef, nx, nx});
-        FP_RSTAMP(11);
-        FP_RSTAMP(0);
+        if (fa.io.best_traj) {
+            KernelArgs kw = ka;
+            kw.r.best_traj = fa.io.best_traj;
+            kw.r.best_flags = fa.io.best_flags;
+            kw.r.traj_stride = fa.io.traj_stride;
+            kw.r.traj_sparse = fa.io.traj_sparse;
+            FP_RSTAMP(10);
+            winner_series_wave(kw, b, b, true, fx[0], fx[1], fx[2], lane, SplineLds{L.knots, L.coef, nx, nx});
+            FP_RSTAMP(11);
+            FP_RSTAMP(0);
+        }
+        // fp_plan_fiss_step: the workgroup that settled the ego's trajectory hands the ego over to its next state itself (after the
+        // series, which describe the trajectory from the OLD state; every other wavefront of the workgroup is done with the state,
+        // and no other workgroup reads it) - no advance_kernel launch behind the pipeline
+        // (the hand-over's arguments are re-read from the kernel's argument segment HERE, through a laundered pointer: as ordinary kernel
+        // arguments the compiler loads the loop structure's eleven fields at the kernel's start and holds them - 47 more spilled SGPRs
+        // and, through their lanes, two spilled VGPRs in a kernel that is at its register budget)
+        if (ka.has_loop && lane == 0) {
+            int off = (int)offsetof(FissArgs, ka);
+            asm volatile("" : "+s"(off) : : "memory");  // (an offset the compiler cannot see through: the loads below depend on it and stay here)
+            const KernelArgs& kl = *(const KernelArgs*)((const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+            advance_ego_to(kl, b, fx[0], fx[1], fx[2], kl.loop);
+        }
     }
 }
 

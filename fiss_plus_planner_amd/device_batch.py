@@ -101,6 +101,9 @@ class ClosedLoopRunner:
             self.eng.plan_dense_device(self.db.params, self.db.fb, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
             _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), self.best_idx.data_ptr(), None, C.byref(self.io),
                                       _abi.FP_MEM_DEVICE, stream or None))
+        elif self.fused:  # fp_plan_fiss_step: FISS+ hands the egos over inside its refinement launch, FISS by the advance kernel behind the pipeline
+            _abi.check(lib.fp_plan_fiss_step(ctx, C.byref(self.db.params), C.byref(self.db.fb), C.byref(self.fopts), C.byref(self.fio), C.byref(self.io),
+                                             _abi.FP_MEM_DEVICE, stream or None))
         else:
             self.eng.plan_fiss_device(self.db.params, self.db.fb, self.fopts, self.fio, stream=stream)
             _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), None, self.end_state.data_ptr(), C.byref(self.io),

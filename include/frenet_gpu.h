@@ -389,6 +389,13 @@ int fp_advance(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, cons
 int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, const fp_loop_io* io, int mem,
                  void* stream);
 
+/* fp_plan_fiss_step = one cycle of the same loop with FissPlanner / FissPlusPlanner planning it: fp_plan_fiss followed by the hand-over of
+ * fp_advance (the returned trajectory's end state decides; loop->done is used as batch->skip).  With refinement rounds (FP_FISS_PLUS,
+ * max_refine_iters > 0) the refinement workgroup that settles an ego's trajectory hands the ego over itself - no advance launch behind
+ * the pipeline; otherwise the advance kernel follows.  Identical to fp_plan_fiss + fp_advance in every output. */
+int fp_plan_fiss_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io,
+                      const fp_loop_io* loop, int mem, void* stream);
+
 /* ---- several devices from one host thread ----------------------------------------------------------------------
  * The path shards over independent egos, one shard per GPU, no collective (planning.py:120-162 plans its scenarios one after the
  * other; nothing is exchanged).  An 8-GPU node running 0.15 ms plan steps - or 0.07 ms closed-loop cycles - per device needs
@@ -410,7 +417,7 @@ typedef struct {
  *   result                        fp_plan_dense(ctx, params, batch, result, FP_MEM_DEVICE, stream)
  *   result + loop                 fp_plan_step (..., result, loop, ...)
  *   fiss_opts + fiss_io           fp_plan_fiss (..., fiss_opts, fiss_io, ...)
- *   fiss_opts + fiss_io + loop    fp_plan_fiss, then fp_advance(..., NULL, fiss_io->end_state, loop, ...)
+ *   fiss_opts + fiss_io + loop    fp_plan_fiss_step(..., fiss_opts, fiss_io, loop, ...)
  * params == NULL: nothing for this ctx in this round. */
 typedef struct {
     const fp_params* params;

@@ -140,6 +140,26 @@ def test_plan_step_equals_plan_dense_plus_advance(engine, B, cfg):
         assert np.array_equal(ra.cost, rb.cost, equal_nan=True) and np.array_equal(ra.done, rb.done) and np.array_equal(ra.stats, rb.stats)
 
 
+@pytest.mark.parametrize("planner,B,cfg", [("FISS+", 7, 2), ("FISS+", 300, 4), ("FISS+", 900, 4), ("FISS", 300, 4)])
+def test_plan_fiss_step_equals_plan_fiss_plus_advance(engine, planner, B, cfg):
+    """fp_plan_fiss_step (FISS+: the refinement workgroup that settles an ego's trajectory hands the ego over itself; FISS: the advance
+    kernel behind the pipeline) == fp_plan_fiss + fp_advance, cycle for cycle and bit for bit, incl. egos that run out of solutions."""
+    from fiss_plus_planner_amd.device_batch import ClosedLoopRunner, DeviceBatch
+
+    goal = np.full((B, 2), 1e9)
+    runs = []
+    for fused in (False, True):
+        batch = synth.make_config(cfg, B=B, kind=planner)
+        runs.append(ClosedLoopRunner(engine, DeviceBatch(batch, 0), goal, planner, fused=fused).run(8, trace=True))
+    a, b = runs
+    for k in ("done", "cycles", "t_now"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k), err_msg=k)
+    assert np.array_equal(a.ego, b.ego) and np.array_equal(a.cart, b.cart, equal_nan=True)
+    assert len(a.trace) == len(b.trace) and a.cycles.sum() > B and (a.done != 0).any() == (b.done != 0).any()
+    for ra, rb in zip(a.trace, b.trace):
+        assert np.array_equal(ra.cost, rb.cost, equal_nan=True) and np.array_equal(ra.done, rb.done) and np.array_equal(ra.stats, rb.stats)
+
+
 def test_goal_region_rule_against_the_oracle(oracle, engine):
     """goal_region.is_reached() on the device (fp_loop_io.goal_poly / goal_intervals) against the oracle's exact predicate: every ego
     gets a polygon placed around, beside or exactly ON the position it reaches after one cycle, with and without intervals."""

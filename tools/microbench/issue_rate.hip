@@ -109,6 +109,74 @@ __global__ __launch_bounds__(1024) void k_cndmask(double* out, int n)
     }
     out[OUT_IDX] = (double)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
 }
+// v_cndmask variants: mask in an SGPR pair (e64), and a v_cmp feeding every select (the compiler's usual pairing)
+__global__ __launch_bounds__(1024) void k_cndmask_sgpr(double* out, int n)
+{
+    int a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7, b = 3;
+    unsigned long long m = 0x5555555555555555ull + blockIdx.x;
+    for (int it = 0; it < n; ++it) {
+        REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                          "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "s"(m));)
+    }
+    out[OUT_IDX] = (double)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+__global__ __launch_bounds__(1024) void k_cmp_cndmask(double* out, int n)
+{
+    int a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, b = 3;
+    for (int it = 0; it < n; ++it) {
+        REP8(asm volatile("v_cmp_gt_i32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %4, vcc\n v_cmp_gt_i32 vcc, %1, %4\n v_cndmask_b32 %1, %1, %4, vcc\n"
+                          "v_cmp_gt_i32 vcc, %2, %4\n v_cndmask_b32 %2, %2, %4, vcc\n v_cmp_gt_i32 vcc, %3, %4\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");)
+    }
+    out[OUT_IDX] = (double)(a0 + a1 + a2 + a3);
+}
+__global__ __launch_bounds__(1024) void k_cmp_i32(double* out, int n)
+{
+    int a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, b = 3;
+    for (int it = 0; it < n; ++it) {
+        REP8(asm volatile("v_cmp_gt_i32 vcc, %0, %4\n v_cmp_gt_i32 vcc, %1, %4\n v_cmp_gt_i32 vcc, %2, %4\n v_cmp_gt_i32 vcc, %3, %4\n"
+                          "v_cmp_gt_i32 vcc, %0, %4\n v_cmp_gt_i32 vcc, %1, %4\n v_cmp_gt_i32 vcc, %2, %4\n v_cmp_gt_i32 vcc, %3, %4\n"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");)
+    }
+    out[OUT_IDX] = (double)(a0 + a1 + a2 + a3);
+}
+__global__ __launch_bounds__(1024) void k_readfirstlane(double* out, int n)
+{
+    int a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int it = 0; it < n; ++it) {
+        REP8(asm volatile("v_readfirstlane_b32 %0, %4\n v_readfirstlane_b32 %1, %5\n v_readfirstlane_b32 %2, %6\n v_readfirstlane_b32 %3, %7\n"
+                          "v_readfirstlane_b32 %0, %4\n v_readfirstlane_b32 %1, %5\n v_readfirstlane_b32 %2, %6\n v_readfirstlane_b32 %3, %7\n"
+                          : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));)
+    }
+    out[OUT_IDX] = (double)(s0 + s1 + s2 + s3);
+}
+__global__ __launch_bounds__(1024) void k_bpermute(double* out, int n)
+{
+    int a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, idx = ((threadIdx.x + 1) & 63) * 4;
+    for (int it = 0; it < n; ++it) {
+        REP8(asm volatile("ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n"
+                          "s_waitcnt lgkmcnt(0)\n"
+                          "ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n"
+                          "s_waitcnt lgkmcnt(0)\n"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(idx));)
+    }
+    out[OUT_IDX] = (double)(a0 + a1 + a2 + a3);
+}
+__global__ __launch_bounds__(1024) void k_dpp_mov(double* out, int n)
+{
+    int a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
+    for (int it = 0; it < n; ++it) {
+        REP8(asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                          "v_mov_b32_dpp %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                          "v_mov_b32_dpp %4, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                          "v_mov_b32_dpp %6, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    }
+    out[OUT_IDX] = (double)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+K2(k_min_f64, double, "v_min_f64")
+
 __global__ __launch_bounds__(1024) void k_s_add(double* out, int n)
 {
     int a0 = blockIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
@@ -177,9 +245,10 @@ int main()
                        {"v_fma_f32", k_fma_f32, 64}, {"v_mul_f32", k_mul_f32, 64}, {"v_add_f32", k_add_f32, 64}, {"v_max_f32", k_max_f32, 64}, {"v_cmp_gt_f32", k_cmp_f32, 64},
                        {"v_rcp_f32", k_rcp_f32, 64}, {"v_rsq_f32", k_rsq_f32, 64}, {"v_pk_fma_f32", k_pk_fma_f32, 64}, {"v_pk_mul_f32", k_pk_mul_f32, 64}, {"v_pk_add_f32", k_pk_add_f32, 64},
                        {"v_add_u32", k_add_u32, 64}, {"v_mul_lo_u32", k_mul_lo_u32, 64}, {"v_mul_u32_u24", k_mul_u24, 64}, {"v_mad_u32_u24", k_mad_u24, 64}, {"v_and_b32", k_and_b32, 64},
-                       {"v_lshlrev_b32", k_lshl_b32, 64}, {"v_mov_b32", k_mov_b32, 64}, {"v_cndmask_b32", k_cndmask, 64}, {"s_add_u32", k_s_add, 64},
+                       {"v_lshlrev_b32", k_lshl_b32, 64}, {"v_mov_b32", k_mov_b32, 64}, {"v_cndmask_b32 vcc", k_cndmask, 64}, {"v_cndmask_b32_e64 sgpr mask", k_cndmask_sgpr, 64}, {"v_cmp_gt_i32 + v_cndmask (per pair)", k_cmp_cndmask, 32}, {"v_cmp_gt_i32", k_cmp_i32, 64},
+                       {"v_readfirstlane_b32", k_readfirstlane, 64}, {"ds_bpermute_b32 (4 in flight)", k_bpermute, 64}, {"v_mov_b32_dpp wave_shr:1", k_dpp_mov, 64}, {"v_min_f64", k_min_f64, 64}, {"s_add_u32", k_s_add, 64},
                        {"ds_read_b128", k_ds_read_b128, 64}, {"mix: f64 fma + i32 add + s_add (per triple)", k_mix, 32}, {"v_fma_f64 dependent chain", k_chain_f64, 64}};
-    for (int waves_per_simd : {8, 6, 2, 1}) {
+    for (int waves_per_simd : {8, 4, 1}) {
         printf("---- %d wave(s) per SIMD\n", waves_per_simd);
         // one workgroup per CU: waves_per_simd x 4 wavefronts
         const int blocks = cus, threads = 256 * waves_per_simd > 1024 ? 1024 : 256 * waves_per_simd;
