@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 FP_ABI_VERSION = 13
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
-FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND, FP_MAX_POLY_VERTS = 128, 512, 4096, 128
+FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND, FP_MAX_POLY_VERTS = 128, 1024, 16384, 128
+FP_MAX_CAND_SEARCH = 4096  # device-side FISS / FISS+ walks (fp_plan_fiss)
 FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED = 1, 2, 4, 8
 FLAG_CURVATURE, FLAG_KAPPA_D, FLAG_KAPPA_DD = 16, 32, 64   # optional checks (fp_params.curvature_mask)
 FLAG_CONSTRAINTS = FLAG_SPEED | FLAG_ACCEL | FLAG_CURVATURE | FLAG_KAPPA_D | FLAG_KAPPA_DD

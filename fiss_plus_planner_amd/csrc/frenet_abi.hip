@@ -1242,6 +1242,8 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     if (!opts || !io) return fail(FP_EINVAL, "opts/io is NULL");
     if (opts->kind != FP_FISS && opts->kind != FP_FISS_PLUS) return fail(FP_EINVAL, "opts.kind must be FP_FISS or FP_FISS_PLUS");
     if (opts->max_refine_iters < 0 || opts->max_refine_iters * 7 > 64) return fail(FP_ELIMIT, "max_refine_iters must be in 0..9");
+    if ((long)params->nd * params->nv * params->nt > FP_MAX_CAND_SEARCH)
+        return fail(FP_ELIMIT, "nd*nv*nt = %ld exceeds FP_MAX_CAND_SEARCH (the device-side search walk): use fp_plan_dense's tables and a host walk", (long)params->nd * params->nv * params->nt);
     if (!io->samp_min || !io->samp_max || !io->samp_res || !io->prev_best_idx || !io->best_ijk || !io->best_cost || !io->end_state ||
         !io->refined || !io->stats)
         return fail(FP_EINVAL, "fp_fiss_io has a NULL mandatory array");

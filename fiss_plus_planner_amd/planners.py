@@ -16,7 +16,7 @@ import itertools
 
 import numpy as np
 
-from . import search
+from . import _abi, search
 from .batch import FISS_KINDS, ProblemBatch
 from .engine import TRAJ_STRIDE, FrenetEngine, host_structs, unpack_flags
 from .frenet import FrenetState, FrenetTrajectory
@@ -380,8 +380,15 @@ class FissPlanner(FrenetOptimalPlanner):
         self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], (fl >> 8) & 0xFFF, fl >> 20, best_cost, end, idx)
         return self.best_traj
 
+    def _device_walk(self) -> bool:
+        """One fp_plan_fiss call, unless the caller wants the host walk, the generated set (`all_trajs`: only the host walk knows it) or
+        a lattice beyond the device walk's FP_MAX_CAND_SEARCH samples (the dense pass takes up to FP_MAX_CAND; its tables are then
+        walked on the host)."""
+        st = self.settings
+        return self.search_on == "device" and not self.materialize_all and st.num_width * st.num_speed * st.num_t <= _abi.FP_MAX_CAND_SEARCH
+
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
-        if self.search_on == "device" and not self.materialize_all:  # the generated set is only known to the host walk
+        if self._device_walk():
             return self._plan_on_device(frenet_state, max_target_speed, obstacles, time_step_now)
         batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
         if idx is None:
@@ -400,7 +407,7 @@ class FissPlusPlanner(FissPlanner):
     _search = staticmethod(search.fissplus_search)
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
-        if self.search_on == "device" and not self.materialize_all:
+        if self._device_walk():
             return self._plan_on_device(frenet_state, max_target_speed, obstacles, time_step_now)
         batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
         if idx is None:

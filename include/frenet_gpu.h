@@ -54,8 +54,11 @@ extern "C" {
 
 /* compiled-in limits */
 #define FP_MAX_POINTS 128   /* N = ceil(T / tick_t) per trajectory */
-#define FP_MAX_KNOTS 512    /* reference-line knots per frame */
-#define FP_MAX_CAND 4096    /* nd*nv*nt */
+#define FP_MAX_KNOTS 1024   /* reference-line knots per frame (72 bytes of LDS each in every kernel that walks the line) */
+#define FP_MAX_CAND 16384   /* nd*nv*nt of the dense pass (fp_plan_dense and everything built on its tables) */
+#define FP_MAX_CAND_SEARCH 4096 /* nd*nv*nt of the device-side FISS / FISS+ walks (fp_plan_fiss: rank bit sets of 64 x 64 bits); above
+                                   it FP_ELIMIT - walk the dense tables on the host (fiss_plus_planner_amd/search.py), as the drop-in
+                                   planner classes then do by themselves */
 #define FP_MAX_POLY_VERTS 128 /* vertices of one convex-polygon obstacle column (shapely's buffer() circle has 64) */
 
 /* candidate flag word: low bits = why a candidate is infeasible, then N and M */

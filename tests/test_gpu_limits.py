@@ -66,6 +66,73 @@ def test_largest_lattice(oracle, engine):
     _check_vs_oracle(oracle, engine, batch)
 
 
+def test_lattice_beyond_the_device_walk(oracle, engine):
+    """C = 20 x 20 x 15 = 6000 candidates: beyond the device-side FISS / FISS+ walk (FP_MAX_CAND_SEARCH = 4096; round 4 refused the
+    dense pass too) - the dense pass runs (both kernels, against the oracle), fp_plan_fiss says FP_ELIMIT, and the drop-in planner
+    classes walk the dense tables on the host by themselves."""
+    batch = synth.make_batch(2, 20, 20, 15, 12, 50, True, 78)
+    assert batch.C == 6000 > _abi.FP_MAX_CAND_SEARCH
+    for kernel in (2, 1):
+        engine.set_option("lattice_kernel", kernel)
+        try:
+            _check_vs_oracle(oracle, engine, batch)
+        finally:
+            engine.set_option("lattice_kernel", 0)
+    fb = synth.make_batch(2, 20, 20, 15, 12, 50, True, 78, kind="FISS+")
+    with pytest.raises(_abi.FrenetGpuError, match="FP_MAX_CAND_SEARCH"):
+        engine.plan_fiss(fb, "FISS+")
+    from fiss_plus_planner_amd import planners as P
+    from fiss_plus_planner_amd.vehicle import Vehicle
+
+    pl = P.FissPlusPlanner(P.FissPlusPlannerSettings(20, 20, 15), Vehicle(), None, engine=engine)
+    assert not pl._device_walk()
+    # (the host walk itself is covered by tests/test_host_search.py and tests/test_gpu_planners.py; here: the planner takes that path)
+
+
+def test_reference_line_of_1024_knots(oracle, engine):
+    """FP_MAX_KNOTS = 1024 (round 4: 512): a 1024-point centerline (CubicSpline2D takes any, cubic_spline.py:145-168) through the
+    fused kernel (72 KB of spline tables in LDS: one workgroup per CU), the lane-per-candidate kernel, the winner series, the frame
+    build and from_state - against the oracle."""
+    from conftest import assert_series_close
+    from fiss_plus_planner_amd.spline import build_frames
+
+    base = synth.make_batch(3, 5, 5, 5, 10, 60, True, 79)
+    NX = 1024
+    xs = np.linspace(0.0, 400.0, NX)
+    pts = np.empty((3, NX, 2))
+    for b in range(3):
+        pts[b, :, 0] = xs
+        pts[b, :, 1] = (2.0 + b) * np.sin(xs / (40.0 + 7 * b))
+    knots, coef = build_frames(pts)
+    gk, gc = engine.build_frames(pts)
+    np.testing.assert_allclose(gk, knots, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gc, coef, rtol=0, atol=1e-7)
+    base.knots, base.coef, base.nx = knots, coef, np.full(3, NX, dtype=np.int32)
+    for kernel in (2, 1, 0):
+        engine.set_option("lattice_kernel", kernel)
+        try:
+            out = _check_vs_oracle(oracle, engine, base)
+        finally:
+            engine.set_option("lattice_kernel", 0)
+    w = engine.plan_dense(base, tables=False, winner=True)
+    for e, pr in enumerate(oracle.problems_from_batch(base)):
+        if w.best_idx[e] < 0:
+            continue
+        bi = int(w.best_idx[e])
+        iv, it, i_d = bi % base.nv, (bi // base.nv) % base.nt, bi // (base.nv * base.nt)
+        t = pr.eval_traj(base.d_samples[i_d], base.v_samples[e, iv], base.t_samples[it], dump=True)
+        assert_series_close(w.best_traj[e], t.arrays, base.tick_t, f"ego {e}")
+    assert (w.best_idx >= 0).any()
+    fb = synth.make_batch(3, 5, 5, 5, 10, 60, True, 79, kind="FISS+")
+    fb.knots, fb.coef, fb.nx = knots, coef, np.full(3, NX, dtype=np.int32)
+    f = engine.plan_fiss(fb, "FISS+", winner=True)
+    for e, pr in enumerate(oracle.problems_from_batch(fb)):
+        r = pr.fissplus_plan()
+        np.testing.assert_array_equal(f.stats[e], r.stats)
+        if not np.isnan(r.best_cost):
+            assert abs(f.best_cost[e] - r.best_cost) < 1e-6
+
+
 def test_largest_lattice_fiss_pipeline(oracle, engine):
     """C = 4096 needs 139 KB of LDS in the search kernel (above the 64 KB default dynamic limit)."""
     batch = synth.make_batch(2, 16, 16, 16, 12, 50, True, 76, kind="FISS+")
