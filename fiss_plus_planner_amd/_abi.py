@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 FP_ABI_VERSION = 13
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
-FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND, FP_MAX_POLY_VERTS = 128, 1024, 16384, 128
+FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND, FP_MAX_POLY_VERTS = 256, 1024, 16384, 128
+FP_FAST_POINTS, FP_DEFAULT_STRIDE = 128, 128  # the fast paths' points per trajectory; columns of a series row when traj_stride = 0
 FP_MAX_CAND_SEARCH = 4096  # device-side FISS / FISS+ walks (fp_plan_fiss)
 FLAG_SPEED, FLAG_ACCEL, FLAG_COLLISION, FLAG_TRUNCATED = 1, 2, 4, 8
 FLAG_CURVATURE, FLAG_KAPPA_D, FLAG_KAPPA_DD = 16, 32, 64   # optional checks (fp_params.curvature_mask)
@@ -37,7 +38,7 @@ class FpParams(C.Structure):
                 ("tick_t", C.c_double), ("cost_horizon", C.c_double),
                 ("w_speed", C.c_double), ("w_accel", C.c_double), ("w_jerk", C.c_double), ("w_offset", C.c_double),
                 ("veh_l", C.c_double), ("veh_w", C.c_double), ("max_speed", C.c_double), ("max_accel", C.c_double),
-                ("curvature_mask", C.c_int32), ("reserved0", C.c_int32),
+                ("curvature_mask", C.c_int32), ("points_max", C.c_int32),
                 ("max_curvature", C.c_double), ("max_kappa_d", C.c_double), ("max_kappa_dd", C.c_double)]
 
 

@@ -327,16 +327,17 @@ int check_params(const fp_params* p)
     if ((long)p->nd * p->nv * p->nt > FP_MAX_CAND) return fail(FP_ELIMIT, "nd*nv*nt = %ld exceeds FP_MAX_CAND", (long)p->nd * p->nv * p->nt);
     if (p->check_stride < 1) return fail(FP_EINVAL, "check_stride must be >= 1");
     if (!(p->tick_t > 0)) return fail(FP_EINVAL, "tick_t must be > 0");
+    if (p->points_max < 0 || p->points_max > FP_MAX_POINTS) return fail(FP_ELIMIT, "points_max=%d outside 0..FP_MAX_POINTS", p->points_max);
     if (p->curvature_mask && (!(p->max_curvature >= 0) || !(p->max_kappa_d >= 0) || !(p->max_kappa_dd >= 0)))
         return fail(FP_EINVAL, "curvature_mask is set but max_curvature / max_kappa_d / max_kappa_dd are not all >= 0");
     return FP_OK;
 }
 
-// Series layout of a call: columns per row (0 = FP_MAX_POINTS).  Host calls can check it against the batch's time samples.
+// Series layout of a call: columns per row (0 = FP_DEFAULT_STRIDE).  Host calls can check it against the batch's time samples.
 int traj_stride_of(int32_t requested, int* stride)
 {
     if (requested < 0) return fail(FP_EINVAL, "traj_stride must be >= 0");
-    *stride = requested > 0 ? requested : FP_MAX_POINTS;
+    *stride = requested > 0 ? requested : FP_DEFAULT_STRIDE;
     return FP_OK;
 }
 int check_stride_host(const fp_params* p, const fp_batch* b, int stride)
@@ -346,6 +347,21 @@ int check_stride_host(const fp_params* p, const fp_batch* b, int stride)
             return fail(FP_EINVAL, "traj_stride=%d is smaller than the %g points of t_samples[%d]=%g", stride, ceil(b->t_samples[k] / p->tick_t), k, b->t_samples[k]);
     return FP_OK;
 }
+
+// Points per trajectory of a FP_MEM_HOST call (fp_params.points_max is the device callers' announcement; host calls look themselves):
+// the largest ceil(T / tick_t) over the time samples (+ `extra_T`: explicit end states / refinement bounds of the call), 0 when the
+// fast paths' FP_FAST_POINTS hold it.
+int host_points_max(const fp_params* p, const fp_batch* b, const double* extra_T, size_t n_extra, size_t extra_step)
+{
+    double n = 0.0;
+    for (int k = 0; k < p->nt; ++k) n = fmax(n, ceil(b->t_samples[k] / p->tick_t));
+    for (size_t i = 0; i < n_extra; ++i) {
+        const double v = ceil(extra_T[i * extra_step] / p->tick_t);
+        if (v == v) n = fmax(n, v);
+    }
+    return n > FP_FAST_POINTS ? (n > FP_MAX_POINTS ? FP_MAX_POINTS : (int)n) : 0;
+}
+bool big_points(const fp_params& p) { return p.points_max > FP_FAST_POINTS; }
 
 int check_batch(const fp_batch* b)
 {
@@ -1078,11 +1094,11 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         const int* perm; int* dur;
         FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
         // (the audit pass may move the winner: the series are written after it, by their own launch)
-        const bool inside = winner_inside_lattice(ctx, batch) && !result->audit;
+        const bool inside = winner_inside_lattice(ctx, batch) && !result->audit && !big_points(ka.p);
         if (result->best_traj && !inside) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
         fp::KernelArgs kl = ka;
         if (!inside) kl.r.best_traj = nullptr;
-        if (!inside && !result->audit) offer_epilogue(ctx, ka, &kl, B, (hipStream_t)stream);
+        if (!inside && !result->audit && !big_points(ka.p)) offer_epilogue(ctx, ka, &kl, B, (hipStream_t)stream);
         LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");
         FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
         if (result->audit) LAUNCH_TRY(fp::launch_audit(ka, result->audit, (hipStream_t)stream), "audit kernel");
@@ -1094,6 +1110,8 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     }
     FP_TRY(check_batch_host(params, batch));
     if (result->best_traj) FP_TRY(check_stride_host(params, batch, stride));
+    ka.p.points_max = host_points_max(params, batch, nullptr, 0, 0);
+    const bool big = big_points(ka.p);
     const size_t traj_doubles = result->best_traj ? B * FP_ARR_COUNT * (size_t)stride : 0;
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<int32_t>(B * 4) + 2 * HostStage::need<double>(B) + HostStage::need<int32_t>(B) +
@@ -1102,7 +1120,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
                       /*zero_copy_out=*/B <= 8));
     // (inline inputs need the fused kernel with the winner's series inside it: no other kernel of this call may read the batch)
     fp::InlineIn inl;
-    const bool try_inline = ctx->inline_inputs && B <= 8 && !params->curvature_mask && ctx->lattice_kernel != 1 &&
+    const bool try_inline = ctx->inline_inputs && B <= 8 && !params->curvature_mask && ctx->lattice_kernel != 1 && !big &&
                             (!result->best_traj || winner_inside_lattice(ctx, batch)) && !result->audit && fp::lattice_group_fit(*params, *batch) >= 1;
     FP_TRY(stage_batch(hs, params, batch, &ka.b, try_inline ? &inl : nullptr));
     FP_TRY(hs.flush_in());
@@ -1127,11 +1145,11 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     const int* perm; int* dur;
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
     fp::KernelArgs kl = ka;
-    if (!winner_inside_lattice(ctx, batch) || result->audit) {
+    if (!winner_inside_lattice(ctx, batch) || result->audit || big) {
         kl.r.best_traj = nullptr;
         if (result->best_traj && !result->audit && !inl.on) {
             ka.idx_shadow = kl.idx_shadow = idx_shadow_for(ctx, B, ctx->stream);
-            offer_epilogue(ctx, ka, &kl, B, ctx->stream);
+            if (!big) offer_epilogue(ctx, ka, &kl, B, ctx->stream);
         }
     }
     LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, inl.on ? &inl : nullptr, tail), "lattice kernel");
@@ -1177,6 +1195,7 @@ int fp_winner_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch,
     }
     FP_TRY(check_batch_host(params, batch));
     FP_TRY(check_stride_host(params, batch, stride));
+    ka.p.points_max = host_points_max(params, batch, nullptr, 0, 0);
     const int C = params->nd * params->nv * params->nt;
     for (size_t i = 0; i < B; ++i)
         if (best_idx[i] >= C) return fail(FP_EINVAL, "best_idx[%zu]=%d out of range", i, best_idx[i]);
@@ -1219,6 +1238,7 @@ int fp_materialize_all(fp_ctx* ctx, const fp_params* params, const fp_batch* bat
     }
     FP_TRY(check_batch_host(params, batch));
     FP_TRY(check_stride_host(params, batch, stride));
+    ka.p.points_max = host_points_max(params, batch, nullptr, 0, 0);
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<uint32_t>(BC) + HostStage::need<double>(traj_doubles)));
     FP_TRY(stage_batch(hs, params, batch, &ka.b));
@@ -1294,6 +1314,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
         if (!trace_doubles) fa.io.trace = nullptr;
     } else {
         FP_TRY(check_batch_host(params, batch));
+        fa.ka.p.points_max = host_points_max(params, batch, R > 0 ? io->samp_max + 2 : nullptr, R > 0 ? B : 0, 3);  // (refined trajectories reach T = samp_max)
         if (io->best_traj) {
             for (size_t i = 0; i < B; ++i)  // refined trajectories reach T = samp_max of their ego
                 if (ceil(io->samp_max[3 * i + 2] / params->tick_t) > stride) return fail(FP_EINVAL, "traj_stride=%d is smaller than the points of samp_max[%zu].T=%g", stride, i, io->samp_max[3 * i + 2]);
@@ -1307,7 +1328,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
         // inside the lattice kernel's argument block, which also leaves them in a device mirror for the search and refinement
         // kernels - no copy kernel, no dependency in front of the lattice kernel (a single-ego FISS+ cycle: ~5 us of ~80).
         fa.io = *io;
-        const bool try_inline = ctx->inline_inputs && B <= 8 && !params->curvature_mask && ctx->lattice_kernel != 1 &&
+        const bool try_inline = ctx->inline_inputs && B <= 8 && !params->curvature_mask && ctx->lattice_kernel != 1 && !big_points(fa.ka.p) &&
                                 fp::lattice_group_fit(*params, *batch) >= 1;
         const InlineExtra ex[3] = {{io->samp_min, sizeof(double) * B * 3, (const void**)&fa.io.samp_min},
                                    {io->samp_max, sizeof(double) * B * 3, (const void**)&fa.io.samp_max},
@@ -1331,6 +1352,8 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
         fa.io.best_traj = hs.out(io->best_traj, traj_doubles);
         if (io->traj_sparse && fa.io.best_traj) HIP_TRY(hipMemcpyAsync(fa.io.best_traj, io->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     }
+    if (big_points(fa.ka.p) && R > 0)
+        return fail(FP_ELIMIT, "FISS+ refinement holds trajectories of at most FP_FAST_POINTS = %d points (this call: up to %d): refine on the host over fp_eval_trajs", FP_FAST_POINTS, fa.ka.p.points_max);
     FP_TRY(lattice_curv_scratch(ctx, params, batch, stream, &fa.ka.curv_tbl));
     int nsplit, group, tail; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group, &tail));
@@ -1493,7 +1516,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
     // the hand-over rides in the lattice launch unless that launch cannot write the series it is asked for itself (the standalone
     // epilogue reads the ego's state, so it has to run BEFORE the state moves on) or the lane-per-candidate kernel is asked for
-    const bool series_elsewhere = result->best_traj && !winner_inside_lattice(ctx, batch);
+    const bool series_elsewhere = result->best_traj && (!winner_inside_lattice(ctx, batch) || big_points(ka.p));
     bool try_fused = !series_elsewhere && ctx->lattice_kernel != 1, launched = false, fused = false;
     bool winner_done = false;
     if (try_fused) {
@@ -1608,6 +1631,7 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
         if (!(n > 0) || n > FP_MAX_POINTS) return fail(FP_ELIMIT, "end_states[%zu].T=%g needs 1..FP_MAX_POINTS points", i, end_states[3 * i + 2]);
         if (traj && ceil(n) > stride) return fail(FP_EINVAL, "traj_stride=%d is smaller than the %g points of end_states[%zu].T=%g", stride, ceil(n), i, end_states[3 * i + 2]);
     }
+    ka.p.points_max = host_points_max(params, batch, end_states + 2, BK, 3);
     const size_t traj_doubles = traj ? BK * FP_ARR_COUNT * (size_t)stride : 0;
     HostStage hs(ctx);
     FP_TRY(hs.reserve(batch_need(params, batch) + HostStage::need<double>(BK * 3) + HostStage::need<double>(BK) + HostStage::need<uint32_t>(BK) +

@@ -17,6 +17,15 @@
 
 namespace fp {
 
+// Points per trajectory this call is sized for: fp_params.points_max when the caller announced more than the fast paths' 128 (FP_MEM_HOST
+// calls: worked out by the library), else FP_FAST_POINTS.  A trajectory that needs more is reported as NaN cost + infeasible by every
+// kernel (include/frenet_gpu.h).
+__host__ __device__ inline int points_cap(const fp_params& p)
+{
+    return p.points_max > FP_FAST_POINTS ? (p.points_max < FP_MAX_POINTS ? p.points_max : FP_MAX_POINTS) : FP_FAST_POINTS;
+}
+
+
 constexpr int kWave = 64;
 
 // ---------------------------------------------------------------------------

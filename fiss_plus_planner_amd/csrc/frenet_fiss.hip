@@ -476,13 +476,13 @@ constexpr int kQueue = 5 * kWave;  // survivor queue entries per wavefront (refi
 constexpr int kHot = 12;           // remembered collision pairs per ego; each is tried with its 2 time steps either side: 5 kHot <= kWave lanes
 
 struct RefineLds {
-    double* S;      // [FP_MAX_POINTS + 1][11]
-    double2* xy;    // [FP_MAX_POINTS]
+    double* S;      // [FP_FAST_POINTS + 1][11]
+    double2* xy;    // [FP_FAST_POINTS]
     double* knots;  // [nx]
     double* coef;   // [8][nx]
     // conservative fp32 broad phase, staged once per ego (nullptr: table over the LDS budget, pairs are read from the scene table)
     float4* pt;     // [rows][n_obs] {x - ox, y - oy, (padded bounding-circle sum)^2 or -1 when absent, (step | obstacle << 8) as int bits}
-    float2* xyf;    // [FP_MAX_POINTS] this wavefront's poses relative to (ox, oy), fp32
+    float2* xyf;    // [FP_FAST_POINTS] this wavefront's poses relative to (ox, oy), fp32
     uint16_t* queue;  // [kQueue] this wavefront's broad-phase survivors (pair table indices)
     // pairs (pair table indices) at which earlier trajectories of this ego collided: the refined trajectories are neighbours in end
     // state space, so the next one most likely collides at the same obstacle a step or two away - tried first (kHot entries + count)
@@ -495,7 +495,7 @@ __device__ __forceinline__ double analytic_cost(const fp_params& p, const double
 {
     const double T = x[2];
     const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
-    if (N <= 0 || N > FP_MAX_POINTS) return __builtin_nan("");
+    if (N <= 0 || N > FP_FAST_POINTS) return __builtin_nan("");
     const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], x[1], 0.0, T);
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
     double S[11], ls[3], ds[3];
@@ -515,7 +515,7 @@ __device__ __forceinline__ double analytic_cost_two_lanes(const fp_params& p, co
 {
     const double T = x[2];
     const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
-    const bool ok = N > 0 && N <= FP_MAX_POINTS;
+    const bool ok = N > 0 && N <= FP_FAST_POINTS;
     double S[11], part[3] = {0.0, 0.0, 0.0};
     if (ok) {
         power_sums_closed(N, p.tick_t, S);
@@ -594,7 +594,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     const double seg_scale = (double)(nx - 1) / (knot_last - knot0);  // (NaN / inf / <= 0: spline_segment divides per point instead)
     unsigned long long off_lo = 0, off_hi = 0;
     bool bad_speed = false, bad_accel = false;
-    const int need_xy = p.curvature_mask ? FP_MAX_POINTS : ((L.scene >= 0 && bt.n_obs > 0) ? L.horizon_cap : -1);
+    const int need_xy = p.curvature_mask ? FP_FAST_POINTS : ((L.scene >= 0 && bt.n_obs > 0) ? L.horizon_cap : -1);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int i = lane + half * kWave;
@@ -799,7 +799,7 @@ constexpr int kRefineWaves = 4;  // trajectories validated speculatively side by
 //   kRefineWaves x (fp64 poses, fp32 relative poses) | knots + coef (9 NX, padded even)
 //   | pair table (float4 per entry) | verdicts (32 B) | kRefineWaves survivor queues
 constexpr int kRefineS = 0;  // (round 2 kept a table S[N][k] of power sums here: 11 KB that cost the fourth workgroup per CU)
-__host__ __device__ constexpr int refine_spline_off() { return kRefineS + 3 * FP_MAX_POINTS * kRefineWaves; }
+__host__ __device__ constexpr int refine_spline_off() { return kRefineS + 3 * FP_FAST_POINTS * kRefineWaves; }
 __host__ __device__ constexpr int refine_pt_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
 __host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
 {
@@ -858,8 +858,8 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 2 * kQueue - 4 * (kHot + 4);
     RefineLds L;
     L.S = (double*)smem;
-    L.xy = (double2*)(L.S + kRefineS) + wave * FP_MAX_POINTS;  // one Cartesian scratch row per wavefront
-    L.xyf = (float2*)(L.S + kRefineS + 2 * FP_MAX_POINTS * kRefineWaves) + wave * FP_MAX_POINTS;
+    L.xy = (double2*)(L.S + kRefineS) + wave * FP_FAST_POINTS;  // one Cartesian scratch row per wavefront
+    L.xyf = (float2*)(L.S + kRefineS + 2 * FP_FAST_POINTS * kRefineWaves) + wave * FP_FAST_POINTS;
     L.knots = L.S + refine_spline_off();
     L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * kQueue;
     L.hot = (int*)(smem + verdict_off + 32 + kRefineWaves * 2 * kQueue);  // [kHot] pairs + [1] count
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     int pt_rows = 0;
     if (sc0 >= 0 && bt.n_obs > 0 && pt_rows_max > 0) {
         int h = L.horizon_cap;
-        if (h > FP_MAX_POINTS) h = FP_MAX_POINTS;
+        if (h > FP_FAST_POINTS) h = FP_FAST_POINTS;
         if (h > bt.T_obs - L.t_now) h = bt.T_obs - L.t_now;
         pt_rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;  // <= pt_rows_max by construction
         L.pt = (float4*)(L.S + refine_pt_off(bt.NX));
@@ -1153,7 +1153,7 @@ hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_
     int pt_rows = 0;
     if (fa.ka.b.n_obs > 0) {
         const int stride = fa.ka.p.check_stride;
-        int rows = (FP_MAX_POINTS + stride - 1) / stride;
+        int rows = (FP_FAST_POINTS + stride - 1) / stride;
         const int rows_tab = (fa.ka.b.T_obs + stride - 1) / stride;
         if (rows_tab < rows) rows = rows_tab;
         if (fa.ka.b.n_obs < (1 << 23) && (long)rows * fa.ka.b.n_obs * 16 <= (long)table_kb * 1024) pt_rows = rows;

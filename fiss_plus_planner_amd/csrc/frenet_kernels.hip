@@ -82,7 +82,7 @@ __device__ void stage_ego(const KernelArgs& ka, int b, double* lds, EgoCtx& e, i
         const int n = e.n_obs;
         e.horizon_cap = bt.final_time_step[sc] - e.t_now;
         const int stride = ka.p.check_stride;
-        int hmax = e.horizon_cap < FP_MAX_POINTS ? e.horizon_cap : FP_MAX_POINTS;
+        int hmax = e.horizon_cap < points_cap(ka.p) ? e.horizon_cap : points_cap(ka.p);
         if (hmax < 0) hmax = 0;
         int rows = (hmax + stride - 1) / stride;  // poses 0, stride, 2*stride, ... < hmax
         // rows past the end of the table hold no state at all: do not stage them
@@ -170,7 +170,7 @@ __device__ TrajOut traj_eval(const KernelArgs& ka, const EgoCtx& e, double d_end
     const fp_params& p = ka.p;
     const int N = arange_len(T_end, p.tick_t);
     TrajOut out;
-    if (N <= 0 || N > FP_MAX_POINTS || (DUMP && N > stride_d)) {  // (a dump row holds stride_d points)
+    if (N <= 0 || N > points_cap(p) || (DUMP && N > stride_d)) {  // (a dump row holds stride_d points)
         out.cost = __builtin_nan("");
         out.flags = FP_FLAG_SPEED | FP_FLAG_ACCEL | FP_FLAG_COLLISION;  // "no trajectory"
         return out;
@@ -359,7 +359,7 @@ __device__ double candidate_min_gap(const KernelArgs& ka, const EgoCtx& e, doubl
 {
     const fp_params& p = ka.p;
     const int N = arange_len(T_end, p.tick_t);
-    if (N <= 0 || N > FP_MAX_POINTS || e.n_obs <= 0) return __builtin_inf();
+    if (N <= 0 || N > points_cap(ka.p) || e.n_obs <= 0) return __builtin_inf();
     const Quintic lat = quintic_bvp(e.d0, e.d_d0, e.d_dd0, d_end, 0.0, 0.0, T_end);
     const Quartic lon = quartic_bvp(e.s0, e.s_d0, e.s_dd0, v_end, 0.0, T_end);
     int seg = -1, M = N;
@@ -505,7 +505,7 @@ __global__ void curvature_flags_kernel(KernelArgs ka, uint8_t* out)
         const double T = bt.t_samples[it];
         const int N = arange_len(T, p.tick_t);
         uint32_t fl = 0;
-        if (N > 0 && N <= FP_MAX_POINTS) {
+        if (N > 0 && N <= points_cap(p)) {
             const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], bt.d_samples[id], 0.0, 0.0, T);
             const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], vs[iv], 0.0, T);
             fl = curvature_flags(p, sp, lon, lat, N);
@@ -592,6 +592,12 @@ __global__ __launch_bounds__(kWave * kWinnerWaves, ALL ? FP_WINNER_OCC : 1) void
     double* my = (double*)wt_smem + (size_t)((int)threadIdx.x / kWave) * 9 * NX;
     const double* gk = bt.knots + (size_t)f * NX;
     const double* gc = bt.coef + (size_t)f * 8 * NX;
+    // more points than the one-chunk writer holds (tick_t < 0.08 s at T = 10 s): the chunked writer, straight from global memory
+    const int n_pts = (best >= 0 && T == T) ? arange_len(T, p.tick_t) : 0;
+    if (n_pts > kSeriesChunk && n_pts <= points_cap(p) && (d_end == d_end) && (v_end == v_end)) {
+        winner_series_wave_long(ka, b, slot, d_end, v_end, T, lane, SplineLds{gk, gc, bt.nx[f], NX});
+        return;
+    }
     if (!spline_in_lds) {  // (a reference line too long for four LDS copies: the tables stay where they are)
         winner_series_wave(ka, b, slot, best >= 0, d_end, v_end, T, lane, SplineLds{gk, gc, bt.nx[f], NX});
         return;
@@ -676,7 +682,7 @@ hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
     const int C = ka.p.nd * ka.p.nv * ka.p.nt;
     const unsigned n = (unsigned)ka.b.B * (unsigned)C;
 #if !defined(FP_MAT_PER_CANDIDATE)
-    {
+    if (points_cap(ka.p) <= FP_FAST_POINTS) {  // (trajectories of more than 128 points: the per-candidate kernel and its chunked writer)
         const unsigned n_tasks = (unsigned)ka.b.B * (unsigned)(ka.p.nt * ka.p.nv);
         const int lds = winner_lds_bytes(ka, true);
         const unsigned n_wg = (n_tasks + kWinnerWaves - 1) / kWinnerWaves, unit = 8 * kMatXcdRun;
@@ -690,7 +696,7 @@ hipError_t launch_materialize_all(const KernelArgs& ka, hipStream_t stream)
 
 static int ego_lds_bytes(const fp_params& p, const fp_batch& b, int max_bytes, int* lds_doubles)
 {
-    int hmax = FP_MAX_POINTS;
+    int hmax = points_cap(p);
     const int rows = (hmax + p.check_stride - 1) / p.check_stride;
     const long base = (long)b.NX * 9 + (long)b.n_obs * 4;
     long full = base + (long)rows * b.n_obs * 4;

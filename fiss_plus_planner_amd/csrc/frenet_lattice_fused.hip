@@ -254,11 +254,11 @@ __device__ __forceinline__ int lut_segment(const double* knots, const unsigned s
 // an ego costs 4 intervals instead of 4 nt and needs no split over workgroups (no ticket, no merge).
 // NTH: threads per workgroup, 512 or - the grouped latency instances, one workgroup per CU - 1024 (twice the wavefronts per pass).
 // the kernel's parameters as one struct: where InlineIn::bytes sits in the argument segment
-// LDS of an epilogue workgroup (kThreads / 128 trajectories): [4][FP_MAX_POINTS] doubles of difference-chain scratch per trajectory,
+// LDS of an epilogue workgroup (kThreads / 128 trajectories): [4][FP_FAST_POINTS] doubles of difference-chain scratch per trajectory,
 // {first point off the spline} x 2, the argmin and the "had to wait" flag per trajectory; then, for reference lines of at most
 // kEpiSplineNX knots, room for one spline copy per trajectory
 constexpr int kEpiPairsC = 512 / (2 * kWave);
-constexpr int kEpiLdsBytes = kEpiPairsC * 4 * FP_MAX_POINTS * 8 + kEpiPairsC * 4 * 4 + 16;
+constexpr int kEpiLdsBytes = kEpiPairsC * 4 * FP_FAST_POINTS * 8 + kEpiPairsC * 4 * 4 + 16;
 constexpr int kEpiSplineNX = 96;
 struct LatticeKernarg {
     KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from, epi_from; FissTail ft; InlineIn inl;
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if (epi_from >= 0 && (int)blockIdx.x >= epi_from) {
             extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
             constexpr int kPairs = NTH / (2 * kWave);  // trajectories per workgroup
-            double* scratch = (double*)esm;                         // [kPairs][4][FP_MAX_POINTS]
-            int* s_m = (int*)(esm + kPairs * 4 * FP_MAX_POINTS * 8);  // [kPairs][2] first point off the spline per wavefront
+            double* scratch = (double*)esm;                         // [kPairs][4][FP_FAST_POINTS]
+            int* s_m = (int*)(esm + kPairs * 4 * FP_FAST_POINTS * 8);  // [kPairs][2] first point off the spline per wavefront
             int* s_idx = s_m + 2 * kPairs;                           // [kPairs] the egos' argmins
             const int pair = (int)threadIdx.x / (2 * kWave), i = (int)threadIdx.x - pair * 2 * kWave;
             const int eslot = ((int)blockIdx.x - epi_from) * kPairs + pair;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             }
             // (a pair beyond the batch still runs the barriers; it writes nothing)
             const SplineLds sp = in_lds ? SplineLds{s_spl, s_spl + bb.NX, bb.nx[ef], bb.NX} : SplineLds{gk, gc, bb.nx[ef], bb.NX};
-            winner_series_pair(ka, eb, eb, win >= 0, d_end, v_end, T_end, i, sp, scratch + pair * 4 * FP_MAX_POINTS, s_m + 2 * pair, handed);
+            winner_series_pair(ka, eb, eb, win >= 0, d_end, v_end, T_end, i, sp, scratch + pair * 4 * FP_FAST_POINTS, s_m + 2 * pair, handed);
             return;
         }
     }
@@ -417,9 +417,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // Timing diagnostic (tools/phase_stamps.py, -DFP_PHASE_STAMPS): thread 0 leaves the time since the workgroup started (10 ns
     // ticks) at the phase boundaries in columns 112.. of the last row of its best_traj block (free with traj_stride = 128, sparse, T <= 11 s).
 #if defined(FP_PHASE_STAMPS)
-#define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x / nsplit) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
+#define FP_STAMP(k) do { if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)(perm ? perm[blockIdx.x] : blockIdx.x / nsplit) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
 // (the one workgroup of an ego that is left after the ticket - whichever part it is - stamps columns 5, 6 and 10)
-#define FP_STAMP_LAST(k) do { if (threadIdx.x == 0 && ka.r.best_traj) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
+#define FP_STAMP_LAST(k) do { if (threadIdx.x == 0 && ka.r.best_traj) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112 + (k)] = (double)(wall_clock64() - t_begin); } while (0)
 #else
 #define FP_STAMP(k) do { } while (0)
 #define FP_STAMP_LAST(k) do { } while (0)
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     int rows = 0;         // obstacle rows the collision horizon can touch: rows of the table below final_time_step
     if (n_obs > 0) {
         horizon_cap = fts - t_now;
-        int h = horizon_cap < FP_MAX_POINTS ? horizon_cap : FP_MAX_POINTS;
+        int h = horizon_cap < points_cap(p) ? horizon_cap : points_cap(p);
         if (h < 0) h = 0;
         rows = (h + stride - 1) / stride;
         if (rows_stage < rows) rows = rows_stage;
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                     __syncthreads();
 #if defined(FP_PHASE_STAMPS)
                     if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) {
-                        double* row = ka.r.best_traj + ((size_t)(perm ? perm[blockIdx.x] : blockIdx.x / nsplit) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112;
+                        double* row = ka.r.best_traj + ((size_t)(perm ? perm[blockIdx.x] : blockIdx.x / nsplit) * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112;
                         row[11] = (double)s_walk_t[0]; row[12] = (double)s_walk_t[1];
                     }
 #endif
@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     FP_STAMP(8);
 #if defined(FP_COUNTERS)
     __syncthreads();
-    if (tid < 16 && ka.r.best_traj) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 14) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + tid] = (double)s_dbg[tid];
+    if (tid < 16 && ka.r.best_traj) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 14) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112 + tid] = (double)s_dbg[tid];
 #endif
     // ---------------------------------------------------------------- per-candidate assembly + argmin
     Best mine{0.0, -1};
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if (ka.curv_tbl) flags |= ka.curv_tbl[(size_t)b * C + c];  // optional curvature checks, computed by curvature_flags_kernel
         double cost = combine_cost(p, N, ls, ds);  // cost_function.py:41-50, same grouping as the reference
         uint32_t word = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
-        if (N <= 0 || N > FP_MAX_POINTS) {  // a time sample the ABI's limits exclude (unvalidated in FP_MEM_DEVICE mode): no trajectory,
+        if (N <= 0 || N > points_cap(p)) {  // a time sample the ABI's limits exclude (unvalidated in FP_MEM_DEVICE mode): no trajectory,
             cost = __builtin_nan("");        // exactly what the lane-per-candidate kernel reports (traj_eval)
             word = flags = FP_FLAG_SPEED | FP_FLAG_ACCEL | FP_FLAG_COLLISION;
         }
@@ -1601,7 +1601,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     if (tid == 0 && dur && (nsplit == 1 || in_tail)) dur[b] = (int)(wall_clock64() - t_begin) * nsplit;
     if (nsplit > 1) FP_STAMP_LAST(10); else FP_STAMP(10);
 #if defined(FP_PHASE_STAMPS)  // column 15: the workgroup's absolute start (10 ns ticks, low 40 bits) - the launch's occupancy over time
-    if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_MAX_POINTS) + 112 + 15] = (double)(t_begin & 0xFFFFFFFFFFll);
+    if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112 + 15] = (double)(t_begin & 0xFFFFFFFFFFll);
 #endif
     // ---------------------------------------------------------------- winner epilogue (what plan() returns), on request
     // The workgroup that found the argmin writes its series itself: no second launch, no re-staging of the ego's tables, and the
@@ -1645,11 +1645,11 @@ static bool fused_shape(const fp_params& p, const fp_batch& b, int* rows_out, in
     const int stride = p.check_stride;
     int rows = 0, hp = 0;
     if (b.n_obs > 0) {
-        rows = (FP_MAX_POINTS + stride - 1) / stride;
+        rows = (points_cap(p) + stride - 1) / stride;
         const int rows_tab = (b.T_obs + stride - 1) / stride;
         if (rows_tab < rows) rows = rows_tab;
         hp = rows * stride + 1;
-        if (hp > FP_MAX_POINTS) hp = FP_MAX_POINTS;
+        if (hp > points_cap(p)) hp = points_cap(p);
         if (rows > 4095 || (long)rows * b.n_obs > 65535) return false;
     }
     *rows_out = rows;

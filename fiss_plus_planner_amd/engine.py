@@ -20,7 +20,7 @@ import numpy as np
 from . import _abi
 from .batch import ProblemBatch
 
-TRAJ_STRIDE = _abi.FP_MAX_POINTS
+TRAJ_STRIDE = _abi.FP_DEFAULT_STRIDE
 
 # CostFunction("WX1") weights, reference common/cost/cost_function.py:6-12 (w_T and w_D are unused there)
 COST_WX1 = dict(cost_horizon=10.0, w_speed=1.0, w_accel=0.1, w_jerk=0.1, w_offset=10.0)
@@ -31,7 +31,7 @@ def make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
     every scalar it is built from."""
     lim0 = getattr(batch, "curvature_limits", None)
     key = (nd or batch.nd, nv or batch.nv, nt or batch.nt, batch.check_stride, batch.tick_t, batch.veh_l, batch.veh_w, batch.max_speed, batch.max_accel,
-           None if lim0 is None else tuple(lim0))
+           None if lim0 is None else tuple(lim0), id(batch.t_samples), id(getattr(batch, "samp_max", None)))  # (the arrays points_max is read from)
     cached = getattr(batch, "__dict__", {}).get("_fp_cache")
     if cached is not None and cached[0] == key:
         return _abi.FpParams.from_buffer_copy(cached[1])  # a copy: callers may edit their struct
@@ -48,6 +48,12 @@ def _make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
     p.tick_t = float(batch.tick_t)
     p.cost_horizon, p.w_speed, p.w_accel, p.w_jerk, p.w_offset = (COST_WX1[k] for k in ("cost_horizon", "w_speed", "w_accel", "w_jerk", "w_offset"))
     p.veh_l, p.veh_w, p.max_speed, p.max_accel = float(batch.veh_l), float(batch.veh_w), float(batch.max_speed), float(batch.max_accel)
+    # fp_params.points_max: what a FP_MEM_DEVICE call cannot see for itself - the points per trajectory (> 128: tick_t below 0.08 s)
+    t_max = float(np.max(batch.t_samples)) if len(batch.t_samples) else 0.0
+    if getattr(batch, "samp_max", None) is not None and len(batch.samp_max):
+        t_max = max(t_max, float(np.nanmax(batch.samp_max[:, 2])))
+    n_pts = int(np.ceil(t_max / float(batch.tick_t))) if t_max > 0 else 0
+    p.points_max = min(n_pts, _abi.FP_MAX_POINTS) if n_pts > _abi.FP_FAST_POINTS else 0
     lim = getattr(batch, "curvature_limits", None)
     if lim is not None:  # optional checks of check_constraints (reference :145-150, commented out there)
         p.curvature_mask = 1

@@ -223,10 +223,17 @@ class FrenetOptimalPlanner:
         batch.t_now[0] = time_step_now
         return batch
 
+    def _stride(self) -> int:
+        """Columns of a series row: 128 as long as max_t / tick_t fits (the ABI's default), else the next multiple of 16 (tick_t = 0.05:
+        200 points -> 208)."""
+        st = self.settings
+        n = int(np.ceil(st.max_t / st.tick_t))
+        return TRAJ_STRIDE if n <= TRAJ_STRIDE else (n + 15) // 16 * 16
+
     def _materialize(self, batch: ProblemBatch, end_states: np.ndarray, idxs=None):
         """end_states [K,3] -> list of FrenetTrajectory (full series from the GPU dump)."""
         es = np.asarray(end_states, dtype=np.float64).reshape(1, -1, 3)
-        out = self._engine.eval_trajs(batch, es, dump=True)
+        out = self._engine.eval_trajs(batch, es, dump=True, traj_stride=self._stride())
         _, N, M = unpack_flags(out.flags[0])
         trajs = []
         for k in range(es.shape[1]):
@@ -243,15 +250,16 @@ class FrenetOptimalPlanner:
     def _dense(self, batch: ProblemBatch, winner: bool = False):
         # the output arrays (and the fp_result over them) are allocated once per planner and reused every cycle; what outlives
         # the call is copied out of them (last_tables here, the winner's series in FrenetTrajectory.from_dump)
-        key = (batch.C, winner)
+        stride = self._stride()
+        key = (batch.C, winner, stride)
         outs = self.__dict__.setdefault("_dense_outs", {})
         reuse = outs.get(key)
         if reuse is None:
-            reuse = outs[key] = self._engine.dense_outputs(1, batch.C, True, winner)
-        out = self._engine.plan_dense(batch, tables=True, winner=winner, out=reuse)
+            reuse = outs[key] = self._engine.dense_outputs(1, batch.C, True, winner, stride)
+        out = self._engine.plan_dense(batch, tables=True, winner=winner, traj_stride=stride, out=reuse)
         self.last_tables = (out.cost[0].copy(), out.flags[0].copy())
         if self.materialize_all:  # visualisation payload (reference :102): every candidate's series in one launch
-            m = self._engine.materialize_all(batch)
+            m = self._engine.materialize_all(batch, traj_stride=stride)
             _, N, M = unpack_flags(m.flags[0])
             self.all_trajs.append([FrenetTrajectory.from_dump(m.traj[0, c], int(N[c]), int(M[c]), float(out.cost[0, c]))
                                    for c in range(batch.C)])
@@ -358,11 +366,12 @@ class FissPlanner(FrenetOptimalPlanner):
         R = st.max_refine_iters if (plus and st.refine_trajectory) else 0
         prev = None if self.prev_best_idx is None else np.asarray(self.prev_best_idx, dtype=np.int32)[None]
         outs = self.__dict__.setdefault("_fiss_outs", {})  # output arrays (+ the fp_fiss_io over them) reused every cycle
-        reuse = outs.get(R)
+        stride = self._stride()
+        reuse = outs.get((R, stride))
         if reuse is None:
-            reuse = outs[R] = self._engine.fiss_outputs(1, R, True)
+            reuse = outs[(R, stride)] = self._engine.fiss_outputs(1, R, True, traj_stride=stride)
         out = self._engine.plan_fiss(batch, self.KIND, prev_best_idx=prev, w_heuristic=st.w_heuristic, max_refine_iters=R,
-                                     decaying_factor=getattr(st, "decaying_factor", 0.5), winner=True, out=reuse)
+                                     decaying_factor=getattr(st, "decaying_factor", 0.5), winner=True, traj_stride=stride, out=reuse)
         # (plain Python scalars from here on: every numpy call on a one-element array costs about a microsecond of the plan cycle)
         self.stats = Stats(*out.stats[0].tolist())
         self.all_trajs.append([])
@@ -385,6 +394,9 @@ class FissPlanner(FrenetOptimalPlanner):
         a lattice beyond the device walk's FP_MAX_CAND_SEARCH samples (the dense pass takes up to FP_MAX_CAND; its tables are then
         walked on the host)."""
         st = self.settings
+        refines = self.KIND == "FISS+" and getattr(st, "refine_trajectory", False) and getattr(st, "max_refine_iters", 0) > 0
+        if refines and np.ceil(st.max_t / st.tick_t) > _abi.FP_FAST_POINTS:  # (the device refinement holds 128 points per trajectory)
+            return False
         return self.search_on == "device" and not self.materialize_all and st.num_width * st.num_speed * st.num_t <= _abi.FP_MAX_CAND_SEARCH
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):

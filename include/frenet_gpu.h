@@ -53,7 +53,13 @@ extern "C" {
 #define FP_MEM_DEVICE 1
 
 /* compiled-in limits */
-#define FP_MAX_POINTS 128   /* N = ceil(T / tick_t) per trajectory */
+#define FP_MAX_POINTS 256   /* N = ceil(T / tick_t) per trajectory (T = 10 s at tick_t = 0.05 s: 200).  Up to FP_FAST_POINTS every
+                               kernel runs its two-points-per-lane fast path; beyond it the series come from a chunked writer, the
+                               epilogue workgroups and the per-profile materialiser give way to winner_traj_kernel, and the FISS+
+                               refinement (fp_plan_fiss with FP_FISS_PLUS and max_refine_iters > 0) answers FP_ELIMIT - refine on the
+                               host over fp_eval_trajs, as the drop-in FissPlusPlanner then does */
+#define FP_FAST_POINTS 128
+#define FP_DEFAULT_STRIDE 128 /* columns of a series row when traj_stride = 0 */
 #define FP_MAX_KNOTS 1024   /* reference-line knots per frame (72 bytes of LDS each in every kernel that walks the line) */
 #define FP_MAX_CAND 16384   /* nd*nv*nt of the dense pass (fp_plan_dense and everything built on its tables) */
 #define FP_MAX_CAND_SEARCH 4096 /* nd*nv*nt of the device-side FISS / FISS+ walks (fp_plan_fiss: rank bit sets of 64 x 64 bits); above
@@ -100,7 +106,11 @@ typedef struct {
      * |c_dd| > max_kappa_dd (c = diff(yaw)/ds, c_d = diff(c)/tick_t, c_dd = diff(c_d)/tick_t, :131-134) fails the constraints
      * like a speed / acceleration violation does.  Limits: Vehicle.max_curvature / max_kappa_d / max_kappa_dd (vehicle.py:44-46). */
     int32_t curvature_mask;
-    int32_t reserved0;
+    /* FP_MEM_DEVICE calls only (FP_MEM_HOST calls look at t_samples / samp_max themselves): an upper bound of the points per trajectory,
+     * ceil(T / tick_t) over every time sample the call can generate.  0 = at most FP_FAST_POINTS (128); a caller whose batch needs
+     * more says so here (<= FP_MAX_POINTS) and gets the kernels that can do it.  A device batch that needs more points than announced
+     * yields NaN cost + FP_FLAG_INFEASIBLE for those candidates, as beyond FP_MAX_POINTS. */
+    int32_t points_max;
     double max_curvature, max_kappa_d, max_kappa_dd;
 } fp_params;
 
@@ -169,7 +179,7 @@ typedef struct {
     uint32_t* audit;     /* NULL or [B]: how thin the margins under this ego's answer are (FP_AUDIT_* bits, see below).  Asking for it
                             adds a pass over the ego's tables (one more launch) and, where FP_AUDIT_NEAR_TIE is found, settles the
                             choice among the tied candidates by the reference's own point-by-point sums. */
-    int32_t traj_stride; /* columns per series row; 0 = FP_MAX_POINTS.  Must be >= the largest N = ceil(T / tick_t) of the batch
+    int32_t traj_stride; /* columns per series row; 0 = FP_DEFAULT_STRIDE.  Must be >= the largest N = ceil(T / tick_t) of the batch
                             (e.g. 100 for T <= 10 s at 0.1 s): a smaller stride is FP_EINVAL (host) / truncates the rows (device) */
     int32_t traj_sparse; /* 0: every element of the [16][traj_stride] block is written (NaN where a row has no element).
                             1: only the rows' leading elements are written - row r gets its len(r) elements (N for the Frenet rows,
@@ -319,7 +329,7 @@ typedef struct {
     double* trace;             /* NULL or [B][max_refine_iters*7][4] = d, v, T, cost of every refinement trajectory */
     uint32_t* best_flags;      /* NULL or [B] flag word (N, M) of the returned trajectory */
     double* best_traj;         /* NULL or [B][16][traj_stride] its full series (requires best_flags) */
-    int32_t traj_stride;       /* as in fp_result (0 = FP_MAX_POINTS) */
+    int32_t traj_stride;       /* as in fp_result (0 = FP_DEFAULT_STRIDE) */
     int32_t traj_sparse;       /* as in fp_result */
 } fp_fiss_io;
 

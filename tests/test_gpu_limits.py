@@ -133,6 +133,103 @@ def test_reference_line_of_1024_knots(oracle, engine):
             assert abs(f.best_cost[e] - r.best_cost) < 1e-6
 
 
+def _tick005(B, nd, nv, nt, n_obs, seed, kind="FOP"):
+    b = synth.make_batch(B, nd, nv, nt, n_obs, 220, True, seed, kind=kind)
+    b.tick_t = 0.05   # T = 8 .. 10 s -> 160 .. 200 points per trajectory (FP_FAST_POINTS = 128 < N <= FP_MAX_POINTS = 256)
+    return b
+
+
+def test_trajectories_of_200_points_dense_and_series(oracle, engine):
+    """tick_t = 0.05 (round 4: FP_ELIMIT): the dense pass on both kernels against the oracle (collision rows up to pose 200), the
+    winners' series through the chunked writer (winner_traj_kernel; also from a 700-ego batch, where N <= 128 would take the epilogue
+    workgroups), fp_eval_trajs dumps, fp_materialize_all and fp_winner_trajs - every series against the oracle's."""
+    from conftest import assert_series_close
+    from fiss_plus_planner_amd.engine import unpack_flags
+
+    batch = _tick005(4, 5, 4, 3, 8, 83)
+    for kernel in (2, 1, 0):
+        engine.set_option("lattice_kernel", kernel)
+        try:
+            out = _check_vs_oracle(oracle, engine, batch)
+        finally:
+            engine.set_option("lattice_kernel", 0)
+    N = (out.flags >> 8) & 0xFFF
+    assert N.min() == 160 and N.max() == 200 and ((out.flags & 4) != 0).any() and (out.best_idx >= 0).any()
+    stride = 208
+    w = engine.plan_dense(batch, tables=False, winner=True, traj_stride=stride)
+    ws = engine.plan_dense(batch, tables=False, winner=True, traj_stride=stride, traj_sparse=True)
+    wt = engine.winner_trajs(batch, w.best_idx, traj_stride=stride)
+    assert np.array_equal(w.best_traj, wt.best_traj, equal_nan=True) and np.array_equal(w.best_flags, wt.best_flags)
+    m = engine.materialize_all(batch, traj_stride=stride)
+    probs = oracle.problems_from_batch(batch)
+    n_series = 0
+    for e, pr in enumerate(probs):
+        for c in range(batch.C):
+            iv, it, i_d = c % batch.nv, (c // batch.nv) % batch.nt, c // (batch.nv * batch.nt)
+            t = pr.eval_traj(batch.d_samples[i_d], batch.v_samples[e, iv], batch.t_samples[it], dump=True, stride=stride)
+            assert ((m.flags[e, c] >> 8) & 0xFFF, m.flags[e, c] >> 20) == (t.N, t.M)
+            assert_series_close(m.traj[e, c], t.arrays, batch.tick_t, f"materialise ego {e} cand {c}")
+            if c == w.best_idx[e]:
+                assert_series_close(w.best_traj[e], t.arrays, batch.tick_t, f"winner ego {e}")
+                live = ~np.isnan(t.arrays)
+                assert np.array_equal(ws.best_traj[e][live], w.best_traj[e][live])
+                n_series += 1
+    assert n_series >= 1
+    # an ego that runs off the end of its reference line: truncated series (M < N) across the chunk boundary at 120
+    batch.ego[1, 0] = batch.knots[1, 80] - 80.0
+    w2 = engine.plan_dense(batch, tables=True, winner=True, traj_stride=stride)
+    _, N2, M2 = unpack_flags(w2.flags[1])
+    cut = np.nonzero((M2 < N2) & (M2 > 118) & (M2 < 126))[0]   # the series ends right behind the first chunk's window
+    cut = cut if len(cut) else np.nonzero((M2 < N2) & (M2 > 100))[0]
+    assert len(cut), (M2, N2)
+    mt = engine.materialize_all(batch, traj_stride=stride)
+    sub = batch.take(np.array([1]))
+    pr = oracle.problems_from_batch(batch, [1])[0]
+    for c in cut[:6]:
+        iv, it, i_d = c % batch.nv, (c // batch.nv) % batch.nt, c // (batch.nv * batch.nt)
+        es = np.array([[[batch.d_samples[i_d], batch.v_samples[1, iv], batch.t_samples[it]]]])
+        t = pr.eval_traj(*es[0, 0], dump=True, stride=stride)
+        assert t.M < t.N and t.M == M2[c]
+        d = engine.eval_trajs(sub, es, dump=True, traj_stride=stride)
+        assert_series_close(d.traj[0, 0], t.arrays, batch.tick_t, "eval_trajs, truncated")
+        assert_series_close(mt.traj[1, c], t.arrays, batch.tick_t, f"chunked writer, truncated at {t.M}")
+    # a multi-round batch: no epilogue workgroups for these (their writer holds 128 points); every ego's series equals the standalone kernel's
+    big = _tick005(700, 5, 4, 3, 8, 84)
+    wb = engine.plan_dense(big, tables=False, winner=True, traj_stride=stride, traj_sparse=True)
+    ref = engine.winner_trajs(big, wb.best_idx, traj_stride=stride, traj_sparse=True)
+    assert np.array_equal(wb.best_traj, ref.best_traj, equal_nan=True) and (wb.best_idx >= 0).sum() > 50
+    egos = np.arange(0, 700, 41)
+    for e, pr in zip(egos, oracle.problems_from_batch(big, egos)):
+        r = pr.fop_plan()
+        assert wb.best_idx[e] == r.best_idx
+
+
+def test_trajectories_of_200_points_search_and_planners(oracle, engine):
+    """FISS on the device (no refinement: walk over the dense tables + chunked winner series); FISS+ refinement beyond 128 points is
+    FP_ELIMIT from the C ABI and the drop-in FissPlusPlanner refines on the host by itself; FrenetOptimalPlanner with tick_t = 0.05."""
+    from conftest import assert_series_close
+    from fiss_plus_planner_amd import planners as P
+    from fiss_plus_planner_amd.vehicle import Vehicle
+
+    fb = _tick005(6, 5, 5, 5, 8, 85, kind="FISS")
+    out = engine.plan_fiss(fb, "FISS", winner=True, traj_stride=208)
+    for e, pr in enumerate(oracle.problems_from_batch(fb)):
+        r = pr.fiss_plan()
+        np.testing.assert_array_equal(out.stats[e], r.stats)
+        assert np.isnan(out.best_cost[e]) == np.isnan(r.best_cost)
+        if not np.isnan(r.best_cost):
+            assert abs(out.best_cost[e] - r.best_cost) < 1e-6
+            t = pr.eval_traj(*out.end_state[e], dump=True, stride=208)
+            assert_series_close(out.best_traj[e], t.arrays, fb.tick_t, f"FISS winner ego {e}")
+    with pytest.raises(_abi.FrenetGpuError, match="FP_FAST_POINTS"):
+        engine.plan_fiss(_tick005(2, 5, 5, 5, 8, 86, kind="FISS+"), "FISS+")
+    st = P.FissPlusPlannerSettings(5, 5, 5)
+    st.tick_t = 0.05
+    assert not P.FissPlusPlanner(st, Vehicle(), None, engine=engine)._device_walk()
+    st1 = P.FissPlusPlannerSettings(5, 5, 5)
+    assert P.FissPlusPlanner(st1, Vehicle(), None, engine=engine)._device_walk()
+
+
 def test_largest_lattice_fiss_pipeline(oracle, engine):
     """C = 4096 needs 139 KB of LDS in the search kernel (above the 64 KB default dynamic limit)."""
     batch = synth.make_batch(2, 16, 16, 16, 12, 50, True, 76, kind="FISS+")
@@ -166,7 +263,7 @@ def test_error_codes(engine):
     assert rc == -1
     rc, msg = _call(engine, batch, lambda p, fb, r: setattr(p, "nd", 4097))
     assert rc == -4 and "FP_MAX_CAND" in msg
-    rc, msg = _call(engine, batch, lambda p, fb, r: setattr(p, "tick_t", 0.01))  # 10 s / 0.01 = 1000 points > FP_MAX_POINTS
+    rc, msg = _call(engine, batch, lambda p, fb, r: setattr(p, "tick_t", 0.01))  # 10 s / 0.01 = 1000 points > FP_MAX_POINTS = 256
     assert rc == -4 and "FP_MAX_POINTS" in msg
     rc, msg = _call(engine, batch, lambda p, fb, r: setattr(p, "check_stride", 0))
     assert rc == -1
