@@ -57,7 +57,7 @@ class FpResult(C.Structure):
                 ("traj_stride", C.c_int32), ("traj_sparse", C.c_int32)]
 
 
-AUDIT_NEAR_TIE, AUDIT_CONTACT, AUDIT_REORDERED = 1, 2, 4
+AUDIT_NEAR_TIE, AUDIT_CONTACT, AUDIT_REORDERED, AUDIT_TIES_OVERFLOW = 1, 2, 4, 8
 
 
 class FpFissOpts(C.Structure):

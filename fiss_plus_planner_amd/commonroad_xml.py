@@ -24,7 +24,7 @@ import numpy as np
 
 from types import SimpleNamespace
 
-from .obstacles import ObstacleTable, buffer_circle_ring, shape_columns
+from .obstacles import CIRCLE_BUFFER_FACTOR, ObstacleTable, buffer_circle_ring, shape_columns
 
 
 @dataclass
@@ -88,7 +88,7 @@ def _shape(node, circle_buffer_factor: float):
     return shapes[0] if len(shapes) == 1 else SimpleNamespace(shapes=shapes)  # several shapes under one <shape>: a ShapeGroup
 
 
-def load_scenario(path: str, circle_buffer_factor: float = 0.5) -> Scenario:
+def load_scenario(path: str, circle_buffer_factor: float = CIRCLE_BUFFER_FACTOR) -> Scenario:
     root = ET.parse(path).getroot()
     lanelets = {}
     for ll in root.findall("lanelet"):

@@ -391,7 +391,7 @@ __device__ double candidate_min_gap(const KernelArgs& ka, const EgoCtx& e, doubl
 }
 
 constexpr int kAuditThreads = 256;
-constexpr int kAuditTies = 64;  // near-tied candidates re-priced per ego (more than that: the first 64 in index order, bit still set)
+constexpr int kAuditTies = 64;  // near-tied candidates re-priced per ego: the first 63 in index order (more: FP_AUDIT_TIES_OVERFLOW)
 __global__ __launch_bounds__(kAuditThreads) void audit_kernel(KernelArgs ka, int lds_doubles, uint32_t* audit)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -417,15 +417,22 @@ __global__ __launch_bounds__(kAuditThreads) void audit_kernel(KernelArgs ka, int
         const int iv = c % p.nv, it = (c / p.nv) % p.nt, id = c / (p.nv * p.nt);
         d_end = ka.b.d_samples[id]; v_end = vs[iv]; T_end = ka.b.t_samples[it];
     };
-    // (1) near ties, in index order (kAuditTies slots)
-    if (win >= 0) {
-        for (int c = tid; c < C; c += kAuditThreads) {
-            if (c == win || (flag[c] & FP_FLAG_INFEASIBLE) || !(cost[c] == cost[c])) continue;
-            if (fabs(cost[c] - cw) <= FP_AUDIT_COST_TOL) {
-                const int pos = atomicAdd(&s_ties[kAuditTies], 1);
+    // (1) near ties: the first kAuditTies - 1 in INDEX order, whatever the thread timing - one wavefront walks the table 64 candidates at
+    // a time and compacts by ballot + popcount (an atomic counter kept a timing-dependent subset when more than 63 tied, and with it a
+    // run-to-run different re-priced winner; the other wavefronts go on to the contact pass meanwhile)
+    if (win >= 0 && tid < kWave) {
+        int n = 0;
+        for (int c0 = 0; c0 < C; c0 += kWave) {
+            const int c = c0 + tid;
+            const bool tie = c < C && c != win && !(flag[c] & FP_FLAG_INFEASIBLE) && cost[c] == cost[c] && fabs(cost[c] - cw) <= FP_AUDIT_COST_TOL;
+            const unsigned long long m = __ballot(tie);
+            if (tie) {
+                const int pos = n + __popcll(m & ((1ull << tid) - 1ull));
                 if (pos < kAuditTies - 1) s_ties[pos] = c;
             }
+            n += __popcll(m);
         }
+        if (tid == 0) s_ties[kAuditTies] = n;
     }
     // (2) thin contacts: the winner + every candidate at most as expensive that only the collision check rejected (no winner: every
     // candidate only the collision check rejected - any of them flipping would give the ego a solution)
@@ -441,6 +448,7 @@ __global__ __launch_bounds__(kAuditThreads) void audit_kernel(KernelArgs ka, int
     __syncthreads();
     const int n_ties = s_ties[kAuditTies] < kAuditTies - 1 ? s_ties[kAuditTies] : kAuditTies - 1;
     uint32_t bits = s_thin ? FP_AUDIT_CONTACT : 0u;
+    if (s_ties[kAuditTies] > kAuditTies - 1) bits |= FP_AUDIT_TIES_OVERFLOW;  // (more tied candidates than are re-priced)
     if (n_ties > 0) {
         bits |= FP_AUDIT_NEAR_TIE;
         // re-price the tied candidates and the winner point by point; the argmin rule on those sums

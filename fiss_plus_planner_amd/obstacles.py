@@ -59,9 +59,17 @@ class ObstacleTable:
             self.dims = np.array(dims, dtype=np.float64, order="C")
         if final_time_step is not None:
             self.final_time_step = int(final_time_step)
+        if (poly is None) != (nvert is None):
+            raise ValueError("ObstacleTable.update: poly and nvert come together (the rings and their vertex counts)")
         if nvert is not None:
             self.poly, self.nvert = np.array(poly, dtype=np.float64, order="C"), np.array(nvert, dtype=np.int32, order="C")
-        assert self.pose.ndim == 3 and self.pose.shape[2] == 4 and self.dims.shape == (self.pose.shape[1], 2)
+        n = self.pose.shape[1] if self.pose.ndim == 3 else -1
+        if self.pose.ndim != 3 or self.pose.shape[2] != 4 or self.dims.shape != (n, 2):
+            raise ValueError(f"ObstacleTable.update: pose {self.pose.shape} / dims {self.dims.shape} are not [T, n, 4] / [n, 2]")
+        if self.nvert is not None and (self.nvert.shape != (n,) or self.poly.ndim != 3 or self.poly.shape[0] != n or self.poly.shape[2] != 2
+                                       or (self.nvert.size and int(self.nvert.max()) > self.poly.shape[1])):
+            raise ValueError(f"ObstacleTable.update: poly {self.poly.shape} / nvert {self.nvert.shape} do not match the {n} obstacle columns "
+                             "(a new pose table with another column count needs new rings too)")
         self.version += 1
         return self
 
@@ -192,9 +200,14 @@ def _convex_pieces(v: np.ndarray, max_vertices: int) -> list:
 
 
 MAX_POLY_VERTS = 128  # FP_MAX_POLY_VERTS (include/frenet_gpu.h)
+# commonroad-io's Circle.shapely_object is `Point(center).buffer(radius / 2)` in the releases of the reference's era (recalled, not
+# checkable offline - like the vehicle constants).  ONE factor for every path that has to make a circle's polygon itself: shape objects
+# that bring a radius but no polygon (shape_columns) and the XML reader (commonroad_xml.load_scenario's default).  Objects that bring
+# their own shapely_object never use it.
+CIRCLE_BUFFER_FACTOR = 0.5
 
 
-def shape_columns(shape) -> list:
+def shape_columns(shape, circle_buffer_factor: float = CIRCLE_BUFFER_FACTOR) -> list:
     """An obstacle shape -> the obstacle columns that stand for it: [(length, width, cx, cy, ring or None)].
 
     The reference hands ``obstacle_shape.shapely_object`` - any polygon - to translate + rotate(origin='center') + intersects
@@ -220,7 +233,7 @@ def shape_columns(shape) -> list:
         v = _ring(poly)
         if v is None and hasattr(sh, "radius"):  # a circle that brings no polygon: the one shapely would make of it
             c = np.asarray(getattr(sh, "center", (0.0, 0.0)), dtype=float)
-            v = buffer_circle_ring(float(sh.radius), float(c[0]), float(c[1]))
+            v = buffer_circle_ring(circle_buffer_factor * float(sh.radius), float(c[0]), float(c[1]))
         if v is None or len(v) < 3:
             raise ValueError(f"obstacle shape {sh!r} exposes no polygon (shapely_object / exterior / vertices) and no radius")
         if not np.all(np.isfinite(v)):
@@ -232,14 +245,22 @@ def shape_columns(shape) -> list:
     cx, cy = 0.5 * (minx + maxx), 0.5 * (miny + maxy)
     if len(rings) == 1:
         v = rings[0]
-        is_rect = len(v) == 4 and all((p[0] in (minx, maxx)) and (p[1] in (miny, maxy)) for p in v) and len({(float(p[0]), float(p[1])) for p in v}) == 4
+        is_rect = len(v) == 4 and all((p[0] in (minx, maxx)) and (p[1] in (miny, maxy)) for p in v) and len({(float(p[0]), float(p[1])) for p in v}) == 4 \
+            and all((v[k][0] == v[(k + 1) % 4][0]) != (v[k][1] == v[(k + 1) % 4][1]) for k in range(4))  # (walked along its sides: the four corners in crossing order are a bow tie)
         if is_rect:
             return [(float(maxx - minx), float(maxy - miny), float(cx), float(cy), None)]
     cols = []
     for v in rings:
         if _signed_area2(v) == 0.0:
             continue  # a degenerate ring has no interior; shapely would call the polygon invalid
-        for pc in _convex_pieces(v, MAX_POLY_VERTS):
+        pieces = _convex_pieces(v, MAX_POLY_VERTS)
+        # a self-intersecting ring has no convex partition on its own vertices: ear clipping then returns triangles that cover area
+        # outside it (or too little).  The pieces of a simple ring tile it exactly - compared by area, with the rounding of a sum of
+        # cross products as slack
+        a_ring, a_pieces = abs(_signed_area2(v)), sum(abs(_signed_area2(pc)) for pc in pieces)
+        if not all(_is_convex(pc) and _signed_area2(pc) >= 0.0 for pc in pieces) or abs(a_pieces - a_ring) > 1e-9 * max(a_ring, 1e-300) + 1e-12:
+            raise ValueError("obstacle shape is not a simple polygon (its ring crosses itself): no convex pieces stand for it")
+        for pc in pieces:
             u = pc - np.array([cx, cy])
             cols.append((float(2.0 * np.abs(u[:, 0]).max()), float(2.0 * np.abs(u[:, 1]).max()), float(cx), float(cy), np.ascontiguousarray(u)))
     if not cols:

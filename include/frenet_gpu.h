@@ -200,10 +200,15 @@ typedef struct {
  *                        colliding, hangs on a pair of boxes within FP_AUDIT_GAP_TOL metres of touching (their deepest overlap over
  *                        all checked poses and obstacles is shallower than that, or their closest miss nearer): a different
  *                        rounding of the same geometry - GEOS, another compiler - could decide this ego differently.
+ *   FP_AUDIT_TIES_OVERFLOW  more than 63 candidates were within the tolerance: the first 63 in index order (and the winner) were
+ *                        re-priced, the others were not - the outcome is deterministic but not settled among all of them.
+ * best_cost of an ego whose FP_AUDIT_NEAR_TIE bit is set is the POINT-BY-POINT sum of its (possibly new) winner; every other ego keeps
+ * the closed-form sum (the two differ by ~1e-12: one output array, two summation orders - compare against cost_tbl with that in mind).
  * No bit set: every comparison behind best_idx was decided by more than the tolerances. */
 #define FP_AUDIT_NEAR_TIE 1u
 #define FP_AUDIT_CONTACT 2u
 #define FP_AUDIT_REORDERED 4u
+#define FP_AUDIT_TIES_OVERFLOW 8u
 #define FP_AUDIT_COST_TOL 1e-9
 #define FP_AUDIT_GAP_TOL 1e-9
 

@@ -78,3 +78,24 @@ def test_audit_is_quiet_on_the_synthetic_configurations(engine):
         assert np.array_equal(out.best_traj, ref.best_traj, equal_nan=True)
         assert (out.audit & (_abi.AUDIT_NEAR_TIE | _abi.AUDIT_REORDERED)).sum() == 0
         assert ((out.audit & _abi.AUDIT_CONTACT) != 0).mean() < 0.01
+
+
+def test_more_ties_than_slots_is_deterministic_and_flagged(oracle, engine):
+    """80 end-speed samples that are all the same speed: 80 candidates per lateral sample with bit-identical costs - more than the 63
+    the audit pass re-prices.  The subset it takes is the first 63 in index order whatever the thread timing (ballot compaction, not
+    an atomic counter): ten calls give the same answer, FP_AUDIT_TIES_OVERFLOW says that not every tied candidate was looked at, and
+    the index is still the reference's (last minimum among equal sums)."""
+    batch = synth.make_batch(3, 2, 80, 1, 0, 0, False, 78)
+    batch.v_samples[:] = batch.v_samples[:, 40:41]
+    ref_idx = np.array([p.fop_plan().best_idx for p in oracle.problems_from_batch(batch)])
+    first = engine.plan_dense(batch, tables=True, audit=True)
+    assert (first.audit & _abi.AUDIT_NEAR_TIE).all() and (first.audit & _abi.AUDIT_TIES_OVERFLOW).all()
+    np.testing.assert_array_equal(first.best_idx, ref_idx)
+    for _ in range(10):
+        out = engine.plan_dense(batch, tables=True, audit=True)
+        np.testing.assert_array_equal(out.best_idx, first.best_idx)
+        np.testing.assert_array_equal(out.audit, first.audit)
+        assert np.array_equal(out.best_cost, first.best_cost)
+    few = synth.make_batch(3, 2, 20, 1, 0, 0, False, 78)
+    few.v_samples[:] = few.v_samples[:, 10:11]
+    assert (engine.plan_dense(few, tables=True, audit=True).audit & _abi.AUDIT_TIES_OVERFLOW == 0).all()

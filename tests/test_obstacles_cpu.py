@@ -88,8 +88,37 @@ def test_a_circle_is_the_polygon_shapely_makes_of_it():
     tab = flatten_obstacles([ob])
     np.testing.assert_array_equal(tab.nvert, [64])
     np.testing.assert_array_equal(tab.pose[0, 0, :2], [10.25, 19.5])
-    np.testing.assert_allclose(tab.dims, [[3.0, 3.0]], rtol=0, atol=1e-15)
-    np.testing.assert_allclose(np.hypot(tab.poly[0, :, 0], tab.poly[0, :, 1]), 1.5, rtol=0, atol=1e-15)
+    # ONE radius convention for every path that builds a circle's polygon itself (obstacles.CIRCLE_BUFFER_FACTOR: commonroad-io's
+    # Point(center).buffer(radius / 2), recalled): a radius-only shape object and the XML reader give the same obstacle
+    from fiss_plus_planner_amd.obstacles import CIRCLE_BUFFER_FACTOR, shape_columns
+    r = CIRCLE_BUFFER_FACTOR * 1.5
+    np.testing.assert_allclose(tab.dims, [[2 * r, 2 * r]], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(np.hypot(tab.poly[0, :, 0], tab.poly[0, :, 1]), r, rtol=0, atol=1e-15)
+    full = shape_columns(ob.obstacle_shape, circle_buffer_factor=1.0)
+    np.testing.assert_allclose(full[0][:2], [3.0, 3.0], rtol=0, atol=1e-15)
+
+
+def test_self_intersecting_rings_and_mismatched_updates_raise():
+    import pytest
+
+    from fiss_plus_planner_amd.obstacles import ObstacleTable, shape_columns
+
+    bowtie = SimpleNamespace(vertices=np.array([(0.0, 0.0), (2.0, 2.0), (2.0, 0.0), (0.0, 2.0)]))
+    with pytest.raises(ValueError, match="no area|simple polygon"):   # (a symmetric bow tie: the signed areas of its lobes cancel)
+        shape_columns(bowtie)
+    with pytest.raises(ValueError, match="simple polygon"):
+        shape_columns(SimpleNamespace(vertices=np.array([(0.0, 0.0), (3.0, 2.0), (3.0, 0.0), (0.0, 1.0)])))   # a lopsided one
+    star = SimpleNamespace(vertices=np.array([(0, 3), (1.8, -2.4), (-2.9, 0.9), (2.9, 0.9), (-1.8, -2.4)], dtype=float))  # pentagram
+    with pytest.raises(ValueError, match="simple polygon"):
+        shape_columns(star)
+    tab = flatten_obstacles([_poly_obstacle([(0, 0), (1, 0), (0, 1)])])
+    with pytest.raises(ValueError, match="come together"):
+        tab.update(poly=tab.poly.copy())
+    with pytest.raises(ValueError, match="do not match"):
+        tab.update(pose=np.zeros((tab.pose.shape[0], 2, 4)), dims=np.ones((2, 2)))   # two columns now, the rings still describe one
+    v = tab.version
+    tab.update(pose=np.zeros((tab.pose.shape[0], 2, 4)), dims=np.ones((2, 2)), poly=np.zeros((2, 3, 2)), nvert=np.zeros(2, dtype=np.int32))
+    assert tab.version == v + 1
 
 
 def test_non_convex_shapes_and_groups_are_cut_into_convex_pieces_about_the_common_centre():
