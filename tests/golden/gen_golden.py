@@ -75,6 +75,8 @@ def make_planner(kind: str, b: ProblemBatch, e: int, refine_iters=3):
         pl = R.FissPlusPlanner(st, veh, None)
     else:
         raise ValueError(kind)
+    if b.tick_t != 0.1:
+        pl.settings.tick_t = float(b.tick_t)  # (a free attribute of the settings object, frenet_optimal_planner.py:38-56; G13)
     f = int(b.frame_of[e])
     nx = int(b.nx[f])
     pts = np.column_stack([b.coef[f, 0, :nx], b.coef[f, 4, :nx]])
@@ -895,8 +897,81 @@ def g12():
     save("g12_shapes.npz", **out)
 
 
+def g13():
+    """tick_t = 0.05 (T = 8 .. 10 s -> 160 .. 200 points per trajectory: beyond round 4's FP_MAX_POINTS = 128): the reference's own
+    tables, series and plans.  Two scenes: 8 moving obstacles over 220 time steps (has_collision's pose k is the obstacle's time
+    step k whatever the planner's tick, :173-176), and a short reference line (truncated series)."""
+    STRIDE = 208
+    b0 = synth.make_batch(2, 5, 4, 3, 8, 220, True, 9113)
+    b0.tick_t = 0.05
+    b0 = with_overrides(b0)
+    bt = short_frame_batch(synth.make_batch(2, 5, 4, 3, 8, 220, True, 9114), 25)
+    bt.tick_t = 0.05
+    bt = with_overrides(bt)
+    out, names = {}, []
+    for name, b in (("tick005", b0), ("tick005_short", bt)):
+        names.append(name)
+        C = b.C
+        cost = np.empty((b.B, C)); N = np.empty((b.B, C), dtype=np.int32); M = np.empty((b.B, C), dtype=np.int32)
+        speed = np.zeros((b.B, C), dtype=bool); accel = np.zeros((b.B, C), dtype=bool); coll = np.zeros((b.B, C), dtype=bool)
+        dumps = np.full((b.B, 3, 16, STRIDE), np.nan); dump_idx = np.zeros((b.B, 3), dtype=np.int32)
+        for e in range(b.B):
+            pl = make_planner("FOP", b, e)
+            pl.settings.highest_speed = float(b.target_speed[e])
+            obstacles = obstacles_for(b, e)
+            fpl = pl.calc_global_paths(pl.calc_frenet_paths(ego_state(b, e)))
+            for i, fp in enumerate(fpl):
+                cost[e, i] = fp.cost_final; N[e, i] = len(fp.t); M[e, i] = len(fp.x)
+                speed[e, i] = any(v > pl.vehicle.max_speed for v in fp.s_d)
+                accel[e, i] = any(abs(a) > pl.vehicle.max_accel for a in fp.s_dd)
+                coll[e, i] = pl.has_collision(fp, obstacles, int(b.t_now[e]), 2)[0]
+            trunc = [i for i in range(C) if 2 <= M[e, i] < N[e, i]]
+            long_cut = [i for i in trunc if M[e, i] > 110]
+            pick = [0, C // 2 + 1, (long_cut or trunc or [C - 1])[len(long_cut or trunc or [0]) // 2]]
+            for k, i in enumerate(pick):
+                dump_idx[e, k] = i
+                dumps[e, k] = dump_traj(fpl[i], STRIDE)
+        out.update(batch_to_dict(b, f"{name}_in_"))
+        out.update({f"{name}_cost": cost, f"{name}_N": N, f"{name}_M": M, f"{name}_speed": speed, f"{name}_accel": accel,
+                    f"{name}_coll": coll, f"{name}_dumps": dumps, f"{name}_dump_idx": dump_idx})
+        print(f"  g13 {name}: N {N.min()}..{N.max()} coll={coll.mean():.2f} trunc={(M < N).mean():.2f} M range {M.min()}..{M.max()}")
+        # plan() of the four planners on the same problems
+        for kind in ("FOP", "FOP+", "FISS", "FISS+"):
+            bb = b
+            if kind in ("FISS", "FISS+"):
+                sw = 3.5 - b.veh_w + 0.3
+                d, rd = np.linspace(-sw / 2, sw / 2, b.nd, retstep=True)
+                smin = b.samp_min.copy(); smax = b.samp_max.copy(); sres = b.samp_res.copy()
+                smin[:, 0] = -sw / 2; smax[:, 0] = sw / 2; sres[:, 0] = rd
+                bb = with_overrides(b, d_samples=d, samp_min=smin, samp_max=smax, samp_res=sres)
+            key = f"{name}_{kind}"
+            B = bb.B
+            idx = np.full((B, 3), -1, dtype=np.int32); pcost = np.full(B, np.nan); stats = np.zeros((B, 4), dtype=np.int32)
+            end = np.full((B, 3), np.nan); found = np.zeros(B, dtype=bool); win = np.full((B, 16, STRIDE), np.nan); NM = np.zeros((B, 2), dtype=np.int32)
+            for e in range(B):
+                pl, best, err = run_plan(kind, bb, e)
+                assert not err, (key, e, err)
+                stats[e] = [pl.stats.num_iter, pl.stats.num_trajs_generated, pl.stats.num_trajs_validated, pl.stats.num_collison_checks]
+                if best is None:
+                    continue
+                found[e] = True
+                pcost[e] = best.cost_final
+                NM[e] = [len(best.t), len(best.x)]
+                win[e] = dump_traj(best, STRIDE)
+                if kind in ("FISS", "FISS+"):
+                    idx[e] = best.idx
+                    end[e] = [best.end_state.d, best.end_state.s_d, best.end_state.t]
+            if kind in ("FISS", "FISS+"):
+                out.update(batch_to_dict(bb, f"{key}_in_"))
+            out.update({f"{key}_idx": idx, f"{key}_cost": pcost, f"{key}_stats": stats, f"{key}_end": end, f"{key}_found": found,
+                        f"{key}_win": win, f"{key}_NM": NM})
+            print(f"  g13 {key}: found={found.tolist()} stats={stats.tolist()}")
+    out["names"] = np.array(names)
+    save("g13_tick005.npz", **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10", "g11", "g12"]
+    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10", "g11", "g12", "g13"]
     for g in todo:
         t0 = time.time()
         print(f"== {g}")

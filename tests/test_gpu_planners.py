@@ -270,3 +270,65 @@ def test_fopplus_batch_on_the_device(oracle, engine):
         r = pr.fopplus_plan()
         assert o3.best_idx[4 * e] == r.best_idx
         np.testing.assert_array_equal(o3.stats[4 * e], r.stats)
+
+
+# ---- G13: the reference run with settings.tick_t = 0.05 (160 .. 200 points per trajectory; round 5: FP_MAX_POINTS 256)
+@pytest.mark.parametrize("name", ["tick005", "tick005_short"])
+def test_dense_tables_match_the_reference_at_tick_005(engine, name):
+    """Cost, N, M, masks and collision verdicts of every candidate on both lattice kernels, and the three full series per ego the
+    fixture holds (through fp_eval_trajs, fp_materialize_all and - for the argmin - the dense call's own series) against the
+    reference's, incl. series truncated beyond point 128."""
+    from conftest import assert_series_close
+
+    g = load_golden("g13_tick005.npz")
+    b = batch_from_golden(g, f"{name}_in_")
+    for kernel in (2, 1):
+        engine.set_option("lattice_kernel", kernel)
+        try:
+            out = engine.plan_dense(b)
+        finally:
+            engine.set_option("lattice_kernel", 0)
+        np.testing.assert_allclose(out.cost, g[f"{name}_cost"], rtol=0, atol=TOL)
+        np.testing.assert_array_equal((out.flags >> 8) & 0xFFF, g[f"{name}_N"])
+        np.testing.assert_array_equal(out.flags >> 20, g[f"{name}_M"])
+        np.testing.assert_array_equal((out.flags & 1) != 0, g[f"{name}_speed"])
+        np.testing.assert_array_equal((out.flags & 2) != 0, g[f"{name}_accel"])
+        np.testing.assert_array_equal((out.flags & 4) != 0, g[f"{name}_coll"])
+    m = engine.materialize_all(b, traj_stride=208)
+    for e in range(b.B):
+        for k, idx in enumerate(g[f"{name}_dump_idx"][e]):
+            want = g[f"{name}_dumps"][e, k]
+            assert_series_close(m.traj[e, idx], want, b.tick_t, f"{name} materialise ego {e} candidate {idx}")
+            iv, it, i_d = idx % b.nv, (idx // b.nv) % b.nt, idx // (b.nv * b.nt)
+            es = np.array([[[b.d_samples[i_d], b.v_samples[e, iv], b.t_samples[it]]]])
+            d = engine.eval_trajs(b.take(np.array([e])), es, dump=True, traj_stride=208)
+            assert_series_close(d.traj[0, 0], want, b.tick_t, f"{name} eval_trajs ego {e} candidate {idx}")
+
+
+@pytest.mark.parametrize("name", ["tick005", "tick005_short"])
+@pytest.mark.parametrize("kind", ["FOP", "FOP+", "FISS", "FISS+"])
+def test_plan_matches_reference_at_tick_005(engine, name, kind):
+    """The drop-in classes with settings.tick_t = 0.05 return the reference's plan: cost, Stats, end state and the winner's series
+    (chunked writer).  FissPlusPlanner refines on the host here (the device refinement holds 128 points), FissPlanner walks on the
+    device."""
+    g = load_golden("g13_tick005.npz")
+    key = f"{name}_{kind}"
+    b = batch_from_golden(g, f"{key}_in_" if kind in ("FISS", "FISS+") else f"{name}_in_")
+    for e in range(b.B):
+        pl = _planner(kind, b, engine)
+        pl.settings.tick_t = 0.05
+        assert kind != "FISS+" or not pl._device_walk()
+        assert kind != "FISS" or pl._device_walk()
+        pts, fs, obs = _inputs(b, e)
+        pl.generate_frenet_frame(pts)
+        best = pl.plan(fs, float(b.target_speed[e]), obs, int(b.t_now[e]))
+        found = bool(g[f"{key}_found"][e])
+        assert (best is not None) == found, (key, e)
+        assert pl.stats.as_tuple() == tuple(g[f"{key}_stats"][e]), (key, e)
+        if not found:
+            continue
+        assert abs(best.cost_final - g[f"{key}_cost"][e]) < TOL
+        if kind in ("FISS", "FISS+"):
+            np.testing.assert_array_equal(best.idx, g[f"{key}_idx"][e])
+            np.testing.assert_allclose([best.end_state.d, best.end_state.s_d, best.end_state.t], g[f"{key}_end"][e], atol=1e-9)
+        _check_winner(best, g[f"{key}_win"][e], g[f"{key}_NM"][e])

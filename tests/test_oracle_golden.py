@@ -245,3 +245,55 @@ def test_g9_plans_with_curvature_checks(oracle, name, kind):
             np.testing.assert_array_equal(r.best_ijk, g[f"{key}_idx"][e])
         else:
             np.testing.assert_allclose(r.end_state, g[f"{key}_end"][e], rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------ G13 tick_t = 0.05: 160 .. 200 points per trajectory
+G13_STRIDE = 208
+
+
+@pytest.mark.parametrize("name", ["tick005", "tick005_short"])
+def test_g13_tables_and_series_at_tick_005(oracle, name):
+    """The reference run with settings.tick_t = 0.05 (round 5: FP_MAX_POINTS 256): cost, N, M, masks, collision verdicts of every
+    candidate and three full series per ego (one of them truncated beyond point 110 in the short-line scene)."""
+    g = load_golden("g13_tick005.npz")
+    b = batch_from_golden(g, f"{name}_in_")
+    assert b.tick_t == 0.05
+    for e, p in enumerate(oracle.problems_from_batch(b)):
+        cost, flags = p.dense_tables()
+        np.testing.assert_allclose(cost, g[f"{name}_cost"][e], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal((flags >> 8) & 0xFFF, g[f"{name}_N"][e])
+        np.testing.assert_array_equal(flags >> 20, g[f"{name}_M"][e])
+        np.testing.assert_array_equal((flags & 1) != 0, g[f"{name}_speed"][e])
+        np.testing.assert_array_equal((flags & 2) != 0, g[f"{name}_accel"][e])
+        np.testing.assert_array_equal((flags & 4) != 0, g[f"{name}_coll"][e])
+        for k, idx in enumerate(g[f"{name}_dump_idx"][e]):
+            iv, it, i_d = idx % b.nv, (idx // b.nv) % b.nt, idx // (b.nv * b.nt)
+            t = p.eval_traj(b.d_samples[i_d], b.v_samples[e, iv], b.t_samples[it], dump=True, stride=G13_STRIDE)
+            want = g[f"{name}_dumps"][e, k]
+            assert np.array_equal(np.isnan(t.arrays), np.isnan(want))
+            m = ~np.isnan(want)
+            np.testing.assert_allclose(t.arrays[:11][m[:11]], want[:11][m[:11]], rtol=0, atol=1e-10)
+            # rows 11-15 are difference chains of x / y divided by ds and by tick_t (0.05 here: four times the amplification of 0.1)
+            from conftest import assert_series_close
+            assert_series_close(t.arrays, want, b.tick_t, f"{name} ego {e} dump {k}")
+    assert g[f"{name}_N"].min() == 160 and g[f"{name}_N"].max() == 200 and g[f"{name}_coll"].any()
+    if name == "tick005_short":
+        assert ((g[f"{name}_M"] < g[f"{name}_N"]) & (g[f"{name}_M"] > 128)).any()
+
+
+@pytest.mark.parametrize("name", ["tick005", "tick005_short"])
+@pytest.mark.parametrize("kind", ["FOP", "FOP+", "FISS", "FISS+"])
+def test_g13_plans_at_tick_005(oracle, name, kind):
+    g = load_golden("g13_tick005.npz")
+    key = f"{name}_{kind}"
+    b = batch_from_golden(g, f"{key}_in_" if kind in ("FISS", "FISS+") else f"{name}_in_")
+    for e, p in enumerate(oracle.problems_from_batch(b)):
+        r = {"FOP": p.fop_plan, "FOP+": p.fopplus_plan, "FISS": p.fiss_plan, "FISS+": p.fissplus_plan}[kind]()
+        found = bool(g[f"{key}_found"][e])
+        assert (not np.isnan(r.best_cost)) == found
+        np.testing.assert_array_equal(r.stats, g[f"{key}_stats"][e])
+        if found:
+            assert abs(r.best_cost - g[f"{key}_cost"][e]) < 1e-9
+            if kind in ("FISS", "FISS+"):
+                end = r.end_state if kind == "FISS+" else np.array([b.d_samples[r.best_ijk[0]], b.v_samples[e, r.best_ijk[1]], b.t_samples[r.best_ijk[2]]])
+                np.testing.assert_allclose(end, g[f"{key}_end"][e], rtol=0, atol=1e-9)
