@@ -1012,7 +1012,11 @@ def main():
                 valu_issue = {"wave_instructions_per_launch": insts, "rate": insts / (kern_ms * 1e-3), "peak": peak,
                               "unit": "wave-instructions/s", "frac": insts / (kern_ms * 1e-3) / peak,
                               "source": f"SQ_INSTS_VALU from profiles/{pmc_file} (rocprofv3 --pmc; kernel instance and commit in profiles/README.md), this run's kernel time; "
-                                        "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction", "pmc_kernel": pmc_kernel}
+                                        "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (the measured issue cost of nearly every instruction "
+                                        "this kernel executes: profiles/r05_valu_issue_rate_microbench.txt)", "pmc_kernel": pmc_kernel}
+                if "SQ_ACTIVE_INST_VALU" in k and k.get("GRBM_GUI_ACTIVE"):  # the hardware's own count of the VALU pipes' busy time in that pass
+                    valu_issue["valu_busy_frac_pmc"] = k["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0)
+                    valu_issue["valu_busy_note"] = "SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): VALU-busy share of the launch, tail included"
                 flops = 64.0 * (2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_TRANS_F64"])
                 fp64_exec = {"executed_flops_per_launch": flops, "achieved": flops / (kern_ms * 1e-3) / 1e12, "rate": flops / (kern_ms * 1e-3) / 1e12,
                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
