@@ -731,6 +731,9 @@ int handover_recover(fp_ctx* ctx, hipStream_t stream)
 {
     const int code = *(volatile int32_t*)ctx->hand_err;
     ctx->appended_ok = false;
+    // (the launch that timed out may still hold workgroups about to give up too: drain the stream before the word is cleared, or one of
+    // them would set it again and a later, healthy call would report a failure of its own)
+    (void)hipStreamSynchronize(stream);
     *(volatile int32_t*)ctx->hand_err = 0;
     if (ctx->epi_flags.base) HIP_TRY(hipMemsetAsync(ctx->epi_flags.base, 0, ctx->epi_flags.cap, stream));
     return fail(FP_EHIP, "a %s workgroup appended to an earlier lattice launch on this ctx waited 2 s for its ego's results and gave up: that call's "
