@@ -429,3 +429,29 @@ def test_tables_tag_keeps_frames_and_scenes_on_the_device(oracle, engine):
         np.testing.assert_array_equal(f_tag.stats, f_ref.stats)
         np.testing.assert_array_equal(f_tag.best_cost, f_ref.best_cost)
         assert np.array_equal(f_tag.best_traj, f_ref.best_traj, equal_nan=True)
+
+
+def test_full_size_config3_at_tick_005(oracle, engine):
+    """BASELINE configs[2] with tick_t = 0.05 (2048 egos x 567 candidates of 160-200 points; the obstacle tables' 50 steps are then the
+    first 2.5 s): the three-per-CU lattice instance with its tail split, winners through winner_traj_kernel's chunked writer - selected
+    index exact and cost within 1e-6 for every ego against the oracle, the series of a sample, invariants of the flag words."""
+    import os
+
+    from conftest import assert_series_close
+
+    batch = synth.make_config(3)
+    batch.tick_t = 0.05
+    out = engine.plan_dense(batch, tables=True, winner=True, traj_stride=208, traj_sparse=True)
+    idx, cost = oracle.fop_plan_batch(oracle.problems_from_batch(batch), threads=len(os.sched_getaffinity(0)))
+    np.testing.assert_array_equal(out.best_idx, idx)
+    ok = idx >= 0
+    assert 0.2 < ok.mean() < 0.95
+    np.testing.assert_allclose(out.best_cost[ok], cost[ok], rtol=0, atol=1e-6)
+    N, M = (out.flags >> 8) & 0xFFF, out.flags >> 20
+    assert N.min() == 160 and N.max() == 200 and (M <= N).all()
+    egos = np.nonzero(ok)[0][::40]
+    for e, pr in zip(egos, oracle.problems_from_batch(batch, egos)):
+        bi = int(out.best_idx[e])
+        iv, it, i_d = bi % batch.nv, (bi // batch.nv) % batch.nt, bi // (batch.nv * batch.nt)
+        t = pr.eval_traj(batch.d_samples[i_d], batch.v_samples[e, iv], batch.t_samples[it], dump=True, stride=208)
+        assert_series_close(out.best_traj[e], t.arrays, batch.tick_t, f"ego {e}")

@@ -32,7 +32,10 @@ def rect_rings(b, frac=0.5):
 
 norect = rect_rings(base)
 norect.obs_nvert = np.zeros_like(norect.obs_nvert)  # (set behind the constructor's back: the POLY instance with no polygon column)
-for name, b in (("rectangles", base), ("POLY instance, no polygon", norect), ("rectangles as 4-vertex rings", rect_rings(base)), (f"polygons <= {mv} vertices", synth.with_random_shapes(base, 4242, frac=0.5, max_vertices=mv))):
+only = os.environ.get("POLY_ONLY")  # POLY_ONLY=3: the random-polygon scenes alone (PMC passes: one scene type per instance)
+for sel, (name, b) in enumerate((("rectangles", base), ("POLY instance, no polygon", norect), ("rectangles as 4-vertex rings", rect_rings(base)), (f"polygons <= {mv} vertices", synth.with_random_shapes(base, 4242, frac=0.5, max_vertices=mv)))):
+    if only is not None and int(only) != sel:
+        continue
     db = DeviceBatch(b, 0)
     B = b.B
     bi = torch.empty(B, dtype=torch.int32, device=dev); bc = torch.empty(B, dtype=torch.float64, device=dev)
