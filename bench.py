@@ -827,36 +827,44 @@ def main():
         # on this GPU, enqueue-only calls; must sit within a few percent of the headline (it is the same launches behind one more
         # Python layer)
         from fiss_plus_planner_amd.sharded import ShardedEngine
-        with ShardedEngine(devices=[local_rank]) as seng:
-            sdbs = [seng.upload(w.batch, winner=True) for w in wls]
-            if prewarm_s > 0:  # device wake-up (the engine has its own ctx: its launch order is learnt here too, like the headline's in `prewarm`)
-                t_w, kw = time.perf_counter(), 0
-                while time.perf_counter() - t_w < prewarm_s:
-                    for _ in range(32):
-                        seng.plan_dense(sdbs[kw % len(sdbs)], winner=True, sync=False)
-                        kw += 1
-                    for sd in sdbs:
-                        sd.synchronize()
-            for k in range(warm_x):
-                seng.plan_dense(sdbs[k % len(sdbs)], winner=True, sync=False)
-            for sd in sdbs:
-                sd.synchronize()
-            barrier()
-            t0 = time.perf_counter()
-            for k in range(steps_x):
-                seng.plan_dense(sdbs[(warm_x + k) % len(sdbs)], winner=True, sync=False)
-            for sd in sdbs:
-                sd.synchronize()
-            el = time.perf_counter() - t0
-            osr = {"value": float(np.mean([w.candidates for w in wls])) * steps_x / el, "unit": "candidates/s", "ms_per_step": el / steps_x * 1e3,
-                   "steps": steps_x, "warmup": warm_x, "shards": seng.world,
-                   "what": "ShardedEngine(devices=[0]).upload(batch) once per batch, then plan_dense(resident shards, winner=True, sync=False) per step"}
-            osr["vs_headline"] = osr["ms_per_step"] / (elapsed / args.steps * 1e3)
-            if args.cpu_seconds > 0:
-                seng.plan_dense(sdbs[-1], winner=True)
-                osr["parity"] = fop_parity("sharded_resident", wls[-1].batch, np.arange(0, B, max(1, B // 64)), sdbs[-1].host.best_idx, sdbs[-1].host.best_cost, gate_threads)
-            extras["sharded_resident"] = osr
-            del sdbs
+
+        def sharded_leg(shards):
+            with ShardedEngine(devices=[local_rank], shards_per_device=shards) as seng:
+                sdbs = [seng.upload(w.batch, winner=True) for w in wls]
+                if prewarm_s > 0:  # device wake-up (the engine has its own ctx: its launch order is learnt here too, like the headline's in `prewarm`)
+                    t_w, kw = time.perf_counter(), 0
+                    while time.perf_counter() - t_w < prewarm_s:
+                        for _ in range(32):
+                            seng.plan_dense(sdbs[kw % len(sdbs)], winner=True, sync=False)
+                            kw += 1
+                        for sd in sdbs:
+                            sd.synchronize()
+                for k in range(warm_x):
+                    seng.plan_dense(sdbs[k % len(sdbs)], winner=True, sync=False)
+                for sd in sdbs:
+                    sd.synchronize()
+                barrier()
+                t0 = time.perf_counter()
+                for k in range(steps_x):
+                    seng.plan_dense(sdbs[(warm_x + k) % len(sdbs)], winner=True, sync=False)
+                for sd in sdbs:
+                    sd.synchronize()
+                el = time.perf_counter() - t0
+                osr = {"value": float(np.mean([w.candidates for w in wls])) * steps_x / el, "unit": "candidates/s", "ms_per_step": el / steps_x * 1e3,
+                       "steps": steps_x, "warmup": warm_x, "shards": seng.world,
+                       "what": f"ShardedEngine(devices=[0], shards_per_device={shards}).upload(batch) once per batch, then plan_dense(resident shards, winner=True, "
+                               "sync=False) per step: one fp_group_submit per step posts every shard's call to the library's per-ctx worker threads"}
+                osr["vs_headline"] = osr["ms_per_step"] / (elapsed / args.steps * 1e3)
+                if args.cpu_seconds > 0:
+                    seng.plan_dense(sdbs[-1], winner=True)
+                    osr["parity"] = fop_parity("sharded_resident", wls[-1].batch, np.arange(0, B, max(1, B // 64)), sdbs[-1].host.best_idx, sdbs[-1].host.best_cost, gate_threads)
+                del sdbs
+            return osr
+
+        extras["sharded_resident"] = sharded_leg(1)
+        # two logical shards on the one device (each step = two 1024-ego launches on two contexts / streams, posted by one FFI call): what
+        # `two_streams` does by hand, through the product's multi-GPU path
+        extras["sharded_resident_two_shards"] = sharded_leg(2)
         # (a4) BASELINE configs[4] on ONE GPU: all 16 384 egos in one launch (21 rounds of workgroups: the tail of the last round
         # amortised over eight times the work of the headline launch)
         if B == 2048:
