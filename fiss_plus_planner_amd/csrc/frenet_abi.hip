@@ -126,6 +126,7 @@ struct fp_ctx {
     int inline_inputs = 1;         // fp_ctx_set_option("inline_inputs"): fp_plan_dense(FP_MEM_HOST) of a tiny batch with cached tables passes the per-ego arrays inside the lattice kernel's argument block
     int stage_kernel = 1;          // fp_ctx_set_option("stage_kernel"): the latency regime's inputs reach the device by a copy kernel instead of a copy command
     int zero_copy_in = 0;          // fp_ctx_set_option("zero_copy_in"): FP_MEM_HOST calls of a handful of egos read inputs from pinned host memory: 0 never (default: even a few hundred bytes read over the link cost every kernel of the call a round trip - measured slower than the copy kernel), 1 the per-ego arrays of a call whose tables are cached (tables_tag), 2 everything
+    int lattice_occupancy = 0;     // fp_ctx_set_option("lattice_occupancy"): 0 auto, 2 / 3: at most that many lattice workgroups per CU
     int lattice_tail = 0;          // fp_ctx_set_option("lattice_tail"): 0 auto, 1 never, n >= 2: the last n dispatch slots of a multi-round launch are cut in two workgroups
     int lattice_group = 0;         // fp_ctx_set_option("lattice_group"): 0 auto, 1 never, n >= 2: up to n slices per barrier interval
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
@@ -1045,6 +1046,11 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->lattice_group = value;
         return FP_OK;
     }
+    if (strcmp(name, "lattice_occupancy") == 0) {
+        if (value != 0 && (value < 2 || value > 4)) return fail(FP_EINVAL, "lattice_occupancy must be 0 (auto), 2, 3 or 4 (workgroups per compute unit at most)");
+        ctx->lattice_occupancy = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_tail") == 0) {
         if (value < 0) return fail(FP_EINVAL, "lattice_tail must be 0 (auto), 1 (never) or the number of egos cut in two");
         ctx->lattice_tail = value;
@@ -1062,7 +1068,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 {
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
-        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"lattice_occupancy", ctx->lattice_occupancy}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
         {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
     for (const auto& t : tab)
@@ -1085,6 +1091,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
+    ka.occ_cap = ctx->lattice_occupancy;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
@@ -1290,6 +1297,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     fp::FissArgs fa;
     fa.ka.p = *params;
     fa.ka.err_word = ctx->hand_err;
+    fa.ka.occ_cap = ctx->lattice_occupancy;
     fa.opts = *opts;
     fa.opts.max_refine_iters = R;
     fa.ka.r = no_result();
@@ -1508,6 +1516,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
+    ka.occ_cap = ctx->lattice_occupancy;
     ka.b = *batch;
     ka.b.skip = io->done;
     if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;

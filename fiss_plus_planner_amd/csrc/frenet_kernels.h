@@ -59,6 +59,8 @@ struct KernelArgs {
     // The ctx's hand-over error word (device-mapped pinned host memory, or nullptr): an appended workgroup whose wait for its ego's flag
     // runs out leaves a code here instead of trapping (1: winner-series epilogue, 2: FISS+ search); the host reads it at the next call.
     int32_t* err_word = nullptr;
+    // host-side launch hint (fp_ctx_set_option("lattice_occupancy")): 0 = auto, 2 / 3 = at most that many lattice workgroups per CU
+    int occ_cap = 0;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

@@ -34,6 +34,8 @@
 //   constraints         planners/frenet_optimal_planner.py:140-160
 //   collision           planners/frenet_optimal_planner.py:168-208 (stride 2, horizon from obstacles[0], M==1 -> collision)
 //   argmin              planners/frenet_optimal_planner.py:263-268
+#include <type_traits>
+
 #include "frenet_device.h"
 #include "frenet_kernels.h"
 #include "frenet_winner.h"
@@ -121,7 +123,7 @@ constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstac
 // block-wide list of (row, obstacle) items that pass the group test (+ their poses, 32 B each).  Two kernel variants: OCC = 4 waves per
 // SIMD (two workgroups per CU, up to 128 VGPRs, winner epilogue inside) and OCC = 6 (THREE workgroups per CU: 80 VGPRs - a few spill
 // - and at most 53 KB of LDS, so a shorter list; no winner epilogue, the batches it serves get theirs from winner_traj_kernel)
-__host__ __device__ constexpr int item_cap(int occ) { return occ > 4 ? 320 : 512; }
+__host__ __device__ constexpr int item_cap(int occ) { return occ > 6 ? 256 : occ > 4 ? 320 : 512; }
 constexpr int kItemCapMax = 512;
 
 struct __attribute__((aligned(16))) Frame {  // reference-line frame of one lon-profile point
@@ -172,17 +174,24 @@ constexpr bool kWalk = true;
 constexpr int kPolyLdsMax = 4 * 1024;
 __host__ __device__ inline int poly_lds_verts(int n_obs, int poly_stride) { return poly_stride > 0 && n_obs * poly_stride * 16 <= kPolyLdsMax ? n_obs * poly_stride : 0; }
 
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs, int nwaves, int poly_stride = 0)
+// the walk's fan bounds in LDS: fp32, or (slim layout) fp16 that is never below the fp32 value: x (1 + 2^-10) survives the rounding to
+// 11 bits (relative error <= 2^-11), the offset keeps the result a normal half (no dependence on the denormal mode), NaN stays NaN
+template <bool SLIM> struct FanType { using type = float; static __device__ __forceinline__ float above(float x) { return x; } };
+template <> struct FanType<true> { using type = _Float16; static __device__ __forceinline__ _Float16 above(float x) { return (_Float16)(x * 1.001f + 6.2e-5f); } };
+
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs, int nwaves, int poly_stride = 0, bool slim = false)
 {
+    // slim (the four-per-CU instance, kWalk, no polygon columns): the same tables in 40 KB - no inner radii, fp16 fan bounds, 16-bit
+    // hit codes, the row boxes inside the power sums' / hit lists' bytes (they are read for the last time before the first hit is written)
     Layout L;
     int o = 0;
-    L.dim = o;      o = align16(o + 32 * n_obs);
+    L.dim = o;      o = align16(o + (slim ? 24 : 32) * n_obs);
     L.pose = o;     o = align16(o + 32 * kItemCap);  // poses of the group test's survivors (x, y, cos, sin), in list order
     if (kWalk) {
         L.frames = o;   o = align16(o + 32 * nwaves * hp);   // [wavefront][point]: the profile the wavefront is working on
         L.lat = o;
-        L.dmax = o;     o = align16(o + 4 * nt * hp);        // [slice][point] float, rounded up: max |d| over the lateral samples
-        L.ddmax = o;    o = align16(o + 4 * nt * hp);        // max |d(i + 1) - d(i)|
+        L.dmax = o;     o = align16(o + (slim ? 2 : 4) * nt * hp);   // [slice][point] float (slim: half), rounded up: max |d| over the lateral samples
+        L.ddmax = o;    o = align16(o + (slim ? 2 : 4) * nt * hp);   // max |d(i + 1) - d(i)|
         L.wfat = o;     o = align16(o + 4 * nwaves * (rows > 0 ? rows : 1));  // [wavefront][row] float, rounded up
     } else {
         L.frames = o;   o = align16(o + 32 * gs * nv * hp);
@@ -199,17 +208,19 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.lon_meta = o; o = align16(o + 8 * nt * nv);    // int M, uint flags
     L.qlon = o;     o = align16(o + 16 * nt * nv);   // a3, a4 of every lon profile (a0..a2 are the ego state)
     L.qlat = o;     o = align16(o + 24 * (kWalk ? nt : gs) * nd);   // a3, a4, a5 of the lat profiles (walk: of every slice; else of the CURRENT slices)
-    L.box = o;      o = align16(o + 16 * (rows > 0 ? rows : 1));  // per checked pose row: bounding box of the slice's reference points (ordered-uint fp32)
+    L.box = o;      if (!slim) o = align16(o + 16 * (rows > 0 ? rows : 1));  // per checked pose row: bounding box of the slice's reference points (ordered-uint fp32)
     L.coll = o;     o = align16(o + (kWalk ? 8 * nt * nv : nd * nv * nt));  // walk: one bit per lateral sample, a 64-bit word per lon profile; else a byte per candidate
     // per-wave hit queues; before the slice loop the same bytes hold the power sums S_k(N) = sum_i (i*tick)^k, k = 0..10, per slice
     L.queue = o;    L.pows = o;
     {
-        const int q = kWalk ? 4 * 64 * nwaves : 4 * kHitCap;
-        o = align16(o + (q > 88 * nt ? q : 88 * nt));
+        const int q = kWalk ? (slim ? 2 : 4) * 64 * nwaves : 4 * kHitCap;
+        int pw = align16(88 * nt);
+        if (slim) { L.box = o + pw; pw += 16 * (rows > 0 ? rows : 1); }
+        o = align16(o + (q > pw ? q : pw));
     }
     L.cnt = o;      o = align16(o + 32);  // list counters (monotone) + scan mask + ticket + two fp32 bounds
     L.nslice = o;   o = align16(o + 4 * nt);  // points per slice, len(np.arange(0, T, tick))
-    L.best = o;     o = align16(o + 16 * 16);  // (up to 16 wavefronts)
+    L.best = o;     o = align16(o + 16 * (slim ? 8 : 16));  // (up to 16 wavefronts; slim: 8)
     L.konst = o;    o = align16(o + 96);  // per-ego constants the collision stages re-read (instead of registers held through the kernel)
     L.nvert = o;    o = align16(o + (poly_stride > 0 ? 4 * n_obs : 0));                              // polygon columns: vertices per obstacle
     L.poly = o;     o = align16(o + 16 * poly_lds_verts(n_obs, poly_stride));                        // ... and the rings, when they fit
@@ -398,11 +409,14 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // divergent loop BEFORE the exec mask is restored (exec = 0: nothing is stored, the reload returns whatever the scratch slot held -
     // zeros in a launch's first round of workgroups, another workgroup's values later), so no instance may spill a VGPR at all
     // (tools/resource_usage.py must show 0 in "VGPRs Spill" for every kernel; tests/test_abi_cpu.py checks it).
-    constexpr bool kEgoLds = ND == 0 && OCC > 4;
+    constexpr bool kEgoLds = (ND == 0 && OCC > 4) || OCC > 6;
+    constexpr bool kEgoEarly = OCC > 6;  // four per CU (64 VGPRs): from the FIRST barrier on
     constexpr bool kGroup = GS != 1;
     constexpr int kThreads = NTH, kWaves = NTH / kWave;  // (shadow the file-scope defaults)
     static_assert(GS == 0 || GS == 1, "GS: 1 or 0 (run-time group size)");
     constexpr int kItemCap = item_cap(OCC);
+    constexpr bool kSlim = OCC > 6;  // four workgroups per CU: the 40 KB layout (make_layout)
+    static_assert(!kSlim || (kWalk && !POLY && NTH <= 512 && item_cap(OCC) <= 256), "slim layout: walk, boxes only, 8 wavefronts, 8-bit survivor index");
     const int gs = kGroup ? gs_arg : 1;
     const int rows_max = kShape ? ROWS : rows_max_arg;
     const int hp_max = kShape ? (ROWS > 0 ? (ROWS * STRIDE + 1 > FP_MAX_POINTS ? FP_MAX_POINTS : ROWS * STRIDE + 1) : 0) : hp_max_arg;
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const int n_obs_tab = kShape ? NOBS : bt.n_obs;  // obstacles per scene of the table
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs, kWaves, POLY ? bt.poly_stride : 0);
+    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs, kWaves, POLY ? bt.poly_stride : 0, kSlim);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
@@ -472,6 +486,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     double* s_lat = (double*)(smem + L.lat);
     float* s_dmax2 = (float*)(smem + L.dmax);    // [2][gs][hp_max]
     float* s_ddmax2 = (float*)(smem + L.ddmax);  // [2][gs][hp_max]
+    using fan_t = typename FanType<kSlim>::type;  // the walk's view of the two: [slice][hp_max]
+    fan_t* s_fan_d = (fan_t*)(smem + L.dmax);
+    fan_t* s_fan_dd = (fan_t*)(smem + L.ddmax);
     float* s_wfat = (float*)(smem + L.wfat);
     ObsDim* s_grp = (ObsDim*)(smem + L.grp);  // reused as {cx, cy, radius, -}
     unsigned short* s_items = (unsigned short*)(smem + L.iqueue);  // item index mul24(r, n_obs) + j
@@ -488,6 +505,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     unsigned char* s_coll = smem + L.coll;
     uint32_t* s_collmask = (uint32_t*)(smem + L.coll);  // walk: [lon profile][2], bit id = lateral sample id of the profile collides
     uint32_t* s_hits = (uint32_t*)(smem + L.queue);
+    using hit_t = typename std::conditional<kSlim, uint16_t, uint32_t>::type;  // walk: (point k, survivor index) codes
     int* s_cnt = (int*)(smem + L.cnt);
     int* s_nslice = (int*)(smem + L.nslice);
     Best* s_best = (Best*)(smem + L.best);
@@ -615,8 +633,16 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         }
     }
     SplineLds sp{s_knots, s_coef, nx, NX};
+    if (kEgoEarly && tid == 8) { s_k[5] = s0; s_k[6] = s_d0; s_k[7] = s_dd0; s_k[8] = d0; s_k[9] = d_d0; s_k[10] = d_dd0; }
     __syncthreads();
     FP_STAMP(0);
+    // the ego's start state as the prologue's solves read it (kEgoEarly: from LDS already)
+    auto pS0 = [&]() -> double { if constexpr (kEgoEarly) return s_k[5]; else return s0; };
+    auto pSd0 = [&]() -> double { if constexpr (kEgoEarly) return s_k[6]; else return s_d0; };
+    auto pSdd0 = [&]() -> double { if constexpr (kEgoEarly) return s_k[7]; else return s_dd0; };
+    auto pD0 = [&]() -> double { if constexpr (kEgoEarly) return s_k[8]; else return d0; };
+    auto pDd0 = [&]() -> double { if constexpr (kEgoEarly) return s_k[9]; else return d_d0; };
+    auto pDdd0 = [&]() -> double { if constexpr (kEgoEarly) return s_k[10]; else return d_dd0; };
     // Arclength buckets -> segment hint: lut[b] = bisect_right(knots, k0 + b*width) - 1, 2*nx buckets.  A point then
     // needs one table read plus a short walk instead of a log2(nx) search (knots may be non-uniform: the walk fixes it).
     const int n_buckets = 2 * nx;
@@ -715,7 +741,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         const int eq = div_by<NV, NT * NV>(e, 1.0f / (float)nv);
         const int it = it_lo + eq, iv = e - mul24(eq, nv);
         const double T = s_ts[it];
-        const Quartic q = quartic_bvp(s0, s_d0, s_dd0, v_samples[iv], 0.0, T);
+        const Quartic q = quartic_bvp(pS0(), pSd0(), pSdd0(), v_samples[iv], 0.0, T);
         s_qlon[2 * (mul24(it, nv) + iv)] = q.a3;
         s_qlon[2 * (mul24(it, nv) + iv) + 1] = q.a4;
         const int N = arange_len(T, tick);
@@ -727,9 +753,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         // evaluations the point-by-point scan would do; anything not proven (including NaNs) falls back to that scan, so the
         // outcome is the scan's outcome either way.
         if (N > 0) {
-            const double a2 = s_dd0 * 0.5, tl = (double)(N - 1) * tick;
+            const double a2 = pSdd0() * 0.5, tl = (double)(N - 1) * tick;
             auto acc = [&](double t) { return fma(fma(12.0 * q.a4, t, 6.0 * q.a3), t, 2.0 * a2); };
-            auto vel = [&](double t) { return fma(fma(fma(4.0 * q.a4, t, 3.0 * q.a3), t, 2.0 * a2), t, s_d0); };
+            auto vel = [&](double t) { return fma(fma(fma(4.0 * q.a4, t, 3.0 * q.a3), t, 2.0 * a2), t, pSd0()); };
             const double qa = 12.0 * q.a4, qb = 6.0 * q.a3, qc = 2.0 * a2;  // s_dd = qa t^2 + qb t + qc
             double amax = fmax(fabs(acc(0.0)), fabs(acc(tl)));
             const double tv = -qb / (2.0 * qa);
@@ -745,9 +771,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             } else if (!(disc < 0.0)) proven = false;  // NaN
             const double pad = amax * 1e-6;  // |s_d(t) - s_d(r)| <= max|s_dd| |t - r|: covers a root off by a microsecond
             proven = proven && vmax + pad <= p.max_speed * (1.0 - 1e-9) - 1e-12 && vmin - pad >= 0.0;
-            const double s_end = fma(fma(fma(fma(q.a4, tl, q.a3), tl, a2), tl, s_d0), tl, s0);
+            const double s_end = fma(fma(fma(fma(q.a4, tl, q.a3), tl, a2), tl, pSd0()), tl, pS0());
             const double eps = 1e-9 * (1.0 + fabs(knot_last) + fabs(knot0));
-            proven = proven && s0 >= knot0 + eps && s_end < knot_last - eps;
+            proven = proven && pS0() >= knot0 + eps && s_end < knot_last - eps;
             if (!proven) atomicOr((unsigned int*)&s_cnt[2], 1u << ((it - it_lo) & 31));
         }
     }
@@ -769,8 +795,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             if (e < n_it * nd) {
                 const int eq = div_by<ND, NT * ND + kWave>(e < n_it * nd ? e : 0, 1.0f / (float)nd);
                 const double T = s_ts[it_lo + eq], de = s_ds[e - mul24(eq, nd)];
-                double bd = (fabs(d0) > fabs(de) ? fabs(d0) : fabs(de)) + 0.1976 * fabs(d_d0) * T + 0.01729 * fabs(d_dd0) * T * T;
-                if (!(d0 == d0) || !(de == de)) bd = __builtin_nan("");
+                const double d0e = pD0();
+                double bd = (fabs(d0e) > fabs(de) ? fabs(d0e) : fabs(de)) + 0.1976 * fabs(pDd0()) * T + 0.01729 * fabs(pDdd0()) * T * T;
+                if (!(d0e == d0e) || !(de == de)) bd = __builtin_nan("");
                 bits = __float_as_uint(float_above(bd) * 1.0000005f);
             }
 #pragma unroll
@@ -782,7 +809,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         }
     }
     if (tid == 0) { s_k[0] = knot0; s_k[1] = inv_bucket_w; s_k[2] = veh_hl; s_k[3] = veh_hw; s_k[4] = r_ego; }
-    if (kEgoLds && tid == 1) { s_k[5] = s0; s_k[6] = s_d0; s_k[7] = s_dd0; s_k[8] = d0; s_k[9] = d_d0; s_k[10] = d_dd0; }
+    if (kEgoLds && !kEgoEarly && tid == 1) { s_k[5] = s0; s_k[6] = s_d0; s_k[7] = s_dd0; s_k[8] = d0; s_k[9] = d_d0; s_k[10] = d_dd0; }
     {   // power sums of every slice (they need nothing but the time samples): a few threads of the middle
         const int i = tid - kThreads / 2;
         if (i >= 0 && i < n_it) power_sums_closed(arange_len(s_ts[it_lo + i], tick), tick, s_pows + (it_lo + i) * 11);
@@ -927,8 +954,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                     ddm = __float_as_uint(fdd) > __float_as_uint(ddm) ? fdd : ddm;
                 }
                 if (d_nan) dm = ddm = __builtin_nanf("");  // a NaN sample: its own profile is NaN everywhere -> every pair passes
-                s_dmax2[mul24(it, hp_max) + i] = dm;
-                s_ddmax2[mul24(it, hp_max) + i] = i + 1 < np_i ? ddm : 0.0f;
+                s_fan_d[mul24(it, hp_max) + i] = FanType<kSlim>::above(dm);
+                s_fan_dd[mul24(it, hp_max) + i] = i + 1 < np_i ? FanType<kSlim>::above(ddm) : (fan_t)0.0f;
             }
         }
     }
@@ -1058,7 +1085,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                     __syncthreads();  // the survivors' (cos, sin), the item list and the lateral bounds are visible to every wavefront
                     const SplitTab<Frame> wfr = s_frames.at(mul24(wave, hp_max));
                     float* wwf = s_wfat + mul24(wave, rows_max > 0 ? rows_max : 1);
-                    uint32_t* wh = s_hits + wave * kWave;
+                    hit_t* wh = (hit_t*)s_hits + wave * kWave;
                     constexpr int kHpwC = ND > 0 ? kWave / ND : 1;
                     const int hpw = kShape ? kHpwC : kWave / nd;  // hits per narrow-phase round
                     const int hh_l = div_by<ND, kWave>(lane, inv_ndf), id_l = lane - mul24(hh_l, nd);
@@ -1094,8 +1121,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         }
     // [/section FRAMES]
                         wave_lds_sync();
-                        const float* dm = s_dmax2 + mul24(it, hp_max);
-                        const float* ddm = s_ddmax2 + mul24(it, hp_max);
+                        const fan_t* dm = s_fan_d + mul24(it, hp_max);
+                        const fan_t* ddm = s_fan_dd + mul24(it, hp_max);
                         {   // prep (see the slice loop's comment for the bound): conservative, fp32
                             const float r_ego_f = float_above(s_k[4]), hl_f = float_above(s_k[2]), hw_f = float_above(s_k[3]);
     // [section PREP]
@@ -1118,7 +1145,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                         wl = vmin_f32(r_ego_f, (hl_f * sigma + hw_f) * (1.0f + 1e-6f));
                                     }
                                 }
-                                wwf[r] = row_ok ? (dm[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
+                                wwf[r] = row_ok ? ((float)dm[k] + wl) * (1.0f + 1e-6f) + 1e-9f : 0.0f;
                             }
     // [/section PREP]
                         }
@@ -1155,13 +1182,13 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                 const double reach = fma(od.hl, a_n, od.hw * a_t), reach_t = fma(od.hl, a_t, od.hw * a_n);
                                 pass = k < M && !(fma(dx, dx, dy * dy) > fat * fat) && !(fabs(w) > (double)wwf[r] + reach) &&
                                        !(fabs(u) > r_ego_b * (1.0 + 1e-12) + reach_t);
-                                code = (uint32_t)k | ((uint32_t)si << 8);  // k < 128, si < 512
+                                code = (uint32_t)k | ((uint32_t)si << 8);  // k < 128, si < 512 (slim: si < 256, 16 bits)
                             }
                             const unsigned long long m = __ballot(pass);
                             if (lane == 0) { FP_COUNT(1, 1); FP_COUNT(2, __popcll(m)); }
                             if (!m) continue;
                             const int n_hits = __popcll(m);
-                            if (pass) wh[__popcll(m & lt_mask)] = code;
+                            if (pass) wh[__popcll(m & lt_mask)] = (hit_t)code;
                             wave_lds_sync();
                             // ---- N: exact narrow phase, hpw hits x nd lateral samples per round
 #if defined(FP_ABL_NO_N)
@@ -1638,6 +1665,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
 // Returns hipErrorInvalidValue when the problem does not fit this kernel (caller falls back to the lane-per-candidate kernel).
 // LDS budget of one workgroup (the CU has 160 KB; beyond ~82 KB only one workgroup fits per CU)
 constexpr int kLdsLimit = 150 * 1024;
+constexpr int kLdsQuarter = 40 * 1024 - 512;  // (a margin below 160 KB / 4 for the allocation granule)
 
 static bool fused_shape(const fp_params& p, const fp_batch& b, int* rows_out, int* hp_out)
 {
@@ -1710,6 +1738,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
 #endif
+    if (ka.occ_cap == 2) three = false;  // (fp_ctx_set_option("lattice_occupancy"))
     const bool epilogue = three && can_epi;
     // the FISS+ search in appended workgroups: three-per-CU launches that write their tables, lattices the 1024-sample search instance holds
     const int C_all = p.nd * p.nv * p.nt;
@@ -1719,9 +1748,18 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FissTail fx = search ? *ft : kNoFiss;
     if (search) fx.NB = 512;  // (a multiple of 64 x the 8 wavefronts of the appended workgroups)
     const int search_lds = search ? fsp::fissplus_lds_bytes(C_all, fx.NB) : 0;
+    // FOUR workgroups per CU: BASELINE.json's dense shape when the slim layout (make_layout) and the appended workgroups' LDS fit a
+    // quarter of the CU (reference lines of up to ~80 knots); 64 VGPRs a lane, the ego's start state re-read from LDS (kEgoLds)
+    const Layout L8 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(8), 1, kThreads / kWave, 0, true);
+    bool four = three && !pstride && p.nd == 9 && p.nv == 9 && p.nt == 7 && p.check_stride == 2 && b.n_obs == 50 && rows == 25 &&
+                L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && b.B > 768;
+#if defined(FP_NO_OCC8)  // (A/B diagnostic)
+    four = false;
+#endif
+    if (ka.occ_cap == 2 || ka.occ_cap == 3) four = false;
     KernelArgs kx = ka;  // (epilogue workgroups offered but not taken: the caller's winner_traj_kernel writes the series)
     if (ka.epi_flag && !epilogue) { kx.r.best_traj = nullptr; kx.epi_flag = nullptr; }
-    Layout L = three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave, pstride);
+    Layout L = four ? L8 : three ? L6 : make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(4), gs, (gs > 1 ? FP_GROUP_THREADS : kThreads) / kWave, pstride);
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (epilogue && L.total < kEpiLds) L.total = kEpiLds;  // (every workgroup of a launch gets the same dynamic LDS)
     if (search && L.total < search_lds) L.total = search_lds;
@@ -1737,7 +1775,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     int tail_from = -1;
 #if !defined(FP_PHASE_STAMPS) && !defined(FP_COUNTERS)
     if (tail != 0 && nsplit == 1 && gs == 1 && part_scratch && p.nt >= 2 && b.S > 0 && b.n_obs > 0 && (size_t)b.B * 4 <= kTicketBytes) {
-        const int resident = (three ? 3 : 2) * (tail < 0 ? -tail : 0);  // workgroups the device holds at once (auto: tail = -compute units)
+        const int resident = (four ? 4 : three ? 3 : 2) * (tail < 0 ? -tail : 0);  // workgroups the device holds at once (auto: tail = -compute units)
         int n_tail = tail > 0 ? tail : (b.B > resident ? resident / 4 : 0);  // (128 ... 384 of 768 measured within 1 %; 576: no gain; 768: slower)
         if (n_tail > b.B - resident && tail < 0) n_tail = b.B - resident;
         if (n_tail > b.B) n_tail = b.B;
@@ -1765,6 +1803,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_555);
     FP_LDS_SLOTS(cfg_generic6);
     FP_LDS_SLOTS(cfg_9976);
+    FP_LDS_SLOTS(cfg_9978);
+    FP_LDS_SLOTS(cfg_9978f);
     FP_LDS_SLOTS(cfg_5556);
     FP_LDS_SLOTS(cfg_generic_g);
     FP_LDS_SLOTS(cfg_997_g);
@@ -1791,10 +1831,12 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4, 0, FP_GROUP_THREADS>, cfg_555_g, FP_GROUP_THREADS);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS>, cfg_generic_g, FP_GROUP_THREADS);
     } else if (search) {
-        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, false, true>, cfg_9976f);
+        if (four) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512, false, true>, cfg_9978f);
+        else if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, false, true>, cfg_9976f);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, false, true>, cfg_generic6f);
     } else if (three) {
-        if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512>, cfg_9976);
+        if (four) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512>, cfg_9978);
+        else if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512>, cfg_9976);
         else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 6, 1, 512>, cfg_5556);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512>, cfg_generic6);
     } else {

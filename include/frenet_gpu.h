@@ -235,6 +235,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "lattice_tail": 0 = auto (default: a launch with more one-workgroup egos than stay resident cuts the LAST quarter round of its
  * dispatch slots in two workgroups each - slices split, ticket + merge as in latency mode - so that it does not end on whole egos
  * that started last), 1 = never, n >= 2 = the last n slots.  Identical results.
+ * "lattice_occupancy": 0 = auto (default: batches of more egos than stay resident run three lattice workgroups per compute unit -
+ * four for BASELINE.json's dense lattice shape on reference lines of up to ~80 knots - instead of two), 2 / 3 = at most that many.
+ * Identical results.
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
  * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
