@@ -1752,7 +1752,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     // quarter of the CU (reference lines of up to ~80 knots); 64 VGPRs a lane, the ego's start state re-read from LDS (kEgoLds)
     const Layout L8 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(8), 1, kThreads / kWave, 0, true);
     bool four = three && !pstride && p.nd == 9 && p.nv == 9 && p.nt == 7 && p.check_stride == 2 && b.n_obs == 50 && rows == 25 &&
-                L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && b.B > 768;
+                L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && b.B > 768 &&
+                !b.skip;  // (a closed-loop batch: its finished egos leave at once, what runs rarely fills three per CU - measured 68 -> 71-75 us per cycle with four)
 #if defined(FP_NO_OCC8)  // (A/B diagnostic)
     four = false;
 #endif
