@@ -113,15 +113,25 @@ class Workload:
     """One problem batch resident in HBM + its output buffers + the step that plans it."""
     kPrevRing = 64
 
-    def __init__(self, torch, eng, batch, dev, stream, fiss=False, tables=False):
+    def order_hint(self, on: bool):
+        self.fb.launch_order = self.dten["launch_order"].data_ptr() if on else None
+        self.hinted = bool(on)
+
+    def __init__(self, torch, eng, batch, dev, stream, fiss=False, tables=False, hint=True):
+        """hint: pass fp_batch.launch_order (legs that cycle DISTINCT batches; a leg that replays one batch leaves it off - the ctx then
+        orders the launch by the durations the same batch left behind, as in every earlier round)."""
         from fiss_plus_planner_amd import _abi
-        from fiss_plus_planner_amd.engine import device_batch, make_params
+        from fiss_plus_planner_amd.engine import device_batch, launch_order_hint, make_params
 
         self.torch, self.eng, self.batch, self.dev, self.stream, self.fiss, self.tables = torch, eng, batch, dev, stream, fiss, tables
         self.dten = {k: torch.from_numpy(getattr(batch, k)).to(dev) for k in BATCH_ARRAYS}
         if getattr(batch, "obs_nvert", None) is not None:  # convex-polygon obstacle columns (ABI 12)
             self.dten.update({k: torch.from_numpy(getattr(batch, k)).to(dev) for k in ("obs_poly", "obs_nvert")})
+        # fp_batch.launch_order (ABI 14), as device_batch.DeviceBatch passes it: the egos by descending speed - input-only, one argsort on the
+        # host at upload; results do not depend on it (BENCH_NO_ORDER_HINT=1: without, the ctx's feedback order as before)
+        self.dten["launch_order"] = torch.from_numpy(launch_order_hint(batch)).to(dev)
         self.fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in self.dten.items()})
+        self.order_hint(hint and not os.environ.get("BENCH_NO_ORDER_HINT"))
         self.params = make_params(batch)
         B, C = batch.B, batch.C
         # per-ego results, packed in one device buffer [cost f64 x B | index i32 x B] so that one async copy brings both to the host
@@ -796,14 +806,24 @@ def main():
             gate = lambda leg, w, n: None  # noqa: E731  (--cpu-seconds 0: profiling runs, no oracle in the process)
         # (a) one batch replayed (the best case for the feedback-directed launch order) and the same in index order
         ordered, launches = eng.get_option("lattice_ordered_launches"), eng.get_option("lattice_launches")
-        extras["single_batch_replayed"] = dict(measure([main_wl], "lattice_fused_kernel, one batch replayed: launch order learnt on the batch itself"),
+        hinted = main_wl.hinted
+        for w in wls:
+            w.order_hint(False)  # (the three legs below: the ctx's own orders)
+        extras["single_batch_replayed"] = dict(measure([main_wl], "lattice_fused_kernel, one batch replayed, no hint: launch order learnt on the batch itself"),
                                                parity=gate("single_batch_replayed", main_wl, 64))
+        extras["launch_order_hint_off"] = dict(measure(wls, "lattice_fused_kernel, no hint: launch order learnt from the durations of an earlier launch - of a DIFFERENT batch"),
+                                               parity=gate("launch_order_hint_off", wls[-1], 64))
         eng.set_option("lattice_order", 0)
         extras["lattice_order_off"] = dict(measure(wls, "lattice_fused_kernel, workgroups dispatched in ego index order"),
                                            parity=gate("lattice_order_off", wls[-1], 64))
         eng.set_option("lattice_order", 1)
-        extras["lattice_order_on"] = {"launches_of_the_main_run": launches, "of_them_in_feedback_order": ordered,
-                                      "note": f"the main run cycles {n_rot} distinct batches, so an order is always one learnt on a DIFFERENT batch"}
+        for w in wls:
+            w.order_hint(hinted)
+        extras["launch_order"] = {"main_run": "fp_batch.launch_order = the egos by descending speed (engine.launch_order_hint: input-only, one host argsort at upload)" if hinted else
+                                  "no hint (BENCH_NO_ORDER_HINT): the ctx's feedback order",
+                                  "launches_of_the_main_run": launches, "of_them_in_a_given_or_learnt_order": ordered,
+                                  "note": f"the main run cycles {n_rot} distinct batches: an order the ctx learns is always one learnt on a DIFFERENT batch (launch_order_hint_off = "
+                                          "lattice_order_off); single_batch_replayed shows the order learnt on the batch itself"}
         # (a2) what SURVEY 8(d)'s metric definition counts in full: the per-candidate cost / flag tables written (12 B per candidate) and
         # the Stats brought to the host every step, next to index / cost / series as in the headline
         wt = [Workload(torch, eng, w.batch, dev, stream, tables=True) for w in wls]
@@ -869,7 +889,7 @@ def main():
         # amortised over eight times the work of the headline launch)
         if B == 2048:
             b5 = synth.make_config(5, layout=args.layout)
-            w5 = Workload(torch, eng, b5, dev, stream)
+            w5 = Workload(torch, eng, b5, dev, stream, hint=False)
             steps_keep, steps_x = steps_x, min(steps_x, 12)
             o5 = measure([w5], "lattice_fused_kernel + winner_traj_kernel, 16384 egos in one launch", ev_every=1)
             steps_x = steps_keep
@@ -886,7 +906,7 @@ def main():
         del w2
         # (c) BASELINE configs[3]: the FISS+ pipeline on 2048 egos; per-stage times from runs that stop after stage 1 / 2
         b4 = synth.make_config(4, B=B, layout=args.layout)
-        w4 = Workload(torch, eng, b4, dev, stream, fiss=True)
+        w4 = Workload(torch, eng, b4, dev, stream, fiss=True, hint=False)
         o4 = measure([w4], "lattice_fused (+ the FISS+ search in workgroups appended to its grid) + fiss_refine: the whole FISS+ pipeline in 2 launches")
         # stage times: the pipeline with the search in its OWN launch (fiss_fused = 0), stopped after stage 1 / 2 / 3; the leg's number
         # above is the default pipeline, whose search runs in workgroups appended to the lattice launch
@@ -910,7 +930,7 @@ def main():
         # (d) the builder's lanes obstacle layout (round 1 / 2 headline): ~15 % of the obstacles in the ego lane, the rest beside it
         other = "lanes" if args.layout == "survey8d" else "survey8d"
         b8 = synth.make_config(3, B=B, layout=other)
-        w8 = Workload(torch, eng, b8, dev, stream)
+        w8 = Workload(torch, eng, b8, dev, stream, hint=False)
         o8 = measure([w8], "lattice_fused_kernel")
         o8["workload"] = f"configs[2] sizes with the '{other}' obstacle layout (synth.py), one batch replayed"
         o8["parity"] = gate(f"{other}_layout", w8, 64)
@@ -920,7 +940,7 @@ def main():
         # (d1) obstacle shapes that are not rectangles (ABI 12): the headline's first batch with half of its obstacle columns turned
         # into random convex polygons (3-12 vertices) - the run-time-shape instances with the polygon narrow phase
         bp = synth.with_random_shapes(batch, 4242, frac=0.5)
-        wp = Workload(torch, eng, bp, dev, stream)
+        wp = Workload(torch, eng, bp, dev, stream, hint=False)
         op = measure([wp], "lattice_fused_kernel<run-time shape, POLY> (polygon narrow phase), one batch replayed")
         op["workload"] = (f"configs[2] sizes, {int((bp.obs_nvert > 0).sum())} of {bp.obs_nvert.size} obstacle columns convex polygons "
                           "(fp_batch.obs_poly / obs_nvert), the rest rectangles; one batch replayed")
@@ -952,7 +972,7 @@ def main():
         torch.cuda.synchronize(dev)
         ws2 = [wls[k] if k % 2 == 0 else Workload(torch, eng2, wls[k].batch, dev, stream2) for k in range(len(wls))] if len(wls) >= 2 else \
               [main_wl, Workload(torch, eng2, batch, dev, stream2)]
-        w4a, w4b = Workload(torch, eng, b4, dev, stream, fiss=True), Workload(torch, eng2, b4, dev, stream2, fiss=True)
+        w4a, w4b = Workload(torch, eng, b4, dev, stream, fiss=True, hint=False), Workload(torch, eng2, b4, dev, stream2, fiss=True, hint=False)
         torch.cuda.synchronize(dev)
         o2 = measure2(ws2)
         o2["what"] = "the headline workload with its steps alternating between two fp_ctx / two HIP streams (launches of consecutive steps overlap)"
@@ -1046,6 +1066,7 @@ def main():
                                    + (f"; rank r plans egos [r*{B}, (r+1)*{B}) of the {world * B}-ego batch (+ {n_rot - 1} further shards of the same stream)" if world > 1 else ""),
                        "egos_per_gpu": B, "candidates_per_ego": C, "tables_written": bool(args.tables), "obstacle_layout": args.layout,
                        "rotating_batches": n_rot, "parallelism": f"ego-shard x{world} (no collectives)",
+                       "launch_order": "fp_batch.launch_order: egos by descending speed (input-only hint, host argsort at upload; results identical)" if main_wl.hinted else "ctx feedback order",
                        "input_digest": batch.digest()[:16], "input_digests": [w.batch.digest()[:16] for w in wls]},
             "parity": parity_main,
             "roofline": roofline_obj(bytes_launch, kern_ms, kname, traffic,

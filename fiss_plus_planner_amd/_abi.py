@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 13
+FP_ABI_VERSION = 14
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND, FP_MAX_POLY_VERTS = 256, 1024, 16384, 128
@@ -48,7 +48,8 @@ class FpBatch(C.Structure):
                 ("ego", C.c_void_p), ("frame_of", C.c_void_p), ("scene_of", C.c_void_p), ("t_now", C.c_void_p),
                 ("nx", C.c_void_p), ("knots", C.c_void_p), ("coef", C.c_void_p),
                 ("obs_pose", C.c_void_p), ("obs_dims", C.c_void_p), ("final_time_step", C.c_void_p), ("skip", C.c_void_p),
-                ("tables_tag", C.c_int32), ("poly_stride", C.c_int32), ("obs_poly", C.c_void_p), ("obs_nvert", C.c_void_p)]
+                ("tables_tag", C.c_int32), ("poly_stride", C.c_int32), ("obs_poly", C.c_void_p), ("obs_nvert", C.c_void_p),
+                ("launch_order", C.c_void_p)]
 
 
 class FpResult(C.Structure):

@@ -558,12 +558,19 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
 // the launch: hands out the permutation to dispatch in (nullptr = index order) and the array the workgroups leave their durations
 // in.  Host work happens only when a fetched duration table has arrived (hipEventQuery, no wait): an argsort of B ints.
 constexpr int kOrderRefresh = 8;  // launches between two fetches of the duration table
-int launch_order_before(fp_ctx* ctx, LaunchOrder& o, int resident, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur)
+int launch_order_before(fp_ctx* ctx, LaunchOrder& o, int resident, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur,
+                        const int* hint = nullptr)
 {
     *perm = nullptr;
     *dur = nullptr;
     if (&o == &ctx->order_lattice) ++ctx->lattice_launches;
-    if (!ctx->lattice_order || nsplit != 1 || b->B <= resident) return FP_OK;
+    if (nsplit != 1 || b->B <= resident) return FP_OK;
+    if (hint) {  // fp_batch.launch_order: the caller's order wins (no durations are collected: the ctx's learnt order stays what it was)
+        *perm = hint;
+        if (&o == &ctx->order_lattice) ++ctx->lattice_ordered_launches;
+        return FP_OK;
+    }
+    if (!ctx->lattice_order) return FP_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     const bool capturing = cap != hipStreamCaptureStatusNone;
@@ -804,6 +811,13 @@ __global__ void validate_batch_kernel(fp_params p, fp_batch b, int* err)
         const double n = b.t_samples[i] / p.tick_t;
         if (!(n > 0) || n > FP_MAX_POINTS) code = 5;
     }
+    // the launch-order hint: a permutation of 0 .. B-1 (an entry out of range would be read as an ego; a repeated one plans an ego twice and
+    // another not at all).  marks: [B] zeros behind the error words.
+    if (!code && b.launch_order && i < b.B) {
+        const int e = b.launch_order[i];
+        if (e < 0 || e >= b.B) code = 11;
+        else if (atomicAdd(&err[2 + e], 1) != 0) code = 12;
+    }
     // polygon columns, one lane per column: a vertex count outside {0} u [3, poly_stride] would walk off the ring table; a ring that is
     // not counter-clockwise and convex, or that reaches outside the box of obs_dims, would be tested as a smaller shape than it is
     // (check_batch_host's checks, same tolerances)
@@ -843,13 +857,16 @@ __global__ void validate_batch_kernel(fp_params p, fp_batch b, int* err)
     if (code && atomicCAS(&err[0], 0, code) == 0) err[1] = i;
 }
 
+static size_t batch_marks(const fp_batch* b) { return b->launch_order && b->B > 0 ? (size_t)b->B : 0; }
+
 int device_validate(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream)
 {
     HIP_TRY(hipSetDevice(ctx->device));
-    FP_TRY(ctx->validate_buf.reserve(2 * sizeof(int)));
+    const size_t marks = batch_marks(b);
+    FP_TRY(ctx->validate_buf.reserve((2 + marks) * sizeof(int)));
     if (!ctx->validate_host) HIP_TRY(hipHostMalloc((void**)&ctx->validate_host, 2 * sizeof(int), hipHostMallocDefault));
     int* d_err = (int*)ctx->validate_buf.base;
-    HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(d_err, 0, (2 + marks) * sizeof(int), stream));
     int n = b->B > b->F ? b->B : b->F;
     if (p->nt > n) n = p->nt;
     if (b->obs_nvert && b->S > 0 && b->n_obs > 0) {  // (polygon columns: a lane per column, grid-stride beyond 64 K lanes)
@@ -873,6 +890,8 @@ int device_validate(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStrea
         case 8: return fail(FP_EINVAL, "obs_poly column %d is not counter-clockwise (device batch)", at);
         case 9: return fail(FP_EINVAL, "obs_poly column %d is not convex (device batch): cut it into convex pieces (obstacles.shape_columns)", at);
         case 10: return fail(FP_EINVAL, "obs_dims of polygon column %d does not contain its vertices (device batch)", at);
+        case 11: return fail(FP_EINVAL, "launch_order[%d] is outside 0 .. B-1 (device batch, B=%d)", at, b->B);
+        case 12: return fail(FP_EINVAL, "launch_order[%d] repeats an ego: not a permutation (device batch)", at);
         default: return fail(FP_ELIMIT, "t_samples[%d] needs more than FP_MAX_POINTS points (device batch)", at);
     }
 }
@@ -1102,7 +1121,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
         bool winner_done = false;
         const int* perm; int* dur;
-        FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
+        FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur, batch->launch_order));
         // (the audit pass may move the winner: the series are written after it, by their own launch)
         const bool inside = winner_inside_lattice(ctx, batch) && !result->audit && !big_points(ka.p);
         if (result->best_traj && !inside) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
@@ -1369,7 +1388,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     int nsplit, group, tail; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group, &tail));
     const int* perm; int* dur;
-    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur));
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur, mem == FP_MEM_DEVICE ? batch->launch_order : nullptr));
     bool search_done = false;
     if (inl.on) {
         fp::KernelArgs kl = fa.ka;
@@ -1525,7 +1544,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     int nsplit, group, tail; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
     const int* perm; int* dur;
-    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur));
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur, batch->launch_order));
     // the hand-over rides in the lattice launch unless that launch cannot write the series it is asked for itself (the standalone
     // epilogue reads the ego's state, so it has to run BEFORE the state moves on) or the lane-per-candidate kernel is asked for
     const bool series_elsewhere = result->best_traj && (!winner_inside_lattice(ctx, batch) || big_points(ka.p));

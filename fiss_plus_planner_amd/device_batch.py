@@ -13,14 +13,15 @@ import numpy as np
 
 from . import _abi
 from .batch import ProblemBatch
-from .engine import FrenetEngine, device_batch, make_params
+from .engine import FrenetEngine, device_batch, launch_order_hint, make_params
 
 _NAMES = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
           "obs_pose", "obs_dims", "final_time_step")
 
 
 class DeviceBatch:
-    def __init__(self, batch: ProblemBatch, device: int = 0):
+    def __init__(self, batch: ProblemBatch, device: int = 0, order_hint: bool = True):
+        """order_hint: pass fp_batch.launch_order = the egos by descending speed (engine.launch_order_hint; results do not depend on it)."""
         import torch
 
         self.torch = torch
@@ -30,8 +31,10 @@ class DeviceBatch:
         for k in ("samp_min", "samp_max", "samp_res", "obs_poly", "obs_nvert"):
             if getattr(batch, k, None) is not None:
                 self.t[k] = torch.from_numpy(getattr(batch, k)).to(self.dev)
+        if order_hint and batch.B > 0:
+            self.t["launch_order"] = torch.from_numpy(launch_order_hint(batch)).to(self.dev)
         self.params = make_params(batch)
-        self.fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in self.t.items() if k in _NAMES + ("obs_poly", "obs_nvert")})
+        self.fb = device_batch(batch, {k: (v.data_ptr() if v.numel() else 0) for k, v in self.t.items() if k in _NAMES + ("obs_poly", "obs_nvert", "launch_order")})
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.dev)
@@ -66,6 +69,7 @@ class ClosedLoopRunner:
         self.goal = torch.from_numpy(np.ascontiguousarray(goal_xy, dtype=np.float64).reshape(B, 2)).to(dbatch.dev)
         self.cart = torch.full((B, 3), float("nan"), dtype=f64, device=dbatch.dev)
         dbatch.fb.skip = self.done.data_ptr()  # finished egos are not planned any more
+        dbatch.fb.launch_order = None  # (the egos' states move on: the order the ctx learns from its own launches follows them, the upload's hint would not)
         self.io = _abi.FpLoopIo()
         self.io.ego, self.io.t_now = dbatch.t["ego"].data_ptr(), dbatch.t["t_now"].data_ptr()
         self.io.done, self.io.cycles = self.done.data_ptr(), self.cycles.data_ptr()

@@ -111,7 +111,16 @@ def device_batch(sizes, ptrs: dict) -> _abi.FpBatch:
         setattr(fb, name, ptrs.get(name) or None)
     if ptrs.get("obs_nvert"):
         fb.obs_poly, fb.obs_nvert, fb.poly_stride = ptrs["obs_poly"], ptrs["obs_nvert"], int(sizes.poly_stride)
+    fb.launch_order = ptrs.get("launch_order") or None  # (fp_batch.launch_order: the caller's launch-order hint, see launch_order_hint)
     return fb
+
+
+def launch_order_hint(batch) -> np.ndarray:
+    """fp_batch.launch_order for a resident batch: the egos by descending speed (ties in index order).  A launch of more egos than the
+    device holds workgroups ends on the egos that start last, and an ego's work grows with its speed (a faster ego reaches more obstacle
+    rows: more group-test survivors, longer walks) - measured on BASELINE config 3: 136.8 -> 130.9 us per 2048-ego step, the same as the
+    order learnt from the batch's own durations.  Input-only, computed once at upload; results do not depend on it."""
+    return np.argsort(-np.asarray(batch.ego)[:, 1], kind="stable").astype(np.int32)
 
 
 def fiss_rounds(kind, max_refine_iters: int) -> int:

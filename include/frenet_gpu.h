@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 13
+#define FP_ABI_VERSION 14
 
 /* error codes */
 #define FP_OK 0
@@ -157,6 +157,14 @@ typedef struct {
     int32_t poly_stride;          /* vertices per column of obs_poly (<= FP_MAX_POLY_VERTS); ignored when obs_nvert == NULL */
     const double* obs_poly;       /* NULL or [S][n_obs][poly_stride][2] */
     const int32_t* obs_nvert;     /* NULL or [S][n_obs] */
+    /* Launch-order hint (ABI 14), FP_MEM_DEVICE calls: NULL, or a permutation of 0 .. B-1 in device memory - the egos in the order their
+     * workgroups should START when the batch has more egos than the device holds workgroups at once (the launch ends on the egos that
+     * start last: put the ones expected to take longest first; ego speed, descending, is a good stand-in - a faster ego reaches more
+     * obstacle rows - and is what fiss_plus_planner_amd.device_batch.DeviceBatch passes, computed once at upload).  Results do not
+     * depend on it; entries outside 0 .. B-1 or repeated entries are the caller's responsibility (fp_ctx_set_option("validate", 1)
+     * checks them).  NULL: the library orders a launch by the durations an earlier launch of the ctx left behind ("lattice_order").
+     * Ignored by FP_MEM_HOST calls. */
+    const int32_t* launch_order;
 } fp_batch;
 
 /* Outputs of the dense lattice pass; any pointer except best_idx/best_cost may be NULL.
