@@ -122,7 +122,9 @@ constexpr int kThreads = 512;
 constexpr int kHitCap = 1024;    // block-wide list of (lon profile, row, obstacle) hits of one B pass  // block-wide list of live narrow-phase items (pair, lateral sample) of one B pass: 24 KB
 // block-wide list of (row, obstacle) items that pass the group test (+ their poses, 32 B each).  Two kernel variants: OCC = 4 waves per
 // SIMD (two workgroups per CU, up to 128 VGPRs, winner epilogue inside) and OCC = 6 (THREE workgroups per CU: 80 VGPRs - a few spill
-// - and at most 53 KB of LDS, so a shorter list; no winner epilogue, the batches it serves get theirs from winner_traj_kernel)
+// - and at most 53 KB of LDS, so a shorter list; no winner epilogue, the batches it serves get theirs from winner_traj_kernel or from the
+// appended epilogue workgroups) and, for BASELINE.json's dense shape, OCC = 8 (FOUR per CU: 64 VGPRs, none spilled, and the 40 KB "slim"
+// layout of make_layout with a 256-entry list - the largest ego of the headline workload keeps 221; longer lists take the chunked redo)
 __host__ __device__ constexpr int item_cap(int occ) { return occ > 6 ? 256 : occ > 4 ? 320 : 512; }
 constexpr int kItemCapMax = 512;
 
