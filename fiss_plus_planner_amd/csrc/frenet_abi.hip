@@ -1089,7 +1089,8 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
     const struct { const char* n; int v; } tab[] = {
         {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"lattice_occupancy", ctx->lattice_occupancy}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
         {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"lattice_launches", ctx->lattice_launches},
-        {"lattice_ordered_launches", ctx->lattice_ordered_launches}};
+        {"lattice_ordered_launches", ctx->lattice_ordered_launches},
+        {"lattice_launches_2", (int)fp::lattice_launches_per_cu(0)}, {"lattice_launches_3", (int)fp::lattice_launches_per_cu(1)}, {"lattice_launches_4", (int)fp::lattice_launches_per_cu(2)}};
     for (const auto& t : tab)
         if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
     return fail(FP_EINVAL, "unknown option '%s'", name);

@@ -130,6 +130,9 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
                                 const int* perm = nullptr, int* dur = nullptr, int group = 1, const InlineIn* inl = nullptr, int tail = 0,
                                 bool* step_done = nullptr, const FissTail* ft = nullptr, bool* search_done = nullptr);
 int lattice_group_fit(const fp_params& p, const fp_batch& b);
+// launches of the fused lattice kernel by workgroups per CU ([0] two, [1] three, [2] four) since the library was loaded: process-wide
+// counters behind fp_ctx_get_option("lattice_launches_2 / _3 / _4") - what the tests use to know which instance family they ran
+long lattice_launches_per_cu(int which);
 hipError_t launch_lattice_percand(const KernelArgs& ka, hipStream_t stream);
 // Curvature flags of every lattice candidate -> out [B][C] (one workgroup per ego, one lane per candidate, spline in LDS).
 hipError_t launch_curvature_flags(const KernelArgs& ka, uint8_t* out, hipStream_t stream);

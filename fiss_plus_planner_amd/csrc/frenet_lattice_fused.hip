@@ -34,6 +34,7 @@
 //   constraints         planners/frenet_optimal_planner.py:140-160
 //   collision           planners/frenet_optimal_planner.py:168-208 (stride 2, horizon from obstacles[0], M==1 -> collision)
 //   argmin              planners/frenet_optimal_planner.py:263-268
+#include <atomic>
 #include <type_traits>
 
 #include "frenet_device.h"
@@ -1701,6 +1702,9 @@ int lattice_group_fit(const fp_params& p, const fp_batch& b)
     return gs;
 }
 
+static std::atomic<long> g_launches_per_cu[3];
+long lattice_launches_per_cu(int which) { return which >= 0 && which < 3 ? g_launches_per_cu[which].load(std::memory_order_relaxed) : 0; }
+
 hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* part_scratch, int nsplit, bool* winner_done, const int* perm, int* dur,
                                 int group, const InlineIn* inl, int tail, bool* step_done, const FissTail* ft, bool* search_done)
 {
@@ -1750,11 +1754,10 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FissTail fx = search ? *ft : kNoFiss;
     if (search) fx.NB = 512;  // (a multiple of 64 x the 8 wavefronts of the appended workgroups)
     const int search_lds = search ? fsp::fissplus_lds_bytes(C_all, fx.NB) : 0;
-    // FOUR workgroups per CU: BASELINE.json's dense shape when the slim layout (make_layout) and the appended workgroups' LDS fit a
-    // quarter of the CU (reference lines of up to ~80 knots); 64 VGPRs a lane, the ego's start state re-read from LDS (kEgoLds)
+    // FOUR workgroups per CU when the slim layout (make_layout) and the appended workgroups' LDS fit a quarter of the CU (BASELINE.json's
+    // dense shape: reference lines of up to ~80 knots); 64 VGPRs a lane, the ego's start state re-read from LDS (kEgoLds)
     const Layout L8 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(8), 1, kThreads / kWave, 0, true);
-    bool four = three && !pstride && p.nd == 9 && p.nv == 9 && p.nt == 7 && p.check_stride == 2 && b.n_obs == 50 && rows == 25 &&
-                L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && b.B > 768 &&
+    bool four = three && !pstride && L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && b.B > 768 &&
                 !b.skip;  // (a closed-loop batch: its finished egos leave at once, what runs rarely fills three per CU - measured 68 -> 71-75 us per cycle with four)
 #if defined(FP_NO_OCC8)  // (A/B diagnostic)
     four = false;
@@ -1808,6 +1811,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_9976);
     FP_LDS_SLOTS(cfg_9978);
     FP_LDS_SLOTS(cfg_9978f);
+    FP_LDS_SLOTS(cfg_generic8);
+    FP_LDS_SLOTS(cfg_generic8f);
     FP_LDS_SLOTS(cfg_5556);
     FP_LDS_SLOTS(cfg_generic_g);
     FP_LDS_SLOTS(cfg_997_g);
@@ -1834,11 +1839,13 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 4, 0, FP_GROUP_THREADS>, cfg_555_g, FP_GROUP_THREADS);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS>, cfg_generic_g, FP_GROUP_THREADS);
     } else if (search) {
-        if (four) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512, false, true>, cfg_9978f);
+        if (four && is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512, false, true>, cfg_9978f);
+        else if (four) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 8, 1, 512, false, true>, cfg_generic8f);
         else if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, false, true>, cfg_9976f);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, false, true>, cfg_generic6f);
     } else if (three) {
-        if (four) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512>, cfg_9978);
+        if (four && is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512>, cfg_9978);
+        else if (four) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 8, 1, 512>, cfg_generic8);
         else if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512>, cfg_9976);
         else if (is(5, 5, 5, 2, 10, 50)) e = go(lattice_fused_kernel<5, 5, 5, 2, 10, 50, 6, 1, 512>, cfg_5556);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512>, cfg_generic6);
@@ -1849,6 +1856,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     }
 #endif
     if (e != hipSuccess) return e;
+    g_launches_per_cu[four ? 2 : three ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
     if (winner_done) *winner_done = kx.r.best_traj != nullptr && (!three || epilogue);
     if (step_done) *step_done = ka.has_loop != 0 && !three;  // (ka.has_loop: the two-per-CU instances hand the egos over themselves)
     if (search_done) *search_done = search;

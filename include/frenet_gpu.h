@@ -243,9 +243,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "lattice_tail": 0 = auto (default: a launch with more one-workgroup egos than stay resident cuts the LAST quarter round of its
  * dispatch slots in two workgroups each - slices split, ticket + merge as in latency mode - so that it does not end on whole egos
  * that started last), 1 = never, n >= 2 = the last n slots.  Identical results.
- * "lattice_occupancy": 0 = auto (default: batches of more egos than stay resident run three lattice workgroups per compute unit -
- * four for BASELINE.json's dense lattice shape on reference lines of up to ~80 knots - instead of two), 2 / 3 = at most that many.
- * Identical results.
+ * "lattice_occupancy": 0 = auto (default: batches of more egos than stay resident run three lattice workgroups per compute unit - four
+ * when a workgroup's tables fit a quarter of the unit's LDS: rectangle scenes, e.g. a 9 x 9 x 7 lattice against 50 obstacles on
+ * reference lines of up to ~80 knots - instead of two), 2 / 3 = at most that many.  Identical results.
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
  * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair
@@ -274,7 +274,8 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * refinement), 1 = stop after the dense lattice pass; with 1 or 2 the outputs of the skipped stages are NOT produced. */
 int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
 /* Reads an option back, or one of the read-only counters "lattice_launches" (dense lattice launches of this ctx so far) and
- * "lattice_ordered_launches" (those dispatched in a feedback order) - bench.py reports when the order took effect. */
+ * "lattice_ordered_launches" (those dispatched in a feedback order or in the order of fp_batch.launch_order) - bench.py reports when an
+ * order took effect -, "lattice_launches_2" / "_3" / "_4" (PROCESS-wide: fused lattice launches so far by workgroups per compute unit). */
 int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value);
 
 /* Dense lattice pass = FrenetOptimalPlanner.plan() for B egos at once:
