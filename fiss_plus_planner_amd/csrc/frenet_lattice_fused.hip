@@ -1497,6 +1497,15 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     if (tid < 16 && ka.r.best_traj) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 14) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112 + tid] = (double)s_dbg[tid];
 #endif
     // ---------------------------------------------------------------- per-candidate assembly + argmin
+    // From here on the kernel's arguments are read through `la`: for the four-per-CU instances (80 SGPRs) a view of the argument segment the
+    // compiler cannot fold into the loads at the kernel's start - result pointers, cost weights and ticket buffers are then scalar loads HERE
+    // instead of values carried through the walk in spilled SGPRs (each spill is a v_writelane / v_readlane pair: VALU issue slots); for
+    // the other instances the same loads as before.
+    int la_off = 0;
+    if constexpr (OCC > 6) asm volatile("" : "+s"(la_off));
+    const LatticeKernarg& la = *(const LatticeKernarg*)((const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + la_off);
+    const KernelArgs& kb = la.ka;
+    const fp_params& pa = la.ka.p;
     Best mine{0.0, -1};
     const float inv_nv_a = 1.0f / (float)nv, inv_nt_a = 1.0f / (float)nt;
     // [section ASM]
@@ -1517,19 +1526,19 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if (n_obs > 0 && M == 1 && horizon_cap >= 1) hit = true;  // traj.yaw is empty -> IndexError -> collision (:178-182)
         if (hit) flags |= FP_FLAG_COLLISION;
         if (M < N) flags |= FP_FLAG_TRUNCATED;
-        if (ka.curv_tbl) flags |= ka.curv_tbl[(size_t)b * C + c];  // optional curvature checks, computed by curvature_flags_kernel
-        double cost = combine_cost(p, N, ls, ds);  // cost_function.py:41-50, same grouping as the reference
+        if (kb.curv_tbl) flags |= kb.curv_tbl[(size_t)b * C + c];  // optional curvature checks, computed by curvature_flags_kernel
+        double cost = combine_cost(pa, N, ls, ds);  // cost_function.py:41-50, same grouping as the reference
         uint32_t word = flags | ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
-        if (N <= 0 || N > points_cap(p)) {  // a time sample the ABI's limits exclude (unvalidated in FP_MEM_DEVICE mode): no trajectory,
+        if (N <= 0 || N > points_cap(pa)) {  // a time sample the ABI's limits exclude (unvalidated in FP_MEM_DEVICE mode): no trajectory,
             cost = __builtin_nan("");        // exactly what the lane-per-candidate kernel reports (traj_eval)
             word = flags = FP_FLAG_SPEED | FP_FLAG_ACCEL | FP_FLAG_COLLISION;
         }
         if constexpr (FISS) {  // (read by the ego's search workgroup in THIS launch: agent-scope stores, see the template's comment)
-            __hip_atomic_store((unsigned long long*)&ka.r.cost_tbl[(size_t)b * C + c], (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ka.r.flag_tbl[(size_t)b * C + c], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned long long*)&kb.r.cost_tbl[(size_t)b * C + c], (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&kb.r.flag_tbl[(size_t)b * C + c], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (ka.r.cost_tbl) ka.r.cost_tbl[(size_t)b * C + c] = cost;
-            if (ka.r.flag_tbl) ka.r.flag_tbl[(size_t)b * C + c] = word;
+            if (kb.r.cost_tbl) kb.r.cost_tbl[(size_t)b * C + c] = cost;
+            if (kb.r.flag_tbl) kb.r.flag_tbl[(size_t)b * C + c] = word;
         }
         if (!(flags & FP_FLAG_INFEASIBLE) && cost == cost) mine = best_merge(mine, Best{cost, c});
     }
@@ -1559,14 +1568,14 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             // of the launch).  The signal fences pin the COMPILER to the same order (no motion of the stores, the wait, the ticket
             // or the loads across each other).  A kernel that faults leaves the ticket counters non-zero, but a GPU fault ends
             // the process on this stack, and with it the ctx that owns the counters.
-            Best* mine = part_best + blockIdx.x;
+            Best* mine = la.part_best + blockIdx.x;
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __hip_atomic_store(&mine->cost, r.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&mine->idx, r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __builtin_amdgcn_s_waitcnt(0);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            const int ticket = __hip_atomic_fetch_add(&part_count[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ticket = __hip_atomic_fetch_add(&la.part_count[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             s_cnt[3] = ticket;
         }
@@ -1574,9 +1583,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         if (s_cnt[3] != nsplit - 1) return;
         FP_STAMP_LAST(5);
         if (tid == 0) {
-            part_count[b] = 0;  // ready for the next launch
+            la.part_count[b] = 0;  // ready for the next launch
             __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the loads below stay behind the ticket
-            Best* pb = part_best + ((size_t)blockIdx.x - part);  // the ego's first workgroup
+            Best* pb = la.part_best + ((size_t)blockIdx.x - part);  // the ego's first workgroup
             auto part = [&](int w) {
                 return Best{__hip_atomic_load(&pb[w].cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                             __hip_atomic_load(&pb[w].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
@@ -1596,39 +1605,39 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         // (the hand-over first: its s_waitcnt would otherwise also wait for the stores below, and best_idx / best_cost may be
         // device-mapped HOST memory - a link round trip in front of every flag)
         if constexpr (OCC > 4) {
-            if (ka.epi_flag) {  // hand the ego to the appended epilogue workgroups: index first, acknowledged by L2, then the flag
+            if (kb.epi_flag) {  // hand the ego to the appended epilogue workgroups: index first, acknowledged by L2, then the flag
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                __hip_atomic_store(&ka.idx_shadow[b], r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&kb.idx_shadow[b], r.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 __builtin_amdgcn_s_waitcnt(0);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                __hip_atomic_store(&ka.epi_flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&kb.epi_flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
-        } else if (ka.idx_shadow) ka.idx_shadow[b] = r.idx;
+            } else if (kb.idx_shadow) kb.idx_shadow[b] = r.idx;
+        } else if (kb.idx_shadow) kb.idx_shadow[b] = r.idx;
 #if defined(FP_TL)
-        __hip_atomic_store((unsigned long long*)&ka.r.best_cost[b], (unsigned long long)__double_as_longlong((double)(wall_clock64() & 0xFFFFFFFFFFll)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ka.r.best_idx[b], (int)(t_begin & 0x7FFFFFFFll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned long long*)&kb.r.best_cost[b], (unsigned long long)__double_as_longlong((double)(wall_clock64() & 0xFFFFFFFFFFll)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&kb.r.best_idx[b], (int)(t_begin & 0x7FFFFFFFll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_waitcnt(0);
 #endif
         if constexpr (FISS) {
-            if (ft.flag) {  // the ego's rows of the tables are complete (both halves of a tail-split ego: the ticket came after theirs)
+            if (la.ft.flag) {  // the ego's rows of the tables are complete (both halves of a tail-split ego: the ticket came after theirs)
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                __hip_atomic_store(&ft.flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&la.ft.flag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
         }
 #if !defined(FP_TL)
-        ka.r.best_idx[b] = r.idx;
-        ka.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
+        kb.r.best_idx[b] = r.idx;
+        kb.r.best_cost[b] = r.idx >= 0 ? r.cost : __builtin_nan("");
 #endif
-        if (ka.r.stats) {
-            int32_t* st = ka.r.stats + (size_t)b * 4;
+        if (kb.r.stats) {
+            int32_t* st = kb.r.stats + (size_t)b * 4;
             st[0] = 0; st[1] = C; st[2] = C; st[3] = C;
         }
     }
     // 10 ns ticks: feeds the next launches' order (a tail ego leaves twice its last part's time: about what it would take whole)
-    if (tid == 0 && dur && (nsplit == 1 || in_tail)) dur[b] = (int)(wall_clock64() - t_begin) * nsplit;
+    if (tid == 0 && la.dur && (nsplit == 1 || in_tail)) la.dur[b] = (int)(wall_clock64() - t_begin) * nsplit;
     if (nsplit > 1) FP_STAMP_LAST(10); else FP_STAMP(10);
 #if defined(FP_PHASE_STAMPS)  // column 15: the workgroup's absolute start (10 ns ticks, low 40 bits) - the launch's occupancy over time
     if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112 + 15] = (double)(t_begin & 0xFFFFFFFFFFll);
