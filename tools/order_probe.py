@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Probe: what an input-only launch order is worth.  Two config-3 batches alternate (so a learnt order never sees its own batch);
-the egos of each batch are permuted before the upload by: nothing, descending ego speed, ascending ego speed."""
+the egos of each batch are permuted before the upload by: nothing, descending ego speed; 1 / 2 / 4 batches cycled (a feedback order is
+learnt on the launch two steps earlier: the same batch with 1 or 2 batches, another one with 4)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,10 +14,10 @@ eng = FrenetEngine(0)
 dev = torch.device("cuda", 0)
 
 
-def measure(tag, keyfn, order_opt):
+def measure(tag, keyfn, order_opt, n_batches=2):
     eng.set_option("lattice_order", order_opt)
     res = []
-    for off in (0, 1):
+    for off in range(n_batches):
         b = synth.make_config(3, ego_offset=off * 4096)
         if keyfn is not None:
             b = b.take(np.argsort(keyfn(b), kind="stable"))
@@ -27,7 +28,7 @@ def measure(tag, keyfn, order_opt):
         res.append((db, bi, bc, bf, bt, torch.cuda.current_stream(dev)))
 
     def run(k):
-        db, bi, bc, bf, bt, st = res[k % 2]
+        db, bi, bc, bf, bt, st = res[k % len(res)]
         eng.plan_dense_device(db.params, db.fb, bi.data_ptr(), bc.data_ptr(), stream=st.cuda_stream, best_flags=bf.data_ptr(), best_traj=bt.data_ptr(), traj_stride=112, traj_sparse=True)
     for k in range(400): run(k)
     torch.cuda.synchronize()
@@ -41,9 +42,15 @@ def measure(tag, keyfn, order_opt):
     print(f"{tag:34s} {np.median(ts):7.1f} us per step (min {min(ts):.1f})", flush=True)
 
 
-for rep in range(2):
-    measure("index order", None, 0)
-    measure("speed descending", lambda b: -b.ego[:, 1], 0)
-    measure("speed ascending", lambda b: b.ego[:, 1], 0)
-    measure("feedback order (other batch)", None, 1)
+# (DeviceBatch passes the speed hint itself: the sorted batches' hint is the identity, "index order" switches it off below)
+import fiss_plus_planner_amd.device_batch as _dbm
+_orig = _dbm.DeviceBatch
+class _NoHint(_orig):
+    def __init__(self, batch, device=0, order_hint=True):
+        super().__init__(batch, device, order_hint=False)
+DeviceBatch = _NoHint
+for nb in (1, 2, 4):  # 85 MB of tables per batch: one or two stay in the 256 MB Infinity Cache, four do not
+    measure(f"{nb} batch(es): index order", None, 0, nb)
+    measure(f"{nb} batch(es): speed descending", lambda b: -b.ego[:, 1], 0, nb)
+    measure(f"{nb} batch(es): feedback order", None, 1, nb)
 eng.set_option("lattice_order", 1)
