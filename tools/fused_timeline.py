@@ -40,3 +40,5 @@ for a, bb in zip(edges[:-1], edges[1:]):
     print(f"  {a:5.0f}..{bb:5.0f} us: lattice workgroups running {((lat_start <= m) & (lat_end > m)).sum():5d}   search workgroups resident {((t_res <= m) & (t_end > m)).sum():5d}  of which working {((t_flag <= m) & (t_end > m)).sum():5d}")
 late = np.argsort(-t_end)[:8]
 print("last searches: " + "; ".join(f"ego {b}: lattice end {lat_end[b] - t0:.0f}, resident {t_res[b] - t0:.0f}, flag {t_flag[b] - t0:.0f}, end {t_end[b] - t0:.0f}" for b in late))
+if len(sys.argv) > 1:  # (durations of the lattice workgroups, for launch-order studies: tools/order_probe.py)
+    np.save(sys.argv[1], np.stack([lat_start - t0, lat_end - t0]))
