@@ -587,7 +587,9 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
 #ifndef FP_POSE_FLIGHT
 #define FP_POSE_FLIGHT 2
 #endif
-    constexpr int kPoseFlight = FP_POSE_FLIGHT;  // pose reads in flight per lane in the group test
+    // pose reads in flight per lane in the group test.  The four-per-CU instances take three (512 x 3 items: the 1250 of config 3 in ONE pass;
+    // same-box A/B 130.7-131.2 against 131.6-132.2 us per step); three in the three-per-CU shaped instance spill two VGPRs.
+    constexpr int kPoseFlight = OCC > 6 ? FP_POSE_FLIGHT + 1 : FP_POSE_FLIGHT;
     auto fetch_poses = [&](int i0, double4* ps) {
 #pragma unroll
         for (int u = 0; u < kPoseFlight; ++u) {
