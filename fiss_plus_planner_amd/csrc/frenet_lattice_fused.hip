@@ -616,7 +616,13 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         for (int i = tid; i < NX; i += kThreads) s_knots[i] = gk[i];
         for (int i = tid; i < nt + nv + nd; i += kThreads)
             s_ts[i] = i < nt ? in_t[i] : (i < nt + nv ? in_v[(size_t)b * nv + (i - nt)] : in_d[i - nt - nv]);
-        for (int i = tid; i < 8 * NX; i += kThreads) s_coef[i] = gc[i];  // [8][NX], same layout
+        // [8][NX], same layout; the four-per-CU instances in 16-byte pieces (8 NX doubles are an even count; a global load needs no more than the
+        // doubles' own alignment) - one trip instead of two; in the polygon three-per-CU instance the same change spills two VGPRs
+        if constexpr (OCC > 6) {
+            for (int i = tid; i < 4 * NX; i += kThreads) ((double2*)s_coef)[i] = ((const double2*)gc)[i];
+        } else {
+            for (int i = tid; i < 8 * NX; i += kThreads) s_coef[i] = gc[i];
+        }
         if (n_obs > 0) {
             const double* gd = bt.obs_dims + (size_t)sc * n_obs * 2;
             if constexpr (POLY) {  // the scene's rings, when they fit (same layout as in global memory: [obstacle][poly_stride] vertex pairs)
