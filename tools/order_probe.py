@@ -12,16 +12,17 @@ from fiss_plus_planner_amd.engine import FrenetEngine
 
 eng = FrenetEngine(0)
 dev = torch.device("cuda", 0)
+_orig = DeviceBatch
 
 
-def measure(tag, keyfn, order_opt, n_batches=2):
+def measure(tag, keyfn, order_opt, n_batches=2, hint=False):
     eng.set_option("lattice_order", order_opt)
     res = []
     for off in range(n_batches):
         b = synth.make_config(3, ego_offset=off * 4096)
         if keyfn is not None:
             b = b.take(np.argsort(keyfn(b), kind="stable"))
-        db = DeviceBatch(b, 0)
+        db = _orig(b, 0, order_hint=hint)
         B = b.B
         bi = torch.empty(B, dtype=torch.int32, device=dev); bc = torch.empty(B, dtype=torch.float64, device=dev)
         bf = torch.zeros(B, dtype=torch.int32, device=dev); bt = torch.empty((B, 16, 112), dtype=torch.float64, device=dev)
@@ -42,15 +43,9 @@ def measure(tag, keyfn, order_opt, n_batches=2):
     print(f"{tag:34s} {np.median(ts):7.1f} us per step (min {min(ts):.1f})", flush=True)
 
 
-# (DeviceBatch passes the speed hint itself: the sorted batches' hint is the identity, "index order" switches it off below)
-import fiss_plus_planner_amd.device_batch as _dbm
-_orig = _dbm.DeviceBatch
-class _NoHint(_orig):
-    def __init__(self, batch, device=0, order_hint=True):
-        super().__init__(batch, device, order_hint=False)
-DeviceBatch = _NoHint
 for nb in (1, 2, 4):  # 85 MB of tables per batch: one or two stay in the 256 MB Infinity Cache, four do not
     measure(f"{nb} batch(es): index order", None, 0, nb)
     measure(f"{nb} batch(es): speed descending", lambda b: -b.ego[:, 1], 0, nb)
     measure(f"{nb} batch(es): feedback order", None, 1, nb)
+    measure(f"{nb} batch(es): speed hint (launch_order)", None, 0, nb, hint=True)
 eng.set_option("lattice_order", 1)
