@@ -128,9 +128,11 @@ def test_plan_step_equals_plan_dense_plus_advance(engine, B, cfg):
 
     goal = np.full((B, 2), 1e9)
     runs = []
+    n4 = engine.get_option("lattice_launches_4")
     for fused in (False, True):
         batch = synth.make_config(cfg, B=B)
         runs.append(ClosedLoopRunner(engine, DeviceBatch(batch, 0), goal, "FOP", fused=fused).run(9, trace=True))
+    assert engine.get_option("lattice_launches_4") == n4  # (a closed loop's skip mask keeps the batch off the four-per-CU instances)
     a, b = runs
     for k in ("done", "cycles", "t_now"):
         np.testing.assert_array_equal(getattr(a, k), getattr(b, k), err_msg=k)
