@@ -36,7 +36,7 @@ only = os.environ.get("POLY_ONLY")  # POLY_ONLY=3: the random-polygon scenes alo
 for sel, (name, b) in enumerate((("rectangles", base), ("POLY instance, no polygon", norect), ("rectangles as 4-vertex rings", rect_rings(base)), (f"polygons <= {mv} vertices", synth.with_random_shapes(base, 4242, frac=0.5, max_vertices=mv)))):
     if only is not None and int(only) != sel:
         continue
-    db = DeviceBatch(b, 0)
+    db = DeviceBatch(b, 0, order_hint=False)  # (one batch replayed: the ctx orders the launch by the durations the batch itself left behind)
     B = b.B
     bi = torch.empty(B, dtype=torch.int32, device=dev); bc = torch.empty(B, dtype=torch.float64, device=dev)
     bf = torch.zeros(B, dtype=torch.int32, device=dev); bt = torch.empty((B, 16, 112), dtype=torch.float64, device=dev)
