@@ -18,12 +18,13 @@ The synthetic scenes come from SURVEY.md section 8(d)'s generator verbatim (`--l
 region cycles through `--rotate` (default 4) DISTINCT batches of that generator, so no launch ever sees the batch the
 feedback-directed launch order was learnt on.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`; at N = 1 the line
-also carries the other single-GPU configurations (`config2`, `config4`), the index-order and single-batch variants of the
-headline workload, the builder's `lanes` obstacle layout, the device-resident closed loop (`closed_loop`) and the
-PCIe-inclusive host-buffer entry (`host_buffers`).  EVERY leg that prints a number carries a `parity` object: its outputs
-were compared with the CPU oracle in this run (index / Stats exact, cost <= 1e-6) and a mismatch aborts before anything
-is printed.
+Prints ONE compact JSON line (rank 0; < 4 KB, the last and only thing on stdout) with the driver's contract fields plus
+`roofline`, `cpu_baseline`, a short `parity` and `legs` (ms per step + parity verdict of the other single-GPU legs).  The
+full record of the run - the other configurations (`config2`, `config4`), the index-order and single-batch variants of
+the headline workload, the builder's `lanes` obstacle layout, the device-resident closed loop (`closed_loop`), the
+PCIe-inclusive host-buffer entry (`host_buffers`), every leg's complete `parity` object - goes to `bench_extras.json`
+next to this file ($BENCH_EXTRAS_FILE overrides the path).  EVERY leg that reports a number was compared with the CPU
+oracle in this run (index / Stats exact, cost <= 1e-6) and a mismatch aborts before anything is printed.
 """
 from __future__ import annotations
 
@@ -38,13 +39,6 @@ import time
 
 import numpy as np
 
-# The CPU-baseline leg runs the oracle with one OpenMP thread per host core; by default the runtime leaves those threads spinning
-# for a while after the parallel region, next to the thread that launches the workloads measured after it.
-os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-# The two-stream legs need their streams on different hardware queues: with the runtime's default of four, two created streams can
-# share one, and their launches then serialise (a two-half-fleet closed loop measured 270 instead of 147 us per cycle).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -53,6 +47,135 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TF = 78.6   # MI355X FP64 vector peak (datasheet)
 BATCH_ARRAYS = ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
                 "obs_pose", "obs_dims", "final_time_step")
+
+
+# ---- the ONE stdout line.  The driver keeps the tail of stdout and parses its last line; a line that outgrows its reader leaves the
+# round unmeasured (round 5's 24.7 KB line did).  So the line is the contract's keys and nothing else, scalars only below the first
+# level, strings short, < LINE_LIMIT bytes, strict JSON (no NaN / Infinity); every other leg of the run goes, in full, to the side
+# file EXTRAS_FILE (bench_extras.json next to this file, or $BENCH_EXTRAS_FILE).
+LINE_LIMIT = 4096
+EXTRAS_FILE = "bench_extras.json"
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline", "parity", "value_cold", "ms_per_step_cold", "plan_cycle_p50_ms", "legs", "extras_file")
+LEG_KEYS = ("config2", "config4", "config5_single_gpu", "launch_order_hint_off", "lattice_order_off", "single_batch_replayed", "tables_written",
+            "lanes_layout", "survey8d_layout", "polygon_scenes", "two_streams", "sharded_resident", "long_reference_lines", "rectangles_as_rings")
+
+
+def _sig(x, digits=6):
+    """A float at `digits` significant digits (None / non-finite -> None: strict JSON has no NaN)."""
+    if x is None:
+        return None
+    x = float(x)
+    return float(f"{x:.{digits}g}") if math.isfinite(x) else None
+
+
+def _parity_ok(p):
+    """One boolean out of a leg's parity object(s): every exactness flag true and every cost error within its tolerance."""
+    if p is None:
+        return None
+    if isinstance(p, (list, tuple)):
+        oks = [_parity_ok(q) for q in p]
+        return None if any(o is None for o in oks) else all(oks)
+    if not isinstance(p, dict):
+        return None
+    if "batches" in p:
+        return _parity_ok(p["batches"])
+    flags = [v for k, v in p.items() if k.endswith("_exact")]
+    err = p.get("max_abs_cost_err")
+    return bool(all(flags) and (err is None or err <= p.get("cost_tolerance", COST_TOL)))
+
+
+def contract_line(full: dict) -> dict:
+    """The compact line the driver reads, built from the run's full record (what EXTRAS_FILE holds)."""
+    cfg, roof, cpu = full.get("config") or {}, full.get("roofline") or {}, full.get("cpu_baseline")
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _sig(line["value"], 9), _sig(line["ms_per_step"], 7)
+    line["config"] = {"workload": str(cfg.get("workload_short") or cfg.get("workload", ""))[:200], "egos_per_gpu": cfg.get("egos_per_gpu"),
+                      "candidates_per_ego": cfg.get("candidates_per_ego"), "parallelism": cfg.get("parallelism")}
+    fp64 = roof.get("valu_fp64") or {}
+    line["roofline"] = {"bound": roof.get("bound"), "achieved": _sig(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
+                        "frac": _sig(roof.get("frac")), "traffic": _sig(roof.get("traffic"), 9),
+                        "algorithmic_bytes_per_launch": _sig(roof.get("algorithmic_bytes_per_launch"), 9),
+                        "kernel": str(roof.get("kernel_short") or roof.get("kernel", ""))[:100], "kernel_ms": _sig(roof.get("kernel_ms")),
+                        "binding": roof.get("binding"), "valu_fp64_tflops": _sig(fp64.get("achieved")), "valu_fp64_peak": fp64.get("peak"),
+                        "valu_fp64_frac": _sig(fp64.get("frac"))}
+    line["cpu_baseline"] = None if not cpu else {"value": _sig(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                                 "sample": str(cpu.get("sample_short") or cpu.get("sample", ""))[:110]}
+    par = full.get("parity")
+    if par:
+        rows = par["batches"] if "batches" in par else [par]
+        errs = [r.get("max_abs_cost_err") for r in rows if r.get("max_abs_cost_err") is not None]
+        line["parity"] = {"checked_egos": int(sum(r.get("checked_egos", 0) for r in rows)), "index_exact": _parity_ok(par),
+                          "max_abs_cost_err": _sig(max(errs)) if errs else None, "cost_tolerance": COST_TOL,
+                          "series_checked": int(sum(r.get("series_checked", 0) for r in rows))}
+    else:
+        line["parity"] = None
+    line["value_cold"], line["ms_per_step_cold"] = _sig(full.get("value_cold"), 9), _sig(full.get("ms_per_step_cold"), 7)
+    pc = full.get("plan_cycle_latency") or {}
+    line["plan_cycle_p50_ms"] = {k: _sig(pc[k]["p50"]) for k in ("FOP", "FISS+") if isinstance(pc.get(k), dict)} or None
+    legs = {}
+    for k in LEG_KEYS:
+        leg = full.get(k)
+        if isinstance(leg, dict) and "ms_per_step" in leg:
+            legs[k] = {"ms_per_step": _sig(leg["ms_per_step"]), "parity_ok": _parity_ok(leg.get("parity"))}
+    if isinstance(full.get("config4"), dict) and "stage_ms" in full["config4"]:
+        st = full["config4"]["stage_ms"]
+        legs["config4"]["refine_ms"] = _sig(next((v for kk, v in st.items() if kk.startswith("fiss_refine")), None))
+    ts = full.get("two_streams") or {}
+    for k in ("config2", "config4"):
+        if isinstance(ts.get(k), dict):
+            legs[f"two_streams_{k}"] = {"ms_per_step": _sig(ts[k]["ms_per_step"]), "parity_ok": _parity_ok(ts[k].get("parity"))}
+    cl = full.get("closed_loop") or {}
+    for k in ("FOP", "FISS+"):
+        if isinstance(cl.get(k), dict):
+            legs[f"closed_loop_{k}"] = {"us_per_cycle": _sig(cl[k].get("us_per_cycle")), "parity_ok": _parity_ok(cl[k].get("parity"))}
+    for k in ("host_buffers", "host_buffers_tagged"):
+        if isinstance(full.get(k), dict):
+            legs[k] = {"ms_per_call": _sig(full[k].get("ms_per_call")), "parity_ok": _parity_ok(full[k].get("parity"))}
+    line["legs"] = legs or None
+    line["extras_file"] = full.get("extras_file")
+    assert tuple(line) == CONTRACT_KEYS
+    return line
+
+
+def dump_line(line: dict) -> str:
+    """Strict, compact JSON of the contract line; refuses a line the driver's reader could not take."""
+    text = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    json.loads(text)
+    if len(text.encode()) >= LINE_LIMIT:
+        raise SystemExit(f"bench.py: the contract line is {len(text.encode())} bytes (limit {LINE_LIMIT}); move fields to {EXTRAS_FILE}")
+    return text
+
+
+def _finite(o):
+    """The full record with non-finite floats replaced by None (the side file is strict JSON too)."""
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (float, np.floating)):
+        return float(o) if math.isfinite(float(o)) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.bool_):
+        return bool(o)
+    return o
+
+
+def emit(full: dict) -> None:
+    """Write the full record to the side file, then print the contract line - the LAST and only thing this process writes to stdout."""
+    path = os.environ.get("BENCH_EXTRAS_FILE") or os.path.join(ROOT, EXTRAS_FILE)
+    full = _finite(full)
+    full["extras_file"] = os.path.basename(path)
+    text = dump_line(contract_line(full))
+    try:
+        with open(path + ".tmp", "w") as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+        os.replace(path + ".tmp", path)
+    except OSError as e:  # a read-only checkout must not cost the round its number
+        print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 def parse():
@@ -644,7 +767,18 @@ def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads, eng2=None, stre
     return out
 
 
+def process_env():
+    """Environment of a bench PROCESS (set in main(), not at import: the tests import this module for the line builder)."""
+    # The CPU-baseline leg runs the oracle with one OpenMP thread per host core; by default the runtime leaves those threads spinning
+    # for a while after the parallel region, next to the thread that launches the workloads measured after it.
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    # The two-stream legs need their streams on different hardware queues: with the runtime's default of four, two created streams can
+    # share one, and their launches then serialise (a two-half-fleet closed loop measured 270 instead of 147 us per cycle).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def main():
+    process_env()
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -1064,6 +1198,8 @@ def main():
                                    f"T_obs={batch.T_obs}, stride-2 OBB checks, " + ("FISS+ search + 3 refinement rounds" if fiss else "FOP argmin")
                                    + f"; SURVEY 8d generator ('{args.layout}' layout), {n_rot} distinct batches cycled through the timed steps"
                                    + (f"; rank r plans egos [r*{B}, (r+1)*{B}) of the {world * B}-ego batch (+ {n_rot - 1} further shards of the same stream)" if world > 1 else ""),
+                       "workload_short": f"BASELINE.json configs[{config - 1}]: {B} egos/GPU x {batch.nd}x{batch.nv}x{batch.nt} ({C} cand/ego), {batch.n_obs} "
+                                         f"{'dynamic' if batch.meta.get('moving') else 'static'} obstacles, " + ("FISS+" if fiss else "FOP") + f", {n_rot} batches cycled",
                        "egos_per_gpu": B, "candidates_per_ego": C, "tables_written": bool(args.tables), "obstacle_layout": args.layout,
                        "rotating_batches": n_rot, "parallelism": f"ego-shard x{world} (no collectives)",
                        "launch_order": "fp_batch.launch_order: egos by descending speed (input-only hint, host argsort at upload; results identical)" if main_wl.hinted else "ctx feedback order",
@@ -1089,8 +1225,12 @@ def main():
             "plan_cycle_latency": plan_cycle,
             "materialize_mode": materialize,
         }
+        line["roofline"]["kernel_short"] = "lattice_fused_kernel (lattice + argmin + winners' series: the one launch of fp_plan_dense)" if not fiss else \
+            "lattice_fused + fiss_refine (the FISS+ pipeline's two launches)"
+        if line["cpu_baseline"]:
+            line["cpu_baseline"]["sample_short"] = f"first {line['cpu_baseline'].get('parity', {}).get('checked_egos', '?')} egos of the first timed batch, oracle/libfrenet_oracle.so"
         line.update(extras)
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -22,23 +22,33 @@ pytestmark = pytest.mark.gpu
 COST_TOL = 1e-6
 
 
-def _run_bench(extra, env_extra=None, timeout=900):
-    env = dict(os.environ, **(env_extra or {}))
+def _run_bench(extra, env_extra=None, timeout=900, tmp_path=None):
+    """Run bench.py; returns (the contract line = ALL of stdout, the full record from the side file)."""
+    import bench as bench_mod
+
+    extras_file = os.path.join(str(tmp_path) if tmp_path else ROOT, "bench_extras_test.json")
+    env = dict(os.environ, BENCH_EXTRAS_FILE=extras_file, **(env_extra or {}))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]   # nothing before, nothing after the line
+    assert len(lines[0].encode()) < bench_mod.LINE_LIMIT
+    line = json.loads(lines[0], parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+    assert tuple(line) == bench_mod.CONTRACT_KEYS
+    full = json.load(open(extras_file))
+    os.remove(extras_file)
+    assert line["extras_file"] == "bench_extras_test.json"
+    return line, full
 
 
-def test_bench_gpus_2_spawns_two_ranks():
-    line = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--egos", "512"],
-                      {"BENCH_DIST_BACKEND": "gloo", "BENCH_ALL_ON_DEVICE0": "1"})
+def test_bench_gpus_2_spawns_two_ranks(tmp_path):
+    line, _ = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--egos", "512"],
+                         {"BENCH_DIST_BACKEND": "gloo", "BENCH_ALL_ON_DEVICE0": "1"}, tmp_path=tmp_path)
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2
     assert line["scaling"] == "weak" and line["unit"] == "candidates/s"
     assert "configs[4]" in line["config"]["workload"]
     # whole-job aggregate: both ranks' candidates over the max-over-ranks time
-    assert abs(line["value"] - 2 * 512 * 567 * 6 / (line["ms_per_step"] * 6e-3)) / line["value"] < 1e-9
+    assert abs(line["value"] - 2 * 512 * 567 * 6 / (line["ms_per_step"] * 6e-3)) / line["value"] < 1e-5
     assert line["roofline"]["frac"] > 0 and line["roofline"]["kernel_ms"] > 0
     assert line["cpu_baseline"] is None  # rank 0 at N = 1 only
 
@@ -50,8 +60,31 @@ def test_bench_rejects_a_world_size_that_disagrees_with_gpus():
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
 
 
-def test_bench_single_gpu_line_has_every_configuration():
-    line = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-seconds", "2", "--no-latency"])
+def test_bench_gpus_8_on_one_device(tmp_path):
+    """The N = 8 line of the driver's scaling run (BASELINE configs[4]: 8 ranks x 2048 egos), with all eight ranks on device 0 over
+    gloo and small shards: rank generation, barrier, max-over-ranks and ONE compact line with n_gpus = 8."""
+    line, full = _run_bench(["--gpus", "8", "--steps", "4", "--warmup", "1", "--egos", "128"],
+                            {"BENCH_DIST_BACKEND": "gloo", "BENCH_ALL_ON_DEVICE0": "1", "BENCH_PREWARM_S": "0.05"}, tmp_path=tmp_path, timeout=1500)
+    assert line["n_gpus"] == 8 and line["steps"] == 4 and line["scaling"] == "weak"
+    assert "configs[4]" in line["config"]["workload"] and line["config"]["egos_per_gpu"] == 128
+    assert "x8" in line["config"]["parallelism"]
+    assert abs(line["value"] - 8 * 128 * 567 * 4 / (line["ms_per_step"] * 4e-3)) / line["value"] < 1e-5
+    assert line["cpu_baseline"] is None and line["legs"] is None and line["roofline"]["frac"] > 0
+    assert full["n_gpus"] == 8
+
+
+def test_bench_single_gpu_line_has_every_configuration(tmp_path):
+    cline, line = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-seconds", "2", "--no-latency"], tmp_path=tmp_path)
+    # the compact line: the contract's numbers, and one ms + verdict per leg
+    assert cline["n_gpus"] == 1 and "configs[2]" in cline["config"]["workload"] and cline["parity"]["index_exact"] is True
+    assert cline["roofline"]["bound"] == "hbm" and 0 < cline["roofline"]["frac"] < 1 and cline["roofline"]["kernel_ms"] > 0
+    assert cline["cpu_baseline"]["kind"] == "port" and cline["cpu_baseline"]["value"] > 0 and cline["cpu_baseline"]["cores"] >= 1
+    assert cline["value_cold"] > 0 and cline["parity"]["max_abs_cost_err"] <= 1e-6 and cline["parity"]["checked_egos"] >= 64
+    for key in ("config2", "config4", "polygon_scenes", "launch_order_hint_off", "two_streams", "closed_loop_FOP", "closed_loop_FISS+"):
+        assert cline["legs"][key]["parity_ok"] is True, key
+    assert abs(cline["legs"]["config4"]["ms_per_step"] - line["config4"]["ms_per_step"]) <= 1e-5 * line["config4"]["ms_per_step"]
+    assert abs(cline["value"] - line["value"]) <= 1e-8 * line["value"]
+    # the full record (the side file)
     assert line["n_gpus"] == 1 and "configs[2]" in line["config"]["workload"]
     assert line["config"]["obstacle_layout"] == "survey8d" and line["config"]["rotating_batches"] == 4
     assert len(set(line["config"]["input_digests"])) == 4
