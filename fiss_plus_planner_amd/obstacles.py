@@ -207,6 +207,49 @@ MAX_POLY_VERTS = 128  # FP_MAX_POLY_VERTS (include/frenet_gpu.h)
 CIRCLE_BUFFER_FACTOR = 0.5
 
 
+def _ring_is_simple(v: np.ndarray) -> bool:
+    """True iff no two non-adjacent edges of the closed ring `v` touch or cross and no two adjacent edges fold back onto each other
+    (O(n^2) orientation tests on the ring's own coordinates; n <= a few hundred).  Ear clipping cannot tell: the ears of a
+    self-crossing ring are all positively oriented and their signed areas still sum to the ring's."""
+    n = len(v)
+    if n < 3:
+        return False
+    a, b = v, np.roll(v, -1, axis=0)
+    if np.any(np.all(a == b, axis=1)):
+        return False  # a repeated vertex: a zero-length edge (shapely: invalid ring)
+
+    def orient(p, q, r):  # sign of the cross product (q - p) x (r - p), vectorised
+        return np.sign((q[..., 0] - p[..., 0]) * (r[..., 1] - p[..., 1]) - (q[..., 1] - p[..., 1]) * (r[..., 0] - p[..., 0]))
+
+    def on_seg(p, q, r):  # r collinear with pq: inside its bounding box?
+        return (np.minimum(p[..., 0], q[..., 0]) <= r[..., 0]) & (r[..., 0] <= np.maximum(p[..., 0], q[..., 0])) & \
+               (np.minimum(p[..., 1], q[..., 1]) <= r[..., 1]) & (r[..., 1] <= np.maximum(p[..., 1], q[..., 1]))
+
+    i, j = np.triu_indices(n, 1)
+    adj = (j == i + 1) | ((i == 0) & (j == n - 1))
+    # adjacent edges share one vertex by construction; they overlap beyond it only when they are collinear and point back
+    ia, ja = i[adj], j[adj]
+    first_last = (ia == 0) & (ja == n - 1)  # edges (n-1 -> 0) and (0 -> 1): shared vertex v[0]
+    shared = np.where(first_last[:, None], a[ia], a[ja])
+    e1 = np.where(first_last[:, None], b[ia] - a[ia], a[ia] - a[ja])   # away from the shared vertex along one edge
+    e2 = np.where(first_last[:, None], a[ja] - shared, b[ja] - a[ja])  # ... and along the other
+    cross = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+    dot = e1[:, 0] * e2[:, 0] + e1[:, 1] * e2[:, 1]
+    if np.any((cross == 0.0) & (dot > 0.0)):
+        return False
+    i, j = i[~adj], j[~adj]
+    if len(i) == 0:
+        return True
+    p1, q1, p2, q2 = a[i], b[i], a[j], b[j]
+    o1, o2, o3, o4 = orient(p1, q1, p2), orient(p1, q1, q2), orient(p2, q2, p1), orient(p2, q2, q1)
+    hit = (o1 != o2) & (o3 != o4)
+    hit |= (o1 == 0) & on_seg(p1, q1, p2)
+    hit |= (o2 == 0) & on_seg(p1, q1, q2)
+    hit |= (o3 == 0) & on_seg(p2, q2, p1)
+    hit |= (o4 == 0) & on_seg(p2, q2, q1)
+    return not bool(hit.any())
+
+
 def shape_columns(shape, circle_buffer_factor: float = CIRCLE_BUFFER_FACTOR) -> list:
     """An obstacle shape -> the obstacle columns that stand for it: [(length, width, cx, cy, ring or None)].
 
@@ -253,10 +296,12 @@ def shape_columns(shape, circle_buffer_factor: float = CIRCLE_BUFFER_FACTOR) -> 
     for v in rings:
         if _signed_area2(v) == 0.0:
             continue  # a degenerate ring has no interior; shapely would call the polygon invalid
+        # a self-intersecting ring has no convex partition on its own vertices.  Tested directly (edge pairs); the area comparison
+        # below stays as a second guard only - the ears of a crossing ring are all positive and sum to the ring's signed area, so by
+        # itself it fires for the 4-vertex bow tie and little else
+        if not _ring_is_simple(v):
+            raise ValueError("obstacle shape is not a simple polygon (its ring crosses itself): no convex pieces stand for it")
         pieces = _convex_pieces(v, MAX_POLY_VERTS)
-        # a self-intersecting ring has no convex partition on its own vertices: ear clipping then returns triangles that cover area
-        # outside it (or too little).  The pieces of a simple ring tile it exactly - compared by area, with the rounding of a sum of
-        # cross products as slack
         a_ring, a_pieces = abs(_signed_area2(v)), sum(abs(_signed_area2(pc)) for pc in pieces)
         if not all(_is_convex(pc) and _signed_area2(pc) >= 0.0 for pc in pieces) or abs(a_pieces - a_ring) > 1e-9 * max(a_ring, 1e-300) + 1e-12:
             raise ValueError("obstacle shape is not a simple polygon (its ring crosses itself): no convex pieces stand for it")

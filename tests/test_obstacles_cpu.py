@@ -172,3 +172,52 @@ def test_fingerprint_follows_the_objects_not_the_list():
     assert obstacles_fingerprint([StubObstacle(4, 2, np.zeros((5, 3))) for _ in range(3)]) != fp
     obs[0].prediction.final_time_step = 2
     assert obstacles_fingerprint(obs) != fp
+
+
+def test_self_crossing_rings_of_more_than_four_vertices_raise():
+    """The ears of a self-crossing ring are all positively oriented and sum to the ring's signed area: only a direct edge-pair test sees
+    it (8 % of random crossing 5-8-gons passed the area comparison and came back as convex columns)."""
+    from fiss_plus_planner_amd.obstacles import _ring_is_simple
+
+    seven = np.array([[-2.46, 2.0], [0.11, -2.23], [0.15, 0.26], [-0.02, -1.76], [-0.39, 2.23], [-0.7, 0.02], [2.58, -1.6]])
+    assert not _ring_is_simple(seven) and not _ring_is_simple(seven[::-1])
+    with pytest.raises(ValueError, match="simple polygon"):
+        shape_columns(SimpleNamespace(vertices=seven))
+    six = np.array([(0.0, 0.0), (4.0, 0.0), (4.0, 3.0), (1.0, -1.0), (0.5, 3.0), (0.0, 3.0)])  # one edge dips through the base
+    with pytest.raises(ValueError, match="simple polygon"):
+        shape_columns(SimpleNamespace(vertices=six))
+    # touching is crossing too (shapely: invalid ring): a vertex ON a non-adjacent edge, a spike folded back, a repeated vertex
+    assert not _ring_is_simple(np.array([(0.0, 0.0), (4.0, 0.0), (4.0, 2.0), (2.0, 0.0), (0.0, 2.0)]))
+    assert not _ring_is_simple(np.array([(0.0, 0.0), (4.0, 0.0), (2.0, 0.0), (2.0, 2.0)]))
+    assert not _ring_is_simple(np.array([(0.0, 0.0), (4.0, 0.0), (4.0, 0.0), (2.0, 2.0)]))
+    # random rings: a brute-force segment test agrees, and every ring the reader accepts is simple
+    rng = np.random.default_rng(5)
+    n_cross = 0
+    for _ in range(400):
+        n = int(rng.integers(5, 9))
+        v = rng.uniform(-3, 3, (n, 2)).round(2)
+
+        def crosses(v):
+            m = len(v)
+            for i in range(m):
+                for j in range(i + 2, m):
+                    if i == 0 and j == m - 1:
+                        continue
+                    p, q, r, s_ = v[i], v[(i + 1) % m], v[j], v[(j + 1) % m]
+                    d = lambda a, b, c: (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])  # noqa: E731
+                    if d(p, q, r) * d(p, q, s_) < 0 and d(r, s_, p) * d(r, s_, q) < 0:
+                        return True
+            return False
+
+        if crosses(v):
+            n_cross += 1
+            assert not _ring_is_simple(v)
+            with pytest.raises(ValueError):
+                shape_columns(SimpleNamespace(vertices=v))
+    assert n_cross > 200
+    # simple non-convex rings still pass: an L and a star
+    ell = np.array([(0, 0), (4, 0), (4, 1), (1, 1), (1, 3), (0, 3)], dtype=float)
+    assert _ring_is_simple(ell) and len(shape_columns(SimpleNamespace(vertices=ell))) >= 2
+    ang = np.linspace(0, 2 * np.pi, 10, endpoint=False)
+    star = np.stack([np.where(np.arange(10) % 2, 1.0, 2.5) * np.cos(ang), np.where(np.arange(10) % 2, 1.0, 2.5) * np.sin(ang)], axis=1)
+    assert _ring_is_simple(star) and len(shape_columns(SimpleNamespace(vertices=star))) >= 3
