@@ -696,12 +696,12 @@ def closed_loop_leg(torch, eng, dev, B, layout, cycles, threads, eng2=None, stre
         snap.t_now[:] = res.t_now
         stream = torch.cuda.current_stream(dev).cuda_stream
         if planner == "FOP":
-            eng.plan_dense_device(run.db.params, run.db.fb, run.best_idx.data_ptr(), run.best_cost.data_ptr(), run.stats.data_ptr(), stream=stream)
+            eng.plan_dense_device(run.db.params, run.fb, run.best_idx.data_ptr(), run.best_cost.data_ptr(), run.stats.data_ptr(), stream=stream)
             torch.cuda.synchronize(dev)
             par = fop_parity(f"closed_loop {planner}", snap, egos, run.best_idx.cpu().numpy(), run.best_cost.cpu().numpy(), threads) if len(egos) else None
         else:
             prev = run.prev.cpu().numpy().copy()
-            eng.plan_fiss_device(run.db.params, run.db.fb, run.fopts, run.fio, stream=stream)
+            eng.plan_fiss_device(run.db.params, run.fb, run.fopts, run.fio, stream=stream)
             torch.cuda.synchronize(dev)
             cost, stats = run.best_cost.cpu().numpy(), run.stats.cpu().numpy()
             err = 0.0

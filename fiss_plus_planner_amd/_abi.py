@@ -28,7 +28,7 @@ _ip = C.POINTER(C.c_int32)
 _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
-EXPORTED_SYMBOLS = ("fp_abi_version", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option", "fp_ctx_get_option",
+EXPORTED_SYMBOLS = ("fp_abi_version", "fp_build_flags", "fp_build_compiler", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option", "fp_ctx_get_option",
                     "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_plan_step", "fp_plan_fiss_step", "fp_frames_build", "fp_from_state", "fp_materialize_all",
                     "fp_group_create", "fp_group_destroy", "fp_group_submit", "fp_group_wait")
 
@@ -118,6 +118,14 @@ def load() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     L.fp_abi_version.restype = C.c_int
     L.fp_last_error.restype = C.c_char_p
+    L.fp_build_flags.restype = C.c_char_p
+    L.fp_build_compiler.restype = C.c_char_p
+    flags = (L.fp_build_flags() or b"").decode()
+    if flags and not os.environ.get("FP_ALLOW_DIAGNOSTIC_BUILD"):
+        raise ImportError(
+            f"{LIB_PATH} is a DIAGNOSTIC build ({flags}): timing ablations and stamp / counter builds share the production file name and ABI "
+            "version, and some of them produce wrong results by design.  Rebuild without EXTRA (make -B -C fiss_plus_planner_amd/csrc), or set "
+            "FP_ALLOW_DIAGNOSTIC_BUILD=1 if this is a profiling run.")
     L.fp_device_count.argtypes = [C.POINTER(C.c_int)]
     L.fp_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.fp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,14 @@
 #include <vector>
 
 #include "frenet_kernels.h"
+
+// Toolchain pin.  The kernels were validated on ROCm 7.2.0's clang 22 (AMD clang 22.0.0git roc-7.2.0): no kernel may spill a VGPR
+// (tests/test_abi_cpu.py:test_no_kernel_spills_a_vgpr - this compiler's spill placement in divergent loop exits is wrong), the build
+// needs -mllvm -disable-machine-licm, and the four-per-CU instances sit exactly on their 64-VGPR / 80-SGPR budgets.  Another major
+// version is another code generator: rebuild with -DFP_ANY_COMPILER only together with tools/resource_usage.py and the GPU test suite.
+#if !defined(FP_ANY_COMPILER) && defined(__clang_major__) && __clang_major__ != 22
+#error "libfrenetgpu was validated on ROCm 7.2.0 (clang 22); build with EXTRA=-DFP_ANY_COMPILER after re-checking spills (tools/resource_usage.py) and the GPU tests"
+#endif
 
 namespace {
 
@@ -137,7 +146,8 @@ struct fp_ctx {
     int* validate_host = nullptr;  // ... and their pinned mirror
     int lattice_winner = 0;        // fp_ctx_set_option("lattice_winner"): 0 auto, 1 inside the lattice kernel, 2 its own launch
     int fiss_fused = 1;            // fp_ctx_set_option("fiss_fused"): 1 = the FISS+ search of a multi-round batch runs in workgroups appended to the lattice launch; 0 = always its own launch
-    int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each)
+    int resident_groups = 512;     // lattice workgroups the device holds at once: 2 per CU (128-VGPR budget, 512 threads each); fp_ctx_set_option("resident_groups")
+    int lds_cu_kb = 160;           // LDS of one compute unit (hipDeviceProp_t::maxSharedMemoryPerMultiProcessor)
     // feedback-directed launch order of the multi-round lattice launch (fp_ctx_set_option("lattice_order")): every workgroup
     // leaves its ego's duration in dur_dev; now and then the host fetches them (async copy + event, never a wait), sorts the egos
     // longest-first and uploads the order the following launches dispatch in.  A stale or missing order only costs speed.
@@ -739,6 +749,11 @@ int handover_recover(fp_ctx* ctx, hipStream_t stream)
 {
     const int code = *(volatile int32_t*)ctx->hand_err;
     ctx->appended_ok = false;
+    // Inside a stream capture nothing may synchronise (and nothing runs): appended workgroups are off from here on, the word stays set,
+    // and the first call outside a capture reports and clears it.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) return FP_OK;
     // (the launch that timed out may still hold workgroups about to give up too: drain the stream before the word is cleared, or one of
     // them would set it again and a later, healthy call would report a failure of its own)
     (void)hipStreamSynchronize(stream);
@@ -912,6 +927,135 @@ extern "C" {
 
 int fp_abi_version(void) { return FP_ABI_VERSION; }
 
+// The diagnostic macros this library was compiled with: "" for a production build.  The timing ablations (FP_ABL_*: results are
+// WRONG by design), the instance switches (FP_NO_*, FP_SLICE_LOOP, ...) and the stamp / counter builds (FP_PHASE_STAMPS, FP_COUNTERS,
+// FP_TL: series blocks carry clock ticks) all live in the production sources behind #if and build into the same file name under the same
+// ABI version; this is how a caller tells them apart.  Two sources: the Makefile's EXTRA verbatim, and - however the macro got onto the
+// command line - the list below.
+const char* fp_build_flags(void)
+{
+    static const std::string flags = [] {
+        std::string o;
+#if defined(FP_BUILD_EXTRA)
+        o = FP_BUILD_EXTRA;
+#endif
+        auto add = [&o](const char* n) {
+            if (o.find(n) == std::string::npos) { if (!o.empty()) o += " "; o += "-D"; o += n; }
+        };
+        (void)add;
+#define FP_FLAG_IF(m) add(#m);
+#if defined(FP_PHASE_STAMPS)
+        FP_FLAG_IF(FP_PHASE_STAMPS)
+#endif
+#if defined(FP_TL)
+        FP_FLAG_IF(FP_TL)
+#endif
+#if defined(FP_RABL)
+        FP_FLAG_IF(FP_RABL)
+#endif
+#if defined(FP_COUNTERS)
+        FP_FLAG_IF(FP_COUNTERS)
+#endif
+#if defined(FP_ABL_MAT_NO_STORE)
+        FP_FLAG_IF(FP_ABL_MAT_NO_STORE)
+#endif
+#if defined(FP_ABL_MAT_STORE_ONLY)
+        FP_FLAG_IF(FP_ABL_MAT_STORE_ONLY)
+#endif
+#if defined(FP_ABL_MAT_NO_MATH)
+        FP_FLAG_IF(FP_ABL_MAT_NO_MATH)
+#endif
+#if defined(FP_ABL_SEARCH_NOWALK)
+        FP_FLAG_IF(FP_ABL_SEARCH_NOWALK)
+#endif
+#if defined(FP_ABL_SEARCH_NOSORT)
+        FP_FLAG_IF(FP_ABL_SEARCH_NOSORT)
+#endif
+#if defined(FP_ABL_NO_N)
+        FP_FLAG_IF(FP_ABL_NO_N)
+#endif
+#if defined(FP_ABL_NO_BN)
+        FP_FLAG_IF(FP_ABL_NO_BN)
+#endif
+#if defined(FP_ABL_NO_GBN)
+        FP_FLAG_IF(FP_ABL_NO_GBN)
+#endif
+#if defined(FP_ABL_NO_COLL)
+        FP_FLAG_IF(FP_ABL_NO_COLL)
+#endif
+#if defined(FP_ABL_NO_WINNER)
+        FP_FLAG_IF(FP_ABL_NO_WINNER)
+#endif
+#if defined(FP_ABL_NO_VMAX)
+        FP_FLAG_IF(FP_ABL_NO_VMAX)
+#endif
+#if defined(FP_ABL_NO_SPLINE_COPY)
+        FP_FLAG_IF(FP_ABL_NO_SPLINE_COPY)
+#endif
+#if defined(FP_ABL_NO_SLICE_SYNC)
+        FP_FLAG_IF(FP_ABL_NO_SLICE_SYNC)
+#endif
+#if defined(FP_ABL_NO_SCAN)
+        FP_FLAG_IF(FP_ABL_NO_SCAN)
+#endif
+#if defined(FP_ABL_NO_DALL)
+        FP_FLAG_IF(FP_ABL_NO_DALL)
+#endif
+#if defined(FP_SLICE_LOOP)
+        FP_FLAG_IF(FP_SLICE_LOOP)
+#endif
+#if defined(FP_NO_SHAPES)
+        FP_FLAG_IF(FP_NO_SHAPES)
+#endif
+#if defined(FP_NO_OCC6)
+        FP_FLAG_IF(FP_NO_OCC6)
+#endif
+#if defined(FP_NO_OCC8)
+        FP_FLAG_IF(FP_NO_OCC8)
+#endif
+#if defined(FP_MAT_PER_CANDIDATE)
+        FP_FLAG_IF(FP_MAT_PER_CANDIDATE)
+#endif
+#if defined(FP_MAT_NO_XCD)
+        FP_FLAG_IF(FP_MAT_NO_XCD)
+#endif
+#if defined(FP_MAT_OCC)
+        FP_FLAG_IF(FP_MAT_OCC)
+#endif
+#if defined(FP_WINNER_OCC)
+        FP_FLAG_IF(FP_WINNER_OCC)
+#endif
+#if defined(FP_REFINE_OCC)
+        FP_FLAG_IF(FP_REFINE_OCC)
+#endif
+#if defined(FP_SEARCH_WAVES)
+        FP_FLAG_IF(FP_SEARCH_WAVES)
+#endif
+#if defined(FP_SEARCH_SMALL)
+        FP_FLAG_IF(FP_SEARCH_SMALL)
+#endif
+#if defined(FP_SEARCH_NB)
+        FP_FLAG_IF(FP_SEARCH_NB)
+#endif
+#if defined(FP_POSE_FLIGHT)
+        FP_FLAG_IF(FP_POSE_FLIGHT)
+#endif
+#if defined(FP_GROUP_THREADS)
+        FP_FLAG_IF(FP_GROUP_THREADS)
+#endif
+#if defined(FP_TEST_HOOKS)
+        FP_FLAG_IF(FP_TEST_HOOKS)
+#endif
+#undef FP_FLAG_IF
+        return o;
+    }();
+    return flags.c_str();
+}
+
+// The compiler this library was built with (the kernels depend on properties of ONE validated toolchain: no VGPR spill in any kernel -
+// this compiler places spill stores before the exec restore of a divergent loop's exit -, -disable-machine-licm, the SGPR budgets).
+const char* fp_build_compiler(void) { return __clang_version__; }
+
 const char* fp_last_error(void) { return g_last_error.c_str(); }
 
 int fp_device_count(int* count)
@@ -962,6 +1106,7 @@ int fp_ctx_create(int device, fp_ctx** out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         if (prop.multiProcessorCount > 0) ctx->resident_groups = 2 * prop.multiProcessorCount;
+        if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_cu_kb = (int)(prop.maxSharedMemoryPerMultiProcessor / 1024);
         // (in-order workgroup dispatch per XCD was verified on these two; anything else gets the series / the search in their own launches)
         ctx->appended_ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0 || strncmp(prop.gcnArchName, "gfx942", 6) == 0;
     }
@@ -1026,6 +1171,7 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         return FP_OK;
     }
     if (strcmp(name, "handover_inject") == 0) {  // test hook: what a timed-out hand-over leaves in the ctx's error word (1 series, 2 search)
+        if (!getenv("FP_TEST_HOOKS")) return fail(FP_EINVAL, "handover_inject is a test hook: set FP_TEST_HOOKS=1 in the environment to use it");
         if (value < 1 || value > 2 || !ctx->hand_err) return fail(FP_EINVAL, "handover_inject must be 1 or 2");
         *(volatile int32_t*)ctx->hand_err = value;
         return FP_OK;
@@ -1070,6 +1216,19 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->lattice_occupancy = value;
         return FP_OK;
     }
+    if (strcmp(name, "resident_groups") == 0) {
+        // lattice workgroups the device holds at once at two per CU (default: 2 x the device's compute units).  Lower it when the process
+        // runs under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK: the runtime still reports every CU), or to model a smaller device: the
+        // latency-mode split, the tail split, the three- / four-per-CU instances and the launch order all key on it.  0 = the device's value.
+        if (value < 0 || (value & 1)) return fail(FP_EINVAL, "resident_groups must be 0 (the device's 2 x compute units) or an even number >= 2");
+        if (value == 0) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+            value = 2 * prop.multiProcessorCount;
+        }
+        ctx->resident_groups = value;
+        return FP_OK;
+    }
     if (strcmp(name, "lattice_tail") == 0) {
         if (value < 0) return fail(FP_EINVAL, "lattice_tail must be 0 (auto), 1 (never) or the number of egos cut in two");
         ctx->lattice_tail = value;
@@ -1087,8 +1246,8 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 {
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
-        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"lattice_occupancy", ctx->lattice_occupancy}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
-        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"lattice_launches", ctx->lattice_launches},
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"lattice_occupancy", ctx->lattice_occupancy}, {"resident_groups", ctx->resident_groups}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"handover_failed", ctx->hand_err ? *(volatile int32_t*)ctx->hand_err : 0}, {"lattice_launches", ctx->lattice_launches},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches},
         {"lattice_launches_2", (int)fp::lattice_launches_per_cu(0)}, {"lattice_launches_3", (int)fp::lattice_launches_per_cu(1)}, {"lattice_launches_4", (int)fp::lattice_launches_per_cu(2)}};
     for (const auto& t : tab)
@@ -1111,7 +1270,7 @@ int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, c
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
-    ka.occ_cap = ctx->lattice_occupancy;
+    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
@@ -1317,7 +1476,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     fp::FissArgs fa;
     fa.ka.p = *params;
     fa.ka.err_word = ctx->hand_err;
-    fa.ka.occ_cap = ctx->lattice_occupancy;
+    fa.ka.occ_cap = ctx->lattice_occupancy; fa.ka.resident2 = ctx->resident_groups; fa.ka.lds_cu_kb = ctx->lds_cu_kb;
     fa.opts = *opts;
     fa.opts.max_refine_iters = R;
     fa.ka.r = no_result();
@@ -1536,7 +1695,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
-    ka.occ_cap = ctx->lattice_occupancy;
+    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb;
     ka.b = *batch;
     ka.b.skip = io->done;
     if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
@@ -1785,8 +1944,19 @@ int fp_group_create(fp_ctx* const* ctxs, int32_t n, fp_group** out)
         GroupWorker* w = new (std::nothrow) GroupWorker();
         if (!w) { fp_group_destroy(g); return fail(FP_ENOMEM, "out of host memory"); }
         w->ctx = ctxs[i];
-        g->workers.push_back(w);
-        w->th = std::thread(group_worker_main, w);
+        try {  // (no exception may leave an extern "C" function: vector growth and thread creation both can throw)
+            g->workers.push_back(w);
+        } catch (...) {
+            delete w;
+            fp_group_destroy(g);
+            return fail(FP_ENOMEM, "out of host memory");
+        }
+        try {
+            w->th = std::thread(group_worker_main, w);
+        } catch (const std::exception& ex) {  // std::system_error: the process is out of threads
+            fp_group_destroy(g);  // (joins the workers that did start; this one is not joinable)
+            return fail(FP_EHIP, "fp_group_create: worker thread %d could not be started: %s", i, ex.what());
+        }
     }
     *out = g;
     return FP_OK;
@@ -1820,12 +1990,18 @@ int fp_group_submit(fp_group* g, const fp_shard_call* calls)
         if (c.result && (c.fiss_opts || c.fiss_io)) return fail(FP_EINVAL, "fp_group_submit: calls[%d] sets both result and the FISS structs", i);
         if (c.n_copies < 0 || c.n_copies > kMaxCopies || (c.n_copies > 0 && !c.copies)) return fail(FP_EINVAL, "fp_group_submit: calls[%d].n_copies must be 0..%d", i, kMaxCopies);
     }
+    // A shard whose earlier call failed takes no new work until fp_group_wait has reported (and cleared) the failure - and the round is
+    // refused as a whole, before any of it is posted: the other shards must not run ahead of a shard that silently skipped its call.
+    for (int i = 0; i < n; ++i) {
+        if (!calls[i].params) continue;
+        GroupWorker& w = *g->workers[i];
+        group_wait_worker(w);  // the mailbox is one deep
+        if (w.rc != FP_OK) return fail(w.rc, "fp_group_submit: shard %d still holds the error of an earlier call (%s); nothing of this round was posted - fp_group_wait reports and clears it", i, w.err.c_str());
+    }
     for (int i = 0; i < n; ++i) {
         const fp_shard_call& c = calls[i];
         if (!c.params) continue;
         GroupWorker& w = *g->workers[i];
-        group_wait_worker(w);  // the mailbox is one deep
-        if (w.rc != FP_OK) continue;  // (a failed call stays visible until fp_group_wait reports it)
         w.params = *c.params;
         w.batch = *c.batch;
         if (c.result) w.result = *c.result;

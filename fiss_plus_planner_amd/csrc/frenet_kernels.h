@@ -61,6 +61,12 @@ struct KernelArgs {
     int32_t* err_word = nullptr;
     // host-side launch hint (fp_ctx_set_option("lattice_occupancy")): 0 = auto, 2 / 3 = at most that many lattice workgroups per CU
     int occ_cap = 0;
+    // host-side launch hints from the ctx: lattice workgroups the device holds at once at TWO per CU (fp_ctx: resident_groups = 2 x compute
+    // units, or what fp_ctx_set_option("resident_groups") says - a process under a CU mask, a test that models a smaller device) and the
+    // LDS of one CU in KB.  A launch takes the three- / four-per-CU instances when it has more egos than resident2 / 1.5 x resident2 and
+    // the CU's LDS holds three / four of their layouts.
+    int resident2 = 512;
+    int lds_cu_kb = 160;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

@@ -1751,12 +1751,13 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     const int kEpiLds = kEpiLdsBytes + (b.NX <= kEpiSplineNX ? kEpiPairs * 9 * b.NX * 8 : 0);
 #if defined(FP_PHASE_STAMPS) || defined(FP_COUNTERS)  // (the stamps travel in the series block: the three-workgroup variant leaves the series themselves unwritten)
     const bool can_epi = false;
-    bool three = gs == 1 && nsplit == 1 && b.B > 512 && L6.total <= 52 * 1024;
+    bool three = gs == 1 && nsplit == 1 && b.B > ka.resident2 && L6.total <= 52 * 1024;
 #else
     const bool can_epi = ka.r.best_traj && ka.epi_flag && ka.idx_shadow && !ka.has_loop;
     // (series asked of THIS kernel pin it to the two-per-CU instances; series offered to the epilogue workgroups do not)
-    bool three = gs == 1 && nsplit == 1 && (!ka.r.best_traj || ka.epi_flag) && b.B > 512 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
+    bool three = gs == 1 && nsplit == 1 && (!ka.r.best_traj || ka.epi_flag) && b.B > ka.resident2 && L6.total <= 52 * 1024;  // (a margin below 160 KB / 3 for the allocation granule)
 #endif
+    if (ka.lds_cu_kb < 160) three = false;  // (the 52 KB / 40 KB layouts are thirds / quarters of gfx950's 160 KB; a CU with less LDS keeps two per CU)
     if (in.on) three = false;  // (inline inputs are read by the two-workgroup instances only; they belong to tiny batches anyway)
 #if defined(FP_NO_OCC6)  // (A/B diagnostic)
     three = false;
@@ -1774,7 +1775,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     // FOUR workgroups per CU when the slim layout (make_layout) and the appended workgroups' LDS fit a quarter of the CU (BASELINE.json's
     // dense shape: reference lines of up to ~80 knots); 64 VGPRs a lane, the ego's start state re-read from LDS (kEgoLds)
     const Layout L8 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(8), 1, kThreads / kWave, 0, true);
-    bool four = three && !pstride && L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && b.B > 768 &&
+    bool four = three && !pstride && L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && (long)b.B * 2 > (long)ka.resident2 * 3 &&
                 !b.skip;  // (a closed-loop batch: its finished egos leave at once, what runs rarely fills three per CU - measured 68 -> 71-75 us per cycle with four)
 #if defined(FP_NO_OCC8)  // (A/B diagnostic)
     four = false;

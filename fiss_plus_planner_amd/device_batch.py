@@ -68,8 +68,10 @@ class ClosedLoopRunner:
         self.cycles = torch.zeros(B, dtype=i32, device=dbatch.dev)
         self.goal = torch.from_numpy(np.ascontiguousarray(goal_xy, dtype=np.float64).reshape(B, 2)).to(dbatch.dev)
         self.cart = torch.full((B, 3), float("nan"), dtype=f64, device=dbatch.dev)
-        dbatch.fb.skip = self.done.data_ptr()  # finished egos are not planned any more
-        dbatch.fb.launch_order = None  # (the egos' states move on: the order the ctx learns from its own launches follows them, the upload's hint would not)
+        # the runner's OWN view of the resident batch (the shared DeviceBatch keeps its skip mask and its launch-order hint for other callers)
+        self.fb = _abi.FpBatch.from_buffer_copy(dbatch.fb)
+        self.fb.skip = self.done.data_ptr()  # finished egos are not planned any more
+        self.fb.launch_order = None  # (the egos' states move on: the order the ctx learns from its own launches follows them, the upload's hint would not)
         self.io = _abi.FpLoopIo()
         self.io.ego, self.io.t_now = dbatch.t["ego"].data_ptr(), dbatch.t["t_now"].data_ptr()
         self.io.done, self.io.cycles = self.done.data_ptr(), self.cycles.data_ptr()
@@ -100,17 +102,17 @@ class ClosedLoopRunner:
 
         lib, ctx = self.eng._lib, self.eng._ctx
         if self.planner == "FOP" and self.fused:
-            self.eng.plan_step_device(self.db.params, self.db.fb, self.io, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
+            self.eng.plan_step_device(self.db.params, self.fb, self.io, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
         elif self.planner == "FOP":
-            self.eng.plan_dense_device(self.db.params, self.db.fb, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
-            _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), self.best_idx.data_ptr(), None, C.byref(self.io),
+            self.eng.plan_dense_device(self.db.params, self.fb, self.best_idx.data_ptr(), self.best_cost.data_ptr(), self.stats.data_ptr(), stream=stream)
+            _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.fb), self.best_idx.data_ptr(), None, C.byref(self.io),
                                       _abi.FP_MEM_DEVICE, stream or None))
         elif self.fused:  # fp_plan_fiss_step: FISS+ hands the egos over inside its refinement launch, FISS by the advance kernel behind the pipeline
-            _abi.check(lib.fp_plan_fiss_step(ctx, C.byref(self.db.params), C.byref(self.db.fb), C.byref(self.fopts), C.byref(self.fio), C.byref(self.io),
+            _abi.check(lib.fp_plan_fiss_step(ctx, C.byref(self.db.params), C.byref(self.fb), C.byref(self.fopts), C.byref(self.fio), C.byref(self.io),
                                              _abi.FP_MEM_DEVICE, stream or None))
         else:
-            self.eng.plan_fiss_device(self.db.params, self.db.fb, self.fopts, self.fio, stream=stream)
-            _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.db.fb), None, self.end_state.data_ptr(), C.byref(self.io),
+            self.eng.plan_fiss_device(self.db.params, self.fb, self.fopts, self.fio, stream=stream)
+            _abi.check(lib.fp_advance(ctx, C.byref(self.db.params), C.byref(self.fb), None, self.end_state.data_ptr(), C.byref(self.io),
                                       _abi.FP_MEM_DEVICE, stream or None))
 
     def run_graph(self, max_cycles: int):

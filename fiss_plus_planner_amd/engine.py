@@ -31,7 +31,7 @@ def make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
     every scalar it is built from."""
     lim0 = getattr(batch, "curvature_limits", None)
     key = (nd or batch.nd, nv or batch.nv, nt or batch.nt, batch.check_stride, batch.tick_t, batch.veh_l, batch.veh_w, batch.max_speed, batch.max_accel,
-           None if lim0 is None else tuple(lim0), id(batch.t_samples), id(getattr(batch, "samp_max", None)))  # (the arrays points_max is read from)
+           None if lim0 is None else tuple(lim0), _t_max(batch))  # (the VALUE points_max is derived from: an in-place edit of the arrays is seen)
     cached = getattr(batch, "__dict__", {}).get("_fp_cache")
     if cached is not None and cached[0] == key:
         return _abi.FpParams.from_buffer_copy(cached[1])  # a copy: callers may edit their struct
@@ -39,6 +39,14 @@ def make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
     if hasattr(batch, "__dict__"):
         batch.__dict__["_fp_cache"] = (key, bytes(p))
     return p
+
+
+def _t_max(batch) -> float:
+    """The longest time horizon a call on this batch can sample: max(t_samples), and for the FISS planners the sampling box's upper edge."""
+    t_max = float(np.max(batch.t_samples)) if len(batch.t_samples) else 0.0
+    if getattr(batch, "samp_max", None) is not None and len(batch.samp_max):
+        t_max = max(t_max, float(np.nanmax(batch.samp_max[:, 2])))
+    return t_max
 
 
 def _make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
@@ -49,9 +57,7 @@ def _make_params(batch, nd=None, nv=None, nt=None) -> _abi.FpParams:
     p.cost_horizon, p.w_speed, p.w_accel, p.w_jerk, p.w_offset = (COST_WX1[k] for k in ("cost_horizon", "w_speed", "w_accel", "w_jerk", "w_offset"))
     p.veh_l, p.veh_w, p.max_speed, p.max_accel = float(batch.veh_l), float(batch.veh_w), float(batch.max_speed), float(batch.max_accel)
     # fp_params.points_max: what a FP_MEM_DEVICE call cannot see for itself - the points per trajectory (> 128: tick_t below 0.08 s)
-    t_max = float(np.max(batch.t_samples)) if len(batch.t_samples) else 0.0
-    if getattr(batch, "samp_max", None) is not None and len(batch.samp_max):
-        t_max = max(t_max, float(np.nanmax(batch.samp_max[:, 2])))
+    t_max = _t_max(batch)
     n_pts = int(np.ceil(t_max / float(batch.tick_t))) if t_max > 0 else 0
     p.points_max = min(n_pts, _abi.FP_MAX_POINTS) if n_pts > _abi.FP_FAST_POINTS else 0
     lim = getattr(batch, "curvature_limits", None)

@@ -389,13 +389,12 @@ class ShardedEngine:
         runners = {}
         for sh in sdb.shards:
             with torch.cuda.device(sh.db.dev), torch.cuda.stream(sh.stream):
-                sh.db.fb.skip = None
-                runners[sh.rank] = ClosedLoopRunner(sh.engine, sh.db, goal[sh.lo:sh.hi], planner)  # (sets fb.skip = its `done` array)
+                runners[sh.rank] = ClosedLoopRunner(sh.engine, sh.db, goal[sh.lo:sh.hi], planner)  # (its own fp_batch view: skip = its `done` array, no hint)
         calls = (_abi.FpShardCall * self.world)()
         keep = []
         for sh in sdb.shards:
             run, c = runners[sh.rank], calls[sh.rank]
-            c.params, c.batch, c.stream, c.loop = C.pointer(sh.db.params), C.pointer(sh.db.fb), sh.stream.cuda_stream, C.pointer(run.io)
+            c.params, c.batch, c.stream, c.loop = C.pointer(sh.db.params), C.pointer(run.fb), sh.stream.cuda_stream, C.pointer(run.io)
             if planner == "FOP":
                 res = _abi.FpResult()
                 res.best_idx, res.best_cost, res.stats = run.best_idx.data_ptr(), run.best_cost.data_ptr(), run.stats.data_ptr()
@@ -409,7 +408,6 @@ class ShardedEngine:
         sdb.synchronize()
         for sh in sdb.shards:
             run = runners[sh.rank]
-            sh.db.fb.skip = None  # (the runner's `done` array dies with it)
             for k, v in (("done", run.done), ("cycles", run.cycles), ("ego", sh.db.t["ego"]), ("t_now", sh.db.t["t_now"]), ("cart", run.cart)):
                 getattr(out, k)[sh.lo:sh.hi] = v.cpu().numpy()
         return out

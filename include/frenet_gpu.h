@@ -223,6 +223,13 @@ typedef struct {
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
+/* Build identity.  fp_build_flags: the diagnostic macros the library was compiled with (the Makefile's EXTRA and every FP_ABL_* /
+ * FP_NO_* / stamp / counter switch of the sources) - "" for a production build; the timing ablations produce WRONG results by design,
+ * so the Python binding refuses a library whose string is not empty (FP_ALLOW_DIAGNOSTIC_BUILD=1 overrides, for the profiling tools).
+ * fp_build_compiler: the compiler's version string (the kernels are validated on one toolchain, see csrc/Makefile). */
+const char* fp_build_flags(void);
+const char* fp_build_compiler(void);
+
 /* Number of visible HIP devices / name+arch of one (buf may be NULL). */
 int fp_device_count(int* count);
 int fp_device_info(int device, char* buf, int buflen, int* compute_units, int64_t* hbm_bytes);
@@ -245,7 +252,11 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * that started last), 1 = never, n >= 2 = the last n slots.  Identical results.
  * "lattice_occupancy": 0 = auto (default: batches of more egos than stay resident run three lattice workgroups per compute unit - four
  * when a workgroup's tables fit a quarter of the unit's LDS: rectangle scenes, e.g. a 9 x 9 x 7 lattice against 50 obstacles on
- * reference lines of up to ~80 knots - instead of two), 2 / 3 = at most that many.  Identical results.
+ * reference lines of up to ~80 knots - instead of two), 2 / 3 / 4 = at most that many.  Identical results.
+ * "resident_groups": lattice workgroups the device holds at once at two per compute unit.  0 / default = 2 x the device's compute units.
+ * The latency-mode split, the tail split, the three- / four-per-unit instances and the launch order key on it: set it to 2 x the units the
+ * process really has when it runs under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK - the runtime still reports every unit), or lower to
+ * model a smaller device (the tests run the multi-round instances on a handful of egos that way).  Even, >= 2.  Identical results.
  * "lattice_order": 1 (default) = launches with more egos than resident workgroups dispatch the egos longest-first, from the
  * durations earlier launches left behind (fetched asynchronously, sorted on the host); 0 = index order.  Identical results.
  * "refine_table_kb": LDS budget (KiB, default 96, 0 = off) of the FISS+ refinement kernel's per-ego pose-obstacle pair

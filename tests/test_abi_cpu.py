@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -138,3 +139,45 @@ def test_no_kernel_spills_a_vgpr():
         # (scratch WITHOUT a spill is a stack object the optimiser emptied but did not delete - fiss_refine_kernel reserves 68 bytes and
         # audit_kernel 20 that no instruction addresses; it only switches the wave's scratch set-up on)
         assert scratch <= 68, l
+
+
+def test_production_library_reports_no_diagnostic_macro_and_its_compiler(lib):
+    lib.fp_build_flags.restype = C.c_char_p
+    lib.fp_build_compiler.restype = C.c_char_p
+    assert lib.fp_build_flags() == b""
+    assert b"roc-7.2.0" in lib.fp_build_compiler() and lib.fp_build_compiler().startswith(b"22.")
+
+
+def test_a_diagnostic_build_names_its_macros_and_the_binding_refuses_it(tmp_path):
+    """The timing ablations (FP_ABL_*: wrong results by design), the instance switches and the stamp / counter builds compile into the
+    same file name under the same ABI version: fp_build_flags() is how a caller tells, and _abi.load() refuses unless told otherwise.
+    (Host-only check: one translation unit with the macro on its command line - the whole library takes a minute to build.)"""
+    csrc = os.path.join(ROOT, "fiss_plus_planner_amd", "csrc")
+    src = open(os.path.join(csrc, "frenet_abi.hip")).read()
+    a = src.index("const char* fp_build_flags(void)")
+    b = src.index("const char* fp_build_compiler(void)")
+    unit = tmp_path / "flags.cpp"
+    unit.write_text('#include <string>\nextern "C" {\n' + src[a:b] + "}\n")
+    for extra, want in (([], ""), (["-DFP_ABL_NO_N", "-DFP_NO_OCC8"], "-DFP_ABL_NO_N -DFP_NO_OCC8"),
+                        (["-DFP_BUILD_EXTRA=\"-DFP_PHASE_STAMPS -DFOO=1\"", "-DFP_PHASE_STAMPS", "-DFP_COUNTERS"], "-DFP_PHASE_STAMPS -DFOO=1 -DFP_COUNTERS")):
+        so = tmp_path / f"flags{len(extra)}.so"
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-std=c++17", "-o", str(so), str(unit)] + extra)
+        L = C.CDLL(str(so))
+        L.fp_build_flags.restype = C.c_char_p
+        assert L.fp_build_flags().decode() == want
+    # the Makefile hands EXTRA to the library, and refuses a toolchain it was not validated on
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "FP_BUILD_EXTRA" in mk and "VALIDATED_ROCM = 7.2.0" in mk and "$(error" in mk
+    assert "__clang_major__ != 22" in src
+    # the binding's refusal (no GPU needed: it happens right after dlopen)
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from fiss_plus_planner_amd import _abi\n"
+            "class Fake:\n"
+            "    def __getattr__(self, n):\n"
+            "        f = lambda *a: b'-DFP_ABL_NO_N' if n == 'fp_build_flags' else 0\n"
+            "        return type('F', (), {'__call__': staticmethod(f), 'restype': None, 'argtypes': None})()\n"
+            "real = _abi.C.CDLL\n"
+            "_abi.C.CDLL = lambda p, *a, **k: Fake() if p == _abi.LIB_PATH else real(p, *a, **k)\n"
+            "try:\n    _abi.load()\nexcept ImportError as e:\n    print('REFUSED', e)\n") % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "FP_ALLOW_DIAGNOSTIC_BUILD"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "REFUSED" in out.stdout and "FP_ABL_NO_N" in out.stdout and "DIAGNOSTIC" in out.stdout, (out.stdout, out.stderr[-2000:])

@@ -8,6 +8,7 @@ no obstacles at all (profiles + cost + argmin only) / per-candidate kernel.
 """
 import argparse
 import os
+os.environ.setdefault("FP_ALLOW_DIAGNOSTIC_BUILD", "1")  # runs against a library built with EXTRA=-DFP_...
 import sys
 
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FP_ALLOW_DIAGNOSTIC_BUILD=1  # these builds carry EXTRA=-DFP_...: the binding refuses them otherwise (fp_build_flags)
 # run one pytest selection against several builds:  bash tools/bisect_test.sh "<pytest args>" "<EXTRA or @base [EXTRA]>" ...
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 SEL=$1; shift

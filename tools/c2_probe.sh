@@ -1,4 +1,5 @@
 #!/bin/bash
+export FP_ALLOW_DIAGNOSTIC_BUILD=1  # these builds carry EXTRA=-DFP_...: the binding refuses them otherwise (fp_build_flags)
 # config 2 (256 egos x 5x5x5, 10 static obstacles): step time under launch-shape options + phase stamps
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for OPT in "lattice_group=0" "lattice_group=1,lattice_split=1" "lattice_group=1,lattice_split=0" "lattice_group=1,lattice_split=2"; do

@@ -2,6 +2,7 @@
 """Timeline of the fused lattice + FISS+ search launch (build with EXTRA=-DFP_TL; run on the GPU box; the outputs carry clock ticks,
 not results): when each ego's lattice workgroup starts and ends, when its search part becomes resident, sees the flag and ends."""
 import os
+os.environ.setdefault("FP_ALLOW_DIAGNOSTIC_BUILD", "1")  # runs against a library built with EXTRA=-DFP_...
 import sys
 
 import numpy as np

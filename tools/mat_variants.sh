@@ -1,4 +1,5 @@
 #!/bin/bash
+export FP_ALLOW_DIAGNOSTIC_BUILD=1  # these builds carry EXTRA=-DFP_...: the binding refuses them otherwise (fp_build_flags)
 # Materialise mode under prebuilt variants of libfrenetgpu.so:  build them here (no GPU needed), time them on the box.
 #   build:  bash tools/mat_variants.sh build name1="-DFLAG ..." name2="..."      -> tools/_tmp/var/<name>.so
 #   run  :  gpurun -- 'bash tools/mat_variants.sh run [script.py]'               (default script: tools/mat_rate.py)

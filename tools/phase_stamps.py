@@ -2,6 +2,7 @@
 """Where a workgroup of lattice_fused_kernel spends its time: phase boundaries stamped by thread 0 (build with
 EXTRA=-DFP_PHASE_STAMPS; run on the GPU box).  Prints the median / p90 duration of every phase over the egos of config 3."""
 import os
+os.environ.setdefault("FP_ALLOW_DIAGNOSTIC_BUILD", "1")  # runs against a library built with EXTRA=-DFP_...
 import sys
 
 import numpy as np

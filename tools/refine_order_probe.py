@@ -4,6 +4,7 @@ durations from the stamps, a list-scheduling model on 768 slots in index order, 
 predictors known before the launch (collision share of the ego's lattice, coarse search statistics)."""
 import heapq
 import os
+os.environ.setdefault("FP_ALLOW_DIAGNOSTIC_BUILD", "1")  # runs against a library built with EXTRA=-DFP_...
 import sys
 
 import numpy as np

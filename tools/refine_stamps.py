@@ -2,6 +2,7 @@
 """Where a workgroup of fiss_refine_kernel spends its time (build with EXTRA=-DFP_PHASE_STAMPS; run on the GPU box): thread 0
 stamps the phase boundaries of every ego that reaches the refinement (config 4)."""
 import os
+os.environ.setdefault("FP_ALLOW_DIAGNOSTIC_BUILD", "1")  # runs against a library built with EXTRA=-DFP_...
 import sys
 
 import numpy as np

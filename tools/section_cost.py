@@ -8,6 +8,8 @@ memory barrier around it: results are unchanged), times the kernel with bench.py
 
     python tools/section_cost.py [--rep 3] [--config 3]
 """
+import os
+os.environ.setdefault("FP_ALLOW_DIAGNOSTIC_BUILD", "1")  # runs against a library built with EXTRA=-DFP_...
 import argparse, csv, os, re, shutil, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FP_ALLOW_DIAGNOSTIC_BUILD=1  # these builds carry EXTRA=-DFP_...: the binding refuses them otherwise (fp_build_flags)
 # kernel-trace stats of the FISS+ pipeline (bench.py --config 4) for build variants:  bash tools/trace_c4.sh "<EXTRA 1>" "<EXTRA 2>" ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

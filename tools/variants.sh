@@ -1,4 +1,5 @@
 #!/bin/bash
+export FP_ALLOW_DIAGNOSTIC_BUILD=1  # these builds carry EXTRA=-DFP_...: the binding refuses them otherwise (fp_build_flags)
 # Build + time variants of libfrenetgpu.so on the GPU box:   bash tools/variants.sh <tag> "<EXTRA flags 1>" "<EXTRA flags 2>" ...
 # ("" = the plain build).  Prints the lattice kernel's time per variant (bench.py's HIP events, config 3, extras off) and, with
 # PMC=1 in the environment, the VALU / SALU / LDS instruction counts of one counter pass.

@@ -3,6 +3,7 @@
 items that survive the group test, (item, profile) pairs tested / passed by stage B, narrow-phase items, how many of them
 belonged to candidates that had collided already, and how many were new collisions."""
 import os
+os.environ.setdefault("FP_ALLOW_DIAGNOSTIC_BUILD", "1")  # runs against a library built with EXTRA=-DFP_...
 import sys
 
 import numpy as np
