@@ -26,7 +26,7 @@ MODES = [
     ("two per CU, latency split", {"lattice_kernel": 2}, "lattice_launches_2"),
     ("two per CU, one workgroup per ego", {"lattice_kernel": 2, "lattice_split": 1}, "lattice_launches_2"),
     ("three per CU", {"lattice_kernel": 2, "resident_groups": 2, "lattice_occupancy": 3}, "lattice_launches_3"),
-    ("four per CU (slim layout)", {"lattice_kernel": 2, "resident_groups": 2}, "lattice_launches_4"),
+    ("four per CU (slim layout; three when the 40 KB layout does not hold the shape)", {"lattice_kernel": 2, "resident_groups": 2}, "lattice_launches_4|lattice_launches_3"),
     ("lane per candidate", {"lattice_kernel": 1}, None),
 ]
 RESET = {"lattice_kernel": 0, "lattice_split": 0, "resident_groups": 0, "lattice_occupancy": 0}
@@ -37,10 +37,10 @@ def run_modes(engine, batch, ref, what, modes=MODES, winner=True):
         for label, opts, counter in modes:
             for k, v in {**RESET, **opts}.items():
                 engine.set_option(k, v)
-            before = engine.get_option(counter) if counter else 0
+            before = sum(engine.get_option(c) for c in counter.split("|")) if counter else 0
             out = engine.plan_dense(batch, winner=winner)
             if counter:
-                assert engine.get_option(counter) > before, f"{what}: '{label}' did not take its instance"
+                assert sum(engine.get_option(c) for c in counter.split("|")) > before, f"{what}: '{label}' did not take its instance"
             for e, r in enumerate(ref):
                 bad = np.nonzero(out.flags[e] != r.flags)[0]
                 assert bad.size == 0, (f"{what} [{label}] ego {e}: {bad.size} flag words differ, first candidate {bad[0]}: "
@@ -70,7 +70,10 @@ def test_obstacles_within_a_millimetre_of_contact(oracle, engine, seed):
     assert len(placed) >= batch.B and decisive >= 0.6 * len(placed), (len(placed), decisive)
     n_coll = sum(int(((r.flags & 4) != 0).sum()) for r in ref)
     assert 0 < n_coll < batch.B * batch.C
+    before4 = engine.get_option("lattice_launches_4")
     run_modes(engine, batch, ref, f"contact scene seed {seed}")
+    if seed % 2 == 0:  # BASELINE's dense shape on 81-knot lines: the slim four-per-CU instance itself (fp16 fan bounds) was attacked
+        assert engine.get_option("lattice_launches_4") > before4
 
 
 @pytest.mark.parametrize("seed", range(max(2, SEEDS // 2)))

@@ -57,22 +57,30 @@ def random_batch(seed):
                         check_stride=int(rng.choice([1, 2, 3])))
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FP_PROPERTY_SEEDS", "40"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FP_PROPERTY_SEEDS", "400"))))
 def test_random_settings_vs_oracle(oracle, engine, seed):
     b = random_batch(1000 + seed)
     probs = oracle.problems_from_batch(b)
     ref = [p.fop_plan() for p in probs]
-    for kernel, split, group in ((2, 1, 1), (2, 2, 1), (2, 1, 3), (2, 1, 99), (1, 1, 1)):
-        engine.set_option("lattice_kernel", kernel)
-        engine.set_option("lattice_split", split)
-        engine.set_option("lattice_group", group)
-        out = engine.plan_dense(b, winner=True)
-        for e, r in enumerate(ref):
-            np.testing.assert_allclose(out.cost[e], r.cost, rtol=0, atol=1e-6, err_msg=f"seed {seed} kernel {kernel} ego {e}")
-            np.testing.assert_array_equal(out.flags[e], r.flags, err_msg=f"seed {seed} kernel {kernel} ego {e}")
-            assert out.best_idx[e] == r.best_idx, (seed, kernel, e)
-    engine.set_option("lattice_kernel", 0)
-    engine.set_option("lattice_group", 0)
+    # (kernel, split, group, resident_groups, occupancy cap): the last two model a one-CU device, so these few egos take the multi-round
+    # instances - three and four workgroups per CU (run-time shapes: 80 / 64 VGPRs, the slim fp16-bound layout where it fits)
+    try:
+        for kernel, split, group, resident, occ in ((2, 1, 1, 0, 0), (2, 2, 1, 0, 0), (2, 1, 3, 0, 0), (2, 1, 99, 0, 0), (1, 1, 1, 0, 0), (2, 1, 1, 2, 3), (2, 1, 1, 2, 0)):
+            engine.set_option("lattice_kernel", kernel)
+            engine.set_option("lattice_split", split)
+            engine.set_option("lattice_group", group)
+            engine.set_option("resident_groups", resident)
+            engine.set_option("lattice_occupancy", occ)
+            out = engine.plan_dense(b, winner=True)
+            for e, r in enumerate(ref):
+                np.testing.assert_allclose(out.cost[e], r.cost, rtol=0, atol=1e-6, err_msg=f"seed {seed} kernel {kernel} ego {e}")
+                np.testing.assert_array_equal(out.flags[e], r.flags, err_msg=f"seed {seed} kernel {kernel} resident {resident} ego {e}")
+                assert out.best_idx[e] == r.best_idx, (seed, kernel, resident, e)
+    finally:
+        engine.set_option("lattice_kernel", 0)
+        engine.set_option("lattice_group", 0)
+        engine.set_option("resident_groups", 0)
+        engine.set_option("lattice_occupancy", 0)
     # the tail split (the last half of the dispatch slots cut in two workgroups each) changes nothing
     engine.set_option("lattice_split", 1)
     engine.set_option("lattice_tail", max(2, b.B // 2))
@@ -113,7 +121,7 @@ def test_random_settings_vs_oracle(oracle, engine, seed):
 
 
 @pytest.mark.parametrize("kind", ["FISS", "FISS+"])
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FP_PROPERTY_SEEDS_SEARCH", "30"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FP_PROPERTY_SEEDS_SEARCH", "200"))))
 def test_random_settings_search_vs_oracle(oracle, engine, seed, kind):
     """The device-side search walk + refinement on the same randomised settings (lattice axes of at least two samples):
     Stats, selected index / refined end state and history index exactly as the oracle's restatement of the planners."""
