@@ -30,7 +30,8 @@ def _run_bench(extra, env_extra=None, timeout=900, tmp_path=None):
     env = dict(os.environ, BENCH_EXTRAS_FILE=extras_file, **(env_extra or {}))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
-    lines = [l for l in out.stdout.splitlines() if not l.startswith("[Gloo]")]  # (the gloo test hook's own chatter; RCCL prints nothing)
+    # (the gloo test hook chats on stdout - "[Gloo] Rank 1 is connected to 7 peer ranks ...", interleaved between ranks; RCCL prints nothing)
+    lines = [l for l in out.stdout.splitlines() if l.strip() and "Gloo" not in l and "peer ranks" not in l]
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]   # nothing before, nothing after the line
     assert out.stdout.rstrip("\n").splitlines()[-1] == lines[0]               # ... and it is the LAST line
     assert len(lines[0].encode()) < bench_mod.LINE_LIMIT
