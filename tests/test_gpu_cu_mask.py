@@ -39,7 +39,12 @@ with FrenetEngine(0) as eng:
             except _abi.FrenetGpuError as ex:   # a reported hand-over failure: the ctx falls back; the NEXT call must be right
                 out.setdefault("reported", []).append(str(ex))
                 continue
-        t0 = time.perf_counter(); eng.plan_dense(b3, tables=False, winner=True, traj_stride=112, traj_sparse=True); out["ms_%%d" %% B] = (time.perf_counter() - t0) * 1e3
+        b4.tables_tag = 4400 + B   # (scene / frame tables stay on the device: the timed calls are kernels, not uploads)
+        eng.plan_fiss(b4, "FISS+")
+        ts = []
+        for rep in range(4):
+            t0 = time.perf_counter(); eng.plan_fiss(b4, "FISS+"); ts.append((time.perf_counter() - t0) * 1e3)
+        out["ms_%%d" %% B] = min(ts)
         np.savez(os.path.join(os.environ["CHILD_OUT"], "r%%d.npz" %% B), idx=d.best_idx, cost=d.best_cost, flags=d.best_flags, traj=d.best_traj,
                  ijk=f.best_ijk, fcost=f.best_cost, stats=f.stats, refined=f.refined)
     out["handover_failed"] = eng.get_option("handover_failed")
@@ -69,7 +74,7 @@ def test_hand_overs_under_a_cu_mask(tmp_path, resident):
         mask["CHILD_RESIDENT"] = resident
     masked, got = _child(tmp_path, "masked", mask)
     # the mask took effect: the same call is several times slower on an eighth of the chip
-    assert masked["ms_2048"] > 1.25 * free["ms_2048"], (masked, free)
+    assert masked["ms_2048"] > 2.0 * free["ms_2048"], (masked, free)
     assert free["handover_failed"] == 0 and free["appended"] == 1 and "reported" not in free
     # no hand-over timed out (the dispatch order held with 32 units) - and if one ever does, it must have been REPORTED, not silent
     assert masked["handover_failed"] == 0
