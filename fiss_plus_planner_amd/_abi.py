@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrenetgpu.so")
 
-FP_ABI_VERSION = 14
+FP_ABI_VERSION = 15
 FP_FISS, FP_FISS_PLUS = 0, 1
 FP_MEM_HOST, FP_MEM_DEVICE = 0, 1
 FP_MAX_POINTS, FP_MAX_KNOTS, FP_MAX_CAND, FP_MAX_POLY_VERTS = 256, 1024, 16384, 128
@@ -28,7 +28,7 @@ _ip = C.POINTER(C.c_int32)
 _up = C.POINTER(C.c_uint32)
 
 # every symbol include/frenet_gpu.h declares (tests check the library exports all of them)
-EXPORTED_SYMBOLS = ("fp_abi_version", "fp_build_flags", "fp_build_compiler", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option", "fp_ctx_get_option",
+EXPORTED_SYMBOLS = ("fp_abi_version", "fp_build_flags", "fp_build_compiler", "fp_last_error", "fp_device_count", "fp_device_info", "fp_ctx_create", "fp_ctx_destroy", "fp_ctx_set_option", "fp_ctx_get_option", "fp_ctx_join",
                     "fp_plan_dense", "fp_winner_trajs", "fp_eval_trajs", "fp_plan_fiss", "fp_advance", "fp_plan_step", "fp_plan_fiss_step", "fp_frames_build", "fp_from_state", "fp_materialize_all",
                     "fp_group_create", "fp_group_destroy", "fp_group_submit", "fp_group_wait")
 
@@ -132,6 +132,7 @@ def load() -> C.CDLL:
     L.fp_ctx_destroy.argtypes = [C.c_void_p]
     L.fp_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.fp_ctx_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+    L.fp_ctx_join.argtypes = [C.c_void_p, C.c_void_p]
     L.fp_plan_dense.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.POINTER(FpResult), C.c_int, C.c_void_p]
     L.fp_winner_trajs.argtypes = [C.c_void_p, C.POINTER(FpParams), C.POINTER(FpBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_int, C.c_void_p]

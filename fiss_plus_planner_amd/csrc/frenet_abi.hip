@@ -164,6 +164,17 @@ struct fp_ctx {
     // (KernelArgs::err_word), and the next call on the ctx reports it, resets the flags and stops offering appended workgroups.
     bool appended_ok = false;
     int32_t* hand_err = nullptr;
+    // fp_ctx_set_option("overlap"): consecutive INDEPENDENT FP_MEM_DEVICE dense calls alternate between two internal streams (this ctx's
+    // and a twin ctx's, each with its own scratch: tickets, hand-over flags, launch order), so the draining tail of one launch runs beside
+    // the ramp of the next.  See fp_plan_dense / fp_ctx_join in include/frenet_gpu.h for what the caller's stream is ordered after.
+    int overlap = 0;
+    bool is_twin = false;
+    fp_ctx* twin = nullptr;
+    hipEvent_t ov_fork = nullptr, ov_done[2] = {nullptr, nullptr};
+    bool ov_pending[2] = {false, false};
+    int ov_next = 0;
+    fp_result ov_last = {};        // the output arrays of the call in flight on the OTHER internal stream (independence check)
+    int overlapped_calls = 0;      // fp_ctx_get_option("overlapped_calls"): dense calls that started without waiting for their predecessor
 };
 
 namespace {
@@ -911,9 +922,22 @@ int device_validate(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStrea
     }
 }
 
+// Orders `stream` after every overlapped dense call still in flight on the ctx's internal streams ("overlap").
+int overlap_join(fp_ctx* ctx, hipStream_t stream)
+{
+    for (int k = 0; k < 2; ++k)
+        if (ctx->ov_pending[k]) {
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->ov_done[k], 0));
+            ctx->ov_pending[k] = false;
+        }
+    return FP_OK;
+}
+
 int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, int mem, void* stream = nullptr)
 {
     if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    // any entry point but the overlapped dense path itself first joins what that path left in flight: its inputs may be those calls' outputs
+    if (ctx->ov_pending[0] || ctx->ov_pending[1]) FP_TRY(overlap_join(ctx, mem == FP_MEM_DEVICE ? (hipStream_t)stream : ctx->stream));
     FP_TRY(check_params(params));
     FP_TRY(check_batch(batch));
     if (mem != FP_MEM_HOST && mem != FP_MEM_DEVICE) return fail(FP_EINVAL, "mem must be FP_MEM_HOST or FP_MEM_DEVICE");
@@ -1118,6 +1142,13 @@ int fp_ctx_destroy(fp_ctx* ctx)
 {
     if (!ctx) return FP_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->twin) {  // ("overlap": drain both internal streams before anything they use is freed)
+        (void)hipStreamSynchronize(ctx->twin->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)fp_ctx_destroy(ctx->twin);
+        for (hipEvent_t e : {ctx->ov_fork, ctx->ov_done[0], ctx->ov_done[1]})
+            if (e) (void)hipEventDestroy(e);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->scratch.base) (void)hipFree(ctx->scratch.base);
@@ -1216,6 +1247,12 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->lattice_occupancy = value;
         return FP_OK;
     }
+    if (strcmp(name, "overlap") == 0) {
+        if (value < 0 || value > 1) return fail(FP_EINVAL, "overlap must be 0 or 1");
+        if (ctx->is_twin) return fail(FP_EINVAL, "overlap: not on a twin ctx");
+        ctx->overlap = value;  // (calls in flight stay in flight: fp_ctx_join / the next entry point joins them)
+        return FP_OK;
+    }
     if (strcmp(name, "resident_groups") == 0) {
         // lattice workgroups the device holds at once at two per CU (default: 2 x the device's compute units).  Lower it when the process
         // runs under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK: the runtime still reports every CU), or to model a smaller device: the
@@ -1247,15 +1284,93 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
         {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"lattice_occupancy", ctx->lattice_occupancy}, {"resident_groups", ctx->resident_groups}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
-        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"handover_failed", ctx->hand_err ? *(volatile int32_t*)ctx->hand_err : 0}, {"lattice_launches", ctx->lattice_launches},
-        {"lattice_ordered_launches", ctx->lattice_ordered_launches},
+        {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"handover_failed", ctx->hand_err ? *(volatile int32_t*)ctx->hand_err : 0}, {"overlap", ctx->overlap}, {"overlapped_calls", ctx->overlapped_calls}, {"lattice_launches", ctx->lattice_launches + (ctx->twin ? ctx->twin->lattice_launches : 0)},
+        {"lattice_ordered_launches", ctx->lattice_ordered_launches + (ctx->twin ? ctx->twin->lattice_ordered_launches : 0)},
         {"lattice_launches_2", (int)fp::lattice_launches_per_cu(0)}, {"lattice_launches_3", (int)fp::lattice_launches_per_cu(1)}, {"lattice_launches_4", (int)fp::lattice_launches_per_cu(2)}};
     for (const auto& t : tab)
         if (strcmp(name, t.n) == 0) { *value = t.v; return FP_OK; }
     return fail(FP_EINVAL, "unknown option '%s'", name);
 }
 
+static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream);
+
+// "overlap": the options the twin ctx must share with its owner (everything a dense call reads)
+static void overlap_sync_options(fp_ctx* twin, const fp_ctx* ctx)
+{
+    twin->lattice_kernel = ctx->lattice_kernel; twin->lattice_split = ctx->lattice_split; twin->lattice_occupancy = ctx->lattice_occupancy;
+    twin->lattice_tail = ctx->lattice_tail; twin->lattice_group = ctx->lattice_group; twin->lattice_winner = ctx->lattice_winner;
+    twin->lattice_order = ctx->lattice_order; twin->resident_groups = ctx->resident_groups; twin->lds_cu_kb = ctx->lds_cu_kb;
+    twin->validate = ctx->validate;
+    if (!ctx->appended_ok) twin->appended_ok = false;
+}
+
+// true when two dense calls write no array in common (NULL members write nothing)
+static bool overlap_disjoint(const fp_result& a, const fp_result& b)
+{
+    const void* pa[] = {a.best_idx, a.best_cost, a.cost_tbl, a.flag_tbl, a.stats, a.best_flags, a.best_traj, a.fopplus, a.audit};
+    const void* pb[] = {b.best_idx, b.best_cost, b.cost_tbl, b.flag_tbl, b.stats, b.best_flags, b.best_traj, b.fopplus, b.audit};
+    for (const void* x : pa)
+        for (const void* y : pb)
+            if (x && x == y) return false;
+    return true;
+}
+
+int fp_ctx_join(fp_ctx* ctx, void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return overlap_join(ctx, (hipStream_t)stream);
+}
+
 int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
+{
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    bool overlapped = ctx->overlap && mem == FP_MEM_DEVICE && !ctx->is_twin && result && batch && batch->B > 0;
+    if (overlapped) {  // (nothing forks inside a stream capture: a captured call is an ordinary stream-ordered one)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) overlapped = false;
+    }
+    if (!overlapped) return plan_dense_impl(ctx, params, batch, result, mem, stream);
+    // ---- overlap: this call goes to the internal stream its predecessor did NOT use.  The internal stream is ordered after everything
+    // the caller has enqueued on `stream` so far; `stream` is ordered after the call BEFORE this one (the deferred join: two calls in
+    // flight at most).  A call that writes an array its predecessor writes is not independent: it joins first and runs behind it.
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->twin) {
+        fp_ctx* tw = nullptr;
+        FP_TRY(fp_ctx_create(ctx->device, &tw));
+        tw->is_twin = true;
+        ctx->twin = tw;
+        for (hipEvent_t* e : {&ctx->ov_fork, &ctx->ov_done[0], &ctx->ov_done[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    const int k = ctx->ov_next;
+    fp_ctx* target = k ? ctx->twin : ctx;
+    if (k) overlap_sync_options(ctx->twin, ctx);
+    const bool independent = !ctx->ov_pending[k ^ 1] || overlap_disjoint(ctx->ov_last, *result);
+    if (!independent) FP_TRY(overlap_join(ctx, (hipStream_t)stream));
+    else if (ctx->ov_pending[k ^ 1]) ++ctx->overlapped_calls;
+    HIP_TRY(hipEventRecord(ctx->ov_fork, (hipStream_t)stream));
+    HIP_TRY(hipStreamWaitEvent(target->stream, ctx->ov_fork, 0));
+    const bool keep[2] = {ctx->ov_pending[0], ctx->ov_pending[1]};
+    ctx->ov_pending[0] = ctx->ov_pending[1] = false;  // (plan_dense_impl's common_checks must not join: that is this function's business)
+    const int rc = plan_dense_impl(target, params, batch, result, FP_MEM_DEVICE, target->stream);
+    ctx->ov_pending[0] = keep[0]; ctx->ov_pending[1] = keep[1];
+    if (rc != FP_OK) {  // nothing (or not everything) was enqueued: leave the caller's stream ordered after whatever is in flight
+        (void)overlap_join(ctx, (hipStream_t)stream);
+        return rc;
+    }
+    HIP_TRY(hipEventRecord(ctx->ov_done[k], target->stream));
+    if (ctx->ov_pending[k ^ 1]) {  // the deferred join of the predecessor
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->ov_done[k ^ 1], 0));
+        ctx->ov_pending[k ^ 1] = false;
+    }
+    ctx->ov_pending[k] = true;
+    ctx->ov_last = *result;
+    ctx->ov_next = k ^ 1;
+    return FP_OK;
+}
+
+static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
 {
     FP_TRY(common_checks(ctx, params, batch, mem, stream));
     if (!result || !result->best_idx || !result->best_cost) return fail(FP_EINVAL, "result.best_idx/best_cost must not be NULL");

@@ -169,6 +169,11 @@ class FrenetEngine:
         """Diagnostic knobs of the ctx, e.g. set_option("lattice_kernel", 1) pins the lane-per-candidate kernel."""
         _abi.check(self._lib.fp_ctx_set_option(self._ctx, name.encode(), int(value)))
 
+    def join(self, stream: int = 0):
+        """set_option("overlap", 1): orders `stream` after every dense call of this engine that is still in flight on its internal streams
+        (fp_ctx_join).  With overlap on, plan_dense_device returns with `stream` ordered after the PREVIOUS call's results only."""
+        _abi.check(self._lib.fp_ctx_join(self._ctx, stream or None))
+
     def get_option(self, name: str) -> int:
         v = C.c_int(0)
         _abi.check(self._lib.fp_ctx_get_option(self._ctx, name.encode(), C.byref(v)))

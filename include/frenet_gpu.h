@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 14
+#define FP_ABI_VERSION 15
 
 /* error codes */
 #define FP_OK 0
@@ -253,6 +253,15 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * "lattice_occupancy": 0 = auto (default: batches of more egos than stay resident run three lattice workgroups per compute unit - four
  * when a workgroup's tables fit a quarter of the unit's LDS: rectangle scenes, e.g. a 9 x 9 x 7 lattice against 50 obstacles on
  * reference lines of up to ~80 knots - instead of two), 2 / 3 / 4 = at most that many.  Identical results.
+ * "overlap": 0 (default) = every call is ordered on the caller's stream like a kernel launch.  1 = FP_MEM_DEVICE fp_plan_dense calls
+ * alternate between two INTERNAL streams of the ctx, so that two consecutive independent calls run side by side on the device: the
+ * draining tail of one launch (a fifth of a 2048-ego launch runs on a chip that is emptying) overlaps the ramp of the next.  Ordering
+ * with "overlap" on: (1) a call starts after everything enqueued on the caller's `stream` before it; (2) when fp_plan_dense returns,
+ * `stream` is ordered after the results of the PREVIOUS dense call on the ctx (and of every older one), not yet after this call's - at
+ * most two calls are in flight; (3) fp_ctx_join(ctx, stream), or any other entry point of the ctx, orders `stream` after all of them;
+ * (4) a call that writes an array its predecessor writes (any fp_result member equal) is not independent: it waits for the predecessor.
+ * The inputs of a call must not be outputs of the call before it (dense outputs are not dense inputs; fp_plan_step / fp_plan_fiss, which
+ * do feed themselves, never overlap).  Calls inside a stream capture are never overlapped.  Identical results.
  * "resident_groups": lattice workgroups the device holds at once at two per compute unit.  0 / default = 2 x the device's compute units.
  * The latency-mode split, the tail split, the three- / four-per-unit instances and the launch order key on it: set it to 2 x the units the
  * process really has when it runs under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK - the runtime still reports every unit), or lower to
@@ -288,6 +297,9 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
  * "lattice_ordered_launches" (those dispatched in a feedback order or in the order of fp_batch.launch_order) - bench.py reports when an
  * order took effect -, "lattice_launches_2" / "_3" / "_4" (PROCESS-wide: fused lattice launches so far by workgroups per compute unit). */
 int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value);
+/* "overlap" = 1: orders `stream` (a hipStream_t, NULL = the default stream) after every dense call of the ctx that is still in flight on
+ * its internal streams.  A no-op otherwise.  Also read-only: "overlapped_calls" = dense calls that started beside their predecessor. */
+int fp_ctx_join(fp_ctx* ctx, void* stream);
 
 /* Dense lattice pass = FrenetOptimalPlanner.plan() for B egos at once:
  *   calc_frenet_paths (:69-104) + CostFunction.cost_total (cost_function.py:41-50)

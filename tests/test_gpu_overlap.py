@@ -1,0 +1,191 @@
+"""GPU: fp_ctx_set_option("overlap", 1) - consecutive independent FP_MEM_DEVICE dense calls on two internal streams (ABI 15).
+
+What include/frenet_gpu.h promises: identical results; a call starts after everything enqueued on the caller's stream before it;
+the caller's stream is ordered after the PREVIOUS call when a call returns and after everything at fp_ctx_join / any other entry
+point; calls that write a common array run one behind the other; captured calls are ordinary stream-ordered calls.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from fiss_plus_planner_amd import synth
+from fiss_plus_planner_amd.device_batch import DeviceBatch
+from fiss_plus_planner_amd.engine import FrenetEngine
+
+pytestmark = pytest.mark.gpu
+
+
+class Slot:
+    """One resident batch with its own result arrays."""
+
+    def __init__(self, torch, batch, dev):
+        self.db = DeviceBatch(batch, 0)
+        B = batch.B
+        self.idx = torch.full((B,), -7, dtype=torch.int32, device=dev)
+        self.cost = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.flags = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.traj = torch.zeros((B, 16, 112), dtype=torch.float64, device=dev)
+
+    def call(self, eng, stream, out=None):
+        o = out or self
+        eng.plan_dense_device(self.db.params, self.db.fb, o.idx.data_ptr(), o.cost.data_ptr(), stream=stream.cuda_stream, best_flags=o.flags.data_ptr(),
+                              best_traj=o.traj.data_ptr(), traj_stride=112, traj_sparse=True)
+
+    def snapshot(self):
+        return [t.cpu().numpy().copy() for t in (self.idx, self.cost, self.flags, self.traj)]
+
+
+def _same(a, b, what):
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True), what
+
+
+@pytest.fixture(scope="module")
+def rig():
+    import torch
+
+    dev = torch.device("cuda", 0)
+    eng = FrenetEngine(0)
+    slots = [Slot(torch, synth.make_config(3, B=B, ego_offset=9000 + 3000 * k), dev) for k, B in enumerate((2048, 1100, 2048, 700))]
+    stream = torch.cuda.Stream(dev)
+    for s in slots:
+        s.call(eng, stream)
+    torch.cuda.synchronize(dev)
+    ref = [s.snapshot() for s in slots]
+    yield torch, dev, eng, slots, stream, ref
+    eng.close()
+
+
+def test_overlapped_calls_return_what_ordered_calls_return(rig):
+    torch, dev, eng, slots, stream, ref = rig
+    eng.set_option("overlap", 1)
+    try:
+        before = eng.get_option("overlapped_calls")
+        for rep in range(6):
+            for s in slots:
+                s.traj.zero_(); s.idx.fill_(-7)   # (on torch's current stream; synchronised below before the calls)
+            torch.cuda.synchronize(dev)
+            for k in range(12):
+                slots[k % 4].call(eng, stream)
+            eng.join(stream.cuda_stream)
+            stream.synchronize()                  # ONLY the caller's stream: the join is what makes that enough
+            for s, r in zip(slots, ref):
+                _same(s.snapshot(), r, f"overlap repetition {rep}")
+        assert eng.get_option("overlapped_calls") - before >= 6 * 10
+    finally:
+        eng.set_option("overlap", 0)
+
+
+def test_the_callers_stream_is_ordered_after_the_previous_call_without_a_join(rig):
+    """Promise (2): when call n returns, `stream` is ordered after call n - 1: a copy of call n - 1's outputs enqueued on `stream` right
+    after call n reads complete results."""
+    torch, dev, eng, slots, stream, ref = rig
+    eng.set_option("overlap", 1)
+    try:
+        a, b = slots[0], slots[2]
+        a.idx.fill_(-7); a.traj.zero_()
+        torch.cuda.synchronize(dev)
+        a.call(eng, stream)
+        b.call(eng, stream)
+        with torch.cuda.stream(stream):
+            got = [t.clone() for t in (a.idx, a.cost, a.flags, a.traj)]   # enqueued on the caller's stream, no join
+        stream.synchronize()
+        _same([g.cpu().numpy() for g in got], ref[0], "previous call's outputs read on the caller's stream")
+        eng.join(stream.cuda_stream)
+        stream.synchronize()
+    finally:
+        eng.set_option("overlap", 0)
+
+
+def test_a_call_sees_what_the_caller_enqueued_before_it(rig):
+    """Promise (1): new ego states copied in on the caller's stream right before the call are the states the call plans."""
+    torch, dev, eng, slots, stream, ref = rig
+    s = slots[1]
+    moved = s.db.host.ego.copy()
+    moved[:, 0] += 3.0
+    moved[:, 1] *= 0.9
+    new = torch.from_numpy(moved).to(dev)
+    old = s.db.t["ego"].clone()
+    torch.cuda.synchronize(dev)
+    try:
+        s.db.t["ego"].copy_(new); torch.cuda.synchronize(dev)
+        s.call(eng, stream); stream.synchronize()
+        want = s.snapshot()
+        s.db.t["ego"].copy_(old); torch.cuda.synchronize(dev)
+        eng.set_option("overlap", 1)
+        for rep in range(5):
+            slots[0].call(eng, stream)
+            with torch.cuda.stream(stream):
+                s.db.t["ego"].copy_(new, non_blocking=True)      # on the caller's stream, before the call
+            s.call(eng, stream)
+            eng.join(stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                got = [t.clone() for t in (s.idx, s.cost, s.flags, s.traj)]
+                s.db.t["ego"].copy_(old, non_blocking=True)      # ... and after the join: the call is done with the states
+            stream.synchronize()
+            _same([g.cpu().numpy() for g in got], want, f"states enqueued before the call, repetition {rep}")
+    finally:
+        eng.set_option("overlap", 0)
+        s.db.t["ego"].copy_(old); torch.cuda.synchronize(dev)
+        s.call(eng, stream); stream.synchronize()
+
+
+def test_calls_that_write_the_same_arrays_run_one_behind_the_other(rig):
+    torch, dev, eng, slots, stream, ref = rig
+    eng.set_option("overlap", 1)
+    try:
+        a, b = slots[0], slots[2]      # same size: b's call writes into a's arrays
+        for rep in range(4):
+            before = eng.get_option("overlapped_calls")
+            a.call(eng, stream)
+            b.call(eng, stream, out=a)
+            eng.join(stream.cuda_stream); stream.synchronize()
+            assert eng.get_option("overlapped_calls") == before   # dependent: it waited
+            _same(a.snapshot(), ref[2], "the later call's results stand")
+            a.call(eng, stream); eng.join(stream.cuda_stream); stream.synchronize()
+            _same(a.snapshot(), ref[0], "restored")
+    finally:
+        eng.set_option("overlap", 0)
+
+
+def test_other_entry_points_join_first_and_host_calls_still_work(rig, oracle):
+    torch, dev, eng, slots, stream, ref = rig
+    eng.set_option("overlap", 1)
+    try:
+        for k in range(5):
+            slots[k % 4].call(eng, stream)
+        small = synth.make_batch(6, 5, 5, 5, 10, 100, False, seed=11)
+        out = eng.plan_dense(small)    # FP_MEM_HOST on the same ctx: joins, runs, synchronises
+        refo = [p.fop_plan() for p in oracle.problems_from_batch(small)]
+        assert np.array_equal(out.best_idx, [r.best_idx for r in refo])
+        assert eng.get_option("overlap") == 1
+        torch.cuda.synchronize(dev)
+        for s, r in zip(slots, ref):
+            _same(s.snapshot(), r, "after a host call")
+    finally:
+        eng.set_option("overlap", 0)
+
+
+def test_overlap_is_faster_than_ordered_calls(rig):
+    torch, dev, eng, slots, stream, ref = rig
+    big = [slots[0], slots[2]]
+
+    def rate(n=200):
+        for k in range(40):
+            big[k % 2].call(eng, stream)
+        eng.join(stream.cuda_stream); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(n):
+            big[k % 2].call(eng, stream)
+        eng.join(stream.cuda_stream); torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e6
+
+    rate(); ordered = min(rate() for _ in range(3))
+    eng.set_option("overlap", 1)
+    try:
+        rate(); lapped = min(rate() for _ in range(3))
+    finally:
+        eng.set_option("overlap", 0)
+    print(f"2048-ego dense call: {ordered:.1f} us ordered, {lapped:.1f} us overlapped")
+    assert lapped < 0.97 * ordered, (ordered, lapped)
