@@ -58,7 +58,7 @@ EXTRAS_FILE = "bench_extras.json"
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                  "config", "roofline", "cpu_baseline", "parity", "value_cold", "ms_per_step_cold", "plan_cycle_p50_ms", "legs", "extras_file")
 LEG_KEYS = ("config2", "config4", "config5_single_gpu", "launch_order_hint_off", "lattice_order_off", "single_batch_replayed", "tables_written",
-            "lanes_layout", "survey8d_layout", "polygon_scenes", "two_streams", "sharded_resident", "long_reference_lines", "rectangles_as_rings")
+            "lanes_layout", "survey8d_layout", "polygon_scenes", "two_streams", "overlap", "overlap_config4", "sharded_resident", "long_reference_lines", "rectangles_as_rings")
 
 
 def _sig(x, digits=6):
@@ -304,6 +304,7 @@ class Workload:
     def step(self):
         if self.fiss:
             if self.prev_k == self.kPrevRing:
+                self.eng.join(self.stream.cuda_stream)  # ("overlap": the fill below must come after the call still in flight; a no-op otherwise)
                 with self.torch.cuda.stream(self.stream):
                     self.prev_ring.fill_(-1)  # (all of the ring's arrays have been used: the kernels before this fill are done with them in stream order)
                 self.prev_k = 0
@@ -1123,6 +1124,45 @@ def main():
         if args.cpu_seconds > 0:
             o2["config4"]["parity"] = fiss_parity("two_streams config4", w4b, np.arange(0, B, max(1, B // 64)))
         extras["two_streams"] = o2
+        # (d3) the same overlap for ONE caller, through the product's own switch: fp_ctx_set_option("overlap", 1) - consecutive independent
+        # FP_MEM_DEVICE calls of ONE engine on ONE caller stream alternate between the ctx's two internal streams (ABI 15; the caller's
+        # stream is joined with the call before the previous one, fp_ctx_join joins it with everything).  Same batches, same outputs.
+        eng.set_option("overlap", 1)
+
+        def measure_ov(ws):
+            if prewarm_s > 0:
+                wake(torch, dev, lambda: [(w.step(), w.fetch()) for w in ws[:2]], 0.5 * prewarm_s)
+            for k in range(warm_x):
+                ws[k % len(ws)].step(); ws[k % len(ws)].fetch()
+            eng.join(stream.cuda_stream)
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps_x):
+                ws[(warm_x + k) % len(ws)].step(); ws[(warm_x + k) % len(ws)].fetch()
+            eng.join(stream.cuda_stream)
+            barrier()
+            el = time.perf_counter() - t0
+            return {"value": float(np.mean([w.candidates for w in ws])) * steps_x / el, "unit": "candidates/s", "ms_per_step": el / steps_x * 1e3,
+                    "steps": steps_x, "warmup": warm_x}
+
+        try:
+            n_ov = eng.get_option("overlapped_calls")
+            oo = measure_ov(wls if len(wls) >= 2 else [main_wl, Workload(torch, eng, batch, dev, stream)])
+            oo["what"] = ("the headline workload with fp_ctx_set_option(\"overlap\", 1): ONE engine, ONE caller stream; consecutive steps (distinct batches, distinct "
+                          "output arrays) run on the ctx's two internal streams")
+            oo["overlapped_calls"] = eng.get_option("overlapped_calls") - n_ov
+            eng.join(stream.cuda_stream); torch.cuda.synchronize(dev)
+            oo["parity"] = gate("overlap", wls[-1], 64)
+            w4c = Workload(torch, eng, b4, dev, stream, fiss=True, hint=False)
+            torch.cuda.synchronize(dev)
+            oo4 = measure_ov([w4a, w4c])
+            eng.join(stream.cuda_stream); torch.cuda.synchronize(dev)
+            if args.cpu_seconds > 0:
+                oo4["parity"] = fiss_parity("overlap config4", w4c, np.arange(0, B, max(1, B // 64)))
+            extras["overlap"], extras["overlap_config4"] = oo, oo4
+            del w4c
+        finally:
+            eng.set_option("overlap", 0)
         del ws2, w4a, w4b
         # (e) many scenarios x many cycles on the device, and the PCIe-inclusive host-buffer entry
         if args.cpu_seconds > 0:

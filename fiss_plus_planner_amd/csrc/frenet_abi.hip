@@ -173,7 +173,7 @@ struct fp_ctx {
     hipEvent_t ov_fork = nullptr, ov_done[2] = {nullptr, nullptr};
     bool ov_pending[2] = {false, false};
     int ov_next = 0;
-    fp_result ov_last = {};        // the output arrays of the call in flight on the OTHER internal stream (independence check)
+    const void* ov_last_p[12] = {};  // the output arrays of the call in flight on the OTHER internal stream (independence check)
     int overlapped_calls = 0;      // fp_ctx_get_option("overlapped_calls"): dense calls that started without waiting for their predecessor
 };
 
@@ -945,6 +945,93 @@ int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
     return FP_OK;
 }
 
+// "overlap": the options the twin ctx must share with its owner (everything a dense call reads)
+void overlap_sync_options(fp_ctx* twin, const fp_ctx* ctx)
+{
+    twin->lattice_kernel = ctx->lattice_kernel; twin->lattice_split = ctx->lattice_split; twin->lattice_occupancy = ctx->lattice_occupancy;
+    twin->lattice_tail = ctx->lattice_tail; twin->lattice_group = ctx->lattice_group; twin->lattice_winner = ctx->lattice_winner;
+    twin->lattice_order = ctx->lattice_order; twin->resident_groups = ctx->resident_groups; twin->lds_cu_kb = ctx->lds_cu_kb;
+    twin->validate = ctx->validate;
+    if (!ctx->appended_ok) twin->appended_ok = false;
+}
+
+// The arrays a call writes (NULL entries write nothing), for the independence check of "overlap"
+struct OverlapOuts {
+    const void* p[12] = {};
+    bool disjoint(const void* const (&o)[12]) const
+    {
+        for (const void* x : p)
+            for (const void* y : o)
+                if (x && x == y) return false;
+        return true;
+    }
+};
+OverlapOuts overlap_outs(const fp_result& a)
+{
+    OverlapOuts o;
+    const void* v[] = {a.best_idx, a.best_cost, a.cost_tbl, a.flag_tbl, a.stats, a.best_flags, a.best_traj, a.fopplus, a.audit};
+    for (int i = 0; i < 9; ++i) o.p[i] = v[i];
+    return o;
+}
+OverlapOuts overlap_outs(const fp_fiss_io& a)
+{
+    OverlapOuts o;
+    const void* v[] = {a.prev_best_idx, a.best_ijk, a.best_cost, a.end_state, a.refined, a.stats, a.trace, a.best_flags, a.best_traj};
+    for (int i = 0; i < 9; ++i) o.p[i] = v[i];
+    return o;
+}
+
+// "overlap": runs `impl(target ctx, its internal stream)` on the internal stream the previous overlapped call did NOT use.  The internal
+// stream is ordered after everything the caller has enqueued on `stream` so far; `stream` is ordered after the call BEFORE this one (the
+// deferred join: two calls in flight at most).  A call that writes an array its predecessor writes is not independent: it joins first
+// and runs behind it.
+template <class Impl>
+int overlapped_call(fp_ctx* ctx, hipStream_t stream, const OverlapOuts& outs, Impl&& impl)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->twin) {
+        fp_ctx* tw = nullptr;
+        FP_TRY(fp_ctx_create(ctx->device, &tw));
+        tw->is_twin = true;
+        ctx->twin = tw;
+        for (hipEvent_t* e : {&ctx->ov_fork, &ctx->ov_done[0], &ctx->ov_done[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    const int k = ctx->ov_next;
+    fp_ctx* target = k ? ctx->twin : ctx;
+    if (k) overlap_sync_options(ctx->twin, ctx);
+    const bool independent = !ctx->ov_pending[k ^ 1] || outs.disjoint(ctx->ov_last_p);
+    if (!independent) FP_TRY(overlap_join(ctx, stream));
+    else if (ctx->ov_pending[k ^ 1]) ++ctx->overlapped_calls;
+    HIP_TRY(hipEventRecord(ctx->ov_fork, stream));
+    HIP_TRY(hipStreamWaitEvent(target->stream, ctx->ov_fork, 0));
+    const bool keep[2] = {ctx->ov_pending[0], ctx->ov_pending[1]};
+    ctx->ov_pending[0] = ctx->ov_pending[1] = false;  // (the implementation's common_checks must not join: that is this function's business)
+    const int rc = impl(target, target->stream);
+    ctx->ov_pending[0] = keep[0]; ctx->ov_pending[1] = keep[1];
+    if (rc != FP_OK) {  // nothing (or not everything) was enqueued: leave the caller's stream ordered after whatever is in flight
+        (void)overlap_join(ctx, stream);
+        return rc;
+    }
+    HIP_TRY(hipEventRecord(ctx->ov_done[k], target->stream));
+    if (ctx->ov_pending[k ^ 1]) {  // the deferred join of the predecessor
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->ov_done[k ^ 1], 0));
+        ctx->ov_pending[k ^ 1] = false;
+    }
+    ctx->ov_pending[k] = true;
+    memcpy(ctx->ov_last_p, outs.p, sizeof(outs.p));
+    ctx->ov_next = k ^ 1;
+    return FP_OK;
+}
+
+// Is this call one the "overlap" option applies to?  (FP_MEM_DEVICE, on the owner ctx, not inside a stream capture: nothing forks there.)
+bool overlap_applies(fp_ctx* ctx, int mem, const fp_batch* batch, void* stream)
+{
+    if (!ctx->overlap || mem != FP_MEM_DEVICE || ctx->is_twin || !batch || batch->B <= 0) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
+    return cap == hipStreamCaptureStatusNone;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1294,27 +1381,6 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 
 static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream);
 
-// "overlap": the options the twin ctx must share with its owner (everything a dense call reads)
-static void overlap_sync_options(fp_ctx* twin, const fp_ctx* ctx)
-{
-    twin->lattice_kernel = ctx->lattice_kernel; twin->lattice_split = ctx->lattice_split; twin->lattice_occupancy = ctx->lattice_occupancy;
-    twin->lattice_tail = ctx->lattice_tail; twin->lattice_group = ctx->lattice_group; twin->lattice_winner = ctx->lattice_winner;
-    twin->lattice_order = ctx->lattice_order; twin->resident_groups = ctx->resident_groups; twin->lds_cu_kb = ctx->lds_cu_kb;
-    twin->validate = ctx->validate;
-    if (!ctx->appended_ok) twin->appended_ok = false;
-}
-
-// true when two dense calls write no array in common (NULL members write nothing)
-static bool overlap_disjoint(const fp_result& a, const fp_result& b)
-{
-    const void* pa[] = {a.best_idx, a.best_cost, a.cost_tbl, a.flag_tbl, a.stats, a.best_flags, a.best_traj, a.fopplus, a.audit};
-    const void* pb[] = {b.best_idx, b.best_cost, b.cost_tbl, b.flag_tbl, b.stats, b.best_flags, b.best_traj, b.fopplus, b.audit};
-    for (const void* x : pa)
-        for (const void* y : pb)
-            if (x && x == y) return false;
-    return true;
-}
-
 int fp_ctx_join(fp_ctx* ctx, void* stream)
 {
     if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
@@ -1325,49 +1391,9 @@ int fp_ctx_join(fp_ctx* ctx, void* stream)
 int fp_plan_dense(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
 {
     if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
-    bool overlapped = ctx->overlap && mem == FP_MEM_DEVICE && !ctx->is_twin && result && batch && batch->B > 0;
-    if (overlapped) {  // (nothing forks inside a stream capture: a captured call is an ordinary stream-ordered one)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
-        if (cap != hipStreamCaptureStatusNone) overlapped = false;
-    }
-    if (!overlapped) return plan_dense_impl(ctx, params, batch, result, mem, stream);
-    // ---- overlap: this call goes to the internal stream its predecessor did NOT use.  The internal stream is ordered after everything
-    // the caller has enqueued on `stream` so far; `stream` is ordered after the call BEFORE this one (the deferred join: two calls in
-    // flight at most).  A call that writes an array its predecessor writes is not independent: it joins first and runs behind it.
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (!ctx->twin) {
-        fp_ctx* tw = nullptr;
-        FP_TRY(fp_ctx_create(ctx->device, &tw));
-        tw->is_twin = true;
-        ctx->twin = tw;
-        for (hipEvent_t* e : {&ctx->ov_fork, &ctx->ov_done[0], &ctx->ov_done[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    }
-    const int k = ctx->ov_next;
-    fp_ctx* target = k ? ctx->twin : ctx;
-    if (k) overlap_sync_options(ctx->twin, ctx);
-    const bool independent = !ctx->ov_pending[k ^ 1] || overlap_disjoint(ctx->ov_last, *result);
-    if (!independent) FP_TRY(overlap_join(ctx, (hipStream_t)stream));
-    else if (ctx->ov_pending[k ^ 1]) ++ctx->overlapped_calls;
-    HIP_TRY(hipEventRecord(ctx->ov_fork, (hipStream_t)stream));
-    HIP_TRY(hipStreamWaitEvent(target->stream, ctx->ov_fork, 0));
-    const bool keep[2] = {ctx->ov_pending[0], ctx->ov_pending[1]};
-    ctx->ov_pending[0] = ctx->ov_pending[1] = false;  // (plan_dense_impl's common_checks must not join: that is this function's business)
-    const int rc = plan_dense_impl(target, params, batch, result, FP_MEM_DEVICE, target->stream);
-    ctx->ov_pending[0] = keep[0]; ctx->ov_pending[1] = keep[1];
-    if (rc != FP_OK) {  // nothing (or not everything) was enqueued: leave the caller's stream ordered after whatever is in flight
-        (void)overlap_join(ctx, (hipStream_t)stream);
-        return rc;
-    }
-    HIP_TRY(hipEventRecord(ctx->ov_done[k], target->stream));
-    if (ctx->ov_pending[k ^ 1]) {  // the deferred join of the predecessor
-        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->ov_done[k ^ 1], 0));
-        ctx->ov_pending[k ^ 1] = false;
-    }
-    ctx->ov_pending[k] = true;
-    ctx->ov_last = *result;
-    ctx->ov_next = k ^ 1;
-    return FP_OK;
+    if (!result || !overlap_applies(ctx, mem, batch, stream)) return plan_dense_impl(ctx, params, batch, result, mem, stream);
+    return overlapped_call(ctx, (hipStream_t)stream, overlap_outs(*result),
+                           [&](fp_ctx* target, hipStream_t is) { return plan_dense_impl(target, params, batch, result, FP_MEM_DEVICE, is); });
 }
 
 static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_result* result, int mem, void* stream)
@@ -1722,7 +1748,12 @@ extern "C" {
 int fp_plan_fiss(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io, int mem,
                  void* stream_v)
 {
-    return plan_fiss_impl(ctx, params, batch, opts, io, nullptr, mem, stream_v);
+    if (!ctx) return fail(FP_EINVAL, "ctx is NULL");
+    if (!io || !overlap_applies(ctx, mem, batch, stream_v)) return plan_fiss_impl(ctx, params, batch, opts, io, nullptr, mem, stream_v);
+    // ("overlap": two FISS / FISS+ pipelines of independent batches side by side - the one-round search and refinement launches of one
+    // run beside the other's lattice kernel; prev_best_idx is in/out, so calls that share it run one behind the other)
+    return overlapped_call(ctx, (hipStream_t)stream_v, overlap_outs(*io),
+                           [&](fp_ctx* target, hipStream_t is) { return plan_fiss_impl(target, params, batch, opts, io, nullptr, FP_MEM_DEVICE, is); });
 }
 
 int fp_plan_fiss_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, const fp_fiss_opts* opts, const fp_fiss_io* io,

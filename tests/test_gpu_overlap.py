@@ -192,3 +192,56 @@ def test_overlap_is_faster_than_ordered_calls(rig):
         eng.set_option("overlap", 0)
     print(f"2048-ego dense call: {ordered:.1f} us ordered, {lapped:.1f} us overlapped")
     assert lapped < 0.97 * ordered, (ordered, lapped)
+
+
+def test_overlapped_fissplus_pipelines_return_what_ordered_ones_return(rig):
+    """fp_plan_fiss under "overlap": two independent FISS+ pipelines (lattice + appended search + refinement each) side by side."""
+    import ctypes as C
+
+    from fiss_plus_planner_amd import _abi
+
+    torch, dev, eng, slots, stream, ref = rig
+
+    class Fiss:
+        def __init__(self, batch):
+            self.db = DeviceBatch(batch, 0)
+            B = batch.B
+            mk = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+            self.prev = torch.full((B, 3), -1, dtype=torch.int32, device=dev)
+            self.ijk, self.cost, self.end = mk((B, 3), torch.int32), mk(B, torch.float64), mk((B, 3), torch.float64)
+            self.refined, self.stats = mk(B, torch.int32), mk((B, 4), torch.int32)
+            self.opts = _abi.FpFissOpts(_abi.FP_FISS_PLUS, 3, 10.0, 0.5)
+            io = self.io = _abi.FpFissIo()
+            io.samp_min, io.samp_max, io.samp_res = (self.db.t[k].data_ptr() for k in ("samp_min", "samp_max", "samp_res"))
+            io.prev_best_idx, io.best_ijk, io.best_cost, io.end_state = self.prev.data_ptr(), self.ijk.data_ptr(), self.cost.data_ptr(), self.end.data_ptr()
+            io.refined, io.stats = self.refined.data_ptr(), self.stats.data_ptr()
+
+        def call(self):
+            self.prev.fill_(-1)
+            torch.cuda.synchronize(dev)
+
+        def launch(self):
+            eng.plan_fiss_device(self.db.params, self.db.fb, self.opts, self.io, stream=stream.cuda_stream)
+
+        def snap(self):
+            return [t.cpu().numpy().copy() for t in (self.ijk, self.cost, self.end, self.refined, self.stats)]
+
+    fs = [Fiss(synth.make_config(4, B=B, ego_offset=20000 + 4000 * k)) for k, B in enumerate((2048, 1300, 2048))]
+    want = []
+    for f in fs:
+        f.call(); f.launch(); torch.cuda.synchronize(dev)
+        want.append(f.snap())
+    eng.set_option("overlap", 1)
+    try:
+        before = eng.get_option("overlapped_calls")
+        for rep in range(5):
+            for f in fs:
+                f.call()
+            for f in fs:
+                f.launch()
+            eng.join(stream.cuda_stream); stream.synchronize()
+            for f, w in zip(fs, want):
+                _same(f.snap(), w, f"FISS+ overlap repetition {rep}")
+        assert eng.get_option("overlapped_calls") - before >= 5 * 2
+    finally:
+        eng.set_option("overlap", 0)
