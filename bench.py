@@ -1083,6 +1083,26 @@ def main():
         op["egos_with_a_feasible_candidate"] = float((wp.h_idx.numpy() >= 0).mean())
         extras["polygon_scenes"] = op
         del wp, bp
+        # (d1b) rectangles handed over as 4-vertex rings (half of the columns): ProblemBatch recognises a ring that IS its column's rectangle
+        # and keeps the column a rectangle - the scene takes the rectangle-only instances again.  Against the same batch as plain rectangles.
+        wr0 = Workload(torch, eng, batch, dev, stream, hint=False)
+        wr1 = Workload(torch, eng, synth.with_rectangle_rings(batch, 99, frac=0.5), dev, stream, hint=False)
+        orr0, orr = measure([wr0], "lattice_fused_kernel, one batch replayed"), measure([wr1], "lattice_fused_kernel, one batch replayed (rectangle rings -> rectangle columns)")
+        orr["workload"] = "the headline's first batch with half of its obstacle columns handed over as 4-vertex rings that are their rectangles (fp_batch.obs_poly)"
+        orr["rectangles_ms_per_step"], orr["vs_rectangles"] = orr0["ms_per_step"], orr["ms_per_step"] / orr0["ms_per_step"]
+        orr["parity"] = gate("rectangles_as_rings", wr1, 64)
+        extras["rectangles_as_rings"] = orr
+        del wr0, wr1
+        # (d1c) reference lines of 200 knots (the same roads sampled every 2 m instead of 5): a workgroup's spline tables no longer fit the
+        # 40 KB layout of the four-per-CU instance, the launch takes three per CU
+        bl = synth.make_batch(B, 9, 9, 7, 50, 50, True, synth.CONFIG_SEEDS[3], "FOP", layout=args.layout, n_knots=200)
+        wl200 = Workload(torch, eng, bl, dev, stream, hint=False)
+        ol = measure([wl200], "lattice_fused_kernel, one batch replayed, 200-knot reference lines")
+        ol["workload"] = "configs[2] sizes on 200-knot reference lines (the same roads, a knot every 2 m), one batch replayed"
+        ol["vs_81_knots"] = ol["ms_per_step"] / orr0["ms_per_step"]
+        ol["parity"] = gate("long_reference_lines", wl200, 48)
+        extras["long_reference_lines"] = ol
+        del wl200, bl
         # (d2) two contexts, two streams: the steps alternate between two engines (each its own fp_ctx and stream, what
         # ShardedEngine(shards_per_device=2) does on the product side), so the draining tail of one launch - and the one-round search /
         # refinement kernels of a FISS+ step - run beside the next step's lattice kernel.  Same batches, same outputs; an extra leg,

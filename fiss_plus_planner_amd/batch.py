@@ -50,6 +50,27 @@ def speed_samples(lowest: float, highest, num_speed: int):
     return v, res
 
 
+def rectangle_rings_to_rectangles(poly: np.ndarray, nvert: np.ndarray, dims: np.ndarray) -> np.ndarray:
+    """obs_nvert with every 4-vertex ring that IS its column's rectangle set to 0 (= "the rectangle of obs_dims").
+
+    A ring whose vertices are exactly the corners (+-l/2, +-w/2) of obs_dims, walked counter-clockwise from any corner, is the same
+    polygon as the rectangle column - and the rectangle column takes the kernels' rectangle narrow phase (a scene made of such rings
+    only takes the rectangle-only instances: the polygon instances carry run-time shapes and ~15 more registers, 5-19 % per launch).
+    Exact comparison on the doubles: anything else stays a polygon column."""
+    nvert = np.array(nvert, dtype=np.int32, copy=True)
+    four = nvert == 4
+    if not four.any():
+        return nvert
+    hl, hw = 0.5 * dims[..., 0], 0.5 * dims[..., 1]
+    corners = np.stack([np.stack([hl, hw], -1), np.stack([-hl, hw], -1), np.stack([-hl, -hw], -1), np.stack([hl, -hw], -1)], axis=-2)  # CCW
+    ring = poly[..., :4, :]
+    is_box = np.zeros(nvert.shape, dtype=bool)
+    for start in range(4):
+        is_box |= np.all(ring == np.roll(corners, -start, axis=-2), axis=(-1, -2))
+    nvert[four & is_box & (hl > 0) & (hw > 0)] = 0
+    return nvert
+
+
 @dataclass
 class ProblemBatch:
     d_samples: np.ndarray
@@ -100,6 +121,8 @@ class ProblemBatch:
         for name in ("samp_min", "samp_max", "samp_res"):
             if getattr(self, name) is not None:
                 setattr(self, name, f8(getattr(self, name)))
+        if self.obs_nvert is not None:
+            self.obs_nvert = rectangle_rings_to_rectangles(np.asarray(self.obs_poly, dtype=np.float64), np.asarray(self.obs_nvert), self.obs_dims)
         if self.obs_nvert is not None and not np.any(np.asarray(self.obs_nvert)):
             self.obs_poly = self.obs_nvert = None  # no polygon column after all
         if self.obs_nvert is not None:

@@ -50,7 +50,7 @@ def sample_frames(knots, coef, s):
 
 def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving: bool, seed: int,
                kind: str = "FOP", vehicle: Vehicle | None = None, max_target_speed: float = 13.5,
-               ego_offset: int = 0, layout: str = "lanes") -> ProblemBatch:
+               ego_offset: int = 0, layout: str = "lanes", n_knots: int = 81) -> ProblemBatch:
     """B egos, each with its own 81-knot centerline and its own n_obs-rectangle scene.
 
     ego_offset lets a rank generate only its shard [ego_offset, ego_offset+B) of a larger batch:
@@ -61,7 +61,7 @@ def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving
     assert layout in ("lanes", "survey8d")
     veh = vehicle or Vehicle()
     st = default_settings(nd, nv, nt)
-    NX = 81
+    NX = int(n_knots)  # knots of every ego's reference line (the same 400 m road sampled finer or coarser; 81 = one knot per 5 m)
     pts = np.empty((B, NX, 2))
     ego = np.empty((B, 6))
     dims = np.empty((B, max(n_obs, 0), 2))
@@ -123,7 +123,26 @@ def make_batch(B: int, nd: int, nv: int, nt: int, n_obs: int, T_obs: int, moving
         frame_of=np.arange(B), scene_of=scene_of, t_now=np.zeros(B), nx=np.full(B, NX), knots=knots, coef=coef,
         obs_pose=pose, obs_dims=dims, final_time_step=fts, veh_l=veh.l, veh_w=veh.w, max_speed=veh.max_speed,
         max_accel=veh.max_accel, tick_t=st.tick_t, check_stride=2, samp_min=samp_min, samp_max=samp_max, samp_res=samp_res,
-        meta=dict(seed=seed, kind=kind, moving=moving, ego_offset=ego_offset, layout=layout))
+        meta=dict(seed=seed, kind=kind, moving=moving, ego_offset=ego_offset, layout=layout, **({"n_knots": NX} if NX != 81 else {})))
+
+
+def with_rectangle_rings(batch: ProblemBatch, seed: int, frac: float = 0.5, canonical: bool = True) -> ProblemBatch:
+    """`batch` with a share of its obstacle columns spelled as 4-vertex rings that ARE their rectangles (the same polygons, handed over as
+    fp_batch.obs_poly / obs_nvert).  canonical=True: through ProblemBatch's constructor, which turns such rings back into rectangle
+    columns; False: behind its back (the polygon code path on rectangle geometry: what the A/B tools and tests measure)."""
+    rng = np.random.default_rng(seed)
+    S, n = batch.S, batch.n_obs
+    hl, hw = 0.5 * batch.obs_dims[..., 0], 0.5 * batch.obs_dims[..., 1]
+    poly = np.stack([np.stack([-hl, -hw], -1), np.stack([hl, -hw], -1), np.stack([hl, hw], -1), np.stack([-hl, hw], -1)], axis=2)
+    nvert = np.where(rng.uniform(size=(S, n)) < frac, 4, 0).astype(np.int32)
+    kw = {k: getattr(batch, k) for k in ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+                                          "obs_pose", "obs_dims", "final_time_step", "veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride",
+                                          "samp_min", "samp_max", "samp_res")}
+    if canonical:
+        return ProblemBatch(**kw, obs_poly=poly, obs_nvert=nvert, meta=dict(batch.meta, rectangle_rings=seed))
+    out = ProblemBatch(**kw, obs_poly=poly, obs_nvert=np.full((S, n), 3, dtype=np.int32), meta=dict(batch.meta, rectangle_rings=seed))
+    out.obs_nvert = nvert
+    return out
 
 
 def make_config(config: int, B: int | None = None, ego_offset: int = 0, kind: str | None = None, layout: str = "survey8d") -> ProblemBatch:

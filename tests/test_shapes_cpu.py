@@ -139,3 +139,34 @@ def test_random_non_convex_shapes_against_the_stand_in_geometry(oracle):
             assert got == want, (case, ring.tolist(), (ex, ey, eyaw), (ox, oy, oyaw))
             n_hit += want
     assert n_nonconvex > 100 and 100 < n_hit < 900
+
+
+def test_rings_that_are_their_rectangles_become_rectangle_columns():
+    """A 4-vertex ring equal to the corners of its column's obs_dims rectangle is the same polygon: ProblemBatch turns it into a
+    rectangle column (nvert 0), and a scene made of such rings only carries no polygon table at all (it takes the rectangle-only kernel
+    instances).  Exact comparison: a ring one ulp off, a clockwise ring, a rotated ring stay polygon columns."""
+    from fiss_plus_planner_amd import synth
+    from fiss_plus_planner_amd.batch import ProblemBatch, rectangle_rings_to_rectangles
+
+    b = synth.make_batch(3, 5, 5, 5, 6, 20, True, seed=5)
+    hl, hw = 0.5 * b.obs_dims[..., 0], 0.5 * b.obs_dims[..., 1]
+    ccw = np.stack([np.stack([-hl, -hw], -1), np.stack([hl, -hw], -1), np.stack([hl, hw], -1), np.stack([-hl, hw], -1)], axis=2)
+    poly = np.concatenate([ccw, np.zeros_like(ccw[:, :, :2])], axis=2)   # poly_stride 6
+    kw = {k: getattr(b, k) for k in ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
+                                      "obs_pose", "obs_dims", "final_time_step", "veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride")}
+    allrect = ProblemBatch(**kw, obs_poly=poly, obs_nvert=np.full(b.obs_dims.shape[:2], 4, dtype=np.int32))
+    assert allrect.obs_nvert is None and allrect.obs_poly is None and allrect.poly_stride == 0
+    nv = np.full(b.obs_dims.shape[:2], 4, dtype=np.int32)
+    p2 = poly.copy()
+    p2[0, 0, 1, 0] = np.nextafter(p2[0, 0, 1, 0], np.inf)       # one ulp off
+    p2[0, 1, :4] = p2[0, 1, :4][::-1]                            # clockwise
+    p2[0, 2, :4] = np.roll(p2[0, 2, :4], 2, axis=0)              # the same ring from another corner: still the rectangle
+    p2[1, 0, :4] = p2[1, 0, :4] @ np.array([[0.0, 1.0], [-1.0, 0.0]])  # turned by 90 degrees: another polygon
+    nv[2, 3] = 5                                                 # not a quadrilateral
+    got = rectangle_rings_to_rectangles(p2, nv, b.obs_dims)
+    want = np.zeros_like(nv)
+    want[0, 0] = want[0, 1] = want[1, 0] = 4
+    want[2, 3] = 5
+    np.testing.assert_array_equal(got, want)
+    mixed = ProblemBatch(**kw, obs_poly=p2, obs_nvert=nv)
+    np.testing.assert_array_equal(mixed.obs_nvert, want)

@@ -18,16 +18,9 @@ base = synth.make_config(3)
 eng = FrenetEngine(0)
 dev = torch.device("cuda", 0)
 def rect_rings(b, frac=0.5):
-    """half of the columns as 4-vertex rings that ARE their rectangles: the same collisions, the polygon code path"""
-    from fiss_plus_planner_amd.batch import ProblemBatch
-    rng = np.random.default_rng(1)
-    S, n = b.S, b.n_obs
-    hl, hw = 0.5 * b.obs_dims[..., 0], 0.5 * b.obs_dims[..., 1]
-    poly = np.stack([np.stack([-hl, -hw], -1), np.stack([hl, -hw], -1), np.stack([hl, hw], -1), np.stack([-hl, hw], -1)], axis=2)
-    nvert = np.where(rng.uniform(size=(S, n)) < frac, 4, 0).astype(np.int32)
-    kw = {k: getattr(b, k) for k in ("d_samples", "t_samples", "v_samples", "target_speed", "ego", "frame_of", "scene_of", "t_now", "nx", "knots", "coef",
-                                      "obs_pose", "obs_dims", "final_time_step", "veh_l", "veh_w", "max_speed", "max_accel", "tick_t", "check_stride")}
-    return ProblemBatch(**kw, obs_poly=poly, obs_nvert=nvert)
+    """half of the columns as 4-vertex rings that ARE their rectangles: the same collisions, the polygon code path (behind the constructor's
+    back: ProblemBatch itself turns such rings into rectangle columns)"""
+    return synth.with_rectangle_rings(b, 1, frac=frac, canonical=False)
 
 
 norect = rect_rings(base)
