@@ -57,7 +57,7 @@ LINE_LIMIT = 4096
 EXTRAS_FILE = "bench_extras.json"
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                  "config", "roofline", "cpu_baseline", "parity", "value_cold", "ms_per_step_cold", "plan_cycle_p50_ms", "legs", "extras_file")
-LEG_KEYS = ("config2", "config4", "config5_single_gpu", "launch_order_hint_off", "lattice_order_off", "single_batch_replayed", "tables_written",
+LEG_KEYS = ("config2", "config4", "config5_single_gpu", "launch_order_hint_off", "launch_order_hint_only", "lattice_order_off", "single_batch_replayed", "tables_written",
             "lanes_layout", "survey8d_layout", "polygon_scenes", "two_streams", "overlap", "overlap_config4", "sharded_resident", "long_reference_lines", "rectangles_as_rings")
 
 
@@ -946,19 +946,25 @@ def main():
             w.order_hint(False)  # (the three legs below: the ctx's own orders)
         extras["single_batch_replayed"] = dict(measure([main_wl], "lattice_fused_kernel, one batch replayed, no hint: launch order learnt on the batch itself"),
                                                parity=gate("single_batch_replayed", main_wl, 64))
-        extras["launch_order_hint_off"] = dict(measure(wls, "lattice_fused_kernel, no hint: launch order learnt from the durations of an earlier launch - of a DIFFERENT batch"),
+        extras["launch_order_hint_off"] = dict(measure(wls, "lattice_fused_kernel, no hint: every batch of the rotation dispatched in the order learnt from ITS OWN earlier launches (one order per resident batch)"),
                                                parity=gate("launch_order_hint_off", wls[-1], 64))
         eng.set_option("lattice_order", 0)
         extras["lattice_order_off"] = dict(measure(wls, "lattice_fused_kernel, workgroups dispatched in ego index order"),
                                            parity=gate("lattice_order_off", wls[-1], 64))
+        for w in wls:
+            w.order_hint(True)
+        extras["launch_order_hint_only"] = dict(measure(wls, "lattice_fused_kernel, fp_batch.launch_order alone (egos by descending speed, input-only; no learnt order): round 5's headline path"),
+                                                parity=gate("launch_order_hint_only", wls[-1], 64))
         eng.set_option("lattice_order", 1)
         for w in wls:
             w.order_hint(hinted)
-        extras["launch_order"] = {"main_run": "fp_batch.launch_order = the egos by descending speed (engine.launch_order_hint: input-only, one host argsort at upload)" if hinted else
-                                  "no hint (BENCH_NO_ORDER_HINT): the ctx's feedback order",
+        extras["launch_order"] = {"main_run": "the order the ctx learnt on each resident batch (durations its own earlier launches left behind; fetched asynchronously every 8 launches, "
+                                              "sorted on the host INSIDE the timed region); until a batch has one: " +
+                                              ("fp_batch.launch_order = the egos by descending speed (engine.launch_order_hint: input-only, one host argsort at upload)" if hinted else "index order"),
                                   "launches_of_the_main_run": launches, "of_them_in_a_given_or_learnt_order": ordered,
-                                  "note": f"the main run cycles {n_rot} distinct batches: an order the ctx learns is always one learnt on a DIFFERENT batch (launch_order_hint_off = "
-                                          "lattice_order_off); single_batch_replayed shows the order learnt on the batch itself"}
+                                  "note": f"the main run cycles {n_rot} distinct batches; since round 6 the ctx keeps one learnt order PER resident batch (keyed by the batch's ego array), "
+                                          "so an order is never applied to another batch than the one it was learnt on. launch_order_hint_only = the input-only order alone; "
+                                          "lattice_order_off = index order"}
         # (a2) what SURVEY 8(d)'s metric definition counts in full: the per-candidate cost / flag tables written (12 B per candidate) and
         # the Stats brought to the host every step, next to index / cost / series as in the headline
         wt = [Workload(torch, eng, w.batch, dev, stream, tables=True) for w in wls]
@@ -1262,7 +1268,7 @@ def main():
                                          f"{'dynamic' if batch.meta.get('moving') else 'static'} obstacles, " + ("FISS+" if fiss else "FOP") + f", {n_rot} batches cycled",
                        "egos_per_gpu": B, "candidates_per_ego": C, "tables_written": bool(args.tables), "obstacle_layout": args.layout,
                        "rotating_batches": n_rot, "parallelism": f"ego-shard x{world} (no collectives)",
-                       "launch_order": "fp_batch.launch_order: egos by descending speed (input-only hint, host argsort at upload; results identical)" if main_wl.hinted else "ctx feedback order",
+                       "launch_order": "per-batch learnt order (ctx feedback); before it exists: " + ("fp_batch.launch_order, egos by descending speed (input-only hint, host argsort at upload; results identical)" if main_wl.hinted else "index order"),
                        "input_digest": batch.digest()[:16], "input_digests": [w.batch.digest()[:16] for w in wls]},
             "parity": parity_main,
             "roofline": roofline_obj(bytes_launch, kern_ms, kname, traffic,

@@ -112,6 +112,36 @@ struct LaunchOrder {
     }
 };
 
+// The feedback orders of one kernel, one per RESIDENT BATCH (keyed by the address of the batch's ego-state array): an order is only ever
+// applied to the batch it was learnt on.  (Until round 6 there was one order per kernel and batch SIZE: a caller cycling through
+// several resident batches of one size dispatched each in the order another one had left behind - for the refinement kernel, whose
+// launch is one round of workgroups with only the egos that found a trajectory doing work, a foreign order is worse than none:
+// rocprofv3 82 us per launch against 55 with its own.)  kOrderSlots batches, least recently used one replaced.
+constexpr int kOrderSlots = 8;
+struct OrderSet {
+    LaunchOrder slot[kOrderSlots];
+    const void* key[kOrderSlots] = {};
+    unsigned long used[kOrderSlots] = {};
+    unsigned long tick = 0;
+    LaunchOrder& of(const void* k)
+    {
+        int lru = 0;
+        for (int i = 0; i < kOrderSlots; ++i) {
+            if (key[i] == k && used[i]) { used[i] = ++tick; return slot[i]; }
+            if (used[i] < used[lru]) lru = i;
+        }
+        LaunchOrder& o = slot[lru];
+        if (o.pending) { (void)hipEventSynchronize(o.event); o.pending = false; }  // (the fetch in flight belongs to the batch that leaves)
+        o.valid_B = o.dur_B = 0;
+        o.since = 0;
+        key[lru] = k;
+        used[lru] = ++tick;
+        return o;
+    }
+    void forget() { for (auto& o : slot) o.valid_B = 0; }
+    void release() { for (auto& o : slot) o.release(); }
+};
+
 struct fp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // used by FP_MEM_HOST calls
@@ -153,7 +183,7 @@ struct fp_ctx {
     // longest-first and uploads the order the following launches dispatch in.  A stale or missing order only costs speed.
     int lattice_order = 1;
     int lattice_launches = 0, lattice_ordered_launches = 0;  // fp_ctx_get_option counters
-    LaunchOrder order_lattice, order_refine;
+    OrderSet order_lattice, order_refine;
     DeviceBuf idx_shadow;          // [B] device copy of best_idx for the winner kernel of a dense call (KernelArgs::idx_shadow)
     DeviceBuf epi_flags;           // [B] hand-over flags of the epilogue workgroups appended to a multi-round lattice launch (KernelArgs::epi_flag); zero between launches
     DeviceBuf curv_buf;            // [B][C] curvature flag bytes of the lattice (fp_params.curvature_mask), written ahead of the fused kernel
@@ -579,24 +609,32 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
 // the launch: hands out the permutation to dispatch in (nullptr = index order) and the array the workgroups leave their durations
 // in.  Host work happens only when a fetched duration table has arrived (hipEventQuery, no wait): an argsort of B ints.
 constexpr int kOrderRefresh = 8;  // launches between two fetches of the duration table
-int launch_order_before(fp_ctx* ctx, LaunchOrder& o, int resident, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur,
-                        const int* hint = nullptr)
+int launch_order_before(fp_ctx* ctx, OrderSet& set, int resident, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur,
+                        const int* hint = nullptr, LaunchOrder** slot = nullptr)
 {
     *perm = nullptr;
     *dur = nullptr;
-    if (&o == &ctx->order_lattice) ++ctx->lattice_launches;
+    if (slot) *slot = nullptr;
+    const bool lattice = &set == &ctx->order_lattice;
+    if (lattice) ++ctx->lattice_launches;
     if (nsplit != 1 || b->B <= resident) return FP_OK;
-    if (hint) {  // fp_batch.launch_order: the caller's order wins (no durations are collected: the ctx's learnt order stays what it was)
-        *perm = hint;
-        if (&o == &ctx->order_lattice) ++ctx->lattice_ordered_launches;
+    // Priority: the order learnt on THIS batch (exact history) > fp_batch.launch_order (the caller's input-only hint) > index order.
+    // Durations are collected under a hint too, so a hinted batch moves on to its own order once it has one.
+    if (!ctx->lattice_order) {
+        if (hint) { *perm = hint; if (lattice) ++ctx->lattice_ordered_launches; }
         return FP_OK;
     }
-    if (!ctx->lattice_order) return FP_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     const bool capturing = cap != hipStreamCaptureStatusNone;
+    LaunchOrder& o = set.of(b->ego);
+    if (slot) *slot = &o;
     if (b->B > o.cap) {
-        if (capturing) return FP_OK;  // no (re)allocation inside a capture: index order
+        if (capturing) {  // no (re)allocation inside a capture: the hint, or index order
+            if (hint) { *perm = hint; if (lattice) ++ctx->lattice_ordered_launches; }
+            if (slot) *slot = nullptr;
+            return FP_OK;
+        }
         if (o.pending) { HIP_TRY(hipEventSynchronize(o.event)); o.pending = false; }
         HIP_TRY(hipStreamSynchronize(stream));
         const int cap_new = b->B + b->B / 4;
@@ -626,15 +664,17 @@ int launch_order_before(fp_ctx* ctx, LaunchOrder& o, int resident, const fp_batc
         (void)hipGetLastError();  // hipErrorNotReady is not an error
     }
     if (o.valid_B == b->B) *perm = d_perm;
+    else if (hint) *perm = hint;
     *dur = d_dur;
-    if (&o == &ctx->order_lattice && *perm) ++ctx->lattice_ordered_launches;
+    if (lattice && *perm) ++ctx->lattice_ordered_launches;
     return FP_OK;
 }
 
 // Right after the launch: every kOrderRefresh launches enqueue the fetch of the durations this launch leaves behind.
-int launch_order_after(LaunchOrder& o, const fp_batch* b, const int* dur, hipStream_t stream)
+int launch_order_after(LaunchOrder* op, const fp_batch* b, const int* dur, hipStream_t stream)
 {
-    if (!dur) return FP_OK;
+    if (!dur || !op) return FP_OK;
+    LaunchOrder& o = *op;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     if (cap != hipStreamCaptureStatusNone || o.pending) return FP_OK;
@@ -1265,7 +1305,7 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
     if (strcmp(name, "lattice_order") == 0) {
         if (value < 0 || value > 1) return fail(FP_EINVAL, "lattice_order must be 0 or 1");
         ctx->lattice_order = value;
-        ctx->order_lattice.valid_B = ctx->order_refine.valid_B = 0;
+        ctx->order_lattice.forget(); ctx->order_refine.forget();
         return FP_OK;
     }
     if (strcmp(name, "refine_table_kb") == 0) {
@@ -1422,7 +1462,8 @@ static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch*
         FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
         bool winner_done = false;
         const int* perm; int* dur;
-        FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur, batch->launch_order));
+        LaunchOrder* oslot = nullptr;
+        FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur, batch->launch_order, &oslot));
         // (the audit pass may move the winner: the series are written after it, by their own launch)
         const bool inside = winner_inside_lattice(ctx, batch) && !result->audit && !big_points(ka.p);
         if (result->best_traj && !inside) ka.idx_shadow = idx_shadow_for(ctx, B, (hipStream_t)stream);
@@ -1430,7 +1471,7 @@ static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch*
         if (!inside) kl.r.best_traj = nullptr;
         if (!inside && !result->audit && !big_points(ka.p)) offer_epilogue(ctx, ka, &kl, B, (hipStream_t)stream);
         LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");
-        FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
+        FP_TRY(launch_order_after(oslot, batch, dur, (hipStream_t)stream));
         if (result->audit) LAUNCH_TRY(fp::launch_audit(ka, result->audit, (hipStream_t)stream), "audit kernel");
         if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
         if (result->fopplus)
@@ -1473,7 +1514,8 @@ static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch*
     FP_TRY(lattice_split_for(ctx, params, batch, ctx->stream, &nsplit, &parts, &group, &tail));
     bool winner_done = false;
     const int* perm; int* dur;
-    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur));
+    LaunchOrder* oslot = nullptr;
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, ctx->stream, &perm, &dur, nullptr, &oslot));
     fp::KernelArgs kl = ka;
     if (!winner_inside_lattice(ctx, batch) || result->audit || big) {
         kl.r.best_traj = nullptr;
@@ -1483,7 +1525,7 @@ static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch*
         }
     }
     LAUNCH_TRY(fp::launch_lattice(kl, ctx->stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, inl.on ? &inl : nullptr, tail), "lattice kernel");
-    FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, ctx->stream));
+    FP_TRY(launch_order_after(oslot, batch, dur, ctx->stream));
     if (d_audit) LAUNCH_TRY(fp::launch_audit(ka, d_audit, ctx->stream), "audit kernel");
     if (result->best_traj && !winner_done) {
         if (inl.on) return fail(FP_EHIP, "internal: inline inputs without the series inside the lattice kernel");
@@ -1689,7 +1731,8 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     int nsplit, group, tail; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group, &tail));
     const int* perm; int* dur;
-    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur, mem == FP_MEM_DEVICE ? batch->launch_order : nullptr));
+    LaunchOrder* oslot = nullptr;
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, stream, &perm, &dur, mem == FP_MEM_DEVICE ? batch->launch_order : nullptr, &oslot));
     bool search_done = false;
     if (inl.on) {
         fp::KernelArgs kl = fa.ka;
@@ -1704,7 +1747,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
         LAUNCH_TRY(fp::launch_lattice(fa.ka, stream, ctx->lattice_kernel, parts, nsplit, nullptr, perm, dur, group, nullptr, tail, ft.flag ? &ft : nullptr, &search_done),
                    "lattice kernel");
     }
-    FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, stream));
+    FP_TRY(launch_order_after(oslot, batch, dur, stream));
     if (ctx->fiss_stages < 2) return mem == FP_MEM_HOST ? hs.fetch_out() : FP_OK;  // timing diagnostic: outputs are not produced
     fa.walk_jump = ctx->fiss_jump;
     if (!search_done) LAUNCH_TRY(fp::launch_fiss_search(fa, stream), "search kernel");
@@ -1712,7 +1755,8 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     if (R > 0 && ctx->fiss_stages >= 3) {
         // three refinement workgroups per CU are resident at once (fiss_refine_kernel: 168 VGPRs, ~52 KB LDS)
         const int* rperm; int* rdur;
-        FP_TRY(launch_order_before(ctx, ctx->order_refine, ctx->resident_groups / 2 * 3, batch, 1, stream, &rperm, &rdur));
+        LaunchOrder* oslot_r = nullptr;
+        FP_TRY(launch_order_before(ctx, ctx->order_refine, ctx->resident_groups / 2 * 3, batch, 1, stream, &rperm, &rdur, nullptr, &oslot_r));
         fp::FissArgs fr = fa;
         if (loop) {  // fp_plan_fiss_step: the refinement workgroup that settles an ego's trajectory hands the ego over itself
             fr.ka.loop = *loop;
@@ -1720,7 +1764,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
             handed_over = true;
         }
         LAUNCH_TRY(fp::launch_fiss_refine(fr, stream, ctx->refine_table_kb, rperm, rdur), "refinement kernel");
-        FP_TRY(launch_order_after(ctx->order_refine, batch, rdur, stream));
+        FP_TRY(launch_order_after(oslot_r, batch, rdur, stream));
     }
     if (fa.io.best_traj && R <= 0) {  // with refinement rounds the refinement kernel writes the series itself
         fp::KernelArgs kw = fa.ka;
@@ -1850,7 +1894,8 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     int nsplit, group, tail; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, (hipStream_t)stream, &nsplit, &parts, &group, &tail));
     const int* perm; int* dur;
-    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur, batch->launch_order));
+    LaunchOrder* oslot = nullptr;
+    FP_TRY(launch_order_before(ctx, ctx->order_lattice, ctx->resident_groups, batch, nsplit, (hipStream_t)stream, &perm, &dur, batch->launch_order, &oslot));
     // the hand-over rides in the lattice launch unless that launch cannot write the series it is asked for itself (the standalone
     // epilogue reads the ego's state, so it has to run BEFORE the state moves on) or the lane-per-candidate kernel is asked for
     const bool series_elsewhere = result->best_traj && (!winner_inside_lattice(ctx, batch) || big_points(ka.p));
@@ -1875,7 +1920,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
         if (series_elsewhere) kl.r.best_traj = nullptr;
         LAUNCH_TRY(fp::launch_lattice(kl, (hipStream_t)stream, ctx->lattice_kernel, parts, nsplit, &winner_done, perm, dur, group, nullptr, tail), "lattice kernel");
     }
-    FP_TRY(launch_order_after(ctx->order_lattice, batch, dur, (hipStream_t)stream));
+    FP_TRY(launch_order_after(oslot, batch, dur, (hipStream_t)stream));
     if (result->best_traj && !winner_done) LAUNCH_TRY(fp::launch_winner_traj(ka, nullptr, (hipStream_t)stream), "winner epilogue");
     if (!fused) LAUNCH_TRY(fp::launch_advance(ka, ka.r.best_idx, nullptr, *io, (hipStream_t)stream), "advance kernel");
     return FP_OK;
