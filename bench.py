@@ -925,7 +925,7 @@ def main():
 
         def measure(ws, label_kernel, ev_every=None):
             if prewarm_s > 0:
-                wake(torch, dev, lambda: (ws[0].step(), ws[0].fetch()), 0.5 * prewarm_s)
+                wake(torch, dev, lambda: (ws[0].step(), ws[0].fetch()), prewarm_s)
             el, kl = timed_run(torch, ws, steps_x, warm_x, stream, barrier, ev_every)
             k_ms = float(np.mean(kl))
             cand = sum(w.candidates for w in ws) / len(ws)
@@ -1118,7 +1118,7 @@ def main():
 
         def measure2(ws):
             if prewarm_s > 0:
-                wake(torch, dev, lambda: [(w.step(), w.fetch()) for w in ws[:2]], 0.5 * prewarm_s)
+                wake(torch, dev, lambda: [(w.step(), w.fetch()) for w in ws[:2]], prewarm_s)
             for k in range(warm_x):
                 ws[k % len(ws)].step(); ws[k % len(ws)].fetch()
             barrier()
@@ -1157,7 +1157,7 @@ def main():
 
         def measure_ov(ws):
             if prewarm_s > 0:
-                wake(torch, dev, lambda: [(w.step(), w.fetch()) for w in ws[:2]], 0.5 * prewarm_s)
+                wake(torch, dev, lambda: [(w.step(), w.fetch()) for w in ws[:2]], prewarm_s)
             for k in range(warm_x):
                 ws[k % len(ws)].step(); ws[k % len(ws)].fetch()
             eng.join(stream.cuda_stream)

@@ -102,6 +102,7 @@ struct LaunchOrder {
     int valid_B = 0;            // the uploaded order is a permutation of [0, valid_B)
     int dur_B = 0;              // batch size of the durations in flight / on the device
     int since = 0;              // launches since the last fetch was enqueued
+    int interval = 8;           // launches between two fetches: kOrderRefresh at first, doubled after every order that landed (up to kOrderRefreshMax)
     bool pending = false;       // a fetch is in flight (event)
     hipEvent_t event = nullptr;
     void release()
@@ -134,6 +135,7 @@ struct OrderSet {
         if (o.pending) { (void)hipEventSynchronize(o.event); o.pending = false; }  // (the fetch in flight belongs to the batch that leaves)
         o.valid_B = o.dur_B = 0;
         o.since = 0;
+        o.interval = kOrderRefresh;
         key[lru] = k;
         used[lru] = ++tick;
         return o;
@@ -608,7 +610,10 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
 // Launch order of a multi-round lattice launch (more egos than resident workgroups, one workgroup per ego).  Called right before
 // the launch: hands out the permutation to dispatch in (nullptr = index order) and the array the workgroups leave their durations
 // in.  Host work happens only when a fetched duration table has arrived (hipEventQuery, no wait): an argsort of B ints.
-constexpr int kOrderRefresh = 8;  // launches between two fetches of the duration table
+// launches between two fetches of the duration table: 8 while a batch's order is young, doubling with every order that lands up to 64 -
+// a fetch and the upload of the order it yields are two copy commands on the launch stream (~13 us of stream time each: a copy engine
+// hand-over), 2.5 % of a 2048-ego step at one pair per 8 launches; a resident batch's durations drift slowly
+constexpr int kOrderRefresh = 8, kOrderRefreshMax = 64;
 int launch_order_before(fp_ctx* ctx, OrderSet& set, int resident, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur,
                         const int* hint = nullptr, LaunchOrder** slot = nullptr)
 {
@@ -658,6 +663,7 @@ int launch_order_before(fp_ctx* ctx, OrderSet& set, int resident, const fp_batch
             for (int i = 0; i < n; ++i) h_perm[i] = i;
             std::stable_sort(h_perm, h_perm + n, [h_dur](int x, int y) { return h_dur[x] > h_dur[y]; });
             HIP_TRY(hipMemcpyAsync(d_perm, h_perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (o.valid_B == n) o.interval = o.interval * 2 < kOrderRefreshMax ? o.interval * 2 : kOrderRefreshMax;
             o.valid_B = n;
         }
     } else if (o.pending) {
@@ -679,7 +685,8 @@ int launch_order_after(LaunchOrder* op, const fp_batch* b, const int* dur, hipSt
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     if (cap != hipStreamCaptureStatusNone || o.pending) return FP_OK;
     const bool first = o.valid_B != b->B;  // no order for this batch size yet: fetch at once
-    if (!first && ++o.since < kOrderRefresh) return FP_OK;
+    if (first) o.interval = kOrderRefresh;
+    if (!first && ++o.since < o.interval) return FP_OK;
     o.since = 0;
     HIP_TRY(hipMemcpyAsync(o.host, dur, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(o.event, stream));
