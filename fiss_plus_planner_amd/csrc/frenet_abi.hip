@@ -94,6 +94,11 @@ struct DeviceBuf {
 
 }  // namespace
 
+// launches between two fetches of the duration table: 8 while a batch's order is young, doubling with every order that lands up to 64 -
+// a fetch and the upload of the order it yields are two copy commands on the launch stream (~13 us of stream time each: a copy engine
+// hand-over), 2.5 % of a 2048-ego step at one pair per 8 launches; a resident batch's durations drift slowly
+constexpr int kOrderRefresh = 8, kOrderRefreshMax = 64;
+
 // State of one kernel's feedback-directed launch order (see lattice_order_before).
 struct LaunchOrder {
     DeviceBuf buf;              // [dur: int x cap][perm: int x cap]
@@ -610,10 +615,6 @@ int stage_batch(HostStage& hs, const fp_params* p, const fp_batch* b, fp_batch* 
 // Launch order of a multi-round lattice launch (more egos than resident workgroups, one workgroup per ego).  Called right before
 // the launch: hands out the permutation to dispatch in (nullptr = index order) and the array the workgroups leave their durations
 // in.  Host work happens only when a fetched duration table has arrived (hipEventQuery, no wait): an argsort of B ints.
-// launches between two fetches of the duration table: 8 while a batch's order is young, doubling with every order that lands up to 64 -
-// a fetch and the upload of the order it yields are two copy commands on the launch stream (~13 us of stream time each: a copy engine
-// hand-over), 2.5 % of a 2048-ego step at one pair per 8 launches; a resident batch's durations drift slowly
-constexpr int kOrderRefresh = 8, kOrderRefreshMax = 64;
 int launch_order_before(fp_ctx* ctx, OrderSet& set, int resident, const fp_batch* b, int nsplit, hipStream_t stream, const int** perm, int** dur,
                         const int* hint = nullptr, LaunchOrder** slot = nullptr)
 {
