@@ -1800,7 +1800,10 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
 #if !defined(FP_PHASE_STAMPS) && !defined(FP_COUNTERS)
     if (tail != 0 && nsplit == 1 && gs == 1 && part_scratch && p.nt >= 2 && b.S > 0 && b.n_obs > 0 && (size_t)b.B * 4 <= kTicketBytes) {
         const int resident = (four ? 4 : three ? 3 : 2) * (tail < 0 ? -tail : 0);  // workgroups the device holds at once (auto: tail = -compute units)
-        int n_tail = tail > 0 ? tail : (b.B > resident ? resident / 4 : 0);  // (128 ... 384 of 768 measured within 1 %; 576: no gain; 768: slower)
+        // (three per CU: 128 ... 384 of 768 slots measured within 1 %; 576: no gain; 768: slower.  Four per CU, launch order = the batch's own
+        // history, round 6: 96-192 of 1024 within 1 % of each other and of no cut at all, 512: 4 % slower - an eighth of a round, which also
+        // halves the inputs staged twice)
+        int n_tail = tail > 0 ? tail : (b.B > resident ? resident / (four ? 8 : 4) : 0);
         if (n_tail > b.B - resident && tail < 0) n_tail = b.B - resident;
         if (n_tail > b.B) n_tail = b.B;
         if (n_tail > 0) tail_from = b.B - n_tail;
