@@ -1228,7 +1228,7 @@ def main():
         # the rates use this run's kernel time
         valu_issue = fp64_exec = None
         # (the newest committed PMC pass; profiles/README.md says which commit it was collected on - the file's kernel name is carried in the line)
-        pmc_file = next((f for f in (f"r05_config3_{args.layout}_pmc_summary.json", f"r04_config3_{args.layout}_pmc_summary.json")
+        pmc_file = next((f for f in (f"r06_config3_{args.layout}_pmc_summary.json", f"r05_config3_{args.layout}_pmc_summary.json", f"r04_config3_{args.layout}_pmc_summary.json")
                          if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
         pmc = load_profile_json(pmc_file) if pmc_file else None
         pmc_kernel = None

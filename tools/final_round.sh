@@ -4,7 +4,7 @@
 #   -> the bench line -> kernel-trace stats of configs 3 / 4 / 2 -> PMC passes of config 4.
 #   gpurun --timeout 2700 -- 'bash tools/final_round.sh <tag> [rnd]'      then, here:  python tools/finalize_profiles.py gpurun_out/pmc_<tag>/summary.json
 set -u
-TAG=${1:-final}; RND=${2:-r05}
+TAG=${1:-final}; RND=${2:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 bash tools/gpu_round.sh $TAG tests

@@ -15,7 +15,7 @@ if has tests; then
   timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log; tail -5 $OUT/pytest.log
 fi
 if has bench; then
-  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; head -c 1500 $OUT/bench.json; echo
+  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; cp $R/bench_extras.json $OUT/bench_extras.json 2>/dev/null
 fi
 if has trace; then
   cd /tmp
