@@ -210,7 +210,7 @@ def spawn_ranks(args) -> None:
 
 
 def read_bytes_per_ego(batch) -> float:
-    """Bytes one ego problem must READ from HBM once (DESIGN.md 'algorithmic bytes')."""
+    """Bytes one ego problem must READ from HBM once."""
     nx = int(batch.nx.max())
     reads = 6 * 8 + 8 + 3 * 4 + batch.nv * 8 + 9 * 8 * nx            # ego, target speed, ids, v samples, spline
     if batch.n_obs:
