@@ -182,7 +182,11 @@ __host__ __device__ inline int poly_lds_verts(int n_obs, int poly_stride) { retu
 template <bool SLIM> struct FanType { using type = float; static __device__ __forceinline__ float above(float x) { return x; } };
 template <> struct FanType<true> { using type = _Float16; static __device__ __forceinline__ _Float16 above(float x) { return (_Float16)(x * 1.001f + 6.2e-5f); } };
 
-__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs, int nwaves, int poly_stride = 0, bool slim = false)
+// coef_cols: columns (segments) of the spline's coefficient rows the workgroup keeps in LDS: all nx_max of them (default), or a WINDOW
+// of that many segments placed at the ego's position (the kernel's `wcap`): 64 of the 76 bytes a knot costs.  Long reference lines
+// (200+ knots) then still fit the three- / four-per-CU layouts; a point whose segment lies outside the window reads global memory.
+__host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, int hp, int nd, int nv, int nt, int kItemCap, int gs, int nwaves, int poly_stride = 0, bool slim = false,
+                                              int coef_cols = -1)
 {
     // slim (the four-per-CU instance, kWalk, no polygon columns): the same tables in 40 KB - no inner radii, fp16 fan bounds, 16-bit
     // hit codes, the row boxes inside the power sums' / hit lists' bytes (they are read for the last time before the first hit is written)
@@ -229,7 +233,7 @@ __host__ __device__ inline Layout make_layout(int nx_max, int n_obs, int rows, i
     L.poly = o;     o = align16(o + 16 * poly_lds_verts(n_obs, poly_stride));                        // ... and the rings, when they fit
     // the spline tables last: theirs is the one size no instance of the kernel knows at compile time, so every other offset folds
     L.knots = o;    o = align16(o + 8 * nx_max);
-    L.coef = o;     o = align16(o + 64 * nx_max);
+    L.coef = o;     o = align16(o + 64 * (coef_cols >= 0 && coef_cols < nx_max ? coef_cols : nx_max));
     L.lut = o;      o = align16(o + 2 * (2 * nx_max + 1));  // uint16 segment hint per arclength bucket
     L.total = o;
     return L;
@@ -275,7 +279,7 @@ constexpr int kEpiPairsC = 512 / (2 * kWave);
 constexpr int kEpiLdsBytes = kEpiPairsC * 4 * FP_FAST_POINTS * 8 + kEpiPairsC * 4 * 4 + 16;
 constexpr int kEpiSplineNX = 96;
 struct LatticeKernarg {
-    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from, epi_from; FissTail ft; InlineIn inl;
+    KernelArgs ka; int rows_max_arg, hp_max_arg, nsplit; Best* part_best; int* part_count; const int* perm; int* dur; int gs_arg, tail_from, epi_from, wcap; FissTail ft; InlineIn inl;
 };
 constexpr size_t kInlineOffset = offsetof(LatticeKernarg, inl) + offsetof(InlineIn, bytes);
 
@@ -287,9 +291,12 @@ constexpr size_t kInlineOffset = offsetof(LatticeKernarg, inl) + offsetof(Inline
 // one round of 4-wavefront workgroups as long as its slowest ego, behind a kernel boundary).  The tables travel between workgroups of
 // ONE launch, possibly on different XCDs whose L2s are not coherent with each other: they are written with agent-scope stores and read
 // with agent-scope loads; the flag follows the stores of ALL threads of the writing workgroup (s_waitcnt + barrier).
-template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH, bool POLY = false, bool FISS = false>
+// WIN: the instance can keep a WINDOW of the spline's coefficient columns in LDS (wcap < NX, see make_layout) - reference lines too long
+// for a residency's LDS share.  Its own instances: the window's bookkeeping costs the others 10-35 spilled SGPRs each (v_writelane /
+// v_readlane pairs in a kernel that is VALU-issue bound), so the instances without it are exactly what they were.
+template <int ND, int NV, int NT, int STRIDE, int NOBS, int ROWS, int OCC, int GS, int NTH, bool POLY = false, bool FISS = false, bool WIN = false>
 __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, int rows_max_arg, int hp_max_arg, int nsplit_arg, Best* part_best, int* part_count, const int* perm,
-                                                                   int* dur, int gs_arg, int tail_from, int epi_from, FissTail ft, InlineIn inl)
+                                                                   int* dur, int gs_arg, int tail_from, int epi_from, int wcap, FissTail ft, InlineIn inl)
 {
     if constexpr (FISS) {
         if (epi_from >= 0 && (int)blockIdx.x >= epi_from) {  // ---- appended search workgroup: one ego, in launch order
@@ -466,7 +473,10 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     const int n_obs_tab = kShape ? NOBS : bt.n_obs;  // obstacles per scene of the table
     const double tick = p.tick_t;
 
-    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs, kWaves, POLY ? bt.poly_stride : 0, kSlim);
+    // wcap < NX: the coefficient rows in LDS are a WINDOW of wcap segments (make_layout's coef_cols) that starts one segment behind the ego
+    const bool windowed = WIN && wcap < bt.NX;
+    const int ld = windowed ? wcap : bt.NX;  // row stride of the LDS coefficient table
+    const Layout L = make_layout(bt.NX, n_obs_tab, rows_max, hp_max, nd, nv, nt, kItemCap, gs, kWaves, POLY ? bt.poly_stride : 0, kSlim, wcap);
     double* s_knots = (double*)(smem + L.knots);
     double* s_coef = (double*)(smem + L.coef);
     unsigned short* s_lut = (unsigned short*)(smem + L.lut);
@@ -603,6 +613,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     };
     const int nx = bt.nx[f];
     const int fts = n_obs > 0 ? bt.final_time_step[sc] : 0;
+    int w0 = 0;  // first segment of the coefficient window (windowed), else 0
     {
         const double* gk = bt.knots + (size_t)f * NX;
         const double* gc = bt.coef + (size_t)f * 8 * NX;
@@ -616,9 +627,23 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         for (int i = tid; i < NX; i += kThreads) s_knots[i] = gk[i];
         for (int i = tid; i < nt + nv + nd; i += kThreads)
             s_ts[i] = i < nt ? in_t[i] : (i < nt + nv ? in_v[(size_t)b * nv + (i - nt)] : in_d[i - nt - nv]);
-        // [8][NX], same layout; the four-per-CU instances in 16-byte pieces (8 NX doubles are an even count; a global load needs no more than the
-        // doubles' own alignment) - one trip instead of two; in the polygon three-per-CU instance the same change spills two VGPRs
-        if constexpr (OCC > 6) {
+        if (windowed) {
+            // Coefficient WINDOW: the segment the ego stands on = (knots <= s0) - 1, counted by the threads that hold a knot each (one more
+            // barrier and one more dependent round trip than the whole-table copy: only lines too long for the layout pay it); the window
+            // starts one segment behind it.  Whatever a trajectory point needs outside the window is read from global memory (rare: the
+            // window is sized by the host for the residency it buys, not for a guarantee).
+            int below = 0;
+            for (int i0 = 0; i0 < NX; i0 += kThreads) below += __syncthreads_count(i0 + tid < nx && gk[i0 + tid] <= s0);
+            w0 = below - 2;  // (the ego's segment - 1)
+            w0 = w0 > nx - 1 - wcap ? nx - 1 - wcap : w0;
+            w0 = __builtin_amdgcn_readfirstlane(w0 < 0 ? 0 : w0);
+            for (int i = tid; i < 8 * wcap; i += kThreads) {
+                const int r = i / wcap, c = i - r * wcap;
+                s_coef[i] = w0 + c < NX ? gc[(size_t)r * NX + w0 + c] : 0.0;
+            }
+        } else if constexpr (OCC > 6) {
+            // [8][NX], same layout; the four-per-CU instances in 16-byte pieces (8 NX doubles are an even count; a global load needs no more
+            // than the doubles' own alignment) - one trip instead of two; in the polygon three-per-CU instance the same change spills two VGPRs
             for (int i = tid; i < 4 * NX; i += kThreads) ((double2*)s_coef)[i] = ((const double2*)gc)[i];
         } else {
             for (int i = tid; i < 8 * NX; i += kThreads) s_coef[i] = gc[i];
@@ -643,7 +668,17 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             }
         }
     }
-    SplineLds sp{s_knots, s_coef, nx, NX};
+    // the LDS spline: every knot, and the coefficient columns of segments [w0, w0 + ld) addressed by their ABSOLUTE segment index
+    SplineLds sp{s_knots, s_coef - w0, nx, ld};
+    // frame of (segment, offset): from the LDS table, or - a segment outside the coefficient window - from the batch's table in global memory
+    auto frame_at = [&](int seg, double dxs, double& px, double& py, double& tx, double& ty) {
+        if (!windowed || (unsigned)(seg - w0) < (unsigned)wcap) {
+            spline_frame(sp, seg, dxs, px, py, tx, ty);
+        } else {
+            const int fg = in_frame[b];
+            spline_frame(SplineLds{bt.knots + (size_t)fg * bt.NX, bt.coef + (size_t)fg * 8 * bt.NX, nx, bt.NX}, seg, dxs, px, py, tx, ty);
+        }
+    };
     if (kEgoEarly && tid == 8) { s_k[5] = s0; s_k[6] = s_d0; s_k[7] = s_dd0; s_k[8] = d0; s_k[9] = d_d0; s_k[10] = d_dd0; }
     __syncthreads();
     FP_STAMP(0);
@@ -680,15 +715,17 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         // little above 1 in bends): per segment the exact maxima of the two quadratic derivative components (ends + vertex).  The
         // once-per-ego group test turns an arclength interval into a circle with it.  Wave maximum of fp32 bit patterns, one LDS
         // atomic per wavefront (a NaN coefficient is the largest pattern: the circle then keeps every obstacle).
-        for (int i0 = wave * kWave; i0 < nx - 1; i0 += kThreads) {
+        // (coefficient window: over its segments only - a row whose arclength range leaves the window gets an infinite circle below)
+        const int seg_end = windowed ? (w0 + wcap < nx - 1 ? w0 + wcap : nx - 1) : nx - 1;
+        for (int i0 = w0 + wave * kWave; i0 < seg_end; i0 += kThreads) {
             const int i = i0 + lane;
             uint32_t bits = 0u;
-            if (i < nx - 1) {
+            if (i < seg_end) {
                 const double h = s_knots[i + 1] - s_knots[i];
                 double m2 = 0.0;
 #pragma unroll
                 for (int ax = 0; ax < 2; ++ax) {
-                    const double b1 = s_coef[(4 * ax + 1) * NX + i], c2 = 2.0 * s_coef[(4 * ax + 2) * NX + i], d3 = 3.0 * s_coef[(4 * ax + 3) * NX + i];
+                    const double b1 = sp.coef[(4 * ax + 1) * ld + i], c2 = 2.0 * sp.coef[(4 * ax + 2) * ld + i], d3 = 3.0 * sp.coef[(4 * ax + 3) * ld + i];
                     double m = fmax(fabs(b1), fabs(fma(fma(d3, h, c2), h, b1)));  // g(u) = b1 + c2 u + d3 u^2 at u = 0, h
                     const double uv = -c2 / (2.0 * d3);
                     if (uv > 0.0 && uv < h) m = fmax(m, fabs(fma(fma(d3, uv, c2), uv, b1)));
@@ -980,7 +1017,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         const float lo_f = f32_from_ordered(bx.x), hi_f = f32_from_ordered(bx.y);
         const double v_max = (double)__uint_as_float((uint32_t)s_cnt[5]), d_all = (double)__uint_as_float((uint32_t)s_cnt[6]);
         // empty row (no valid pose): radius -1 rejects every obstacle; an infinite range or a NaN bound keeps every obstacle
-        double rad = -1.0, cx = s_coef[0], cy = s_coef[4 * NX];  // first knot: fallback centre of an empty row circle
+        double rad = -1.0, cx = sp.coef[w0], cy = sp.coef[4 * ld + w0];  // a knot: fallback centre of an empty row circle
         if (hi_f >= lo_f) {
             // the ends were rounded to nearest fp32: half an ulp each, covered by slack; points off the spline do not exist
             const double slack = ((double)fabsf(lo_f) + (double)fabsf(hi_f)) * 1.2e-7 + 1e-6;
@@ -991,9 +1028,11 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             if (!(s_mid < knot_last)) s_mid = knot0 + 0.5 * (knot_last - knot0);  // infinite range: any centre will do
             const int seg = lut_segment(s_knots, s_lut, nx, s_mid, s_k[0], s_k[1], n_buckets);
             double tx, ty;
-            spline_frame(sp, seg, s_mid - s_knots[seg], cx, cy, tx, ty);
+            frame_at(seg, s_mid - s_knots[seg], cx, cy, tx, ty);
             rad = (v_max * (0.5 * (s_hi - s_lo)) * (1.0 + 1e-9) + s_k[4] + d_all) * (1.0 + 1e-9) + 1e-6;
             if (!(hi_f <= 3.0e38f) || !(lo_f >= -3.0e38f)) rad = __builtin_inf();
+            // (coefficient window: v_max bounds |P'| over the window's segments only - a range that leaves them keeps every obstacle)
+            if (windowed && (!(s_lo >= s_knots[w0]) || !(s_hi <= s_knots[w0 + wcap < nx - 1 ? w0 + wcap : nx - 1]))) rad = __builtin_inf();
         }
         s_grp[r].hl = cx;
         s_grp[r].hw = cy;
@@ -1127,7 +1166,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                             const double s = fma(fma(fma(fma(a4, t, a3), t, eSdd0() * 0.5), t, eSd0()), t, eS0());
                             const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
                             Frame fr;
-                            spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
+                            frame_at(seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
                             wfr.set(i, fr.px, fr.py, fr.tx, fr.ty);
                         }
     // [/section FRAMES]
@@ -1302,7 +1341,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         const double s = fma(fma(fma(fma(ql.a4, t, ql.a3), t, ql.a2), t, ql.a1), t, ql.a0);
                         const int seg = lut_segment(s_knots, s_lut, nx, s, s_k[0], s_k[1], n_buckets);
                         Frame fr;
-                        spline_frame(sp, seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
+                        frame_at(seg, s - s_knots[seg], fr.px, fr.py, fr.tx, fr.ty);
                         s_frames.set(mul24(q, hp_max) + i, fr.px, fr.py, fr.tx, fr.ty);
                     }
                 }
@@ -1677,7 +1716,12 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         const int id = div_by<NT, ND * NT>(q1, inv_nt_a), it = q1 - mul24(id, nt);
         d_end = s_ds[id]; v_end = s_vs[iv]; T_end = s_ts[it];
     }
-    winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp, eg);
+    if (ld != NX) {  // (coefficient window: the series run over the WHOLE horizon - straight from the batch's table)
+        const int fg = in_frame[b];
+        winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, SplineLds{bt.knots + (size_t)fg * NX, bt.coef + (size_t)fg * 8 * NX, nx, NX}, eg);
+    } else {
+        winner_series_wave(ka, b, b, win >= 0, d_end, v_end, T_end, lane, sp, eg);
+    }
     FP_STAMP_LAST(6);
     if (ka.has_loop && tid == 0) advance_ego(ka, b, win, nullptr, ka.loop);
 }
@@ -1744,7 +1788,17 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         gs = fit < 1 ? 1 : (gs > fit ? fit : gs);
     }
     const int pstride = b.obs_nvert && b.n_obs > 0 ? b.poly_stride : 0;  // (polygon columns: their counts - and rings, when they fit - live in LDS)
-    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1, kThreads / kWave, pstride);
+    // Coefficient window (the kernel's wcap): when the whole spline does not fit a residency's LDS share, the largest window that does -
+    // if it is at least kWinMin segments (below that too many points would read global memory)
+    constexpr int kWinMin = 32;
+    auto window_for = [&](int cap_bytes, int occ, int ps, bool slim) {
+        const int base = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(occ), 1, kThreads / kWave, ps, slim, 0).total;
+        const int w = (cap_bytes - base - 16) / 64;
+        if (ps > 0 || gs > 1) return w >= b.NX ? b.NX : 0;  // (no WIN instance with the polygon narrow phase / grouped slices)
+        return w >= b.NX ? b.NX : (w >= kWinMin ? w : 0);  // 0: not even a useful window fits
+    };
+    const int w6 = window_for(52 * 1024, 6, pstride, false);
+    const Layout L6 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(6), 1, kThreads / kWave, pstride, false, w6 > 0 ? w6 : b.NX);
     // the series of a three-per-CU launch: by epilogue workgroups appended to the grid (ka.epi_flag + ka.idx_shadow from the caller), if
     // there are fewer of them than resident slots (see the kernel); else the caller launches winner_traj_kernel behind this launch
     constexpr int kEpiPairs = kEpiPairsC;
@@ -1766,7 +1820,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     const bool epilogue = three && can_epi;
     // the FISS+ search in appended workgroups: three-per-CU launches that write their tables, lattices the 1024-sample search instance holds
     const int C_all = p.nd * p.nv * p.nt;
-    const bool search = three && ft && ft->flag && ka.r.cost_tbl && ka.r.flag_tbl && !ka.r.best_traj && !ka.has_loop && C_all > 4 * kWave && C_all <= 1024 &&
+    bool search = three && ft && ft->flag && ka.r.cost_tbl && ka.r.flag_tbl && !ka.r.best_traj && !ka.has_loop && C_all > 4 * kWave && C_all <= 1024 &&
                         ft->opts.kind == FP_FISS_PLUS && !(b.obs_nvert && b.n_obs > 0);
     static const FissTail kNoFiss{};
     FissTail fx = search ? *ft : kNoFiss;
@@ -1774,7 +1828,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     const int search_lds = search ? fsp::fissplus_lds_bytes(C_all, fx.NB) : 0;
     // FOUR workgroups per CU when the slim layout (make_layout) and the appended workgroups' LDS fit a quarter of the CU (BASELINE.json's
     // dense shape: reference lines of up to ~80 knots); 64 VGPRs a lane, the ego's start state re-read from LDS (kEgoLds)
-    const Layout L8 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(8), 1, kThreads / kWave, 0, true);
+    const int w8 = window_for(kLdsQuarter, 8, 0, true);
+    const Layout L8 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(8), 1, kThreads / kWave, 0, true, w8 > 0 ? w8 : b.NX);
     bool four = three && !pstride && L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && (long)b.B * 2 > (long)ka.resident2 * 3 &&
                 !b.skip;  // (a closed-loop batch: its finished egos leave at once, what runs rarely fills three per CU - measured 68 -> 71-75 us per cycle with four)
 #if defined(FP_NO_OCC8)  // (A/B diagnostic)
@@ -1787,6 +1842,9 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     if (L.total > kLdsLimit) return hipErrorInvalidValue;
     if (epilogue && L.total < kEpiLds) L.total = kEpiLds;  // (every workgroup of a launch gets the same dynamic LDS)
     if (search && L.total < search_lds) L.total = search_lds;
+    const int wcap = in.on ? b.NX : four ? (w8 > 0 ? w8 : b.NX) : three ? (w6 > 0 ? w6 : b.NX) : b.NX;  // (two per CU: the whole table, as before)
+    const bool windowed = wcap < b.NX;
+    if (windowed && search) { search = false; fx = kNoFiss; }  // (no WIN instance with appended search workgroups: the search follows in its own launch)
     if (nsplit > p.nt) nsplit = p.nt;
     // part_scratch: [ticket counters: kTicketBytes, zero between launches][partial argmins: Best x B x nsplit]
     int* part_count = (int*)part_scratch;
@@ -1822,7 +1880,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     auto go = [&](auto kernel, int* configured, int threads = kThreads) -> hipError_t {
         hipError_t err = ensure_dynamic_lds((const void*)kernel, L.total, configured);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, stream, kx, rows, hp, nsplit, part_best, part_count, perm, dur, gs, tail_from, epi_from, fx, in);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, stream, kx, rows, hp, nsplit, part_best, part_count, perm, dur, gs, tail_from, epi_from, wcap, fx, in);
         return hipGetLastError();
     };
     FP_LDS_SLOTS(cfg_generic);
@@ -1844,6 +1902,10 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_poly6);
     FP_LDS_SLOTS(cfg_poly9976);
     FP_LDS_SLOTS(cfg_poly_g);
+    FP_LDS_SLOTS(cfg_9978w);
+    FP_LDS_SLOTS(cfg_generic8w);
+    FP_LDS_SLOTS(cfg_9976w);
+    FP_LDS_SLOTS(cfg_generic6w);
     auto is = [&](int nd, int nv, int nt, int stride, int n_obs, int r) {
         return p.nd == nd && p.nv == nv && p.nt == nt && p.check_stride == stride && b.n_obs == n_obs && rows == r;
     };
@@ -1864,6 +1926,11 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         else if (four) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 8, 1, 512, false, true>, cfg_generic8f);
         else if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, false, true>, cfg_9976f);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, false, true>, cfg_generic6f);
+    } else if (three && windowed) {  // long reference lines: the instances that keep a window of the coefficient columns in LDS
+        if (four && is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512, false, false, true>, cfg_9978w);
+        else if (four) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 8, 1, 512, false, false, true>, cfg_generic8w);
+        else if (is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, false, false, true>, cfg_9976w);
+        else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, false, false, true>, cfg_generic6w);
     } else if (three) {
         if (four && is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 8, 1, 512>, cfg_9978);
         else if (four) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 8, 1, 512>, cfg_generic8);
