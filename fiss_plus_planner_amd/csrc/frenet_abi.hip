@@ -1733,8 +1733,6 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
         fa.io.best_traj = hs.out(io->best_traj, traj_doubles);
         if (io->traj_sparse && fa.io.best_traj) HIP_TRY(hipMemcpyAsync(fa.io.best_traj, io->best_traj, traj_doubles * sizeof(double), hipMemcpyDefault, ctx->stream));
     }
-    if (big_points(fa.ka.p) && R > 0)
-        return fail(FP_ELIMIT, "FISS+ refinement holds trajectories of at most FP_FAST_POINTS = %d points (this call: up to %d): refine on the host over fp_eval_trajs", FP_FAST_POINTS, fa.ka.p.points_max);
     FP_TRY(lattice_curv_scratch(ctx, params, batch, stream, &fa.ka.curv_tbl));
     int nsplit, group, tail; void* parts;
     FP_TRY(lattice_split_for(ctx, params, batch, stream, &nsplit, &parts, &group, &tail));

@@ -491,11 +491,11 @@ struct RefineLds {
     int scene, t_now, horizon_cap;  // per-ego scene facts read once (scene < 0: none; horizon_cap = final_time_step - t_now)
 };
 
-__device__ __forceinline__ double analytic_cost(const fp_params& p, const double* eg, double target_speed, const double* x, const double* Stab)
+__device__ __forceinline__ double analytic_cost(const fp_params& p, const double* eg, double target_speed, const double* x, const double* Stab, int n_max = FP_FAST_POINTS)
 {
     const double T = x[2];
     const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
-    if (N <= 0 || N > FP_FAST_POINTS) return __builtin_nan("");
+    if (N <= 0 || N > n_max) return __builtin_nan("");
     const Quartic lon = quartic_bvp(eg[0], eg[1], eg[2], x[1], 0.0, T);
     const Quintic lat = quintic_bvp(eg[3], eg[4], eg[5], x[0], 0.0, 0.0, T);
     double S[11], ls[3], ds[3];
@@ -511,11 +511,11 @@ __device__ __forceinline__ double analytic_cost(const fp_params& p, const double
 // them), then lane L fetches the lateral sums and recombines.  Same arithmetic per term, so the value is analytic_cost's bit for bit;
 // the chain of one evaluation is ~45 % shorter (the refinement rounds are R + 1 evaluations one after the other on a lone wavefront).
 // Valid in role-0 lanes; x must be the same in lanes L and L + 8.
-__device__ __forceinline__ double analytic_cost_two_lanes(const fp_params& p, const double* eg, double target_speed, const double* x, int role)
+__device__ __forceinline__ double analytic_cost_two_lanes(const fp_params& p, const double* eg, double target_speed, const double* x, int role, int n_max = FP_FAST_POINTS)
 {
     const double T = x[2];
     const int N = (T == T) ? arange_len(T, p.tick_t) : 0;
-    const bool ok = N > 0 && N <= FP_FAST_POINTS;
+    const bool ok = N > 0 && N <= n_max;
     double S[11], part[3] = {0.0, 0.0, 0.0};
     if (ok) {
         power_sums_closed(N, p.tick_t, S);
@@ -537,12 +537,13 @@ __device__ __forceinline__ double analytic_cost_two_lanes(const fp_params& p, co
 // the whole wavefront: lane l holds elements l and l + 64 of every chain (M <= 128).  Same difference chains as CurvTrack /
 // winner_series: yaw_k = atan2 of segment k (the last point repeats the previous heading, :129), c = diff(yaw) / ds,
 // c_d = diff(c) / dt, c_dd = diff(c_d) / dt; element i + 1 comes from the neighbouring lane.
+template <int NCH>
 __device__ __forceinline__ uint32_t wave_curvature_flags(const fp_params& p, const double2* xy, int M, int lane)
 {
     if (M < 2) return 0u;
-    double yaw[2], ds[2];
+    double yaw[NCH], ds[NCH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NCH; ++h) {
         const int i = lane + h * kWave;
         const int k = i < M - 1 ? i : M - 2;  // segment whose heading element i carries
         const double2 a = xy[k], b2 = xy[k + 1];
@@ -551,23 +552,23 @@ __device__ __forceinline__ uint32_t wave_curvature_flags(const fp_params& p, con
     }
     auto next = [&](const double* v, int h) {  // element (lane + 64 h) + 1 of a chain
         const double dn = __shfl_down(v[h], 1, kWave);
-        return (h == 0 && lane == kWave - 1) ? lane_value(v[1], 0) : dn;
+        return (h + 1 < NCH && lane == kWave - 1) ? lane_value(v[h + 1 < NCH ? h + 1 : h], 0) : dn;
     };
     uint32_t flags = 0;
-    double c[2], cd[2];
+    double c[NCH], cd[NCH];
     bool bad_c = false, bad_cd = false, bad_cdd = false;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NCH; ++h) {
         c[h] = (next(yaw, h) - yaw[h]) / ds[h];
         bad_c |= lane + h * kWave < M - 1 && fabs(c[h]) > p.max_curvature;
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NCH; ++h) {
         cd[h] = (next(c, h) - c[h]) / p.tick_t;
         bad_cd |= lane + h * kWave < M - 2 && fabs(cd[h]) > p.max_kappa_d;
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NCH; ++h) {
         const double cdd = (next(cd, h) - cd[h]) / p.tick_t;
         bad_cdd |= lane + h * kWave < M - 3 && fabs(cdd) > p.max_kappa_dd;
     }
@@ -577,7 +578,9 @@ __device__ __forceinline__ uint32_t wave_curvature_flags(const fp_params& p, con
     return flags;
 }
 
-// constraint + collision flags of ONE trajectory, computed by the whole wavefront (all arguments wave-uniform)
+// constraint + collision flags of ONE trajectory, computed by the whole wavefront (all arguments wave-uniform).  NCH = points per lane:
+// 2 (trajectories of up to FP_FAST_POINTS = 128 points: the instance every default setting takes) or 4 (up to FP_MAX_POINTS = 256).
+template <int NCH>
 __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* eg, const double* x, const RefineLds& L, int nx, int lane, double* stamp = nullptr,
                                 long long t_begin = 0)
 {
@@ -592,11 +595,12 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     SplineLds sp{L.knots, L.coef, nx, nx};
     const double knot0 = L.knots[0], knot_last = L.knots[nx - 1];
     const double seg_scale = (double)(nx - 1) / (knot_last - knot0);  // (NaN / inf / <= 0: spline_segment divides per point instead)
-    unsigned long long off_lo = 0, off_hi = 0;
+    constexpr int kPts = NCH * kWave;
+    unsigned long long off_m[NCH];
     bool bad_speed = false, bad_accel = false;
-    const int need_xy = p.curvature_mask ? FP_FAST_POINTS : ((L.scene >= 0 && bt.n_obs > 0) ? L.horizon_cap : -1);
+    const int need_xy = p.curvature_mask ? kPts : ((L.scene >= 0 && bt.n_obs > 0) ? L.horizon_cap : -1);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < NCH; ++half) {
         const int i = lane + half * kWave;
         bool off = false;
         if (i < N) {
@@ -618,21 +622,23 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
                 if (L.pt) L.xyf[i] = make_float2((float)(cx - L.ox), (float)(cy - L.oy));
             }
         }
-        const unsigned long long m = __ballot(off);
-        if (half == 0) off_lo = m; else off_hi = m;
+        off_m[half] = __ballot(off);
     }
     FP_WSTAMP(12);
     uint32_t flags = 0;
     if (__ballot(bad_speed)) flags |= FP_FLAG_SPEED;
     if (__ballot(bad_accel)) flags |= FP_FLAG_ACCEL;
-    const int M = off_lo ? __ffsll((long long)off_lo) - 1 : (off_hi ? kWave + __ffsll((long long)off_hi) - 1 : N);
+    int M = N;
+#pragma unroll
+    for (int half = NCH - 1; half >= 0; --half)
+        if (off_m[half]) M = half * kWave + __ffsll((long long)off_m[half]) - 1;
     if (M < N) flags |= FP_FLAG_TRUNCATED;
     flags |= ((uint32_t)N << FP_FLAG_N_SHIFT) | ((uint32_t)M << FP_FLAG_M_SHIFT);
     if (p.curvature_mask && M >= 2) {  // optional checks (:145-150): they read the points this wavefront just wrote
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        flags |= wave_curvature_flags(p, L.xy, M, lane);
+        flags |= wave_curvature_flags<NCH>(p, L.xy, M, lane);
     }
     // collision (frenet_optimal_planner.py:168-195)
     const int sc = L.scene;
@@ -655,7 +661,7 @@ __device__ uint32_t wave_traj_flags(const KernelArgs& ka, int b, const double* e
     {
         bool broken = false;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NCH; ++half) {
             const int i = lane + half * kWave;
             if (i < k_end && (i % stride) == 0) {
                 const double2 q = L.xy[i];
@@ -799,18 +805,22 @@ constexpr int kRefineWaves = 4;  // trajectories validated speculatively side by
 //   kRefineWaves x (fp64 poses, fp32 relative poses) | knots + coef (9 NX, padded even)
 //   | pair table (float4 per entry) | verdicts (32 B) | kRefineWaves survivor queues
 constexpr int kRefineS = 0;  // (round 2 kept a table S[N][k] of power sums here: 11 KB that cost the fourth workgroup per CU)
-__host__ __device__ constexpr int refine_spline_off() { return kRefineS + 3 * FP_FAST_POINTS * kRefineWaves; }
-__host__ __device__ constexpr int refine_pt_off(int NX) { return refine_spline_off() + ((9 * NX + 1) & ~1); }
-__host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries)
+__host__ __device__ constexpr int refine_spline_off(int pts) { return kRefineS + 3 * pts * kRefineWaves; }
+__host__ __device__ constexpr int refine_pt_off(int NX, int pts) { return refine_spline_off(pts) + ((9 * NX + 1) & ~1); }
+__host__ __device__ constexpr int refine_lds_bytes(int NX, int pt_entries, int pts)
 {
-    return (int)sizeof(double) * (refine_pt_off(NX) + 2 * pt_entries) + 32 + kRefineWaves * 2 * kQueue + 4 * (kHot + 4);
+    return (int)sizeof(double) * (refine_pt_off(NX, pts) + 2 * pt_entries) + 32 + kRefineWaves * 2 * kQueue + 4 * (kHot + 4);
 }
 
 #ifndef FP_REFINE_OCC
 #define FP_REFINE_OCC 3   // workgroups per CU (= waves per SIMD) the register budget is sized for: 4 fits the LDS (40.7 KB) but spills 61 VGPRs, measured slower
 #endif
-__global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refine_kernel(FissArgs fa, int pt_rows_max, const int* perm, int* dur)
+// NCH = 2: trajectories of up to 128 points (three workgroups per CU); NCH = 4: up to FP_MAX_POINTS = 256 (tick_t below ~0.04 s at the default
+// horizons: twice the per-wavefront point scratch, two workgroups per CU - the register budget of a loop nest twice as deep).
+template <int NCH>
+__global__ __launch_bounds__(kWave * kRefineWaves, NCH == 2 ? FP_REFINE_OCC : 2) void fiss_refine_kernel(FissArgs fa, int pt_rows_max, const int* perm, int* dur)
 {
+    constexpr int kPts = NCH * kWave;  // points per trajectory this instance holds
 #if defined(FP_PHASE_STAMPS)
     const long long t_begin = wall_clock64();
 #else
@@ -855,12 +865,12 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     }
     const int f = bt.frame_of[b];
     const int nx = bt.nx[f];
-    const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs) - 32 - kRefineWaves * 2 * kQueue - 4 * (kHot + 4);
+    const int verdict_off = refine_lds_bytes(bt.NX, pt_rows_max * bt.n_obs, kPts) - 32 - kRefineWaves * 2 * kQueue - 4 * (kHot + 4);
     RefineLds L;
     L.S = (double*)smem;
-    L.xy = (double2*)(L.S + kRefineS) + wave * FP_FAST_POINTS;  // one Cartesian scratch row per wavefront
-    L.xyf = (float2*)(L.S + kRefineS + 2 * FP_FAST_POINTS * kRefineWaves) + wave * FP_FAST_POINTS;
-    L.knots = L.S + refine_spline_off();
+    L.xy = (double2*)(L.S + kRefineS) + wave * kPts;  // one Cartesian scratch row per wavefront
+    L.xyf = (float2*)(L.S + kRefineS + 2 * kPts * kRefineWaves) + wave * kPts;
+    L.knots = L.S + refine_spline_off(kPts);
     L.queue = (uint16_t*)(smem + verdict_off + 32) + wave * kQueue;
     L.hot = (int*)(smem + verdict_off + 32 + kRefineWaves * 2 * kQueue);  // [kHot] pairs + [1] count
     if (tid == 0) L.hot[kHot] = 0;  // (the barrier behind the rounds orders it before the first validation)
@@ -881,10 +891,10 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
     int pt_rows = 0;
     if (sc0 >= 0 && bt.n_obs > 0 && pt_rows_max > 0) {
         int h = L.horizon_cap;
-        if (h > FP_FAST_POINTS) h = FP_FAST_POINTS;
+        if (h > kPts) h = kPts;
         if (h > bt.T_obs - L.t_now) h = bt.T_obs - L.t_now;
         pt_rows = h > 0 ? (h + p.check_stride - 1) / p.check_stride : 0;  // <= pt_rows_max by construction
-        L.pt = (float4*)(L.S + refine_pt_off(bt.NX));
+        L.pt = (float4*)(L.S + refine_pt_off(bt.NX, kPts));
     }
     const double nan = __builtin_nan("");
     double eg[6];
@@ -953,7 +963,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
             }
             const bool bad = lane < 6 && (!(xp[0] == xp[0]) || !(xp[1] == xp[1]) || !(xp[2] == xp[2]));
             if (__ballot(bad)) break;
-            const double cp = analytic_cost_two_lanes(p, eg, target_speed, xp, (lane >> 3) & 1);  // valid in lanes 0..6 (6: the cost of x itself)
+            const double cp = analytic_cost_two_lanes(p, eg, target_speed, xp, (lane >> 3) & 1, kPts);  // valid in lanes 0..6 (6: the cost of x itself)
             {
                 const double cx0 = __shfl(cp, 6, kWave);
                 if (!have_coarse) { coarse_cost0 = cx0; have_coarse = true; }
@@ -990,7 +1000,7 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
             x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
         }
         if (!have_coarse || pending >= 0) {  // (x is the coarse winner while no round got as far as its evaluation)
-            const double cl = analytic_cost(p, eg, target_speed, x, L.S);
+            const double cl = analytic_cost(p, eg, target_speed, x, L.S, kPts);
             if (!have_coarse) coarse_cost0 = cl;
             if (lane == pending) my_cost = cl;
         }
@@ -1066,9 +1076,9 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
         if (mine >= 0) {
             const double cx[3] = {__shfl(my_x[0], mine, kWave), __shfl(my_x[1], mine, kWave), __shfl(my_x[2], mine, kWave)};
 #if defined(FP_PHASE_STAMPS)
-            const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane, (wave == 0 && grp == 0 && fa.io.best_traj) ? fa.io.best_traj + ((size_t)b * FP_ARR_COUNT + 15) * fa.io.traj_stride + 112 : nullptr, t_begin);
+            const uint32_t fl = wave_traj_flags<NCH>(ka, b, eg, cx, L, nx, lane, (wave == 0 && grp == 0 && fa.io.best_traj) ? fa.io.best_traj + ((size_t)b * FP_ARR_COUNT + 15) * fa.io.traj_stride + 112 : nullptr, t_begin);
 #else
-            const uint32_t fl = wave_traj_flags(ka, b, eg, cx, L, nx, lane);
+            const uint32_t fl = wave_traj_flags<NCH>(ka, b, eg, cx, L, nx, lane);
 #endif
             if (lane == 0) verdict[(grp & 1) * kRefineWaves + wave] = fl;
         }
@@ -1128,7 +1138,13 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
             kw.r.traj_stride = fa.io.traj_stride;
             kw.r.traj_sparse = fa.io.traj_sparse;
             FP_RSTAMP(10);
-            winner_series_wave(kw, b, b, true, fx[0], fx[1], fx[2], lane, SplineLds{L.knots, L.coef, nx, nx});
+            bool long_series = false;
+            if constexpr (NCH > 2) {  // more points than the one-chunk writer holds: the chunked writer (frenet_winner.h), same arithmetic per element
+                const int n_pts = (fx[2] == fx[2]) ? arange_len(fx[2], p.tick_t) : 0;
+                long_series = n_pts > kSeriesChunk && n_pts <= points_cap(p) && (fx[0] == fx[0]) && (fx[1] == fx[1]);
+                if (long_series) winner_series_wave_long(kw, b, b, fx[0], fx[1], fx[2], lane, SplineLds{L.knots, L.coef, nx, nx});
+            }
+            if (!long_series) winner_series_wave(kw, b, b, true, fx[0], fx[1], fx[2], lane, SplineLds{L.knots, L.coef, nx, nx});
             FP_RSTAMP(11);
             FP_RSTAMP(0);
         }
@@ -1149,20 +1165,30 @@ __global__ __launch_bounds__(kWave * kRefineWaves, FP_REFINE_OCC) void fiss_refi
 
 hipError_t launch_fiss_refine(const FissArgs& fa, hipStream_t stream, int table_kb, const int* perm, int* dur)
 {
+    // trajectories of more than FP_FAST_POINTS points (fp_params.points_max): the four-points-per-lane instance
+    const bool big = fa.ka.p.points_max > FP_FAST_POINTS;
+    const int pts = big ? FP_MAX_POINTS : FP_FAST_POINTS;
     // pair table of the checked obstacle rows when it fits in a modest LDS budget (keeps >= 3 workgroups per CU)
     int pt_rows = 0;
     if (fa.ka.b.n_obs > 0) {
         const int stride = fa.ka.p.check_stride;
-        int rows = (FP_FAST_POINTS + stride - 1) / stride;
+        int rows = (pts + stride - 1) / stride;
         const int rows_tab = (fa.ka.b.T_obs + stride - 1) / stride;
         if (rows_tab < rows) rows = rows_tab;
         if (fa.ka.b.n_obs < (1 << 23) && (long)rows * fa.ka.b.n_obs * 16 <= (long)table_kb * 1024) pt_rows = rows;
     }
-    const int bytes = refine_lds_bytes(fa.ka.b.NX, pt_rows * fa.ka.b.n_obs);
+    const int bytes = refine_lds_bytes(fa.ka.b.NX, pt_rows * fa.ka.b.n_obs, pts);
     FP_LDS_SLOTS(configured);
-    hipError_t e = ensure_dynamic_lds((const void*)fiss_refine_kernel, bytes, configured);
+    FP_LDS_SLOTS(configured_big);
+    if (big) {
+        hipError_t e = ensure_dynamic_lds((const void*)fiss_refine_kernel<4>, bytes, configured_big);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fiss_refine_kernel<4>, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, pt_rows, perm, dur);
+        return hipGetLastError();
+    }
+    hipError_t e = ensure_dynamic_lds((const void*)fiss_refine_kernel<2>, bytes, configured);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fiss_refine_kernel, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, pt_rows, perm, dur);
+    hipLaunchKernelGGL(fiss_refine_kernel<2>, dim3(fa.ka.b.B), dim3(kWave * kRefineWaves), bytes, stream, fa, pt_rows, perm, dur);
     return hipGetLastError();
 }
 

@@ -394,9 +394,7 @@ class FissPlanner(FrenetOptimalPlanner):
         a lattice beyond the device walk's FP_MAX_CAND_SEARCH samples (the dense pass takes up to FP_MAX_CAND; its tables are then
         walked on the host)."""
         st = self.settings
-        refines = self.KIND == "FISS+" and getattr(st, "refine_trajectory", False) and getattr(st, "max_refine_iters", 0) > 0
-        if refines and np.ceil(st.max_t / st.tick_t) > _abi.FP_FAST_POINTS:  # (the device refinement holds 128 points per trajectory)
-            return False
+        # (round 6: the device refinement holds up to FP_MAX_POINTS = 256 points per trajectory - fiss_refine_kernel<4> -, as the dense pass does)
         return self.search_on == "device" and not self.materialize_all and st.num_width * st.num_speed * st.num_t <= _abi.FP_MAX_CAND_SEARCH
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):

@@ -56,8 +56,7 @@ extern "C" {
 #define FP_MAX_POINTS 256   /* N = ceil(T / tick_t) per trajectory (T = 10 s at tick_t = 0.05 s: 200).  Up to FP_FAST_POINTS every
                                kernel runs its two-points-per-lane fast path; beyond it the series come from a chunked writer, the
                                epilogue workgroups and the per-profile materialiser give way to winner_traj_kernel, and the FISS+
-                               refinement (fp_plan_fiss with FP_FISS_PLUS and max_refine_iters > 0) answers FP_ELIMIT - refine on the
-                               host over fp_eval_trajs, as the drop-in FissPlusPlanner then does */
+                               refinement runs its four-points-per-lane instance (two workgroups per CU instead of three) */
 #define FP_FAST_POINTS 128
 #define FP_DEFAULT_STRIDE 128 /* columns of a series row when traj_stride = 0 */
 #define FP_MAX_KNOTS 1024   /* reference-line knots per frame (72 bytes of LDS each in every kernel that walks the line) */

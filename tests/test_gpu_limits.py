@@ -205,8 +205,9 @@ def test_trajectories_of_200_points_dense_and_series(oracle, engine):
 
 
 def test_trajectories_of_200_points_search_and_planners(oracle, engine):
-    """FISS on the device (no refinement: walk over the dense tables + chunked winner series); FISS+ refinement beyond 128 points is
-    FP_ELIMIT from the C ABI and the drop-in FissPlusPlanner refines on the host by itself; FrenetOptimalPlanner with tick_t = 0.05."""
+    """FISS on the device (walk over the dense tables + chunked winner series) and - since round 6 - FISS+ WITH its refinement on the device
+    for trajectories of 160-200 points (fiss_refine_kernel<4>: four points per lane, the chunked series writer): Stats, refined flag, end
+    state, cost and the winner's series against the oracle; the drop-in FissPlusPlanner takes the device walk at tick_t = 0.05."""
     from conftest import assert_series_close
     from fiss_plus_planner_amd import planners as P
     from fiss_plus_planner_amd.vehicle import Vehicle
@@ -221,11 +222,27 @@ def test_trajectories_of_200_points_search_and_planners(oracle, engine):
             assert abs(out.best_cost[e] - r.best_cost) < 1e-6
             t = pr.eval_traj(*out.end_state[e], dump=True, stride=208)
             assert_series_close(out.best_traj[e], t.arrays, fb.tick_t, f"FISS winner ego {e}")
-    with pytest.raises(_abi.FrenetGpuError, match="FP_FAST_POINTS"):
-        engine.plan_fiss(_tick005(2, 5, 5, 5, 8, 86, kind="FISS+"), "FISS+")
+    n_refined = 0
+    for seed, (nd, nv, nt, n_obs) in ((86, (5, 5, 5, 8)), (87, (7, 6, 4, 20)), (88, (9, 9, 7, 30))):
+        pb = _tick005(8, nd, nv, nt, n_obs, seed, kind="FISS+")
+        po = engine.plan_fiss(pb, "FISS+", winner=True, traj_stride=208)
+        for e, pr in enumerate(oracle.problems_from_batch(pb)):
+            r = pr.fissplus_plan()
+            np.testing.assert_array_equal(po.stats[e], r.stats, err_msg=f"seed {seed} ego {e}")
+            np.testing.assert_array_equal(po.best_ijk[e], r.best_ijk, err_msg=f"seed {seed} ego {e}")
+            assert bool(po.refined[e]) == r.refined, (seed, e)
+            assert np.isnan(po.best_cost[e]) == np.isnan(r.best_cost)
+            if not np.isnan(r.best_cost):
+                assert abs(po.best_cost[e] - r.best_cost) < 1e-6
+                np.testing.assert_allclose(po.end_state[e], r.end_state, rtol=0, atol=1e-9)
+                t = pr.eval_traj(*po.end_state[e], dump=True, stride=208)
+                assert t.N > 128   # (the point of the test: more points than the one-chunk paths hold)
+                assert_series_close(po.best_traj[e], t.arrays, pb.tick_t, f"FISS+ winner seed {seed} ego {e}")
+                n_refined += int(r.refined)
+    assert n_refined >= 3
     st = P.FissPlusPlannerSettings(5, 5, 5)
     st.tick_t = 0.05
-    assert not P.FissPlusPlanner(st, Vehicle(), None, engine=engine)._device_walk()
+    assert P.FissPlusPlanner(st, Vehicle(), None, engine=engine)._device_walk()
     st1 = P.FissPlusPlannerSettings(5, 5, 5)
     assert P.FissPlusPlanner(st1, Vehicle(), None, engine=engine)._device_walk()
 
