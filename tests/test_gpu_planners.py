@@ -309,16 +309,17 @@ def test_dense_tables_match_the_reference_at_tick_005(engine, name):
 @pytest.mark.parametrize("kind", ["FOP", "FOP+", "FISS", "FISS+"])
 def test_plan_matches_reference_at_tick_005(engine, name, kind):
     """The drop-in classes with settings.tick_t = 0.05 return the reference's plan: cost, Stats, end state and the winner's series
-    (chunked writer).  FissPlusPlanner refines on the host here (the device refinement holds 128 points), FissPlanner walks on the
-    device."""
+    (chunked writer).  Both FISS planners walk on the device - since round 6 FissPlusPlanner's refinement too (fiss_refine_kernel<4>: up to
+    256 points per trajectory; rounds 4-5 refined on the host here) - and, a second time, on the host: same plan either way."""
     g = load_golden("g13_tick005.npz")
     key = f"{name}_{kind}"
     b = batch_from_golden(g, f"{key}_in_" if kind in ("FISS", "FISS+") else f"{name}_in_")
-    for e in range(b.B):
+    for e, where in [(e, w) for e in range(b.B) for w in (("device", "host") if kind in ("FISS", "FISS+") else ("device",))]:
         pl = _planner(kind, b, engine)
         pl.settings.tick_t = 0.05
-        assert kind != "FISS+" or not pl._device_walk()
-        assert kind != "FISS" or pl._device_walk()
+        if kind in ("FISS", "FISS+"):
+            pl.search_on = where
+            assert pl._device_walk() == (where == "device")
         pts, fs, obs = _inputs(b, e)
         pl.generate_frenet_frame(pts)
         best = pl.plan(fs, float(b.target_speed[e]), obs, int(b.t_now[e]))
