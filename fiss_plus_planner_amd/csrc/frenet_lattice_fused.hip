@@ -1831,7 +1831,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     const int w8 = window_for(kLdsQuarter, 8, 0, true);
     const Layout L8 = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(8), 1, kThreads / kWave, 0, true, w8 > 0 ? w8 : b.NX);
     bool four = three && !pstride && L8.total <= kLdsQuarter && (!epilogue || kEpiLds <= kLdsQuarter) && (!search || search_lds <= kLdsQuarter) && (long)b.B * 2 > (long)ka.resident2 * 3 &&
-                !b.skip;  // (a closed-loop batch: its finished egos leave at once, what runs rarely fills three per CU - measured 68 -> 71-75 us per cycle with four)
+                (!b.skip || ka.occ_cap == 4);  // (a closed-loop batch: its finished egos leave at once, what runs rarely fills three per CU - measured 68 -> 71-75 us per cycle with four; "lattice_occupancy" 4 asks for it anyway)
 #if defined(FP_NO_OCC8)  // (A/B diagnostic)
     four = false;
 #endif
