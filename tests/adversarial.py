@@ -26,8 +26,26 @@ def _copy(batch, **kw):
              frame_of=batch.frame_of, scene_of=batch.scene_of, t_now=batch.t_now, nx=batch.nx, knots=batch.knots, coef=batch.coef,
              obs_pose=batch.obs_pose, obs_dims=batch.obs_dims, final_time_step=batch.final_time_step, veh_l=batch.veh_l, veh_w=batch.veh_w,
              max_speed=batch.max_speed, max_accel=batch.max_accel, tick_t=batch.tick_t, check_stride=batch.check_stride)
+    if getattr(batch, "obs_nvert", None) is not None:
+        f.update(obs_poly=batch.obs_poly, obs_nvert=batch.obs_nvert)
     f.update(kw)
     return ProblemBatch(**f)
+
+
+def _contact_distance_ring(O, ego_box, ring, yaw, theta, reach):
+    """The same for a convex ring (relative to its rotation centre) at orientation yaw: the oracle's own polygon predicate decides."""
+    ux, uy = np.cos(theta), np.sin(theta)
+    lo, hi = 0.0, 0.5 * np.hypot(ego_box[0], ego_box[1]) + reach + 1.0
+    hit = lambda D: O.box_ring_intersect(ego_box, ring, (ego_box[2] + D * ux, ego_box[3] + D * uy, yaw))  # noqa: E731
+    if not hit(lo) or hit(hi):
+        return None  # (the ring does not cover its own rotation centre, or is larger than thought: another draw)
+    for _ in range(80):
+        mid = 0.5 * (lo + hi)
+        if hit(mid):
+            lo = mid
+        else:
+            hi = mid
+    return lo
 
 
 def _contact_distance(O, ego_box, l, w, yaw, theta):
@@ -47,13 +65,20 @@ def _contact_distance(O, ego_box, l, w, yaw, theta):
     return lo
 
 
-def contact_scene(O, batch, seed, active=(1, 1, 2, 3), gaps=(1e-6, 1e-5, 1e-4, 1e-3)):
-    """-> (batch with rebuilt obstacle tables, list of (ego, candidate, pose, obstacle, eps) placements)."""
+def contact_scene(O, batch, seed, active=(1, 1, 2, 3), gaps=(1e-6, 1e-5, 1e-4, 1e-3), polygons=0.0, max_vertices=9):
+    """-> (batch with rebuilt obstacle tables, list of (ego, candidate, pose, obstacle, eps) placements).
+    polygons: share of the ACTIVE obstacles that are random convex rings (fp_batch.obs_poly / obs_nvert; obs_dims = the ring's centred
+    box) - the contact distance then comes from the oracle's polygon predicate, and what is attacked is the ring narrow phase with its
+    inner-disk shortcut and the box test in front of it."""
+    from fiss_plus_planner_amd.synth import random_convex_ring
+
     rng = np.random.default_rng(seed)
     B, nd, nv, nt = batch.B, len(batch.d_samples), batch.v_samples.shape[1], len(batch.t_samples)
     n_obs, T_obs, stride = batch.n_obs, batch.T_obs, batch.check_stride
     pose = np.zeros((B, T_obs, n_obs, 4))
     dims = np.empty((B, n_obs, 2))
+    poly = np.zeros((B, n_obs, max(max_vertices, 3), 2))
+    nvert = np.zeros((B, n_obs), dtype=np.int32)
     placed = []
     free = O.problems_from_batch(_copy(batch, scene_of=np.full(B, -1)))
     for b in range(B):
@@ -85,7 +110,19 @@ def contact_scene(O, batch, seed, active=(1, 1, 2, 3), gaps=(1e-6, 1e-5, 1e-4, 1
                 base = a[YAW, k] + (np.pi / 2 * (1 if rng.random() < 0.5 else -1) if mode < 0.45 else (0.0 if rng.random() < 0.5 else np.pi) if mode < 0.7 else 0.0)
                 theta = base + (rng.uniform(-0.15, 0.15) if mode < 0.7 else rng.uniform(-np.pi, np.pi))
                 oyaw = float(a[YAW, k] + (rng.choice([0.0, np.pi / 2, np.pi]) if rng.random() < 0.3 else rng.uniform(-np.pi, np.pi)))
-                D = _contact_distance(O, ego_box, dims[b, j, 0], dims[b, j, 1], oyaw, theta)
+                if rng.random() < polygons:
+                    nv_ring = int(rng.integers(3, max_vertices + 1))
+                    ring = random_convex_ring(rng, nv_ring, 0.5 * dims[b, j, 0], 0.5 * dims[b, j, 1])
+                    lo_r, hi_r = ring.min(axis=0), ring.max(axis=0)
+                    ring = ring - 0.5 * (lo_r + hi_r)                      # centred on its own bounding box: the pose is the rotation centre
+                    D = _contact_distance_ring(O, ego_box, ring, oyaw, theta, float(np.hypot(*(hi_r - lo_r))))
+                    if D is None:
+                        continue
+                    dims[b, j] = hi_r - lo_r
+                    poly[b, j, :nv_ring] = ring
+                    nvert[b, j] = nv_ring
+                else:
+                    D = _contact_distance(O, ego_box, dims[b, j, 0], dims[b, j, 1], oyaw, theta)
                 eps = float(rng.choice(gaps)) * (1.0 if rng.random() < 0.5 else -1.0)
                 D += eps
                 row = t_now + k
@@ -93,7 +130,8 @@ def contact_scene(O, batch, seed, active=(1, 1, 2, 3), gaps=(1e-6, 1e-5, 1e-4, 1
                 pose[b, row, j] = (ego_box[2] + D * np.cos(theta), ego_box[3] + D * np.sin(theta), oyaw, 1.0)
                 placed.append((b, (i_d * nt + i_t) * nv + i_v, k, int(j), eps))
                 break
-    out = _copy(batch, obs_pose=pose, obs_dims=dims, scene_of=np.arange(B, dtype=np.int32), final_time_step=np.asarray(batch.final_time_step)[np.clip(batch.scene_of, 0, None)])
+    kw = dict(obs_poly=poly, obs_nvert=nvert) if nvert.any() else {}
+    out = _copy(batch, obs_pose=pose, obs_dims=dims, scene_of=np.arange(B, dtype=np.int32), final_time_step=np.asarray(batch.final_time_step)[np.clip(batch.scene_of, 0, None)], **kw)
     return out, placed
 
 

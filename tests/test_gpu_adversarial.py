@@ -19,7 +19,7 @@ import adversarial as A
 from fiss_plus_planner_amd import synth
 
 pytestmark = pytest.mark.gpu
-SEEDS = int(os.environ.get("FP_ADVERSARIAL_SEEDS", "6"))
+SEEDS = int(os.environ.get("FP_ADVERSARIAL_SEEDS", "12"))
 
 # (label, ctx options, which per-CU launch counter must move)
 MODES = [
@@ -74,6 +74,20 @@ def test_obstacles_within_a_millimetre_of_contact(oracle, engine, seed):
     run_modes(engine, batch, ref, f"contact scene seed {seed}")
     if seed % 2 == 0:  # BASELINE's dense shape on 81-knot lines: the slim four-per-CU instance itself (fp16 fan bounds) was attacked
         assert engine.get_option("lattice_launches_4") > before4
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_polygon_obstacles_within_a_millimetre_of_contact(oracle, engine, seed):
+    """The same attack with convex-polygon columns (the POLY instances: ring narrow phase behind the box test, inner-disk shortcut): the
+    contact distance is the oracle's polygon predicate's own edge.  The four-per-CU instances have no polygon variant: three per CU."""
+    base = shapes(seed)
+    batch, placed = A.contact_scene(oracle, base, 1100 + seed, polygons=0.7, gaps=(1e-6, 1e-5, 1e-4, 1e-3) if seed % 2 else (1e-6, 2e-6))
+    assert batch.obs_nvert is not None and (batch.obs_nvert > 0).sum() >= batch.B // 2
+    ref = [p.fop_plan() for p in oracle.problems_from_batch(batch)]
+    decisive = sum(bool(ref[e].flags[c] & 4) == (eps < 0) for e, c, _k, _j, eps in placed)
+    assert decisive >= 0.5 * len(placed), (len(placed), decisive)
+    poly_modes = [m for m in MODES if "four per CU" not in m[0]] + [("three per CU (no cap)", {"lattice_kernel": 2, "resident_groups": 2}, "lattice_launches_3")]
+    run_modes(engine, batch, ref, f"polygon contact scene seed {seed}", modes=poly_modes)
 
 
 @pytest.mark.parametrize("seed", range(max(2, SEEDS // 2)))
