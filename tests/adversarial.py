@@ -118,7 +118,7 @@ def contact_scene(O, batch, seed, active=(1, 1, 2, 3), gaps=(1e-6, 1e-5, 1e-4, 1
                     D = _contact_distance_ring(O, ego_box, ring, oyaw, theta, float(np.hypot(*(hi_r - lo_r))))
                     if D is None:
                         continue
-                    dims[b, j] = hi_r - lo_r
+                    dims[b, j] = 2.0 * np.abs(ring).max(axis=0)   # (the centred box that contains the centred ring, to the last bit: the library checks it)
                     poly[b, j, :nv_ring] = ring
                     nvert[b, j] = nv_ring
                 else:
