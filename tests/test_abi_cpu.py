@@ -136,9 +136,11 @@ def test_no_kernel_spills_a_vgpr():
         cols = l.split()
         spill_v, scratch = int(cols[-5]), int(cols[-3])   # ... VGPRs Spill, SGPRs Spill, ScratchSize, Occupancy, LDS Size
         assert spill_v == 0, l
-        # (scratch WITHOUT a spill is a stack object the optimiser emptied but did not delete - fiss_refine_kernel reserves 68 bytes and
-        # audit_kernel 20 that no instruction addresses; it only switches the wave's scratch set-up on)
-        assert scratch <= 68, l
+        # (scratch WITHOUT a spill is a stack object: fiss_refine_kernel<2> reserves 68 bytes and audit_kernel 20 that no instruction
+        # addresses - the optimiser emptied them but did not delete them.  fiss_refine_kernel<4>, the four-points-per-lane instance for
+        # trajectories beyond 128 points, keeps its per-lane difference-chain arrays there: ordinary stack accesses under their own exec
+        # mask, not spill code - the rare-path instance pays for it in speed, its results are pinned by G13 and the oracle.)
+        assert scratch <= 68 or "fiss_refine_kernel<4>" in l, l
 
 
 def test_production_library_reports_no_diagnostic_macro_and_its_compiler(lib):
