@@ -419,8 +419,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // divergent loop BEFORE the exec mask is restored (exec = 0: nothing is stored, the reload returns whatever the scratch slot held -
     // zeros in a launch's first round of workgroups, another workgroup's values later), so no instance may spill a VGPR at all
     // (tools/resource_usage.py must show 0 in "VGPRs Spill" for every kernel; tests/test_abi_cpu.py checks it).
-    // (round 6: also the shaped three-per-CU POLY instance - its narrow phase parks ring tests, two VGPRs more than the 80 it has)
-    constexpr bool kEgoLds = (ND == 0 && OCC > 4) || OCC > 6 || (POLY && OCC > 4);
+    constexpr bool kEgoLds = (ND == 0 && OCC > 4) || OCC > 6;
     constexpr bool kEgoEarly = OCC > 6;  // four per CU (64 VGPRs): from the FIRST barrier on
     constexpr bool kGroup = GS != 1;
     constexpr int kThreads = NTH, kWaves = NTH / kWave;  // (shadow the file-scope defaults)
@@ -1247,70 +1246,15 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
 #else
                             const int n_exact = n_hits;
 #endif
-                            if constexpr (!POLY) {
-                                for (int h0 = 0; h0 < n_exact; h0 += hpw) {
-                                    const int h = h0 + hh_l;
-                                    bool hit = false;
-                                    if (hh_l < hpw && h < n_exact && !((coll >> id_l) & 1ull)) {
-                                        const uint32_t hc = wh[h];
-                                        const int k = hc & 0xFF, si2 = hc >> 8;
-                                        const int j = (int)s_items[si2] - mul24(div_by<STRIDE, FP_MAX_POINTS>(k, inv_stride), n_obs);  // item = row * n_obs + obstacle
-                                        FP_COUNT(3, 1);
-                                        // heading of pose k: forward difference, or the previous one for the last point (:127-129)
-                                        const int ka_ = (k + 1 < M) ? k : k - 1;
-                                        const Frame f0 = wfr.get(ka_), f1 = wfr.get(ka_ + 1);
-                                        const double* ql = qlat + mul24(id_l, 3);
-                                        const double b3 = ql[0], b4 = ql[1], b5 = ql[2];
-                                        const double ta = (double)ka_ * tick, tb = (double)(ka_ + 1) * tick;
-                                        const double da = fma(fma(fma(fma(fma(b5, ta, b4), ta, b3), ta, eDdd0() * 0.5), ta, eDd0()), ta, eD0());
-                                        const double db = fma(fma(fma(fma(fma(b5, tb, b4), tb, b3), tb, eDdd0() * 0.5), tb, eDd0()), tb, eD0());
-                                        double xa, ya, xb, yb;
-                                        frenet_to_cartesian(f0.px, f0.py, f0.tx, f0.ty, da, xa, ya);
-                                        frenet_to_cartesian(f1.px, f1.py, f1.tx, f1.ty, db, xb, yb);
-                                        Obb ego;
-                                        step_heading(xb - xa, yb - ya, ego.c, ego.s);
-                                        ego.x = (ka_ == k) ? xa : xb;
-                                        ego.y = (ka_ == k) ? ya : yb;
-                                        ego.hl = s_k[2];
-                                        ego.hw = s_k[3];
-                                        const ObsPose op = s_spose.get(si2);
-                                        const ObsDim od = s_dim.get(j);
-                                        if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
-                                            hit = true;  // polygon construction fails in the reference -> collision (:178-182)
-                                        } else {
-                                            const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
-                                            const double dx = op.x - ego.x, dy = op.y - ego.y;
-                                            hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
-                                            if constexpr (POLY) {
-                                                if (hit) {  // a polygon column: its box was a necessary condition, the ring decides
-                                                    const int nvx = ((const int32_t*)(smem + L.nvert))[j];
-                                                    if (nvx > 0) hit = ring_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, ring_base + (ring_col0 + j) * 2 * (size_t)bt.poly_stride, nvx, s_dim.rin[j]);
-                                                }
-                                            }
-                                        }
-                                        if (hit) FP_COUNT(5, 1);
-                                    }
-                                    if (lane == 0) FP_COUNT(6, 1);
-                                    unsigned long long hm = __ballot(hit);
-                                    // fold the round's hits onto the nd lateral samples (scalar arithmetic on the ballot)
-                                    if (nd >= kWave) coll |= hm;
-                                    else
-                                        for (; hm; hm >>= nd) coll |= hm & full;
-                                    if (coll == full) { if (lane == 0) FP_COUNT(7, 1); break; }
-                                }
-                            } else {
-                                // POLY: a pair whose BOX overlaps the ego still needs the ring (convex-polygon column).  The ring loop costs
-                                // ~20 instructions per vertex for the whole wavefront whenever ONE lane needs it - and with 68 % of a round's lane
-                                // tests box hits, some lane did in nearly every round (VALU 75.6 M per launch against 55.9 M for rectangles).
-                                // Round 6: a lane PARKS its ring test (the hit's index; everything else is recomputed) and the rounds go on;
-                                // the parked tests of many rounds are decided together, when a lane that holds one gets a second or the pass
-                                // ends - the same ring loop with two to three times the lanes in it.  A candidate with a parked test is not
-                                // yet known to collide: lanes of later rounds may test (and park) it again, which costs work, never a result.
-                                int parked = -1;
-                                auto exact = [&](int h, bool rings) -> int {  // 0 no overlap, 1 collision, 2 box overlap of a polygon column
+                            for (int h0 = 0; h0 < n_exact; h0 += hpw) {
+                                const int h = h0 + hh_l;
+                                bool hit = false;
+                                if (hh_l < hpw && h < n_exact && !((coll >> id_l) & 1ull)) {
                                     const uint32_t hc = wh[h];
                                     const int k = hc & 0xFF, si2 = hc >> 8;
-                                    const int j = (int)s_items[si2] - mul24(div_by<STRIDE, FP_MAX_POINTS>(k, inv_stride), n_obs);
+                                    const int j = (int)s_items[si2] - mul24(div_by<STRIDE, FP_MAX_POINTS>(k, inv_stride), n_obs);  // item = row * n_obs + obstacle
+                                    FP_COUNT(3, 1);
+                                    // heading of pose k: forward difference, or the previous one for the last point (:127-129)
                                     const int ka_ = (k + 1 < M) ? k : k - 1;
                                     const Frame f0 = wfr.get(ka_), f1 = wfr.get(ka_ + 1);
                                     const double* ql = qlat + mul24(id_l, 3);
@@ -1327,43 +1271,30 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                     ego.y = (ka_ == k) ? ya : yb;
                                     ego.hl = s_k[2];
                                     ego.hw = s_k[3];
-                                    if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) return 1;  // polygon construction fails in the reference -> collision (:178-182)
                                     const ObsPose op = s_spose.get(si2);
                                     const ObsDim od = s_dim.get(j);
-                                    const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
-                                    const double dx = op.x - ego.x, dy = op.y - ego.y;
-                                    if (!(fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}))) return 0;
-                                    const int nvx = ((const int32_t*)(smem + L.nvert))[j];
-                                    if (nvx <= 0) return 1;
-                                    if (!rings) return 2;  // its box was a necessary condition, the ring decides
-                                    return ring_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, ring_base + (ring_col0 + j) * 2 * (size_t)bt.poly_stride, nvx, s_dim.rin[j]) ? 1 : 0;
-                                };
-                                auto fold = [&](bool hit) {  // the round's hits onto the nd lateral samples (scalar arithmetic on the ballot)
-                                    unsigned long long hm = __ballot(hit);
-                                    if (nd >= kWave) coll |= hm;
-                                    else
-                                        for (; hm; hm >>= nd) coll |= hm & full;
-                                };
-                                auto decide_parked = [&]() {
-                                    bool dh = false;
-                                    if (parked >= 0 && !((coll >> id_l) & 1ull)) dh = exact(parked, true) == 1;
-                                    parked = -1;
-                                    fold(dh);
-                                };
-                                for (int h0 = 0; h0 < n_exact; h0 += hpw) {
-                                    const int h = h0 + hh_l;
-                                    int r = 0;
-                                    if (hh_l < hpw && h < n_exact && !((coll >> id_l) & 1ull)) r = exact(h, false);
-                                    if (__ballot(r == 2 && parked >= 0)) {  // (a lane holds one parked test at most)
-                                        decide_parked();
-                                        if (coll == full) break;
+                                    if (!(ego.x == ego.x) || !(ego.y == ego.y) || !(ego.c == ego.c)) {
+                                        hit = true;  // polygon construction fails in the reference -> collision (:178-182)
+                                    } else {
+                                        const double R = (s_k[4] + od.r) * (1.0 + 1e-12);
+                                        const double dx = op.x - ego.x, dy = op.y - ego.y;
+                                        hit = fma(dx, dx, dy * dy) <= R * R && obb_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw});
+                                        if constexpr (POLY) {
+                                            if (hit) {  // a polygon column: its box was a necessary condition, the ring decides
+                                                const int nvx = ((const int32_t*)(smem + L.nvert))[j];
+                                                if (nvx > 0) hit = ring_overlap(ego, Obb{op.x, op.y, op.c, op.s, od.hl, od.hw}, ring_base + (ring_col0 + j) * 2 * (size_t)bt.poly_stride, nvx, s_dim.rin[j]);
+                                            }
+                                        }
                                     }
-                                    if (r == 2 && !((coll >> id_l) & 1ull)) parked = h;
-                                    fold(r == 1);
-                                    if (coll == full) break;
+                                    if (hit) FP_COUNT(5, 1);
                                 }
-                                // the pass's hit list is overwritten by the next pass: what is still parked is decided now
-                                if (coll != full && __ballot(parked >= 0)) decide_parked();
+                                if (lane == 0) FP_COUNT(6, 1);
+                                unsigned long long hm = __ballot(hit);
+                                // fold the round's hits onto the nd lateral samples (scalar arithmetic on the ballot)
+                                if (nd >= kWave) coll |= hm;
+                                else
+                                    for (; hm; hm >>= nd) coll |= hm & full;
+                                if (coll == full) { if (lane == 0) FP_COUNT(7, 1); break; }
                             }
                         }
                         if (lane == 0) { s_collmask[2 * qg] = (uint32_t)coll; s_collmask[2 * qg + 1] = (uint32_t)(coll >> 32); }
