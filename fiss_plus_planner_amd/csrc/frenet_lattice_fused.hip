@@ -1294,7 +1294,17 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                                 if (nd >= kWave) coll |= hm;
                                 else
                                     for (; hm; hm >>= nd) coll |= hm & full;
-                                if (coll == full) { if (lane == 0) FP_COUNT(7, 1); break; }
+                                if (coll == full) {
+#if defined(FP_COUNTERS)  // when a blocked profile dies: the pose index of the last hit of the deciding round, in bins of 8 steps (slots 10..15)
+                                    if (lane == 0) {
+                                        FP_COUNT(7, 1);
+                                        const int hl = (h0 + hpw < n_exact ? h0 + hpw : n_exact) - 1;
+                                        const int kd = (int)(wh[hl] & 0xFF) >> 3;
+                                        FP_COUNT(10 + (kd > 5 ? 5 : kd), 1);
+                                    }
+#endif
+                                    break;
+                                }
                             }
                         }
                         if (lane == 0) { s_collmask[2 * qg] = (uint32_t)coll; s_collmask[2 * qg + 1] = (uint32_t)(coll >> 32); }

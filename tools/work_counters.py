@@ -44,4 +44,6 @@ if os.environ.get("FP_SLICE_LOOP"):  # the counters of the older slice-loop buil
 print(f"config {config}, layout {layout}: per ego, {B} egos")
 for k, n in enumerate(names):
     print(f"  {n:40s} mean {c[:, k].mean():9.1f}  median {np.median(c[:, k]):9.1f}  p90 {np.percentile(c[:, k], 90):9.1f}  max {c[:, k].max():9.0f}")
+print("  blocked profiles by the pose index at which the last lateral sample collided (bins of 8 steps = 0.8 s): " +
+      "  ".join(f"k<{8 * (i + 1)}: {c[:, 10 + i].mean():.1f}" if i < 5 else f"k>=40: {c[:, 15].mean():.1f}" for i in range(6)) + "   (mean per ego)")
 print("  slices whose lon profiles needed the point-by-point mask scan: mean", round(float(c[:, 9].mean()), 2), "of", batch.nt)
