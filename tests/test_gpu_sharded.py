@@ -209,6 +209,10 @@ def test_group_reports_the_failing_shard():
         p.nd = 0
         bad[1].params = C.pointer(p)
         eng.group().submit(bad)
+        # a shard that holds an unreported error takes no new work - and the NEXT round is refused as a whole, before any of it is posted
+        # (round 5 skipped that one shard's call silently and let the others run ahead)
+        with pytest.raises(_abi.FrenetGpuError, match="shard 1 still holds the error"):
+            eng.group().submit(calls)
         with pytest.raises(_abi.FrenetGpuError, match="shard 1: lattice sizes"):
             eng.group().wait()
         np.testing.assert_array_equal(eng.plan_dense(sdb).best_idx, good)
