@@ -201,6 +201,7 @@ struct fp_ctx {
     // (KernelArgs::err_word), and the next call on the ctx reports it, resets the flags and stops offering appended workgroups.
     bool appended_ok = false;
     int32_t* hand_err = nullptr;
+    int handover_timeout_us = 0;   // fp_ctx_set_option("handover_timeout_us") (FP_TEST_HOOKS): KernelArgs::handover_timeout_us
     // fp_ctx_set_option("overlap"): consecutive INDEPENDENT FP_MEM_DEVICE dense calls alternate between two internal streams (this ctx's
     // and a twin ctx's, each with its own scratch: tickets, hand-over flags, launch order), so the draining tail of one launch runs beside
     // the ramp of the next.  See fp_plan_dense / fp_ctx_join in include/frenet_gpu.h for what the caller's stream is ordered after.
@@ -1336,6 +1337,12 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->appended_ok = value != 0;
         return FP_OK;
     }
+    if (strcmp(name, "handover_timeout_us") == 0) {  // test hook: appended workgroups give up after this many microseconds (0 = 2 s)
+        if (!getenv("FP_TEST_HOOKS")) return fail(FP_EINVAL, "handover_timeout_us is a test hook: set FP_TEST_HOOKS=1 in the environment to use it");
+        if (value < 0 || value > 10000000) return fail(FP_EINVAL, "handover_timeout_us must be in 0..10^7");
+        ctx->handover_timeout_us = value;
+        return FP_OK;
+    }
     if (strcmp(name, "handover_inject") == 0) {  // test hook: what a timed-out hand-over leaves in the ctx's error word (1 series, 2 search)
         if (!getenv("FP_TEST_HOOKS")) return fail(FP_EINVAL, "handover_inject is a test hook: set FP_TEST_HOOKS=1 in the environment to use it");
         if (value < 1 || value > 2 || !ctx->hand_err) return fail(FP_EINVAL, "handover_inject must be 1 or 2");
@@ -1459,7 +1466,7 @@ static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch*
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
-    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb;
+    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb; ka.handover_timeout_us = ctx->handover_timeout_us;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
@@ -1667,7 +1674,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     fp::FissArgs fa;
     fa.ka.p = *params;
     fa.ka.err_word = ctx->hand_err;
-    fa.ka.occ_cap = ctx->lattice_occupancy; fa.ka.resident2 = ctx->resident_groups; fa.ka.lds_cu_kb = ctx->lds_cu_kb;
+    fa.ka.occ_cap = ctx->lattice_occupancy; fa.ka.resident2 = ctx->resident_groups; fa.ka.lds_cu_kb = ctx->lds_cu_kb; fa.ka.handover_timeout_us = ctx->handover_timeout_us;
     fa.opts = *opts;
     fa.opts.max_refine_iters = R;
     fa.ka.r = no_result();
@@ -1891,7 +1898,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
-    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb;
+    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb; ka.handover_timeout_us = ctx->handover_timeout_us;
     ka.b = *batch;
     ka.b.skip = io->done;
     if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;

@@ -67,6 +67,10 @@ struct KernelArgs {
     // the CU's LDS holds three / four of their layouts.
     int resident2 = 512;
     int lds_cu_kb = 160;
+    // test hook (fp_ctx_set_option("handover_timeout_us"), FP_TEST_HOOKS only): how long an appended workgroup waits for its ego's flag
+    // before it gives up; 0 = the production value (2 s).  A microsecond makes REAL waits run out, which is how the tests drive the
+    // device side of the time-out path (error word, workgroup leaves without output, the launch completes) instead of injecting its result.
+    int handover_timeout_us = 0;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

@@ -98,12 +98,13 @@ __device__ __forceinline__ void wave_lds_sync()
 // system scope: the host sees it without a synchronisation) and the workgroup returns without output; the slot falls free, the
 // launch completes, and the next call on the ctx reports the failure, resets the flags and stops using appended workgroups.
 constexpr long long kHandoverTimeout = 200000000ll;  // 2 s
-__device__ __forceinline__ bool handover_wait(const int32_t* flag, int32_t* err_word, int code)
+__device__ __forceinline__ bool handover_wait(const int32_t* flag, int32_t* err_word, int code, int timeout_us = 0)
 {
     const long long t0 = wall_clock64();
+    const long long limit = timeout_us > 0 ? (long long)timeout_us * 100ll : kHandoverTimeout;  // (100 MHz wall clock; timeout_us: KernelArgs::handover_timeout_us, tests only)
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > kHandoverTimeout) {
+        if (wall_clock64() - t0 > limit) {
             if (err_word) __hip_atomic_store(err_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
 #endif
             int timed_out = 0;
             if (threadIdx.x == 0) {
-                timed_out = !handover_wait(&ft.flag[eb], ka.err_word, 2);
+                timed_out = !handover_wait(&ft.flag[eb], ka.err_word, 2, ka.handover_timeout_us);
                 if (!timed_out) __hip_atomic_store(&ft.flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
 #if defined(FP_TL)
                 tl1 = wall_clock64();
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             if (in_lds)
                 for (int k = i; k < 9 * bb.NX; k += 2 * kWave) s_spl[k] = k < bb.NX ? gk[k] : gc[k - bb.NX];
             if (have && i == 0) {
-                if (handover_wait(&ka.epi_flag[eb], ka.err_word, 1)) {
+                if (handover_wait(&ka.epi_flag[eb], ka.err_word, 1, ka.handover_timeout_us)) {
                     __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the index is read after the flag
                     s_idx[pair] = __hip_atomic_load(&ka.idx_shadow[eb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&ka.epi_flag[eb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
