@@ -58,7 +58,7 @@ EXTRAS_FILE = "bench_extras.json"
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                  "config", "roofline", "cpu_baseline", "parity", "value_cold", "ms_per_step_cold", "plan_cycle_p50_ms", "legs", "extras_file")
 LEG_KEYS = ("config2", "config4", "config5_single_gpu", "launch_order_hint_off", "launch_order_hint_only", "lattice_order_off", "single_batch_replayed", "tables_written",
-            "lanes_layout", "survey8d_layout", "polygon_scenes", "two_streams", "overlap", "overlap_config4", "sharded_resident", "long_reference_lines", "rectangles_as_rings")
+            "lanes_layout", "survey8d_layout", "polygon_scenes", "two_streams", "overlap", "overlap_config4", "overlap_config2", "sharded_resident", "long_reference_lines", "rectangles_as_rings")
 
 
 def _sig(x, digits=6):
@@ -1189,6 +1189,14 @@ def main():
                 oo4["parity"] = fiss_parity("overlap config4", w4c, np.arange(0, B, max(1, B // 64)))
             extras["overlap"], extras["overlap_config4"] = oo, oo4
             del w4c
+            # config 2 (256 egos: one workgroup per CU, latency bound): two such launches share the chip
+            w2c, w2d = Workload(torch, eng, b2, dev, stream), Workload(torch, eng, b2, dev, stream)
+            torch.cuda.synchronize(dev)
+            oo2 = measure_ov([w2c, w2d])
+            eng.join(stream.cuda_stream); torch.cuda.synchronize(dev)
+            oo2["parity"] = gate("overlap config2", w2d, b2.B)
+            extras["overlap_config2"] = oo2
+            del w2c, w2d
         finally:
             eng.set_option("overlap", 0)
         del ws2, w4a, w4b
