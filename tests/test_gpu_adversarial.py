@@ -53,7 +53,10 @@ def run_modes(engine, batch, ref, what, modes=MODES, winner=True):
 
 
 def shapes(seed):
-    """BASELINE's dense shape (the shaped instances) and an odd one (the run-time-shape instances)."""
+    """BASELINE's dense shape (the shaped instances), an odd one (the run-time-shape instances) and, every sixth seed, BASELINE's shape on
+    220-knot reference lines (the WIN instances: a window of the spline's coefficient columns in LDS, the rest read from global memory)."""
+    if seed % 6 == 4:
+        return synth.make_batch(12, 9, 9, 7, 50, 50, True, 7000 + seed, layout="survey8d", n_knots=220)
     if seed % 2 == 0:
         return synth.make_batch(12, 9, 9, 7, 50, 50, True, 7000 + seed, layout="survey8d")
     return synth.make_batch(10, 7, 5, 4, 23, 64, True, 7000 + seed, layout="lanes")
@@ -72,7 +75,7 @@ def test_obstacles_within_a_millimetre_of_contact(oracle, engine, seed):
     assert 0 < n_coll < batch.B * batch.C
     before4 = engine.get_option("lattice_launches_4")
     run_modes(engine, batch, ref, f"contact scene seed {seed}")
-    if seed % 2 == 0:  # BASELINE's dense shape on 81-knot lines: the slim four-per-CU instance itself (fp16 fan bounds) was attacked
+    if seed % 2 == 0:  # BASELINE's dense shape (81-knot lines, or 220 knots through the WIN instance): the slim four-per-CU layout (fp16 fan bounds) was attacked
         assert engine.get_option("lattice_launches_4") > before4
 
 
