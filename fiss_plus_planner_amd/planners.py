@@ -13,6 +13,7 @@ planner without a GPU / built library raises.
 from __future__ import annotations
 
 import itertools
+import time
 
 import numpy as np
 
@@ -84,8 +85,12 @@ class FissPlannerSettings(FrenetOptimalPlannerSettings):
 
 
 class FissPlusPlannerSettings(FissPlannerSettings):
-    """reference fiss_plus_planner.py:15-22.  The reference enforces `time_limit` inside refine_solution even with
-    has_time_limit=False (wall-clock dependent); here refinement always runs its max_refine_iters rounds."""
+    """reference fiss_plus_planner.py:15-22.  `time_limit` is a WALL-CLOCK budget (:152-158, :293-299): refinement is entered when
+    `not has_time_limit or time_left > 0` and its loop breaks after the first gradient step that ends past `time_left` - even with
+    has_time_limit False.  The drop-in applies it with its own clock (FissPlusPlanner._refine_rounds): a budget that is already spent
+    when the coarse search returns gives no refinement (has_time_limit) or exactly one round (fixture G14: the two cases the clock
+    cannot change); otherwise all rounds run - on the device they take tens of microseconds, far inside any budget the reference's
+    own coarse search (tens of milliseconds on a CPU) would leave."""
 
     def __init__(self, num_width: int = 5, num_speed: int = 5, num_t: int = 5, refine_iters: int = 3):
         super().__init__(num_width, num_speed, num_t)
@@ -363,7 +368,7 @@ class FissPlanner(FrenetOptimalPlanner):
         self.sizes = np.array([batch.nd, batch.nv, batch.nt])
         st = self.settings
         plus = self.KIND == "FISS+"
-        R = st.max_refine_iters if (plus and st.refine_trajectory) else 0
+        R = self._refine_rounds() if plus else 0
         prev = None if self.prev_best_idx is None else np.asarray(self.prev_best_idx, dtype=np.int32)[None]
         outs = self.__dict__.setdefault("_fiss_outs", {})  # output arrays (+ the fp_fiss_io over them) reused every cycle
         stride = self._stride()
@@ -388,6 +393,21 @@ class FissPlanner(FrenetOptimalPlanner):
         idx = [-1, -1, -1] if out.refined[0] else out.best_ijk[0].tolist()
         self.best_traj = FrenetTrajectory.from_dump(out.best_traj[0], (fl >> 8) & 0xFFF, fl >> 20, best_cost, end, idx)
         return self.best_traj
+
+    def _refine_rounds(self) -> int:
+        """FissPlusPlanner's refinement rounds for this plan() call under the reference's wall-clock budget (fiss_plus_planner.py:152-158,
+        :293-299): time_left = time_limit - (time since plan() started).  Spent already: none with has_time_limit, else ONE (the loop
+        checks the clock after its first gradient step).  Otherwise max_refine_iters."""
+        st = self.settings
+        if not getattr(st, "refine_trajectory", False):
+            return 0
+        R = int(getattr(st, "max_refine_iters", 0))
+        if R <= 0:
+            return 0
+        time_left = float(getattr(st, "time_limit", float("inf"))) - (time.perf_counter() - getattr(self, "_t_plan", time.perf_counter()))
+        if time_left <= 0.0:
+            return 0 if getattr(st, "has_time_limit", False) else 1
+        return R
 
     def _device_walk(self) -> bool:
         """One fp_plan_fiss call, unless the caller wants the host walk, the generated set (`all_trajs`: only the host walk knows it) or
@@ -417,6 +437,7 @@ class FissPlusPlanner(FissPlanner):
     _search = staticmethod(search.fissplus_search)
 
     def plan(self, frenet_state: FrenetState, max_target_speed: float, obstacles, time_step_now: int = 0):
+        self._t_plan = time.perf_counter()  # (the reference's start_time: `time_limit` is measured from here, :152-154)
         if self._device_walk():
             return self._plan_on_device(frenet_state, max_target_speed, obstacles, time_step_now)
         batch, idx = self._coarse(frenet_state, max_target_speed, obstacles, time_step_now)
@@ -427,15 +448,17 @@ class FissPlusPlanner(FissPlanner):
         self.prev_best_idx = np.array(idx)  # stays the coarse index even if a refined trajectory wins (:140)
         winner = (x, np.array(idx))
         st = self.settings
-        if st.refine_trajectory and st.max_refine_iters > 0:
-            refined = self._refine(batch, x, coarse_cost)
+        # refinement is entered when `not has_time_limit or time_left > 0` (:156); inside, the clock is checked after every gradient step
+        time_left = float(getattr(st, "time_limit", float("inf"))) - (time.perf_counter() - self._t_plan)
+        if st.refine_trajectory and st.max_refine_iters > 0 and (not getattr(st, "has_time_limit", False) or time_left > 0.0):
+            refined = self._refine(batch, x, coarse_cost, time_left)
             if refined is not None:
                 winner = (refined, np.array([-1, -1, -1]))
         trajs, _ = self._materialize(batch, winner[0][None], [winner[1]])
         self.best_traj = trajs[0]
         return self.best_traj
 
-    def _refine(self, batch: ProblemBatch, x: np.ndarray, coarse_cost: float):
+    def _refine(self, batch: ProblemBatch, x: np.ndarray, coarse_cost: float, time_limit: float = float("inf")):
         """refine_solution + gradient_decent (reference :207-326): per round six probe trajectories at
         clip(x -/+ res_dim e_dim), finite-difference gradient, resolution decay, one trajectory at the new x.
         All 7 trajectories of a round are evaluated on the GPU (two launches: 6 probes, then the step)."""
@@ -446,6 +469,7 @@ class FissPlusPlanner(FissPlanner):
         # The coarse cost is re-evaluated by the same kernel as the refined trajectories: a probe clipped back onto x is
         # the same trajectory and must tie with it exactly (`cost > coarse cost` ends the validation loop, :303-304).
         coarse_cost = float(self._engine.eval_trajs(batch, x[None, None]).cost[0, 0])
+        t_start = time.perf_counter()
         for _ in range(st.max_refine_iters):
             probes = np.empty((6, 3)); x_l = []; x_r = []
             for dim in range(3):
@@ -467,6 +491,8 @@ class FissPlusPlanner(FissPlanner):
             self.stats.num_trajs_generated += 1
             cand.append((float(out1.cost[0, 0]), len(cand), x_new.copy(), int(out1.flags[0, 0])))
             x = x_new
+            if time.perf_counter() - t_start >= time_limit:  # "Refinement time is up" (:296-299): checked AFTER a gradient step
+                break
         # refined_trajs PriorityQueue: pop in cost order while cost <= coarse cost (:301-323)
         for cost, _, es, fl in sorted(cand, key=lambda c: (c[0], c[1])):
             if cost > coarse_cost:

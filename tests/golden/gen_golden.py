@@ -970,8 +970,57 @@ def g13():
     save("g13_tick005.npz", **out)
 
 
+def g14():
+    """FissPlusPlanner's wall-clock `time_limit` (fiss_plus_planner.py:152-158, :293-299), in the two cases the clock cannot change:
+    a limit that is already over when the coarse search returns (time_limit = -1).  has_time_limit = False: refine_solution is entered
+    with a negative time_left and its loop breaks after the FIRST gradient step (7 refinement trajectories instead of 21);
+    has_time_limit = True: no refinement at all, plan() returns the coarse winner."""
+    out, names = {}, []
+    for name, b in fop_cases():
+        if name not in ("c2_static10", "c3_moving50", "tnow"):
+            continue
+        sw = 3.5 - b.veh_w + 0.3
+        d, rd = np.linspace(-sw / 2, sw / 2, b.nd, retstep=True)
+        smin = b.samp_min.copy(); smax = b.samp_max.copy(); sres = b.samp_res.copy()
+        smin[:, 0] = -sw / 2; smax[:, 0] = sw / 2; sres[:, 0] = rd
+        bb = with_overrides(b, d_samples=d, samp_min=smin, samp_max=smax, samp_res=sres)
+        for mode, has_limit in (("over_unlimited", False), ("over_limited", True)):
+            key = f"{name}_{mode}"
+            names.append(key)
+            B = bb.B
+            idx = np.full((B, 3), -1, dtype=np.int32); cost = np.full(B, np.nan); stats = np.zeros((B, 4), dtype=np.int32)
+            end = np.full((B, 3), np.nan); found = np.zeros(B, dtype=bool); n_refined = np.zeros(B, dtype=np.int32)
+            for e in range(B):
+                pl = make_planner("FISS+", bb, e)
+                pl.settings.time_limit = -1.0
+                pl.settings.has_time_limit = has_limit
+                tr = []
+                orig = pl.generate_trajectory_by_end_state
+
+                def hooked(end_state, orig=orig, tr=tr):
+                    J = orig(end_state)
+                    tr.append(J)
+                    return J
+
+                pl.generate_trajectory_by_end_state = hooked
+                best = pl.plan(ego_state(bb, e), float(bb.target_speed[e]), obstacles_for(bb, e), int(bb.t_now[e]))
+                stats[e] = [pl.stats.num_iter, pl.stats.num_trajs_generated, pl.stats.num_trajs_validated, pl.stats.num_collison_checks]
+                n_refined[e] = len(tr)
+                if best is None:
+                    continue
+                found[e] = True
+                cost[e] = best.cost_final
+                idx[e] = best.idx
+                end[e] = [best.end_state.d, best.end_state.s_d, best.end_state.t]
+            out.update(batch_to_dict(bb, f"{key}_in_"))
+            out.update({f"{key}_idx": idx, f"{key}_cost": cost, f"{key}_stats": stats, f"{key}_end": end, f"{key}_found": found, f"{key}_n_refined": n_refined})
+            print(f"  g14 {key}: found={found.tolist()} refinement trajectories={n_refined.tolist()} stats={stats.tolist()}")
+    out["names"] = np.array(names)
+    save("g14_time_limit.npz", **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10", "g11", "g12", "g13"]
+    todo = sys.argv[1:] or ["g1", "g2", "g7", "g8", "g3", "g4", "g6", "g5", "g9", "g10", "g11", "g12", "g13", "g14"]
     for g in todo:
         t0 = time.time()
         print(f"== {g}")

@@ -333,3 +333,35 @@ def test_plan_matches_reference_at_tick_005(engine, name, kind):
             np.testing.assert_array_equal(best.idx, g[f"{key}_idx"][e])
             np.testing.assert_allclose([best.end_state.d, best.end_state.s_d, best.end_state.t], g[f"{key}_end"][e], atol=1e-9)
         _check_winner(best, g[f"{key}_win"][e], g[f"{key}_NM"][e])
+
+
+def _g14_names():
+    return [str(n) for n in load_golden("g14_time_limit.npz")["names"]]
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+@pytest.mark.parametrize("key", _g14_names())
+def test_fissplus_time_limit_already_spent(engine, key, where):
+    """FissPlusPlannerSettings.time_limit is a wall-clock budget in the reference (fiss_plus_planner.py:152-158, :293-299).  Fixture G14
+    holds the reference's plans for the two cases the clock cannot change - the budget is spent when the coarse search returns
+    (time_limit = -1): has_time_limit False -> ONE refinement round, True -> none - and the drop-in class returns them, whichever side
+    walks (device: one fp_plan_fiss call with 1 / 0 rounds; host: the loop's own clock check)."""
+    g = load_golden("g14_time_limit.npz")
+    b = batch_from_golden(g, f"{key}_in_")
+    for e in range(b.B):
+        pl = _planner("FISS+", b, engine, search_on=where)
+        pl.settings.time_limit = -1.0
+        pl.settings.has_time_limit = key.endswith("_over_limited")
+        pts, fs, obs = _inputs(b, e)
+        pl.generate_frenet_frame(pts)
+        best = pl.plan(fs, float(b.target_speed[e]), obs, int(b.t_now[e]))
+        found = bool(g[f"{key}_found"][e])
+        assert (best is not None) == found, (key, e)
+        assert pl.stats.as_tuple() == tuple(g[f"{key}_stats"][e]), (key, e, where)
+        if found:
+            assert abs(best.cost_final - g[f"{key}_cost"][e]) < TOL
+            np.testing.assert_array_equal(best.idx, g[f"{key}_idx"][e])
+            np.testing.assert_allclose([best.end_state.d, best.end_state.s_d, best.end_state.t], g[f"{key}_end"][e], atol=1e-9)
+    # and a budget that is NOT spent changes nothing: the default 0.5 s gives the same plan as no limit at all
+    pl = _planner("FISS+", b, engine, search_on=where)
+    assert pl._refine_rounds() == pl.settings.max_refine_iters

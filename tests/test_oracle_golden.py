@@ -297,3 +297,30 @@ def test_g13_plans_at_tick_005(oracle, name, kind):
             if kind in ("FISS", "FISS+"):
                 end = r.end_state if kind == "FISS+" else np.array([b.d_samples[r.best_ijk[0]], b.v_samples[e, r.best_ijk[1]], b.t_samples[r.best_ijk[2]]])
                 np.testing.assert_allclose(end, g[f"{key}_end"][e], rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------ G14 FissPlusPlanner's wall-clock budget, where the clock cannot matter
+def _g14_names():
+    return [str(n) for n in load_golden("g14_time_limit.npz")["names"]]
+
+
+@pytest.mark.parametrize("key", _g14_names())
+def test_g14_spent_time_budget(oracle, key):
+    """fiss_plus_planner.py:152-158, :293-299 with time_limit = -1 (generated by running the reference): has_time_limit False -> the
+    refinement loop breaks after its first gradient step = the oracle with max_refine_iters = 1; True -> no refinement = 0 rounds."""
+    g = load_golden("g14_time_limit.npz")
+    b = batch_from_golden(g, f"{key}_in_")
+    rounds = 0 if key.endswith("_over_limited") else 1
+    for e, p in enumerate(oracle.problems_from_batch(b)):
+        r = p.fissplus_plan(max_refine_iters=rounds)
+        found = bool(g[f"{key}_found"][e])
+        assert (not np.isnan(r.best_cost)) == found
+        np.testing.assert_array_equal(r.stats, g[f"{key}_stats"][e])
+        assert g[f"{key}_n_refined"][e] in (0, 7 * rounds)
+        if found:
+            assert abs(r.best_cost - g[f"{key}_cost"][e]) < 1e-9
+            np.testing.assert_allclose(r.end_state, g[f"{key}_end"][e], rtol=0, atol=1e-9)
+            want_idx = g[f"{key}_idx"][e]
+            assert r.refined == bool(want_idx[0] < 0)
+            if not r.refined:
+                np.testing.assert_array_equal(r.best_ijk, want_idx)
