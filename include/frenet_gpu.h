@@ -342,7 +342,8 @@ int fp_eval_trajs(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
  * fiss_plus_planner.py:30-59,106-116, cost-ordered validation :229-258) -> FISS+ only: refinement
  * (gradient_decent :207-277, refine_solution :279-326; 6 probes + 1 step per round, all rounds in one launch).
  * Tie rule: exact cost ties resolve to the lower (i_d, i_v, i_t) raster index (the reference raises ValueError).
- * The wall-clock `time_limit` of refine_solution is never applied. */
+ * The wall-clock `time_limit` of refine_solution (:152-158, :293-299) is the CALLER's business: this entry point runs max_refine_iters
+ * rounds; the drop-in FissPlusPlanner turns a budget that is already spent into 0 rounds (has_time_limit) or 1 (fixture G14). */
 #define FP_FISS 0
 #define FP_FISS_PLUS 1
 
