@@ -1001,6 +1001,8 @@ void overlap_sync_options(fp_ctx* twin, const fp_ctx* ctx)
     twin->lattice_tail = ctx->lattice_tail; twin->lattice_group = ctx->lattice_group; twin->lattice_winner = ctx->lattice_winner;
     twin->lattice_order = ctx->lattice_order; twin->resident_groups = ctx->resident_groups; twin->lds_cu_kb = ctx->lds_cu_kb;
     twin->validate = ctx->validate;
+    twin->refine_table_kb = ctx->refine_table_kb; twin->fiss_stages = ctx->fiss_stages; twin->fiss_jump = ctx->fiss_jump; twin->fiss_fused = ctx->fiss_fused;
+    twin->handover_timeout_us = ctx->handover_timeout_us;
     if (!ctx->appended_ok) twin->appended_ok = false;
 }
 
