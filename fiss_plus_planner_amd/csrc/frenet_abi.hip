@@ -202,11 +202,6 @@ struct fp_ctx {
     bool appended_ok = false;
     int32_t* hand_err = nullptr;
     int handover_timeout_us = 0;   // fp_ctx_set_option("handover_timeout_us") (FP_TEST_HOOKS): KernelArgs::handover_timeout_us
-    // EXPERIMENT fp_ctx_set_option("pose_digest"): fp32 (x, y) copies of the scene tables seen so far, keyed by the table's address
-    int pose_digest = 0;
-    struct Digest { const double* key = nullptr; size_t n = 0; DeviceBuf buf; };
-    Digest digests[8];
-    int digest_next = 0;
     // fp_ctx_set_option("overlap"): consecutive INDEPENDENT FP_MEM_DEVICE dense calls alternate between two internal streams (this ctx's
     // and a twin ctx's, each with its own scratch: tickets, hand-over flags, launch order), so the draining tail of one launch runs beside
     // the ramp of the next.  See fp_plan_dense / fp_ctx_join in include/frenet_gpu.h for what the caller's stream is ordered after.
@@ -225,15 +220,6 @@ namespace {
 // Latency regime: the pinned window goes to the arena by a copy KERNEL (16 bytes per lane, read straight from the pinned host block)
 // instead of a copy command: for ~100 KB the copy engine takes ~9 us and the kernel behind it starts ~8 us after the copy ends
 // (cross-engine dependency); a kernel-to-kernel dependency on the same queue costs ~2-3 us and the copy itself ~4 us.
-__global__ __launch_bounds__(256) void pose_digest_kernel(const double4* __restrict__ pose, float2* __restrict__ out, size_t n)
-{
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double4 p = pose[i];
-        const bool ok = p.w != 0.0 && p.x == p.x;
-        out[i] = make_float2(ok ? (float)p.x : __builtin_nanf(""), (float)p.y);
-    }
-}
-
 __global__ __launch_bounds__(256) void stage_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
@@ -839,21 +825,6 @@ int handover_recover(fp_ctx* ctx, hipStream_t stream)
 }
 int handover_check(fp_ctx* ctx, hipStream_t stream) { return handover_failed(ctx) ? handover_recover(ctx, stream) : FP_OK; }
 
-// EXPERIMENT: the fp32 (x, y) digest of a scene table (KernelArgs::pose_xy), built by a kernel the first time the table's address is seen
-const float* pose_digest_for(fp_ctx* ctx, const fp_batch* b, hipStream_t stream)
-{
-    if (!ctx->pose_digest || !(b->S > 0 && b->n_obs > 0) || !b->obs_pose) return nullptr;
-    const size_t n = (size_t)b->S * b->T_obs * b->n_obs;
-    for (auto& d : ctx->digests)
-        if (d.key == b->obs_pose && d.n == n) return (const float*)d.buf.base;
-    fp_ctx::Digest& d = ctx->digests[ctx->digest_next++ % 8];
-    if (d.buf.reserve(n * 8 + kAlign) != FP_OK) return nullptr;
-    hipLaunchKernelGGL(pose_digest_kernel, dim3(1024), dim3(256), 0, stream, (const double4*)b->obs_pose, (float2*)d.buf.base, n);
-    d.key = b->obs_pose;
-    d.n = n;
-    return (const float*)d.buf.base;
-}
-
 // Optional curvature checks: the fused lattice kernel reads them from a [B][C] byte table that launch_lattice fills first.
 int lattice_curv_scratch(fp_ctx* ctx, const fp_params* p, const fp_batch* b, hipStream_t stream, const uint8_t** out)
 {
@@ -1368,10 +1339,6 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->appended_ok = value != 0;
         return FP_OK;
     }
-    if (strcmp(name, "pose_digest") == 0) {  // EXPERIMENT
-        ctx->pose_digest = value != 0;
-        return FP_OK;
-    }
     if (strcmp(name, "handover_timeout_us") == 0) {  // test hook: appended workgroups give up after this many microseconds (0 = 2 s)
         if (!getenv("FP_TEST_HOOKS")) return fail(FP_EINVAL, "handover_timeout_us is a test hook: set FP_TEST_HOOKS=1 in the environment to use it");
         if (value < 0 || value > 10000000) return fail(FP_EINVAL, "handover_timeout_us must be in 0..10^7");
@@ -1506,7 +1473,6 @@ static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch*
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
         ka.r = *result;
-        ka.pose_xy = pose_digest_for(ctx, batch, (hipStream_t)stream);
         if ((result->fopplus || result->audit) && (!ka.r.cost_tbl || !ka.r.flag_tbl)) FP_TRY(fopplus_tables(ctx, B, C, &ka.r, (hipStream_t)stream));
         FP_TRY(lattice_curv_scratch(ctx, params, batch, (hipStream_t)stream, &ka.curv_tbl));
         int nsplit, group, tail; void* parts;

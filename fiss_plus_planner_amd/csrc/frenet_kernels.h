@@ -71,9 +71,6 @@ struct KernelArgs {
     // before it gives up; 0 = the production value (2 s).  A microsecond makes REAL waits run out, which is how the tests drive the
     // device side of the time-out path (error word, workgroup leaves without output, the launch completes) instead of injecting its result.
     int handover_timeout_us = 0;
-    // EXPERIMENT (fp_ctx_set_option("pose_digest")): [S][T_obs][n_obs] float2 = (x, y) of obs_pose in fp32, x = NaN where the obstacle has no
-    // state - what the once-per-ego group test reads instead of the 32-byte pose rows (a survivor's full pose is then read from obs_pose)
-    const float* pose_xy = nullptr;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

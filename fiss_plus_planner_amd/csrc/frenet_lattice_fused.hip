@@ -608,12 +608,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
             ps[u] = make_double4(0.0, 0.0, 0.0, 0.0);
             if (i < rows_stage * n_obs) {
                 const int r = div_by<NOBS, ROWS * NOBS>(i, inv_nobs_s), j = i - mul24(r, n_obs);
-                if (ka.pose_xy) {  // (experiment: 8 bytes per item instead of 32)
-                    const float2 v = ((const float2*)ka.pose_xy)[((size_t)(sc >= 0 ? sc : 0) * bt.T_obs + mul24(r, stride) + t_now) * n_obs_tab + j];
-                    ps[u] = make_double4((double)v.x, (double)v.y, 0.0, v.x == v.x ? 1.0 : 0.0);
-                } else {
-                    ps[u] = *(const double4*)(gp + ((size_t)(mul24(r, stride) + t_now) * n_obs + j) * 4);
-                }
+                ps[u] = *(const double4*)(gp + ((size_t)(mul24(r, stride) + t_now) * n_obs + j) * 4);
             }
         }
     };
@@ -1089,14 +1084,8 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
                         const int r = div_by<NOBS, ROWS * NOBS>(e, inv_nobs), j = e - mul24(r, n_obs);
                         const int k = mul24(r, stride);
                         const ObsDim g = s_grp[r];
-                        const double dx = ps[u].x - g.hl, dy = ps[u].y - g.hw;
-                        // (digest: the fp32 coordinates are within 2^-24 relative of the table's - a slack of 2.4e-7 (|x| + |y|) + 1e-6 covers both)
-                        const double R = g.r + s_dim.rad[j] + (ka.pose_xy ? 2.4e-7 * (fabs(ps[u].x) + fabs(ps[u].y)) + 1e-6 : 0.0);
+                        const double dx = ps[u].x - g.hl, dy = ps[u].y - g.hw, R = g.r + s_dim.rad[j];
                         keep = k < pose_limit && ps[u].w != 0.0 && (ps[u].x == ps[u].x) && !(g.r < 0.0) && !(fma(dx, dx, dy * dy) > R * R);
-                        if (keep && ka.pose_xy) {  // a survivor: its exact pose from the table (NaN x / valid = 0 were dropped above)
-                            ps[u] = *(const double4*)(gp + ((size_t)(k + t_now) * n_obs + j) * 4);
-                            keep = ps[u].w != 0.0 && (ps[u].x == ps[u].x);
-                        }
                     }
                     const unsigned long long m = __ballot(keep);
                     if (m) {
