@@ -173,7 +173,6 @@ struct fp_ctx {
     int stage_kernel = 1;          // fp_ctx_set_option("stage_kernel"): the latency regime's inputs reach the device by a copy kernel instead of a copy command
     int zero_copy_in = 0;          // fp_ctx_set_option("zero_copy_in"): FP_MEM_HOST calls of a handful of egos read inputs from pinned host memory: 0 never (default: even a few hundred bytes read over the link cost every kernel of the call a round trip - measured slower than the copy kernel), 1 the per-ego arrays of a call whose tables are cached (tables_tag), 2 everything
     int lattice_occupancy = 0;     // fp_ctx_set_option("lattice_occupancy"): 0 auto, 2 / 3: at most that many lattice workgroups per CU
-    int lattice_head = 0;          // fp_ctx_set_option("lattice_head"): 0 auto, 1 never, n >= 2: the first n slots of an ordered multi-round launch are cut in two workgroups
     int lattice_tail = 0;          // fp_ctx_set_option("lattice_tail"): 0 auto, 1 never, n >= 2: the last n dispatch slots of a multi-round launch are cut in two workgroups
     int lattice_group = 0;         // fp_ctx_set_option("lattice_group"): 0 auto, 1 never, n >= 2: up to n slices per barrier interval
     int refine_table_kb = 96;      // fp_ctx_set_option("refine_table_kb")
@@ -999,7 +998,7 @@ int common_checks(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, i
 void overlap_sync_options(fp_ctx* twin, const fp_ctx* ctx)
 {
     twin->lattice_kernel = ctx->lattice_kernel; twin->lattice_split = ctx->lattice_split; twin->lattice_occupancy = ctx->lattice_occupancy;
-    twin->lattice_tail = ctx->lattice_tail; twin->lattice_head = ctx->lattice_head; twin->lattice_group = ctx->lattice_group; twin->lattice_winner = ctx->lattice_winner;
+    twin->lattice_tail = ctx->lattice_tail; twin->lattice_group = ctx->lattice_group; twin->lattice_winner = ctx->lattice_winner;
     twin->lattice_order = ctx->lattice_order; twin->resident_groups = ctx->resident_groups; twin->lds_cu_kb = ctx->lds_cu_kb;
     twin->validate = ctx->validate;
     twin->refine_table_kb = ctx->refine_table_kb; twin->fiss_stages = ctx->fiss_stages; twin->fiss_jump = ctx->fiss_jump; twin->fiss_fused = ctx->fiss_fused;
@@ -1411,11 +1410,6 @@ int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value)
         ctx->resident_groups = value;
         return FP_OK;
     }
-    if (strcmp(name, "lattice_head") == 0) {
-        if (value < 0) return fail(FP_EINVAL, "lattice_head must be 0 (auto), 1 (never) or the number of egos cut in two");
-        ctx->lattice_head = value;
-        return FP_OK;
-    }
     if (strcmp(name, "lattice_tail") == 0) {
         if (value < 0) return fail(FP_EINVAL, "lattice_tail must be 0 (auto), 1 (never) or the number of egos cut in two");
         ctx->lattice_tail = value;
@@ -1433,7 +1427,7 @@ int fp_ctx_get_option(fp_ctx* ctx, const char* name, int* value)
 {
     if (!ctx || !name || !value) return fail(FP_EINVAL, "ctx/name/value is NULL");
     const struct { const char* n; int v; } tab[] = {
-        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"lattice_head", ctx->lattice_head}, {"lattice_occupancy", ctx->lattice_occupancy}, {"resident_groups", ctx->resident_groups}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
+        {"lattice_kernel", ctx->lattice_kernel}, {"lattice_split", ctx->lattice_split}, {"lattice_group", ctx->lattice_group}, {"lattice_tail", ctx->lattice_tail}, {"lattice_occupancy", ctx->lattice_occupancy}, {"resident_groups", ctx->resident_groups}, {"zero_copy_in", ctx->zero_copy_in}, {"stage_kernel", ctx->stage_kernel}, {"inline_inputs", ctx->inline_inputs}, {"lattice_order", ctx->lattice_order},
         {"refine_table_kb", ctx->refine_table_kb}, {"fiss_stages", ctx->fiss_stages}, {"fiss_jump", ctx->fiss_jump}, {"validate", ctx->validate}, {"lattice_winner", ctx->lattice_winner}, {"fiss_fused", ctx->fiss_fused}, {"appended_workgroups", ctx->appended_ok ? 1 : 0}, {"handover_failed", ctx->hand_err ? *(volatile int32_t*)ctx->hand_err : 0}, {"overlap", ctx->overlap}, {"overlapped_calls", ctx->overlapped_calls}, {"lattice_launches", ctx->lattice_launches + (ctx->twin ? ctx->twin->lattice_launches : 0)},
         {"lattice_ordered_launches", ctx->lattice_ordered_launches + (ctx->twin ? ctx->twin->lattice_ordered_launches : 0)},
         {"lattice_launches_2", (int)fp::lattice_launches_per_cu(0)}, {"lattice_launches_3", (int)fp::lattice_launches_per_cu(1)}, {"lattice_launches_4", (int)fp::lattice_launches_per_cu(2)}};
@@ -1474,7 +1468,7 @@ static int plan_dense_impl(fp_ctx* ctx, const fp_params* params, const fp_batch*
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
-    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb; ka.handover_timeout_us = ctx->handover_timeout_us; ka.head_cut = ctx->lattice_head;
+    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb; ka.handover_timeout_us = ctx->handover_timeout_us;
     if (mem == FP_MEM_DEVICE) {
         ka.b = *batch;
         if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;
@@ -1682,7 +1676,7 @@ int plan_fiss_impl(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, 
     fp::FissArgs fa;
     fa.ka.p = *params;
     fa.ka.err_word = ctx->hand_err;
-    fa.ka.occ_cap = ctx->lattice_occupancy; fa.ka.resident2 = ctx->resident_groups; fa.ka.lds_cu_kb = ctx->lds_cu_kb; fa.ka.handover_timeout_us = ctx->handover_timeout_us; fa.ka.head_cut = ctx->lattice_head;
+    fa.ka.occ_cap = ctx->lattice_occupancy; fa.ka.resident2 = ctx->resident_groups; fa.ka.lds_cu_kb = ctx->lds_cu_kb; fa.ka.handover_timeout_us = ctx->handover_timeout_us;
     fa.opts = *opts;
     fa.opts.max_refine_iters = R;
     fa.ka.r = no_result();
@@ -1906,7 +1900,7 @@ int fp_plan_step(fp_ctx* ctx, const fp_params* params, const fp_batch* batch, co
     fp::KernelArgs ka;
     ka.p = *params;
     ka.err_word = ctx->hand_err;
-    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb; ka.handover_timeout_us = ctx->handover_timeout_us; ka.head_cut = ctx->lattice_head;
+    ka.occ_cap = ctx->lattice_occupancy; ka.resident2 = ctx->resident_groups; ka.lds_cu_kb = ctx->lds_cu_kb; ka.handover_timeout_us = ctx->handover_timeout_us;
     ka.b = *batch;
     ka.b.skip = io->done;
     if (!(batch->S > 0 && batch->n_obs > 0)) ka.b.n_obs = 0;

@@ -71,9 +71,6 @@ struct KernelArgs {
     // before it gives up; 0 = the production value (2 s).  A microsecond makes REAL waits run out, which is how the tests drive the
     // device side of the time-out path (error word, workgroup leaves without output, the launch completes) instead of injecting its result.
     int handover_timeout_us = 0;
-    // Head cut (launch_lattice_fused; host: fp_ctx_set_option("lattice_head"), the kernel: the resolved count): the first head_cut slots of
-    // an ORDERED multi-round launch - its longest egos - are cut in two workgroups each (slices split, ticket + merge, like the tail split)
-    int head_cut = 0;
 };
 
 // Inline inputs (latency regime of the FP_MEM_HOST entry, fused lattice kernel only): the per-ego arrays of a tiny batch travel

@@ -409,17 +409,10 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
     // Dispatch slot -> (ego, part).  Uniform split (latency mode): slot = blockIdx / nsplit.  Tail split (tail_from >= 0, nsplit_arg
     // == 1): the slots from tail_from on - the workgroups that start when the launch's last round is already draining - are cut in
     // two like a latency-mode ego, so the launch does not end on whole egos that started last (see launch_lattice_fused).
-    // Head cut (ka.head_cut > 0, nsplit_arg == 1, an ordered launch): the FIRST head slots - the launch's longest egos - are cut in two as
-    // well, workgroups [0, 2 head): with the order exact the launch ends one short ego after its LONGEST one (86 + 42 us of a 128 us
-    // launch, round 6's stamps), so it is the long egos whose halves shorten it, not the short ones at the end.
-    const int head = nsplit_arg == 1 ? ka.head_cut : 0;
-    const int bid = (int)blockIdx.x;
-    const bool in_head = bid < 2 * head;
-    const int bid_t = bid - head;  // (the index in the numbering behind the head: slot bid_t while nothing else is cut)
-    const bool in_tail = !in_head && tail_from >= 0 && bid_t >= tail_from;
-    const int nsplit = (in_head || in_tail) ? 2 : nsplit_arg;
-    const int slot = in_head ? (bid >> 1) : in_tail ? tail_from + ((bid_t - tail_from) >> 1) : (head > 0 ? bid_t : bid / nsplit_arg);
-    const int part_of_slot = in_head ? (bid & 1) : in_tail ? ((bid_t - tail_from) & 1) : (head > 0 ? 0 : bid - slot * nsplit_arg);
+    const bool in_tail = tail_from >= 0 && (int)blockIdx.x >= tail_from;
+    const int nsplit = in_tail ? 2 : nsplit_arg;
+    const int slot = in_tail ? tail_from + (((int)blockIdx.x - tail_from) >> 1) : (int)blockIdx.x / nsplit_arg;
+    const int part_of_slot = in_tail ? (((int)blockIdx.x - tail_from) & 1) : (int)blockIdx.x - slot * nsplit_arg;
     constexpr bool kShape = ND > 0;  // (all six are set together)
     // The run-time-shape three-per-CU instances have no register to spare (80 VGPRs, run-time sizes in place of immediates): from the
     // prologue's second barrier on they re-read the ego's start state from LDS (s_k[5..10]) where it is used instead of holding twelve
@@ -1702,7 +1695,7 @@ __global__ __launch_bounds__(NTH, OCC) void lattice_fused_kernel(KernelArgs ka, 
         }
     }
     // 10 ns ticks: feeds the next launches' order (a tail ego leaves twice its last part's time: about what it would take whole)
-    if (tid == 0 && la.dur && (nsplit == 1 || in_tail || in_head)) la.dur[b] = (int)(wall_clock64() - t_begin) * nsplit;
+    if (tid == 0 && la.dur && (nsplit == 1 || in_tail)) la.dur[b] = (int)(wall_clock64() - t_begin) * nsplit;
     if (nsplit > 1) FP_STAMP_LAST(10); else FP_STAMP(10);
 #if defined(FP_PHASE_STAMPS)  // column 15: the workgroup's absolute start (10 ns ticks, low 40 bits) - the launch's occupancy over time
     if (threadIdx.x == 0 && ka.r.best_traj && (perm || blockIdx.x % nsplit == 0)) ka.r.best_traj[((size_t)b * FP_ARR_COUNT + 15) * (ka.r.traj_stride > 0 ? ka.r.traj_stride : FP_DEFAULT_STRIDE) + 112 + 15] = (double)(t_begin & 0xFFFFFFFFFFll);
@@ -1885,19 +1878,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
         if (n_tail > 0) tail_from = b.B - n_tail;
     }
 #endif
-    // Head cut: only an ORDERED launch has its longest egos in front (perm: the batch's own history, or the caller's hint)
-    int head_to = 0;
-#if !defined(FP_PHASE_STAMPS) && !defined(FP_COUNTERS)
-    if (ka.head_cut != 1 && perm && nsplit == 1 && gs == 1 && part_scratch && p.nt >= 2 && b.S > 0 && b.n_obs > 0 && (size_t)b.B * 4 <= kTicketBytes) {
-        const int resident_h = (four ? 4 : three ? 3 : 2) * ka.resident2 / 2;
-        head_to = ka.head_cut >= 2 ? ka.head_cut : (b.B > resident_h ? resident_h / 8 : 0);
-        if (head_to > b.B) head_to = b.B;
-        if (tail_from >= 0 && tail_from < head_to) tail_from = head_to < b.B ? head_to : -1;  // (an ego is cut once)
-    }
-#endif
-    kx.head_cut = head_to;
-    const int n_cut_tail = tail_from >= 0 ? b.B - tail_from : 0;
-    const unsigned lattice_grid = nsplit == 1 ? (unsigned)(b.B + head_to + n_cut_tail) : (unsigned)(b.B * nsplit);
+    const unsigned lattice_grid = tail_from >= 0 ? (unsigned)(2 * b.B - tail_from) : (unsigned)(b.B * nsplit);
     const int epi_from = epilogue || search ? (int)lattice_grid : -1;
     const unsigned grid = lattice_grid + (epilogue ? (unsigned)((b.B + kEpiPairs - 1) / kEpiPairs) : 0u) + (search ? (unsigned)b.B : 0u);
     hipError_t e;
