@@ -109,3 +109,15 @@ def test_emit_prints_one_line_and_writes_the_side_file(full, tmp_path, capsys, m
     assert _strict(out)["extras_file"] == "x.json"
     side = json.load(open(tmp_path / "x.json"))
     assert side["config4"]["stage_ms"] and side["closed_loop"]["FOP"]["value"] > 0
+
+
+def test_line_from_the_current_rounds_full_record():
+    """The same on round 6's own full record (profiles/r06_bench_extras.json: the side file of the run behind profiles/r06_bench.json):
+    the line bench.py printed equals the line built again from the record."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_extras.json")))
+    printed = _strict(open(os.path.join(ROOT, "profiles", "r06_bench.json")).read())
+    built = _strict(bench.dump_line(bench.contract_line(rec)))
+    assert tuple(printed) == bench.CONTRACT_KEYS
+    assert built == printed
+    assert printed["legs"]["overlap"]["parity_ok"] is True and printed["legs"]["config4"]["ms_per_step"] < 0.21
+    assert printed["roofline"]["traffic"] < 1.2 * printed["roofline"]["algorithmic_bytes_per_launch"]
