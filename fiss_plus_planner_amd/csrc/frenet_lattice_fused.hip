@@ -1805,7 +1805,7 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     auto window_for = [&](int cap_bytes, int occ, int ps, bool slim) {
         const int base = make_layout(b.NX, b.n_obs, rows, hp, p.nd, p.nv, p.nt, item_cap(occ), 1, kThreads / kWave, ps, slim, 0).total;
         const int w = (cap_bytes - base - 16) / 64;
-        if (ps > 0 || gs > 1) return w >= b.NX ? b.NX : 0;  // (no WIN instance with the polygon narrow phase / grouped slices)
+        if (gs > 1) return w >= b.NX ? b.NX : 0;  // (no WIN instance with grouped slices)
         return w >= b.NX ? b.NX : (w >= kWinMin ? w : 0);  // 0: not even a useful window fits
     };
     const int w6 = window_for(52 * 1024, 6, pstride, false);
@@ -1912,6 +1912,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
     FP_LDS_SLOTS(cfg_poly);
     FP_LDS_SLOTS(cfg_poly6);
     FP_LDS_SLOTS(cfg_poly9976);
+    FP_LDS_SLOTS(cfg_poly6w);
+    FP_LDS_SLOTS(cfg_poly9976w);
     FP_LDS_SLOTS(cfg_poly_g);
     FP_LDS_SLOTS(cfg_9978w);
     FP_LDS_SLOTS(cfg_generic8w);
@@ -1925,6 +1927,8 @@ hipError_t launch_lattice_fused(const KernelArgs& ka, hipStream_t stream, void* 
 #else
     if (b.obs_nvert && b.n_obs > 0) {  // convex-polygon columns: the run-time-shape instances with the polygon narrow phase
         if (gs > 1) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 0, FP_GROUP_THREADS, true>, cfg_poly_g, FP_GROUP_THREADS);
+        else if (three && windowed && is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, true, false, true>, cfg_poly9976w);
+        else if (three && windowed) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, true, false, true>, cfg_poly6w);
         else if (three && is(9, 9, 7, 2, 50, 25)) e = go(lattice_fused_kernel<9, 9, 7, 2, 50, 25, 6, 1, 512, true>, cfg_poly9976);
         else if (three) e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 6, 1, 512, true>, cfg_poly6);
         else e = go(lattice_fused_kernel<0, 0, 0, 0, 0, 0, 4, 1, 512, true>, cfg_poly);

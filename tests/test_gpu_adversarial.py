@@ -83,8 +83,8 @@ def test_obstacles_within_a_millimetre_of_contact(oracle, engine, seed):
 def test_polygon_obstacles_within_a_millimetre_of_contact(oracle, engine, seed):
     """The same attack with convex-polygon columns (the POLY instances: ring narrow phase behind the box test, inner-disk shortcut): the
     contact distance is the oracle's polygon predicate's own edge.  The four-per-CU instances have no polygon variant: three per CU
-    (and no windowed one: polygon scenes on long reference lines run two per CU, so the long-line seeds take the 81-knot shape here)."""
-    base = shapes(seed if seed % 6 != 4 else seed + 2)
+    (on the 220-knot seeds: the windowed POLY instances)."""
+    base = shapes(seed)
     batch, placed = A.contact_scene(oracle, base, 1100 + seed, polygons=0.7, gaps=(1e-6, 1e-5, 1e-4, 1e-3) if seed % 2 else (1e-6, 2e-6))
     assert batch.obs_nvert is not None and (batch.obs_nvert > 0).sum() >= batch.B // 2
     ref = [p.fop_plan() for p in oracle.problems_from_batch(batch)]

@@ -78,3 +78,21 @@ def test_fissplus_on_long_lines(oracle, engine):
         np.testing.assert_array_equal(out.stats[e], r.stats, err_msg=f"ego {e}")
         assert bool(out.refined[e]) == r.refined
         assert (np.isnan(out.best_cost[e]) and np.isnan(r.best_cost)) or abs(out.best_cost[e] - r.best_cost) <= 1e-6
+
+
+def test_polygon_scenes_on_long_lines(oracle, engine):
+    """Convex-polygon obstacle columns on 240-knot lines: the windowed POLY instances (three per CU), against the oracle and against two per CU."""
+    base = synth.make_batch(900, 9, 9, 7, 50, 50, True, 8903, layout="survey8d", n_knots=240)
+    batch = synth.with_random_shapes(base, 77, frac=0.5)
+    before = engine.get_option("lattice_launches_3")
+    out = engine.plan_dense(batch, tables=True, winner=True)
+    assert engine.get_option("lattice_launches_3") > before
+    _check(oracle, batch, out, np.arange(0, 900, 50), "polygons on 240-knot lines")
+    engine.set_option("lattice_occupancy", 2)
+    try:
+        ref = engine.plan_dense(batch, tables=True, winner=True)
+    finally:
+        engine.set_option("lattice_occupancy", 0)
+    np.testing.assert_array_equal(out.flags, ref.flags)
+    np.testing.assert_array_equal(out.best_idx, ref.best_idx)
+    assert np.array_equal(out.best_traj, ref.best_traj, equal_nan=True)
